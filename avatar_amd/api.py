@@ -1,0 +1,307 @@
+"""Python mirror of the reference's class surface for the hot path, on top of the C ABI (include/avt.h).
+
+Same names, members, defaults and call protocol as `ark::AvatarModel`, `ark::Avatar` (include/Avatar.h:64-220)
+and `ark::AvatarOptimizer` (include/AvatarOptimizer.h:11-61), so that the parity tests read like the callers in
+demo.cpp:137-143,251-268.  numpy arrays stand in for Eigen types: clouds are (N,3) float64 (each row one
+column of the reference's 3xN matrix), rotations (J,3,3).  All compute goes through libavatar_hip.so; there is
+no CPU path here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+from .capi import ModelArrays, Options, Profile, Stats, bptr, dptr, iptr
+
+
+class AvtError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise AvtError(capi.load_library().avt_last_error().decode())
+
+
+# ---- rotation <-> quaternion exactly as optimize() converts (AvatarOptimizer.cpp:1250-1254, :1494-1496):
+# Matrix3 -> Quaternion -> AngleAxis -> Quaternion on the way in, Quaternion::toRotationMatrix on the way out
+# (Eigen 3.3 closed forms).
+def rot_to_quat(R):
+    R = np.asarray(R, np.float64).reshape(-1, 3, 3)
+    out = np.empty((R.shape[0], 4))
+    for n, m in enumerate(R):
+        q = np.empty(4)
+        t = m[0, 0] + m[1, 1] + m[2, 2]
+        if t > 0:
+            t = np.sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t
+            q[0] = (m[2, 1] - m[1, 2]) * t; q[1] = (m[0, 2] - m[2, 0]) * t; q[2] = (m[1, 0] - m[0, 1]) * t
+        else:
+            i = 0
+            if m[1, 1] > m[0, 0]: i = 1
+            if m[2, 2] > m[i, i]: i = 2
+            j = (i + 1) % 3; k = (j + 1) % 3
+            t = np.sqrt(m[i, i] - m[j, j] - m[k, k] + 1.0); q[i] = 0.5 * t; t = 0.5 / t
+            q[3] = (m[k, j] - m[j, k]) * t; q[j] = (m[j, i] + m[i, j]) * t; q[k] = (m[k, i] + m[i, k]) * t
+        nrm = np.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2])
+        if nrm < np.finfo(float).eps:
+            mx = np.abs(q[:3]).max()
+            nrm = mx * np.sqrt(((q[:3] / mx) ** 2).sum()) if mx > 0 else 0.0
+        if nrm != 0.0:
+            ang = 2.0 * np.arctan2(nrm, abs(q[3]))
+            if q[3] < 0: nrm = -nrm
+            axis = q[:3] / nrm
+        else:
+            ang, axis = 0.0, np.array([1.0, 0.0, 0.0])
+        ha = 0.5 * ang
+        out[n, 3] = np.cos(ha); out[n, :3] = np.sin(ha) * axis
+    return out
+
+
+def quat_to_rot(q):
+    q = np.asarray(q, np.float64).reshape(-1, 4)
+    out = np.empty((q.shape[0], 3, 3))
+    for n, (x, y, z, w) in enumerate(q):
+        tx, ty, tz = 2 * x, 2 * y, 2 * z
+        twx, twy, twz = tx * w, ty * w, tz * w
+        txx, txy, txz = tx * x, ty * x, tz * x
+        tyy, tyz, tzz = ty * y, tz * y, tz * z
+        out[n] = [[1 - (tyy + tzz), txy - twz, txz + twy],
+                  [txy + twz, 1 - (txx + tzz), tyz - twx],
+                  [txz - twy, tyz + twx, 1 - (txx + tyy)]]
+    return out
+
+
+class AvatarModel:
+    """`struct AvatarModel` (Avatar.h:64-151).  Built from SMPL-npz-style arrays (dict) or from a directory
+    holding `model.npz` (+ optional `pose_prior.txt`), the reference's model_dir convention (AvatarModel.cpp:18-23)."""
+
+    def __init__(self, model=None, limit_one_joint_per_point=False):
+        if limit_one_joint_per_point:
+            raise NotImplementedError("limit_one_joint_per_point is a legacy-format option (AvatarModel.cpp:128-288)")
+        if isinstance(model, (str, os.PathLike)):
+            model = load_model_dir(model)
+        if model is None:
+            raise AvtError("AvatarModel: no model data (the reference's data/avatar-model download is not bundled)")
+        self.smpl = model
+        self.arrays = ModelArrays(model)
+        self._desc = self.arrays.desc()
+        self._lib = capi.load_library()
+        self.h = C.c_void_p()
+        _check(self._lib.avt_model_create(C.byref(self._desc), C.byref(self.h)))
+        self.parent = self.arrays.parent
+        self.mesh = self.arrays.mesh
+        ijp = np.empty(3 * self.numJoints()); jsr = np.empty(3 * self.numJoints() * self.numShapeKeys())
+        _check(self._lib.avt_model_joint_regression(self.h, dptr(ijp), dptr(jsr)))
+        self.initialJointPos = ijp.reshape(-1, 3)
+        self.jointShapeReg = jsr.reshape(self.numShapeKeys(), -1).T
+        mj = np.empty(self.numPoints(), np.int32)
+        _check(self._lib.avt_model_main_joint(self.h, iptr(mj)))
+        self.mainJoint = mj
+        self._default_ctx = None
+
+    def numJoints(self): return self.arrays.J
+    def numPoints(self): return self.arrays.V
+    def numShapeKeys(self): return self.arrays.K
+    def numFaces(self): return self.arrays.F
+    def hasPosePrior(self): return self.arrays.ncomps > 0
+
+    def default_ctx(self):
+        if self._default_ctx is None:
+            self._default_ctx = Context(self, self.numJoints(), np.arange(self.numJoints(), dtype=np.int32), 1024, 8)
+        return self._default_ctx
+
+    def __del__(self):
+        try:
+            self._default_ctx = None
+            self._lib.avt_model_destroy(self.h)
+        except Exception:
+            pass
+
+
+def load_model_dir(path):
+    """model.npz in SMPL layout (AvatarModel.cpp:26-104) + pose_prior.txt (GaussianMixture.cpp:12-58)."""
+    with np.load(os.path.join(path, "model.npz")) as z:
+        m = {k: z[k] for k in z.files}
+    pp = os.path.join(path, "pose_prior.txt")
+    if os.path.exists(pp) and "prior_weight" not in m:
+        tok = open(pp).read().split()
+        nc, nd = int(tok[0]), int(tok[1])
+        vals = np.array(tok[2:], dtype=np.float64)
+        m["prior_weight"] = vals[:nc]
+        m["prior_mean"] = vals[nc:nc + nc * nd].reshape(nc, nd)
+        m["prior_cov"] = vals[nc + nc * nd:nc + nc * nd + nc * nd * nd].reshape(nc, nd, nd)
+    return m
+
+
+class Context:
+    """One HIP device + stream + persistent buffers (avt_ctx)."""
+
+    def __init__(self, model: AvatarModel, num_parts, part_map, max_points, max_frames, device=None):
+        self.model = model
+        self._lib = capi.load_library()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        pm = np.ascontiguousarray(part_map, np.int32)
+        if len(pm) < model.numJoints():
+            raise AvtError("part_map must have at least numJoints entries (AvatarOptimizer.cpp:1229)")
+        self.h = C.c_void_p()
+        _check(self._lib.avt_ctx_create(C.c_int(device), model.h, C.c_int(num_parts), iptr(pm), C.c_int(max_points),
+                                        C.c_int(max_frames), C.byref(self.h)))
+        self.max_points, self.max_frames, self.num_parts = max_points, max_frames, num_parts
+
+    def __del__(self):
+        try:
+            self._lib.avt_ctx_destroy(self.h)
+        except Exception:
+            pass
+
+    # ---- thin wrappers -------------------------------------------------------------------------
+    def lbs_update(self, w, p, R):
+        """Batched Avatar::update. w (F,K), p (F,3), R (F,J,3,3). Returns cloud (F,V,3), jointPos (F,J,3),
+        jointTrans (F,J,12)."""
+        m = self.model
+        w = np.ascontiguousarray(np.atleast_2d(w), np.float64); p = np.ascontiguousarray(np.atleast_2d(p), np.float64)
+        R = np.asarray(R, np.float64).reshape(-1, m.numJoints(), 3, 3)
+        F = w.shape[0]
+        Rcm = np.ascontiguousarray(np.transpose(R, (0, 1, 3, 2)))  # column-major 3x3 blocks
+        cloud = np.empty((F, m.numPoints(), 3)); jp = np.empty((F, m.numJoints(), 3)); jt = np.empty((F, m.numJoints(), 12))
+        _check(self._lib.avt_lbs_update(self.h, C.c_int(F), dptr(w), dptr(p), dptr(Rcm), dptr(cloud), dptr(jp), dptr(jt)))
+        return cloud, jp, jt
+
+    def visibility(self, cloud, enable=True):
+        cloud = np.ascontiguousarray(cloud, np.float64)
+        vis = np.empty(self.model.numPoints(), np.uint8)
+        _check(self._lib.avt_visibility(self.h, dptr(cloud), C.c_int(int(enable)), bptr(vis)))
+        return vis
+
+    def nn(self, model_cloud, visible, data, labels):
+        mc = np.ascontiguousarray(model_cloud, np.float64); vis = np.ascontiguousarray(visible, np.uint8)
+        data = np.ascontiguousarray(data, np.float64); labels = np.ascontiguousarray(labels, np.int32)
+        out = np.empty(len(labels), np.int32)
+        _check(self._lib.avt_nn(self.h, dptr(mc), bptr(vis), dptr(data), iptr(labels), C.c_int(len(labels)), iptr(out)))
+        return out
+
+    def optimize_batch(self, datas, labels, opt: Options, p, q, w):
+        """datas/labels: lists of per-frame arrays. p (F,3), q (F,J,4), w (F,K) start states. Returns p,q,w,stats."""
+        F = len(datas)
+        offs = np.zeros(F + 1, np.int32)
+        for f in range(F):
+            offs[f + 1] = offs[f] + len(labels[f])
+        data = np.ascontiguousarray(np.concatenate([np.asarray(d, np.float64).reshape(-1, 3) for d in datas], 0))
+        lab = np.ascontiguousarray(np.concatenate([np.asarray(l, np.int32) for l in labels]))
+        p = np.array(p, np.float64).reshape(F, 3).copy(); q = np.array(q, np.float64).reshape(F, -1).copy()
+        w = np.array(w, np.float64).reshape(F, -1).copy()
+        st = (Stats * F)()
+        _check(self._lib.avt_optimize_batch(self.h, C.c_int(F), dptr(data), iptr(lab), iptr(offs), C.byref(opt), dptr(p),
+                                            dptr(q), dptr(w), st))
+        return p, q.reshape(F, -1, 4), w, list(st)
+
+    def frames_upload(self, datas, labels):
+        F = len(datas)
+        offs = np.zeros(F + 1, np.int32)
+        for f in range(F):
+            offs[f + 1] = offs[f] + len(labels[f])
+        data = np.ascontiguousarray(np.concatenate([np.asarray(d, np.float64).reshape(-1, 3) for d in datas], 0))
+        lab = np.ascontiguousarray(np.concatenate([np.asarray(l, np.int32) for l in labels]))
+        _check(self._lib.avt_frames_upload(self.h, C.c_int(F), dptr(data), iptr(lab), iptr(offs)))
+        self._F = F
+
+    def state_upload(self, p, q, w):
+        F = self._F
+        p = np.ascontiguousarray(np.asarray(p, np.float64).reshape(F, 3)); q = np.ascontiguousarray(np.asarray(q, np.float64).reshape(F, -1))
+        w = np.ascontiguousarray(np.asarray(w, np.float64).reshape(F, -1))
+        _check(self._lib.avt_state_upload(self.h, C.c_int(F), dptr(p), dptr(q), dptr(w)))
+
+    def optimize_resident(self, opt: Options):
+        _check(self._lib.avt_optimize_resident(self.h, C.byref(opt)))
+
+    def sync(self):
+        _check(self._lib.avt_sync(self.h))
+
+    def state_download(self):
+        F = self._F; m = self.model
+        p = np.empty((F, 3)); q = np.empty((F, m.numJoints() * 4)); w = np.empty((F, m.numShapeKeys()))
+        st = (Stats * F)()
+        _check(self._lib.avt_state_download(self.h, dptr(p), dptr(q), dptr(w), st))
+        return p, q.reshape(F, -1, 4), w, list(st)
+
+    def correspondences(self, frame, n):
+        out = np.empty(n, np.int32)
+        _check(self._lib.avt_get_correspondences(self.h, C.c_int(frame), iptr(out)))
+        return out
+
+    def cloud(self, frame=0):
+        out = np.empty((self.model.numPoints(), 3))
+        _check(self._lib.avt_get_cloud(self.h, C.c_int(frame), dptr(out)))
+        return out
+
+    def normal_equations(self, frame=0):
+        P = self.model.arrays.P
+        H = np.empty((P, P)); g = np.empty(P); cost = C.c_double()
+        _check(self._lib.avt_get_normal_equations(self.h, C.c_int(frame), dptr(H), dptr(g), C.byref(cost)))
+        return H, g, cost.value
+
+    def profile_begin(self):
+        _check(self._lib.avt_profile_begin(self.h))
+
+    def profile_end(self):
+        pr = Profile()
+        _check(self._lib.avt_profile_end(self.h, C.byref(pr)))
+        return {capi.AVT_K_NAMES[i]: (pr.ms[i], pr.launches[i]) for i in range(capi.AVT_K_COUNT)}
+
+
+class Avatar:
+    """`class Avatar` (Avatar.h:155-220): state w, p, r -> update() -> cloud, jointPos, jointTrans."""
+
+    def __init__(self, model: AvatarModel):
+        self.model = model
+        self.w = np.zeros(model.numShapeKeys())
+        self.p = np.zeros(3)
+        self.r = np.tile(np.eye(3), (model.numJoints(), 1, 1))   # Avatar.cpp:12-20
+        self.cloud = np.zeros((0, 3)); self.jointPos = np.zeros((0, 3)); self.jointTrans = np.zeros((0, 12))
+
+    def update(self):
+        c, jp, jt = self.model.default_ctx().lbs_update(self.w[None], self.p[None], self.r[None])
+        self.cloud, self.jointPos, self.jointTrans = c[0], jp[0], jt[0]
+
+
+class AvatarOptimizer:
+    """`class AvatarOptimizer` (AvatarOptimizer.h:11-61).  `intrin` and `image_size` are accepted for signature
+    parity; they do not influence optimize() in the reference either (renderer unused, AvatarOptimizer.cpp:1271,
+    :1369-1385)."""
+
+    ROT_SIZE = 4
+
+    def __init__(self, ava: Avatar, intrin=None, image_size=None, num_parts=None, part_map=None, max_points=200000):
+        self.ava = ava
+        self.intrin, self.imageSize = intrin, image_size
+        J = ava.model.numJoints()
+        self.partMap = np.arange(J, dtype=np.int32) if part_map is None else np.asarray(part_map, np.int32)
+        self.numParts = J if num_parts is None else num_parts
+        self.betaPose, self.betaShape = 0.1, 1.0          # AvatarOptimizer.h:28
+        self.nnStep = 20                                   # :33
+        self.maxItersPerICP = 10                           # :36
+        self.enableOcclusion = True                        # :39
+        self.r = np.zeros((J, 4)); self.r[:, 3] = 1.0      # quaternions (x,y,z,w), :25
+        self.ctx = Context(ava.model, self.numParts, self.partMap, max_points, 1)
+        self.last_stats = None
+
+    def options(self, icp_iters=1, num_threads=4) -> Options:
+        o = Options.reference_defaults()
+        o.beta_pose, o.beta_shape = self.betaPose, self.betaShape
+        o.nn_step, o.max_iters_per_icp = self.nnStep, self.maxItersPerICP
+        o.enable_occlusion, o.icp_iters, o.num_threads = int(self.enableOcclusion), icp_iters, num_threads
+        return o
+
+    def optimize(self, data_cloud, data_part_labels, icp_iters=1, num_threads=4):
+        ava = self.ava
+        self.r = rot_to_quat(ava.r)                                              # :1250-1254
+        p, q, w, st = self.ctx.optimize_batch([data_cloud], [data_part_labels], self.options(icp_iters, num_threads),
+                                              ava.p[None], self.r[None], ava.w[None])
+        ava.p, self.r, ava.w = p[0], q[0], w[0]
+        ava.r = quat_to_rot(self.r)                                              # :1494-1496
+        ava.update()                                                             # :1497
+        self.last_stats = st[0]

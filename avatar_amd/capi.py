@@ -1,0 +1,201 @@
+"""ctypes view of include/avt.h: struct layouts, model-descriptor marshalling and the library loader.
+
+The product path is libavatar_hip.so (hand-written HIP for gfx950 behind the C ABI).  There is NO CPU
+fallback: if the shared library is missing or fails to load, `load_library()` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import scipy.sparse as sp
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libavatar_hip.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+c_ubyte_p = C.POINTER(C.c_ubyte)
+
+AVT_K_NAMES = ["lbs", "visibility", "bucket", "nn", "aggregate", "prepare", "eval", "reduce", "solve"]
+AVT_K_COUNT = len(AVT_K_NAMES)
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("num_points", C.c_int), ("num_joints", C.c_int), ("num_shape_keys", C.c_int), ("num_faces", C.c_int),
+        ("base_cloud", c_double_p), ("key_clouds", c_double_p), ("parent", c_int_p), ("mesh", c_int_p),
+        ("weights_colptr", c_int_p), ("weights_row", c_int_p), ("weights_val", c_double_p),
+        ("jreg_colptr", c_int_p), ("jreg_row", c_int_p), ("jreg_val", c_double_p),
+        ("prior_ncomps", C.c_int), ("prior_ndims", C.c_int),
+        ("prior_weight", c_double_p), ("prior_mean", c_double_p), ("prior_cov", c_double_p),
+    ]
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("beta_pose", C.c_double), ("beta_shape", C.c_double),
+        ("nn_step", C.c_int), ("max_iters_per_icp", C.c_int), ("enable_occlusion", C.c_int),
+        ("icp_iters", C.c_int), ("num_threads", C.c_int), ("reserved0", C.c_int),
+        ("lm_lambda0", C.c_double), ("lm_up", C.c_double), ("lm_down", C.c_double),
+        ("lm_lambda_min", C.c_double), ("lm_lambda_max", C.c_double),
+    ]
+
+    @classmethod
+    def reference_defaults(cls):
+        """AvatarOptimizer.h:28-39 member defaults + the LM step-rule defaults."""
+        return cls(beta_pose=0.1, beta_shape=1.0, nn_step=20, max_iters_per_icp=10, enable_occlusion=1,
+                   icp_iters=1, num_threads=4, reserved0=0, lm_lambda0=1e-3, lm_up=4.0, lm_down=1.0 / 3.0,
+                   lm_lambda_min=1e-12, lm_lambda_max=1e8)
+
+    @classmethod
+    def demo(cls, **kw):
+        """The knobs the reference's trackers run with (demo.cpp:54-57,139-143)."""
+        o = cls.reference_defaults()
+        o.beta_pose, o.beta_shape = 0.05, 0.12
+        for k, v in kw.items():
+            setattr(o, k, v)
+        return o
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("initial_cost", C.c_double), ("final_cost", C.c_double), ("lambda_", C.c_double),
+        ("num_correspondences", C.c_int), ("matched_model_points", C.c_int),
+        ("gn_iterations", C.c_int), ("accepted_steps", C.c_int),
+    ]
+
+
+class Profile(C.Structure):
+    _fields_ = [("ms", C.c_double * AVT_K_COUNT), ("launches", C.c_int * AVT_K_COUNT)]
+
+
+def dptr(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def iptr(a):
+    return a.ctypes.data_as(c_int_p)
+
+
+def bptr(a):
+    return a.ctypes.data_as(c_ubyte_p)
+
+
+class ModelArrays:
+    """Host arrays in the layout avt_model_desc wants, built from SMPL-npz-style arrays
+    (AvatarModel.cpp:26-104: v_template (V,3), f (F,3), kintree_table (2,J), J_regressor (J,V),
+    weights (V,J), shapedirs (V,3,K)) plus the GMM (prior_weight, prior_mean, prior_cov)."""
+
+    def __init__(self, smpl: dict):
+        v = np.ascontiguousarray(smpl["v_template"], dtype=np.float64)
+        self.V = V = v.shape[0]
+        self.J = J = int(np.asarray(smpl["kintree_table"]).shape[1])
+        sd = np.asarray(smpl["shapedirs"], dtype=np.float64)
+        self.K = K = sd.shape[2]
+        f = np.asarray(smpl["f"])
+        self.F = f.shape[0]
+        self.P = 3 + 3 * J + K
+        self.base_cloud = v.reshape(-1).copy()                                    # x1 y1 z1 ... (AvatarModel.cpp:46-48)
+        self.key_clouds = np.asfortranarray(sd.reshape(3 * V, K))                 # 3V x K col-major (:99-103)
+        self.parent = np.asarray(smpl["kintree_table"])[0].astype(np.int32).copy()
+        self.parent[0] = -1                                                       # SMPL stores 2^32-1 for the root
+        self.mesh = np.ascontiguousarray(f.astype(np.int32))                      # (F,3) rows == 3xF col-major
+        W = sp.csc_matrix(np.asarray(smpl["weights"], dtype=np.float64).T)        # J x V (sparseView, :67-71)
+        W.sort_indices()
+        self.w_colptr = W.indptr.astype(np.int32); self.w_row = W.indices.astype(np.int32)
+        self.w_val = W.data.astype(np.float64)
+        R = sp.csc_matrix(np.asarray(smpl["J_regressor"], dtype=np.float64).T)    # V x J (:58-63)
+        R.sort_indices()
+        self.r_colptr = R.indptr.astype(np.int32); self.r_row = R.indices.astype(np.int32)
+        self.r_val = R.data.astype(np.float64)
+        if "prior_weight" in smpl and smpl["prior_weight"] is not None:
+            self.prior_weight = np.ascontiguousarray(smpl["prior_weight"], dtype=np.float64)
+            self.prior_mean = np.ascontiguousarray(smpl["prior_mean"], dtype=np.float64)
+            self.prior_cov = np.ascontiguousarray(smpl["prior_cov"], dtype=np.float64)
+            self.ncomps, self.ndims = self.prior_mean.shape
+        else:
+            self.prior_weight = self.prior_mean = self.prior_cov = None
+            self.ncomps, self.ndims = 0, 0
+
+    def desc(self) -> ModelDesc:
+        d = ModelDesc()
+        d.num_points, d.num_joints, d.num_shape_keys, d.num_faces = self.V, self.J, self.K, self.F
+        d.base_cloud = dptr(self.base_cloud); d.key_clouds = dptr(self.key_clouds)
+        d.parent = iptr(self.parent); d.mesh = iptr(self.mesh)
+        d.weights_colptr = iptr(self.w_colptr); d.weights_row = iptr(self.w_row); d.weights_val = dptr(self.w_val)
+        d.jreg_colptr = iptr(self.r_colptr); d.jreg_row = iptr(self.r_row); d.jreg_val = dptr(self.r_val)
+        d.prior_ncomps, d.prior_ndims = self.ncomps, self.ndims
+        if self.ncomps > 0:
+            d.prior_weight = dptr(self.prior_weight); d.prior_mean = dptr(self.prior_mean)
+            d.prior_cov = dptr(self.prior_cov)
+        return d
+
+
+_lib = None
+
+
+def load_library():
+    """Load libavatar_hip.so (the HIP product path).  Raises if it is missing: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (hipcc --offload-arch=gfx950). There is deliberately no CPU fallback.")
+    try:  # torch bundles its own libamdhip64.so.7; load it first so both share ONE HIP runtime in-process
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib.avt_last_error.restype = C.c_char_p
+    lib.avt_kernel_name.restype = C.c_char_p
+    lib.avt_kernel_name.argtypes = [C.c_int]
+    vp = C.c_void_p
+    sigs = {
+        "avt_options_default": [C.POINTER(Options)],
+        "avt_model_create": [C.POINTER(ModelDesc), C.POINTER(vp)],
+        "avt_model_destroy": [vp],
+        "avt_model_dims": [vp, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p],
+        "avt_model_main_joint": [vp, c_int_p],
+        "avt_model_joint_regression": [vp, c_double_p, c_double_p],
+        "avt_ctx_create": [C.c_int, vp, C.c_int, c_int_p, C.c_int, C.c_int, C.POINTER(vp)],
+        "avt_ctx_destroy": [vp],
+        "avt_sync": [vp],
+        "avt_lbs_update": [vp, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p],
+        "avt_visibility": [vp, c_double_p, C.c_int, c_ubyte_p],
+        "avt_nn": [vp, c_double_p, c_ubyte_p, c_double_p, c_int_p, C.c_int, c_int_p],
+        "avt_optimize": [vp, c_double_p, c_int_p, C.c_int, C.POINTER(Options), c_double_p, c_double_p, c_double_p,
+                         C.POINTER(Stats)],
+        "avt_optimize_batch": [vp, C.c_int, c_double_p, c_int_p, c_int_p, C.POINTER(Options), c_double_p, c_double_p,
+                               c_double_p, C.POINTER(Stats)],
+        "avt_frames_upload": [vp, C.c_int, c_double_p, c_int_p, c_int_p],
+        "avt_state_upload": [vp, C.c_int, c_double_p, c_double_p, c_double_p],
+        "avt_optimize_resident": [vp, C.POINTER(Options)],
+        "avt_state_download": [vp, c_double_p, c_double_p, c_double_p, C.POINTER(Stats)],
+        "avt_get_correspondences": [vp, C.c_int, c_int_p],
+        "avt_get_cloud": [vp, C.c_int, c_double_p],
+        "avt_get_normal_equations": [vp, C.c_int, c_double_p, c_double_p, c_double_p],
+        "avt_profile_begin": [vp],
+        "avt_profile_end": [vp, C.POINTER(Profile)],
+    }
+    for name, args in sigs.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.argtypes = args
+        if name not in ("avt_model_destroy", "avt_ctx_destroy", "avt_options_default"):
+            fn.restype = C.c_int
+        else:
+            fn.restype = None
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "avt_last_error", "avt_kernel_name", "avt_options_default", "avt_model_create", "avt_model_destroy",
+    "avt_model_dims", "avt_model_main_joint", "avt_model_joint_regression", "avt_ctx_create", "avt_ctx_destroy",
+    "avt_sync", "avt_lbs_update", "avt_visibility", "avt_nn", "avt_optimize", "avt_optimize_batch",
+    "avt_frames_upload", "avt_state_upload", "avt_optimize_resident", "avt_state_download",
+    "avt_get_correspondences", "avt_get_cloud", "avt_get_normal_equations", "avt_profile_begin", "avt_profile_end",
+]

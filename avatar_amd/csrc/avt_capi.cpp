@@ -1,0 +1,420 @@
+// avt_capi.cpp — the C ABI of include/avt.h: context management, host<->device staging and the launch
+// sequence of AvatarOptimizer::optimize() (AvatarOptimizer.cpp:1246-1517).  Compiled with hipcc (host only).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "avt_internal.h"
+
+int avt_solve_set_attributes();
+
+#define HIP_OK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            avt_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+namespace {
+
+template <class T>
+int dev_alloc(avt_ctx* c, T** p, size_t n) {
+    void* q = nullptr;
+    HIP_OK(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+    c->allocs.push_back(q);
+    *p = (T*)q;
+    return 0;
+}
+template <class T>
+int dev_upload(avt_ctx* c, T** p, const std::vector<T>& v) {
+    if (dev_alloc(c, p, v.size())) return 1;
+    if (!v.empty()) HIP_OK(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int choose_G(int nframes) { return std::max(2, std::min(64, 512 / std::max(1, nframes))); }
+
+hipEvent_t next_event(avt_ctx* c) {
+    if (c->event_pool_used == c->event_pool.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        c->event_pool.push_back(e);
+    }
+    return c->event_pool[c->event_pool_used++];
+}
+
+struct ProfScope {
+    avt_ctx* c;
+    int cls;
+    hipEvent_t a, b;
+    ProfScope(avt_ctx* c_, int cls_) : c(c_), cls(cls_) {
+        if (c->profiling) { a = next_event(c); b = next_event(c); hipEventRecord(a, c->stream); }
+    }
+    ~ProfScope() {
+        if (c->profiling) { hipEventRecord(b, c->stream); c->prof_events.push_back({cls, {a, b}}); }
+    }
+};
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { avt_set_error(std::string(what) + ": " + hipGetErrorString(e)); return 1; }
+    return 0;
+}
+
+// the launch sequence of one optimize() over the resident frames
+int run_optimize(avt_ctx* c, const avt_options* o) {
+    const int nf = c->nframes;
+    if (nf <= 0) { avt_set_error("avt_optimize: no frames resident"); return 1; }
+    if (o->max_iters_per_icp < 0 || o->max_iters_per_icp > 62 || o->icp_iters < 0) { avt_set_error("avt_optimize: bad iteration counts"); return 1; }
+    c->fb.G = choose_G(nf);
+    c->ran_icp_iters = 0;
+    c->ran_max_iters = o->max_iters_per_icp;
+    { ProfScope ps(c, AVT_K_BUCKET); launch_bucket(c, nf); }
+    { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 1); }   // ava.update() precondition (:1356)
+    for (int icp = 0; icp < o->icp_iters; ++icp) {
+        { ProfScope ps(c, AVT_K_VISIBILITY); launch_visibility(c, nf, o->enable_occlusion); }
+        { ProfScope ps(c, AVT_K_NN); launch_nn(c, nf); }
+        { ProfScope ps(c, AVT_K_AGGREGATE); launch_finalize(c, nf, o); }
+        { ProfScope ps(c, AVT_K_PREPARE); launch_solve(c, nf, SOLVE_INIT, o); }
+        { ProfScope ps(c, AVT_K_EVAL); launch_eval(c, nf); }
+        { ProfScope ps(c, AVT_K_REDUCE); launch_reduce(c, nf); }
+        for (int it = 1; it <= std::max(1, o->max_iters_per_icp); ++it) {
+            { ProfScope ps(c, AVT_K_SOLVE); launch_solve(c, nf, it == 1 ? SOLVE_FIRST : SOLVE_NORMAL, o); }
+            if (o->max_iters_per_icp == 0) break;
+            { ProfScope ps(c, AVT_K_EVAL); launch_eval(c, nf); }
+            { ProfScope ps(c, AVT_K_REDUCE); launch_reduce(c, nf); }
+        }
+        if (o->max_iters_per_icp > 0) { ProfScope ps(c, AVT_K_SOLVE); launch_solve(c, nf, SOLVE_LAST, o); }
+        { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 1); }   // :1494-1497
+        c->ran_icp_iters++;
+    }
+    return check_launch("optimize launch sequence");
+}
+
+int upload_frames(avt_ctx* c, int nframes, const double* data, const int* labels, const int* offs) {
+    if (nframes <= 0 || nframes > c->fb.max_frames) { avt_set_error("frames: nframes out of range for this context"); return 1; }
+    c->nframes = nframes;
+    c->frame_N.assign(nframes, 0);
+    c->frame_off.assign(offs, offs + nframes + 1);
+    for (int f = 0; f < nframes; ++f) {
+        const int N = offs[f + 1] - offs[f];
+        if (N < 0 || N > c->fb.max_points) { avt_set_error("frames: a frame has more points than max_points_per_frame"); return 1; }
+        c->frame_N[f] = N;
+        if (N == 0) continue;
+        HIP_OK(hipMemcpyAsync(c->fb.data_raw + (size_t)f * c->fb.max_points * 3, data + (size_t)offs[f] * 3, (size_t)N * 3 * sizeof(double),
+                              hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(c->fb.labels_raw + (size_t)f * c->fb.max_points, labels + offs[f], (size_t)N * sizeof(int), hipMemcpyHostToDevice,
+                              c->stream));
+    }
+    return 0;
+}
+
+int upload_state(avt_ctx* c, int nframes, const double* p, const double* q, const double* w) {
+    const AvtDims& d = c->dm.d;
+    if (nframes != c->nframes) { avt_set_error("state: nframes differs from the resident frames"); return 1; }
+    std::vector<double> xs((size_t)nframes * 2 * d.xsize, 0.0);
+    std::vector<AvtFrameCtl> ctl(nframes);
+    for (int f = 0; f < nframes; ++f) {
+        double* x = &xs[(size_t)f * 2 * d.xsize];
+        std::copy(p + 3 * f, p + 3 * f + 3, x);
+        std::copy(q + (size_t)4 * d.J * f, q + (size_t)4 * d.J * (f + 1), x + 3);
+        std::copy(w + (size_t)d.K * f, w + (size_t)d.K * (f + 1), x + 3 + 4 * d.J);
+        std::memset(&ctl[f], 0, sizeof(AvtFrameCtl));
+        ctl[f].N = c->frame_N[f];
+        ctl[f].data_off = c->frame_off[f];
+        ctl[f].comp_cur = ctl[f].comp_try = -1;
+    }
+    HIP_OK(hipMemcpyAsync(c->fb.x, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(c->fb.ctl, ctl.data(), ctl.size() * sizeof(AvtFrameCtl), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));  // host vectors go out of scope
+    return 0;
+}
+
+int download_state(avt_ctx* c, double* p, double* q, double* w, avt_stats* st) {
+    const AvtDims& d = c->dm.d;
+    const int nf = c->nframes;
+    std::vector<double> xs((size_t)nf * 2 * d.xsize);
+    std::vector<AvtFrameCtl> ctl(nf);
+    HIP_OK(hipMemcpyAsync(xs.data(), c->fb.x, xs.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipMemcpyAsync(ctl.data(), c->fb.ctl, ctl.size() * sizeof(AvtFrameCtl), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    for (int f = 0; f < nf; ++f) {
+        const double* x = &xs[((size_t)f * 2 + ctl[f].cur_slot) * d.xsize];
+        if (p) std::copy(x, x + 3, p + 3 * f);
+        if (q) std::copy(x + 3, x + 3 + 4 * d.J, q + (size_t)4 * d.J * f);
+        if (w) std::copy(x + 3 + 4 * d.J, x + d.xsize, w + (size_t)d.K * f);
+        if (st) {
+            st[f].initial_cost = ctl[f].cost_initial;
+            st[f].final_cost = ctl[f].cost_cur;
+            st[f].lambda = ctl[f].lambda;
+            st[f].num_correspondences = ctl[f].T;
+            st[f].matched_model_points = ctl[f].M;
+            st[f].gn_iterations = ctl[f].gn_iterations;
+            st[f].accepted_steps = ctl[f].accepted;
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* part_map, int max_points, int max_frames, avt_ctx** out) {
+    if (!m || !part_map || !out) { avt_set_error("avt_ctx_create: null argument"); return 1; }
+    if (num_parts <= 0 || num_parts > AVT_MAX_PARTS) { avt_set_error("avt_ctx_create: num_parts out of range (1..64)"); return 1; }
+    if (max_points <= 0 || max_frames <= 0) { avt_set_error("avt_ctx_create: max_points/max_frames must be positive"); return 1; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        avt_set_error("avt_ctx_create: no HIP device available (this library has no CPU fallback)");
+        return 2;
+    }
+    if (device < 0 || device >= ndev) { avt_set_error("avt_ctx_create: device index out of range"); return 1; }
+    HIP_OK(hipSetDevice(device));
+    avt_ctx* c = new avt_ctx();
+    c->device = device;
+    c->model = m;
+    c->profiling = false;
+    c->event_pool_used = 0;
+    c->nframes = 0;
+    c->ran_icp_iters = 0;
+    c->ran_max_iters = 0;
+    HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (avt_solve_set_attributes()) { avt_set_error("avt_ctx_create: hipFuncSetAttribute failed"); return 1; }
+    DeviceModel& dm = c->dm;
+    dm.d = m->d;
+    dm.d.num_parts = num_parts;
+    const int V = dm.d.V, J = dm.d.J;
+    c->part_map.assign(part_map, part_map + J);   // >= J entries (AvatarOptimizer.cpp:1229)
+    // model part buckets (AvatarOptimizer.cpp:1227-1243)
+    std::vector<int> pov(V), pstart(num_parts + 1, 0), pverts(V), ppos(V);
+    for (int v = 0; v < V; ++v) {
+        const int q = part_map[m->main_joint[v]];
+        if (q < 0 || q >= num_parts) { avt_set_error("avt_ctx_create: part_map entry out of [0,num_parts)"); return 1; }
+        pov[v] = q;
+        pstart[q + 1]++;
+    }
+    for (int q = 0; q < num_parts; ++q) pstart[q + 1] += pstart[q];
+    {
+        std::vector<int> fill(pstart.begin(), pstart.end() - 1);
+        for (int v = 0; v < V; ++v) { const int pos = fill[pov[v]]++; pverts[pos] = v; ppos[v] = pos; }
+    }
+    if (dev_upload(c, &dm.shape_planes, m->shape_planes) || dev_upload(c, &dm.lbs_w, m->lbs_w) || dev_upload(c, &dm.lbs_j, m->lbs_j) ||
+        dev_upload(c, &dm.asg_w, m->asg_w) || dev_upload(c, &dm.asg_j, m->asg_j) || dev_upload(c, &dm.anc_n, m->anc_n) ||
+        dev_upload(c, &dm.anc, m->anc) || dev_upload(c, &dm.mesh, m->mesh_soa) || dev_upload(c, &dm.parent, m->parent) ||
+        dev_upload(c, &dm.jsr_base, m->jsr_base) || dev_upload(c, &dm.jsr, m->jsr) || dev_upload(c, &dm.S, m->S) ||
+        dev_upload(c, &dm.Sp, m->Sp) || dev_upload(c, &dm.prior_mean, m->prior_mean) || dev_upload(c, &dm.prior_prec, m->prior_prec) ||
+        dev_upload(c, &dm.prior_L, m->prior_L) || dev_upload(c, &dm.prior_clog, m->prior_clog) || dev_upload(c, &dm.part_of_vertex, pov) ||
+        dev_upload(c, &dm.part_start, pstart) || dev_upload(c, &dm.part_vertices, pverts) || dev_upload(c, &dm.part_pos, ppos))
+        return 1;
+    FrameBuffers& fb = c->fb;
+    std::memset(&fb, 0, sizeof(fb));
+    fb.max_frames = max_frames;
+    fb.max_points = max_points;
+    fb.G = choose_G(max_frames);
+    fb.const_blocks = (max_points + 255) / 256;
+    const size_t FN = (size_t)max_frames * max_points, FV = (size_t)max_frames * V;
+    const AvtDims& d = dm.d;
+    // eval workgroups over all frames: nf*choose_G(nf) <= max(min(64*nf, 512), 2*nf)
+    const size_t part_cap = std::max<size_t>(std::min<size_t>((size_t)64 * max_frames, 512), (size_t)2 * max_frames);
+    char* cntsum = nullptr;
+    if (dev_alloc(c, &fb.data_raw, FN * 3) || dev_alloc(c, &fb.labels_raw, FN) || dev_alloc(c, &fb.dx, FN) || dev_alloc(c, &fb.dy, FN) ||
+        dev_alloc(c, &fb.dz, FN) || dev_alloc(c, &fb.dorig, FN) || dev_alloc(c, &fb.part_off, (size_t)max_frames * (num_parts + 1)) ||
+        dev_alloc(c, &fb.corr, FN) || dev_alloc(c, &fb.corr_sorted, FN) || dev_alloc(c, &fb.cloud, FV * 3) || dev_alloc(c, &fb.pcx, FV) ||
+        dev_alloc(c, &fb.pcy, FV) || dev_alloc(c, &fb.pcz, FV) || dev_alloc(c, &fb.visible, FV) ||
+        dev_alloc(c, &cntsum, FV * (sizeof(int) + 3 * sizeof(long long)) + 64) || dev_alloc(c, &fb.matched, FV) || dev_alloc(c, &fb.mcnt, FV) ||
+        dev_alloc(c, &fb.mdbar, FV * 3) || dev_alloc(c, &fb.const_part, (size_t)max_frames * fb.const_blocks) ||
+        dev_alloc(c, &fb.x, (size_t)max_frames * 2 * d.xsize) || dev_alloc(c, &fb.prep, (size_t)max_frames * 2 * d.prep_size) ||
+        dev_alloc(c, &fb.partial, part_cap * d.NPAIR * 256) || dev_alloc(c, &fb.tiles, (size_t)max_frames * d.NPAIR * 256) ||
+        dev_alloc(c, &fb.Hfin, (size_t)max_frames * 2 * (d.P + 1) * d.P) || dev_alloc(c, &fb.ctl, (size_t)max_frames) ||
+        dev_alloc(c, &fb.jointpos, (size_t)max_frames * 3 * J) || dev_alloc(c, &fb.jointtrans, (size_t)max_frames * 12 * J) ||
+        dev_alloc(c, &fb.trace, (size_t)max_frames * (64 + 2 + 3 * AVT_MAX_JOINTS)))
+        return 1;
+    fb.fsum = (long long*)cntsum;                                   // 8-byte aligned first
+    fb.cnt = (int*)(cntsum + FV * 3 * sizeof(long long));
+    HIP_OK(hipMemset(fb.trace, 0, (size_t)max_frames * (64 + 2 + 3 * AVT_MAX_JOINTS) * sizeof(double)));
+    HIP_OK(hipMemset(fb.ctl, 0, (size_t)max_frames * sizeof(AvtFrameCtl)));
+    HIP_OK(hipDeviceSynchronize());
+    *out = c;
+    return 0;
+}
+
+void avt_ctx_destroy(avt_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (void* p : c->allocs) hipFree(p);
+    for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int avt_sync(avt_ctx* c) {
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int avt_lbs_update(avt_ctx* c, int nframes, const double* w, const double* p, const double* R, double* cloud, double* joint_pos,
+                   double* joint_trans) {
+    if (!c || !w || !p || !R) { avt_set_error("avt_lbs_update: null argument"); return 1; }
+    const AvtDims& d = c->dm.d;
+    if (nframes <= 0 || nframes > c->fb.max_frames) { avt_set_error("avt_lbs_update: nframes out of range"); return 1; }
+    HIP_OK(hipSetDevice(c->device));
+    // stage the parameters in the (otherwise unused here) prep buffer: w | p | R
+    double* dw = c->fb.prep;
+    double* dp = dw + (size_t)nframes * d.K;
+    double* dR = dp + (size_t)nframes * 3;
+    if ((size_t)nframes * (d.K + 3 + 9 * d.J) > (size_t)c->fb.max_frames * 2 * d.prep_size) { avt_set_error("avt_lbs_update: staging overflow"); return 1; }
+    HIP_OK(hipMemcpyAsync(dw, w, (size_t)nframes * d.K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(dp, p, (size_t)nframes * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(dR, R, (size_t)nframes * 9 * d.J * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nframes, nullptr, dw, dp, dR, 0); }
+    if (check_launch("k_lbs")) return 1;
+    if (cloud) HIP_OK(hipMemcpyAsync(cloud, c->fb.cloud, (size_t)nframes * 3 * d.V * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (joint_pos) HIP_OK(hipMemcpyAsync(joint_pos, c->fb.jointpos, (size_t)nframes * 3 * d.J * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (joint_trans) HIP_OK(hipMemcpyAsync(joint_trans, c->fb.jointtrans, (size_t)nframes * 12 * d.J * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int avt_visibility(avt_ctx* c, const double* cloud, int enable, unsigned char* visible) {
+    if (!c || !cloud || !visible) { avt_set_error("avt_visibility: null argument"); return 1; }
+    const AvtDims& d = c->dm.d;
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipMemcpyAsync(c->fb.cloud, cloud, (size_t)3 * d.V * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    { ProfScope ps(c, AVT_K_VISIBILITY); launch_visibility(c, 1, enable); }
+    if (check_launch("k_visibility")) return 1;
+    HIP_OK(hipMemcpyAsync(visible, c->fb.visible, (size_t)d.V, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int avt_nn(avt_ctx* c, const double* model_cloud, const unsigned char* visible, const double* data, const int* labels, int N, int* out) {
+    if (!c || !model_cloud || !visible || !data || !labels || !out) { avt_set_error("avt_nn: null argument"); return 1; }
+    const AvtDims& d = c->dm.d;
+    const int V = d.V;
+    HIP_OK(hipSetDevice(c->device));
+    if (N == 0) return 0;
+    const int offs[2] = {0, N};
+    if (upload_frames(c, 1, data, labels, offs)) return 1;
+    // part-sorted SoA copy of the model cloud
+    std::vector<int> ppos(V);
+    HIP_OK(hipMemcpy(ppos.data(), c->dm.part_pos, (size_t)V * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<double> px(V), py(V), pz(V);
+    for (int v = 0; v < V; ++v) { px[ppos[v]] = model_cloud[3 * v]; py[ppos[v]] = model_cloud[3 * v + 1]; pz[ppos[v]] = model_cloud[3 * v + 2]; }
+    HIP_OK(hipMemcpyAsync(c->fb.pcx, px.data(), V * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(c->fb.pcy, py.data(), V * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(c->fb.pcz, pz.data(), V * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(c->fb.visible, visible, (size_t)V, hipMemcpyHostToDevice, c->stream));
+    AvtFrameCtl ctl;
+    std::memset(&ctl, 0, sizeof(ctl));
+    ctl.N = N;
+    HIP_OK(hipMemcpyAsync(c->fb.ctl, &ctl, sizeof(ctl), hipMemcpyHostToDevice, c->stream));
+    { ProfScope ps(c, AVT_K_BUCKET); launch_bucket(c, 1); }
+    { ProfScope ps(c, AVT_K_NN); launch_nn(c, 1); }
+    if (check_launch("k_nn")) return 1;
+    HIP_OK(hipMemcpyAsync(out, c->fb.corr, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int avt_frames_upload(avt_ctx* c, int nframes, const double* data, const int* labels, const int* frame_offsets) {
+    if (!c || !data || !labels || !frame_offsets) { avt_set_error("avt_frames_upload: null argument"); return 1; }
+    HIP_OK(hipSetDevice(c->device));
+    if (upload_frames(c, nframes, data, labels, frame_offsets)) return 1;
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int avt_state_upload(avt_ctx* c, int nframes, const double* p, const double* q, const double* w) {
+    if (!c || !p || !q || !w) { avt_set_error("avt_state_upload: null argument"); return 1; }
+    HIP_OK(hipSetDevice(c->device));
+    return upload_state(c, nframes, p, q, w);
+}
+
+int avt_optimize_resident(avt_ctx* c, const avt_options* opt) {
+    if (!c || !opt) { avt_set_error("avt_optimize_resident: null argument"); return 1; }
+    HIP_OK(hipSetDevice(c->device));
+    return run_optimize(c, opt);
+}
+
+int avt_state_download(avt_ctx* c, double* p, double* q, double* w, avt_stats* stats) {
+    if (!c) { avt_set_error("avt_state_download: null context"); return 1; }
+    HIP_OK(hipSetDevice(c->device));
+    return download_state(c, p, q, w, stats);
+}
+
+int avt_optimize_batch(avt_ctx* c, int nframes, const double* data, const int* labels, const int* frame_offsets, const avt_options* opt,
+                       double* p, double* q, double* w, avt_stats* stats) {
+    if (!c || !data || !labels || !frame_offsets || !opt || !p || !q || !w) { avt_set_error("avt_optimize_batch: null argument"); return 1; }
+    HIP_OK(hipSetDevice(c->device));
+    if (upload_frames(c, nframes, data, labels, frame_offsets)) return 1;
+    if (upload_state(c, nframes, p, q, w)) return 1;
+    if (run_optimize(c, opt)) return 1;
+    return download_state(c, p, q, w, stats);
+}
+
+int avt_optimize(avt_ctx* c, const double* data, const int* labels, int N, const avt_options* opt, double* p, double* q, double* w,
+                 avt_stats* stats) {
+    const int offs[2] = {0, N};
+    return avt_optimize_batch(c, 1, data, labels, offs, opt, p, q, w, stats);
+}
+
+int avt_get_correspondences(avt_ctx* c, int frame, int* out) {
+    if (!c || !out || frame < 0 || frame >= c->nframes) { avt_set_error("avt_get_correspondences: bad argument"); return 1; }
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipMemcpyAsync(out, c->fb.corr + (size_t)frame * c->fb.max_points, (size_t)c->frame_N[frame] * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int avt_get_cloud(avt_ctx* c, int frame, double* cloud) {
+    if (!c || !cloud || frame < 0 || frame >= c->fb.max_frames) { avt_set_error("avt_get_cloud: bad argument"); return 1; }
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipMemcpyAsync(cloud, c->fb.cloud + (size_t)frame * 3 * c->dm.d.V, (size_t)3 * c->dm.d.V * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int avt_get_normal_equations(avt_ctx* c, int frame, double* H, double* g, double* cost) {
+    if (!c || frame < 0 || frame >= c->nframes) { avt_set_error("avt_get_normal_equations: bad argument"); return 1; }
+    const AvtDims& d = c->dm.d;
+    HIP_OK(hipSetDevice(c->device));
+    AvtFrameCtl ctl;
+    HIP_OK(hipMemcpy(&ctl, c->fb.ctl + frame, sizeof(ctl), hipMemcpyDeviceToHost));
+    std::vector<double> buf((size_t)(d.P + 1) * d.P);
+    HIP_OK(hipMemcpy(buf.data(), c->fb.Hfin + ((size_t)frame * 2 + ctl.cur_slot) * buf.size(), buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if (H) std::copy(buf.begin(), buf.begin() + (size_t)d.P * d.P, H);
+    if (g) std::copy(buf.begin() + (size_t)d.P * d.P, buf.end(), g);
+    if (cost) *cost = ctl.cost_cur;
+    return 0;
+}
+
+int avt_profile_begin(avt_ctx* c) {
+    if (!c) { avt_set_error("avt_profile_begin: null context"); return 1; }
+    c->profiling = true;
+    c->prof_events.clear();
+    c->event_pool_used = 0;
+    return 0;
+}
+
+int avt_profile_end(avt_ctx* c, avt_profile* out) {
+    if (!c || !out) { avt_set_error("avt_profile_end: null argument"); return 1; }
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    std::memset(out, 0, sizeof(*out));
+    for (auto& rec : c->prof_events) {
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, rec.second.first, rec.second.second));
+        out->ms[rec.first] += ms;
+        out->launches[rec.first] += 1;
+    }
+    c->profiling = false;
+    c->prof_events.clear();
+    c->event_pool_used = 0;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,174 @@
+// avt_internal.h — private data layout of libavatar_hip.so (host + device), gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/avt.h"
+
+#define AVT_ANC_MAX 16        // max deduplicated ancestors per skin point (SMPL needs <= 12)
+#define AVT_TILE 16           // MFMA f64 16x16x4 tile edge
+#define AVT_EVAL_PTS 16       // model points per eval batch (48 Jacobian rows)
+#define AVT_EVAL_ROWS (3 * AVT_EVAL_PTS)
+#define AVT_EVAL_RS 50        // LDS row stride (doubles) of the transposed Jacobian tile: conflict-free b64 reads
+#define AVT_MAX_TILES 8       // ceil((P+1)/16) <= 8  (J<=32, K<=16)
+#define AVT_FIX_SCALE 1099511627776.0  // 2^40 fixed-point scale of the centred correspondence sums
+
+// ---- per-frame state block (doubles), double-buffered: slot 0/1 --------------------------------
+// x = (p[3], q[4J], w[K])
+struct AvtDims {
+    int V, J, K, F, P;       // P = 3 + 3J + K
+    int NT;                  // column tiles of the augmented matrix [J | r]: ceil((P+1)/16)
+    int NPAIR;               // NT*(NT+1)/2 upper-triangular tile pairs
+    int xsize;               // 3 + 4J + K
+    int prep_size;           // doubles per prep block
+    int num_parts;
+    int anc_max;             // actual max #ancestors in this model
+    int ncomps, ndims;       // GMM
+};
+
+// prep block layout (doubles), one per frame per slot: what an evaluation needs about the skeleton state
+//   Rw[J][9] row-major world rotations R(-1,j)        (AvatarOptimizer.cpp:303-315)
+//   o[J][3]  world joint origins t(-1,j)
+//   Jh[J][3] jointPosInit, root-subtracted             (AvatarOptimizer.cpp:249-281)
+//   G[J][3][K] = H[j] - Rw[j]*S[j]                     (AvatarOptimizer.cpp:318-324, :568-580)
+//   q[J][4], w[K], off[3] (root joint offset), pad
+__host__ __device__ inline int prep_off_Rw(const AvtDims& d) { return 0; }
+__host__ __device__ inline int prep_off_o(const AvtDims& d) { return 9 * d.J; }
+__host__ __device__ inline int prep_off_Jh(const AvtDims& d) { return 12 * d.J; }
+__host__ __device__ inline int prep_off_G(const AvtDims& d) { return 15 * d.J; }
+__host__ __device__ inline int prep_off_q(const AvtDims& d) { return 15 * d.J + 3 * d.J * d.K; }
+__host__ __device__ inline int prep_off_w(const AvtDims& d) { return 19 * d.J + 3 * d.J * d.K; }
+__host__ __device__ inline int prep_off_off(const AvtDims& d) { return 19 * d.J + 3 * d.J * d.K + d.K; }
+__host__ __device__ inline int prep_total(const AvtDims& d) { return ((19 * d.J + 3 * d.J * d.K + d.K + 3) + 7) & ~7; }
+
+// per-frame scalar control block
+struct AvtFrameCtl {
+    double lambda;
+    double cost_cur;          // objective of the current state (data part uses centred form + cost_const)
+    double cost_try;
+    double cost_const;        // 0.5 * sum_i |d_i - dbar_m(i)|^2 for the current correspondences
+    double cost_initial;
+    double sbp, sbs;          // scaledBetaPose / scaledBetaShape (AvatarOptimizer.cpp:1457-1458)
+    double centre[3];         // fixed-point centring offset of this frame's data
+    int cur_slot;             // which state/H slot holds the current point
+    int try_valid;            // trial point is a real LM step (Cholesky succeeded)
+    int M;                    // matched model points
+    int T;                    // total correspondences
+    int gn_iterations;
+    int accepted;
+    int comp_cur, comp_try;   // GMM component chosen at cur / try
+    int N;                    // data points of this frame
+    int data_off;             // offset of this frame's points in the packed data arrays
+    int pad[2];
+};
+
+struct DeviceModel {
+    AvtDims d;
+    // shape planes [(K+1)*3][V]: plane k*3+c = keyClouds component c of key k; planes K*3+c = baseCloud
+    double* shape_planes;
+    // LBS weights exactly as the sparse matrix (CSC order, all nnz, <=4): Avatar::update (Avatar.cpp:69)
+    double* lbs_w;   // [4][V]
+    int* lbs_j;      // [4][V]
+    // assignedJoints (weight > 1e-12, sorted desc): the optimiser's forward model (AvatarOptimizer.cpp:508-514)
+    double* asg_w;   // [4][V], 0-padded
+    int* asg_j;      // [4][V], padded with joint 0
+    // ancestors: anc_n[V]; anc[a][V] = jid | (mask<<8), mask bit t set if assigned joint t lies under jid
+    unsigned char* anc_n;
+    unsigned short* anc;  // [AVT_ANC_MAX][V]
+    int* mesh;            // [3][F] SoA
+    int* parent;          // [J]
+    double* jsr_base;     // [3J] initialJointPos
+    double* jsr;          // [3J][K] row-major jointShapeReg
+    double* S;            // [J][3][K]
+    double* Sp;           // [J][3][K]
+    // GMM
+    double* prior_mean;   // [C][n]
+    double* prior_prec;   // [C][n][n] precision = L L^T
+    double* prior_L;      // [C][n][n] lower Cholesky of the precision
+    double* prior_clog;   // [C]
+    // part structure (context-level, depends on part_map)
+    int* part_of_vertex;  // [V]
+    int* part_start;      // [num_parts+1] into part_vertices
+    int* part_vertices;   // [V] vertex ids grouped by part, ascending inside a part
+    int* part_pos;        // [V] inverse of part_vertices
+};
+
+struct FrameBuffers {
+    int max_frames, max_points;   // per frame
+    int G;                        // eval blocks per frame
+    // raw inputs
+    double* data_raw;     // [max_frames*max_points][3]
+    int* labels_raw;      // [max_frames*max_points]
+    // part-sorted data (per frame segment at frame*max_points)
+    double* dx; double* dy; double* dz;
+    int* dorig;           // original index of sorted point
+    int* part_off;        // [max_frames][num_parts+1] offsets (relative to frame segment)
+    int* corr;            // [max_frames*max_points] model idx per ORIGINAL data index (-1 none)
+    int* corr_sorted;     // per sorted position
+    // model-side per frame
+    double* cloud;        // [max_frames][3V] xyz interleaved (ava.cloud)
+    double* pcx; double* pcy; double* pcz;   // [max_frames][V] cloud in part-sorted order; invisible -> +inf
+    unsigned char* visible;                  // [max_frames][V]
+    // correspondence aggregation
+    int* cnt;             // [max_frames][V]
+    long long* fsum;      // [max_frames][3][V] fixed-point centred sums
+    int* matched;         // [max_frames][V] compacted matched vertex ids
+    double* mcnt;         // [max_frames][V] sqrt(c) per compacted entry
+    double* mdbar;        // [max_frames][3][V] mean data point per compacted entry
+    double* const_part;   // [max_frames][const_blocks]
+    int const_blocks;
+    // optimiser state
+    double* x;            // [max_frames][2][xsize]
+    double* prep;         // [max_frames][2][prep_size]
+    double* partial;      // [max_frames][G][NPAIR][256]
+    double* tiles;        // [max_frames][NPAIR][256]  reduced raw (data-term) tiles of the last evaluation
+    double* Hfin;         // [max_frames][2][(P+1)*P]   finalised H (P x P) + g (P) per slot
+    AvtFrameCtl* ctl;     // [max_frames]
+    double* jointpos;     // [max_frames][3J]
+    double* jointtrans;   // [max_frames][12J]
+    double* trace;        // [max_frames][64] cost trace (debug)
+};
+
+struct avt_model {
+    AvtDims d;
+    // host copies (used by avt_ctx_create to build the device model and by accessors)
+    std::vector<double> shape_planes, lbs_w, asg_w, jsr_base, jsr, S, Sp;
+    std::vector<int> lbs_j, asg_j, mesh_soa, parent, main_joint;
+    std::vector<unsigned char> anc_n;
+    std::vector<unsigned short> anc;
+    std::vector<double> prior_mean, prior_prec, prior_L, prior_clog;
+};
+
+struct avt_ctx {
+    int device;
+    hipStream_t stream;
+    const avt_model* model;
+    DeviceModel dm;
+    FrameBuffers fb;
+    std::vector<int> part_map;
+    int nframes;                     // frames currently resident
+    std::vector<int> frame_N, frame_off;
+    bool profiling;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
+    std::vector<hipEvent_t> event_pool;
+    size_t event_pool_used;
+    std::vector<void*> allocs;
+    int ran_icp_iters, ran_max_iters;
+};
+
+void avt_set_error(const std::string& s);
+
+// kernel launch wrappers (avt_kernels.hip / avt_nn.hip)
+enum { SOLVE_INIT = 0, SOLVE_FIRST = 1, SOLVE_NORMAL = 2, SOLVE_LAST = 3 };
+void launch_lbs(avt_ctx* c, int nframes, const double* x_state_or_null, const double* w, const double* p, const double* R,
+                int from_state);
+void launch_visibility(avt_ctx* c, int nframes, int enable);
+void launch_bucket(avt_ctx* c, int nframes);
+void launch_nn(avt_ctx* c, int nframes);
+void launch_finalize(avt_ctx* c, int nframes, const avt_options* o);
+void launch_eval(avt_ctx* c, int nframes);
+void launch_reduce(avt_ctx* c, int nframes);
+void launch_solve(avt_ctx* c, int nframes, int mode, const avt_options* o);
+void launch_nn_single(avt_ctx* c);  // avt_nn(): uses frame 0 buffers with caller-provided cloud/visible

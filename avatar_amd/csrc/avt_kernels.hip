@@ -1,0 +1,304 @@
+// avt_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the fitting path, part 1:
+// linear-blend skinning, back-face visibility, data bucketing by body part, correspondence finalisation.
+// (nearest neighbour: avt_nn.hip; residual/Jacobian/J^T J/solve: avt_solve.hip)
+#include "avt_device.h"
+
+// =================================================================================================
+// Avatar::update()  (Avatar.cpp:22-75)
+// grid (ceil(V/256), nframes), block 256.  Joint matrices are staged in LDS (<= 32 joints x 24 doubles),
+// the per-vertex loads are SoA and fully coalesced: 3(K+1) shape planes + 4 (weight, joint) pairs in,
+// 3 doubles out => ~336 B/vertex algorithmic traffic.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, const double* __restrict__ w_in,
+                                             const double* __restrict__ p_in, const double* __restrict__ R_in,
+                                             int from_state) {
+    const AvtDims d = dm.d;
+    const int J = d.J, K = d.K, V = d.V;
+    const int f = blockIdx.y, t = threadIdx.x;
+    __shared__ double s_rot[AVT_MAX_JOINTS * 9], s_Rw[AVT_MAX_JOINTS * 9], s_o[AVT_MAX_JOINTS * 3], s_jp[AVT_MAX_JOINTS * 3];
+    __shared__ double s_T[AVT_MAX_JOINTS * 12];  // jointTrans, column-major 3x4 per joint (Avatar.h:215)
+    __shared__ double s_w[AVT_MAX_SHAPE], s_p[3];
+    __shared__ int s_parent[AVT_MAX_JOINTS];
+
+    const double* xs = nullptr;
+    if (from_state) xs = fb.x + ((size_t)f * 2 + fb.ctl[f].cur_slot) * d.xsize;
+    if (t < K) s_w[t] = from_state ? xs[3 + 4 * J + t] : w_in[(size_t)f * K + t];
+    if (t < 3) s_p[t] = from_state ? xs[t] : p_in[(size_t)f * 3 + t];
+    if (t < J) s_parent[t] = dm.parent[t];
+    if (from_state) {
+        if (t < J) quat_to_rot(xs + 3 + 4 * t, s_rot + 9 * t);
+    } else {
+        for (int e = t; e < 9 * J; e += 256) {  // R is column-major per joint -> row-major in LDS
+            const int j = e / 9, r = (e % 9) / 3, c = e % 3;
+            s_rot[e] = R_in[(size_t)f * 9 * J + 9 * j + 3 * c + r];
+        }
+    }
+    __syncthreads();
+    // jointPos = initialJointPos + jointShapeReg * w   (Avatar.cpp:31-36)
+    if (t < 3 * J) {
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) s += dm.jsr[(size_t)t * K + k] * s_w[k];
+        s_jp[t] = dm.jsr_base[t] + s;
+    }
+    __syncthreads();
+    fk_chain(J, s_parent, s_rot, s_jp, s_p, s_Rw, s_o);
+    // jointPos_i <- t_i ; t_i -= R_i * jPosInit   (Avatar.cpp:59-64)
+    if (t < 3 * J) {
+        const int j = t / 3, r = t % 3;
+        const double tr = s_o[t] - (s_Rw[9 * j + 3 * r] * s_jp[3 * j] + s_Rw[9 * j + 3 * r + 1] * s_jp[3 * j + 1] +
+                                    s_Rw[9 * j + 3 * r + 2] * s_jp[3 * j + 2]);
+        s_T[12 * j + 9 + r] = tr;
+    }
+    for (int e = t; e < 9 * J; e += 256) {
+        const int j = e / 9, r = (e % 9) / 3, c = e % 3;
+        s_T[12 * j + 3 * c + r] = s_Rw[e];
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        if (t < 3 * J) fb.jointpos[(size_t)f * 3 * J + t] = s_o[t];
+        for (int e = t; e < 12 * J; e += 256) fb.jointtrans[(size_t)f * 12 * J + e] = s_T[e];
+    }
+    const int v = blockIdx.x * 256 + t;
+    if (v >= V) return;
+    // shapedCloud = keyClouds * w + baseCloud  (Avatar.cpp:26)
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const double wk = s_w[k];
+        sx += dm.shape_planes[((size_t)k * 3 + 0) * V + v] * wk;
+        sy += dm.shape_planes[((size_t)k * 3 + 1) * V + v] * wk;
+        sz += dm.shape_planes[((size_t)k * 3 + 2) * V + v] * wk;
+    }
+    sx += dm.shape_planes[((size_t)K * 3 + 0) * V + v];
+    sy += dm.shape_planes[((size_t)K * 3 + 1) * V + v];
+    sz += dm.shape_planes[((size_t)K * 3 + 2) * V + v];
+    // pointTrans = jointTrans * weights (sparse column, CSC order)  (Avatar.cpp:69)
+    double pt[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) pt[e] = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const double wt = dm.lbs_w[(size_t)a * V + v];
+        if (wt != 0.0) {
+            const double* T = s_T + 12 * dm.lbs_j[(size_t)a * V + v];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) pt[e] += T[e] * wt;
+        }
+    }
+    // cloud.col(i) = pointTrans_i * [shaped_i; 1]  (Avatar.cpp:70-73)
+    const double cx = pt[0] * sx + pt[3] * sy + pt[6] * sz + pt[9];
+    const double cy = pt[1] * sx + pt[4] * sy + pt[7] * sz + pt[10];
+    const double cz = pt[2] * sx + pt[5] * sy + pt[8] * sz + pt[11];
+    double* cl = fb.cloud + (size_t)f * 3 * V + 3 * (size_t)v;
+    cl[0] = cx; cl[1] = cy; cl[2] = cz;
+    if (dm.part_pos) {
+        const int pp = dm.part_pos[v];
+        fb.pcx[(size_t)f * V + pp] = cx;
+        fb.pcy[(size_t)f * V + pp] = cy;
+        fb.pcz[(size_t)f * V + pp] = cz;
+    }
+}
+
+void launch_lbs(avt_ctx* c, int nframes, const double*, const double* w, const double* p, const double* R, int from_state) {
+    dim3 grid((c->dm.d.V + 255) / 256, nframes);
+    hipLaunchKernelGGL(k_lbs, grid, dim3(256), 0, c->stream, c->dm, c->fb, w, p, R, from_state);
+}
+
+// =================================================================================================
+// back-face visibility (AvatarOptimizer.cpp:1349-1367): a face whose ((p2-p1)x(p1-p3)).z > 1e-4 marks its
+// three vertices visible.  `visible` is cleared (or set, when occlusion is off) by a memset node first.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_visibility(DeviceModel dm, FrameBuffers fb) {
+    const int F = dm.d.F, V = dm.d.V;
+    const int f = blockIdx.y;
+    const int face = blockIdx.x * 256 + threadIdx.x;
+    if (face >= F) return;
+    const int i1 = dm.mesh[face], i2 = dm.mesh[(size_t)F + face], i3 = dm.mesh[2 * (size_t)F + face];
+    const double* cl = fb.cloud + (size_t)f * 3 * V;
+    const double p1x = cl[3 * i1], p1y = cl[3 * i1 + 1];
+    const double p2x = cl[3 * i2], p2y = cl[3 * i2 + 1];
+    const double p3x = cl[3 * i3], p3y = cl[3 * i3 + 1];
+    const double ax = p2x - p1x, ay = p2y - p1y, bx = p1x - p3x, by = p1y - p3y;
+    const double z = __dsub_rn(__dmul_rn(ax, by), __dmul_rn(ay, bx));  // no FMA: same rounding as the CPU expression
+    if (z > 1e-4) {
+        unsigned char* vis = fb.visible + (size_t)f * V;
+        vis[i1] = 1; vis[i2] = 1; vis[i3] = 1;
+    }
+}
+
+void launch_visibility(avt_ctx* c, int nframes, int enable) {
+    const int V = c->dm.d.V;
+    hipMemsetAsync(c->fb.visible, enable ? 0 : 1, (size_t)nframes * V, c->stream);
+    if (enable) {
+        dim3 grid((c->dm.d.F + 255) / 256, nframes);
+        hipLaunchKernelGGL(k_visibility, grid, dim3(256), 0, c->stream, c->dm, c->fb);
+    }
+}
+
+// =================================================================================================
+// Data bucketing by body-part label (the data-side counterpart of AvatarOptimizer.cpp:1274-1293): a stable
+// counting sort, one workgroup per frame.  Within a part the original index order is preserved, which the
+// ordered nearest-neighbour scan and the ordered correspondence lists rely on.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_bucket(DeviceModel dm, FrameBuffers fb) {
+    const int f = blockIdx.x, t = threadIdx.x;
+    const int np = dm.d.num_parts;
+    AvtFrameCtl& ctl = fb.ctl[f];
+    const int N = ctl.N;
+    const size_t base = (size_t)f * fb.max_points;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* hist = (int*)smem;                 // [np+1][256] (row np = invalid labels)
+    int* tot = hist + (size_t)(np + 1) * 256;   // [np+2]
+    const int chunk = (N + 255) / 256;
+    const int lo = min(N, t * chunk), hi = min(N, lo + chunk);
+    for (int q = 0; q <= np; ++q) hist[q * 256 + t] = 0;
+    const int* lab = fb.labels_raw + base;
+    for (int i = lo; i < hi; ++i) {
+        int q = lab[i];
+        if (q < 0 || q >= np) q = np;
+        hist[q * 256 + t] += 1;
+    }
+    __syncthreads();
+    // per-part exclusive scan across the 256 thread columns: wave w takes parts w, w+4, ...
+    for (int q = wave_id(); q <= np; q += 4) {
+        const int l = lane_id();
+        int v0 = hist[q * 256 + 4 * l], v1 = hist[q * 256 + 4 * l + 1], v2 = hist[q * 256 + 4 * l + 2], v3 = hist[q * 256 + 4 * l + 3];
+        const int s = v0 + v1 + v2 + v3;
+        const int incl = wave_incl_scan(s);
+        const int ex = incl - s;
+        hist[q * 256 + 4 * l] = ex;
+        hist[q * 256 + 4 * l + 1] = ex + v0;
+        hist[q * 256 + 4 * l + 2] = ex + v0 + v1;
+        hist[q * 256 + 4 * l + 3] = ex + v0 + v1 + v2;
+        if (l == 63) tot[q] = incl;
+    }
+    __syncthreads();
+    if (t == 0) {
+        int acc = 0;
+        int* po = fb.part_off + (size_t)f * (np + 1);
+        for (int q = 0; q < np; ++q) {
+            const int n = tot[q];
+            tot[q] = acc;
+            po[q] = acc;
+            acc += n;
+        }
+        po[np] = acc;
+        tot[np] = acc;  // invalid labels go after all parts
+        if (N > 0) {
+            ctl.centre[0] = fb.data_raw[3 * base];
+            ctl.centre[1] = fb.data_raw[3 * base + 1];
+            ctl.centre[2] = fb.data_raw[3 * base + 2];
+        }
+    }
+    __syncthreads();
+    for (int i = lo; i < hi; ++i) {
+        int q = lab[i];
+        if (q < 0 || q >= np) q = np;
+        const int pos = tot[q] + hist[q * 256 + t]++;
+        fb.dx[base + pos] = fb.data_raw[3 * (base + i)];
+        fb.dy[base + pos] = fb.data_raw[3 * (base + i) + 1];
+        fb.dz[base + pos] = fb.data_raw[3 * (base + i) + 2];
+        fb.dorig[base + pos] = i;
+        if (q == np) fb.corr[base + i] = -1;
+    }
+}
+
+void launch_bucket(avt_ctx* c, int nframes) {
+    const int np = c->dm.d.num_parts;
+    const size_t lds = ((size_t)(np + 1) * 256 + np + 2) * sizeof(int);
+    hipLaunchKernelGGL(k_bucket, dim3(nframes), dim3(256), lds, c->stream, c->dm, c->fb);
+}
+
+// =================================================================================================
+// Correspondence finalisation: turns the per-vertex (count, fixed-point sum) accumulated by the NN kernel
+// into the compacted list of matched model points (the `caches` of AvatarOptimizer.cpp:1419-1431) with
+// sqrt(count) and the mean data point, and the prior weight rescale (AvatarOptimizer.cpp:1457-1458).
+// One workgroup of 1024 threads per frame; the compaction keeps ascending vertex order.
+// =================================================================================================
+__global__ __launch_bounds__(1024) void k_finalize(DeviceModel dm, FrameBuffers fb, double beta_pose, double beta_shape,
+                                                   double lambda0, int first_icp) {
+    const int f = blockIdx.x, t = threadIdx.x, V = dm.d.V;
+    AvtFrameCtl& ctl = fb.ctl[f];
+    __shared__ int s_wave_m[16], s_wave_t[16];
+    const int chunk = (V + 1023) / 1024;
+    const int lo = min(V, t * chunk), hi = min(V, lo + chunk);
+    const int* cnt = fb.cnt + (size_t)f * V;
+    int m = 0, tt = 0;
+    for (int v = lo; v < hi; ++v) {
+        const int c = cnt[v];
+        m += (c > 0);
+        tt += c;
+    }
+    const int im = wave_incl_scan(m), it = wave_incl_scan(tt);
+    if (lane_id() == 63) { s_wave_m[wave_id()] = im; s_wave_t[wave_id()] = it; }
+    __syncthreads();
+    int mbase = 0, total_m = 0, total_t = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave_id()) mbase += s_wave_m[w];
+        total_m += s_wave_m[w];
+        total_t += s_wave_t[w];
+    }
+    int pos = mbase + im - m;
+    const long long* fs = fb.fsum + (size_t)f * 3 * V;
+    for (int v = lo; v < hi; ++v) {
+        const int c = cnt[v];
+        if (c > 0) {
+            fb.matched[(size_t)f * V + pos] = v;
+            fb.mcnt[(size_t)f * V + pos] = sqrt((double)c);
+            for (int k = 0; k < 3; ++k) {
+                const double mean = ctl.centre[k] + ((double)fs[(size_t)k * V + v] / AVT_FIX_SCALE) / (double)c;
+                fb.mdbar[((size_t)f * 3 + k) * V + pos] = mean;
+            }
+            ++pos;
+        }
+    }
+    if (t == 0) {
+        ctl.M = total_m;
+        ctl.T = total_t;
+        ctl.sbp = beta_pose * sqrt((double)total_t) / 15.0;
+        ctl.sbs = beta_shape * sqrt((double)total_t) / 15.0;
+        if (first_icp) {
+            ctl.lambda = lambda0;
+            ctl.gn_iterations = 0;
+            ctl.accepted = 0;
+        }
+    }
+}
+
+// 0.5*sum_i |d_i - dbar_m(i)|^2: the part of the data cost that does not depend on the parameters once the
+// correspondences are fixed.  Deterministic two-level reduction (block partials, summed in order by the
+// solve kernel).
+__global__ __launch_bounds__(256) void k_cost_const(DeviceModel dm, FrameBuffers fb) {
+    const int f = blockIdx.y, t = threadIdx.x, V = dm.d.V;
+    const AvtFrameCtl& ctl = fb.ctl[f];
+    const int N = ctl.N;
+    const size_t base = (size_t)f * fb.max_points;
+    const int s = blockIdx.x * 256 + t;
+    double acc = 0.0;
+    if (s < N) {
+        const int m = fb.corr_sorted[base + s];
+        if (m >= 0) {
+            const int c = fb.cnt[(size_t)f * V + m];
+            const long long* fs = fb.fsum + (size_t)f * 3 * V;
+            const double mx = ctl.centre[0] + ((double)fs[m] / AVT_FIX_SCALE) / (double)c;
+            const double my = ctl.centre[1] + ((double)fs[(size_t)V + m] / AVT_FIX_SCALE) / (double)c;
+            const double mz = ctl.centre[2] + ((double)fs[2 * (size_t)V + m] / AVT_FIX_SCALE) / (double)c;
+            const double ex = fb.dx[base + s] - mx, ey = fb.dy[base + s] - my, ez = fb.dz[base + s] - mz;
+            acc = ex * ex + ey * ey + ez * ez;
+        }
+    }
+    __shared__ double s_part[4];
+    acc = wave_sum(acc);
+    if (lane_id() == 0) s_part[wave_id()] = acc;
+    __syncthreads();
+    if (t == 0) fb.const_part[(size_t)f * fb.const_blocks + blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
+void launch_finalize(avt_ctx* c, int nframes, const avt_options* o) {
+    hipLaunchKernelGGL(k_finalize, dim3(nframes), dim3(1024), 0, c->stream, c->dm, c->fb, o->beta_pose, o->beta_shape,
+                       o->lm_lambda0, c->ran_icp_iters == 0 ? 1 : 0);
+    int maxN = 0;
+    for (int f = 0; f < nframes; ++f) maxN = std::max(maxN, c->frame_N[f]);
+    const int nb = (maxN + 255) / 256;
+    hipMemsetAsync(c->fb.const_part, 0, (size_t)nframes * c->fb.const_blocks * sizeof(double), c->stream);
+    if (nb > 0) hipLaunchKernelGGL(k_cost_const, dim3(nb, nframes), dim3(256), 0, c->stream, c->dm, c->fb);
+}

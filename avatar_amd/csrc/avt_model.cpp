@@ -1,0 +1,244 @@
+// avt_model.cpp — host-side, pose-independent model preparation behind avt_model_create().
+//
+// Replaces, for the hot path only:
+//   * AvatarModel::AvatarModel data derivation (AvatarModel.cpp:74-127): assignedJoints (threshold 1e-12,
+//     sorted by descending (weight, joint)), initialJointPos, jointShapeReg;
+//   * the pose-independent tables of AvatarEvaluationCommonData (AvatarOptimizer.cpp:187-245): per-point
+//     deduplicated ancestor lists and the shape tables S, Sp;
+//   * GaussianMixture::load factorisations (GaussianMixture.cpp:44-76): Cholesky of the precision, consts.
+// and lays everything out SoA for coalesced device access.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "avt_internal.h"
+
+static thread_local std::string g_err;
+void avt_set_error(const std::string& s) { g_err = s; }
+extern "C" const char* avt_last_error(void) { return g_err.c_str(); }
+
+static bool chol_lower(const double* A, int n, double* L) {
+    std::fill(L, L + (size_t)n * n, 0.0);
+    for (int j = 0; j < n; ++j) {
+        double d = A[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+        if (!(d > 0.0)) return false;
+        const double l = std::sqrt(d);
+        L[(size_t)j * n + j] = l;
+        for (int i = j + 1; i < n; ++i) {
+            double s = A[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) s -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
+            L[(size_t)i * n + j] = s / l;
+        }
+    }
+    return true;
+}
+
+extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
+    if (!desc || !out) { avt_set_error("avt_model_create: null argument"); return 1; }
+    const int V = desc->num_points, J = desc->num_joints, K = desc->num_shape_keys, F = desc->num_faces;
+    if (V <= 0 || J <= 0 || J > AVT_MAX_JOINTS || K < 0 || K > AVT_MAX_SHAPE || F < 0) {
+        avt_set_error("avt_model_create: unsupported dimensions (J<=32, K<=16)");
+        return 1;
+    }
+    if (desc->parent[0] != -1) { avt_set_error("avt_model_create: parent[0] must be -1 (AvatarModel.cpp:41)"); return 1; }
+    for (int j = 1; j < J; ++j)
+        if (desc->parent[j] < 0 || desc->parent[j] >= j) { avt_set_error("avt_model_create: parent[] must be topologically sorted"); return 1; }
+    avt_model* m = new avt_model();
+    AvtDims& d = m->d;
+    d.V = V; d.J = J; d.K = K; d.F = F; d.P = 3 + 3 * J + K;
+    d.NT = (d.P + 1 + AVT_TILE - 1) / AVT_TILE;
+    d.NPAIR = d.NT * (d.NT + 1) / 2;
+    d.xsize = 3 + 4 * J + K;
+    d.prep_size = prep_total(d);
+    d.num_parts = 0;
+    m->parent.assign(desc->parent, desc->parent + J);
+
+    // shape planes
+    m->shape_planes.assign((size_t)(K + 1) * 3 * V, 0.0);
+    for (int k = 0; k < K; ++k)
+        for (int v = 0; v < V; ++v)
+            for (int c = 0; c < 3; ++c)
+                m->shape_planes[((size_t)k * 3 + c) * V + v] = desc->key_clouds[(size_t)k * 3 * V + 3 * v + c];
+    for (int v = 0; v < V; ++v)
+        for (int c = 0; c < 3; ++c) m->shape_planes[((size_t)K * 3 + c) * V + v] = desc->base_cloud[3 * v + c];
+
+    // skinning weights: raw CSC (<=4 nnz) and assignedJoints
+    m->lbs_w.assign((size_t)4 * V, 0.0); m->lbs_j.assign((size_t)4 * V, 0);
+    m->asg_w.assign((size_t)4 * V, 0.0); m->asg_j.assign((size_t)4 * V, 0);
+    m->main_joint.assign(V, 0);
+    std::vector<std::vector<std::pair<double, int>>> assigned(V);
+    for (int v = 0; v < V; ++v) {
+        const int b = desc->weights_colptr[v], e = desc->weights_colptr[v + 1];
+        if (e - b > AVT_MAX_ASSIGN) {
+            delete m;
+            avt_set_error("avt_model_create: more than 4 skinning weights on a vertex (MAX_ASSIGN, AvatarOptimizer.cpp:164)");
+            return 1;
+        }
+        for (int i = b; i < e; ++i) {
+            const int j = desc->weights_row[i];
+            if (j < 0 || j >= J) { delete m; avt_set_error("avt_model_create: weight row out of range"); return 1; }
+            m->lbs_w[(size_t)(i - b) * V + v] = desc->weights_val[i];
+            m->lbs_j[(size_t)(i - b) * V + v] = j;
+            if (desc->weights_val[i] > 1e-12) assigned[v].push_back({desc->weights_val[i], j});
+        }
+        std::sort(assigned[v].begin(), assigned[v].end(), std::greater<std::pair<double, int>>());
+        if (assigned[v].empty()) { delete m; avt_set_error("avt_model_create: vertex without skinning weights"); return 1; }
+        for (size_t a = 0; a < assigned[v].size(); ++a) {
+            m->asg_w[a * V + v] = assigned[v][a].first;
+            m->asg_j[a * V + v] = assigned[v][a].second;
+        }
+        m->main_joint[v] = assigned[v][0].second;
+    }
+
+    // joint regression (AvatarModel.cpp:112-127)
+    m->jsr_base.assign(3 * J, 0.0);
+    m->jsr.assign((size_t)3 * J * K, 0.0);
+    for (int j = 0; j < J; ++j)
+        for (int e = desc->jreg_colptr[j]; e < desc->jreg_colptr[j + 1]; ++e) {
+            const int v = desc->jreg_row[e];
+            const double wt = desc->jreg_val[e];
+            for (int c = 0; c < 3; ++c) m->jsr_base[3 * j + c] += desc->base_cloud[3 * v + c] * wt;
+            for (int k = 0; k < K; ++k)
+                for (int c = 0; c < 3; ++c)
+                    m->jsr[(size_t)(3 * j + c) * K + k] += desc->key_clouds[(size_t)k * 3 * V + 3 * v + c] * wt;
+        }
+    // S, Sp (AvatarOptimizer.cpp:215-245)
+    m->S.assign((size_t)J * 3 * K, 0.0); m->Sp.assign((size_t)J * 3 * K, 0.0);
+    for (int j = 0; j < J; ++j)
+        for (int c = 0; c < 3; ++c)
+            for (int k = 0; k < K; ++k) m->S[((size_t)j * 3 + c) * K + k] = m->jsr[(size_t)(3 * j + c) * K + k];
+    for (int j = 1; j < J; ++j)
+        for (int e = 0; e < 3 * K; ++e)
+            m->Sp[(size_t)j * 3 * K + e] = m->S[(size_t)j * 3 * K + e] - m->S[(size_t)desc->parent[j] * 3 * K + e];
+
+    // ancestors (AvatarOptimizer.cpp:187-213): union of root chains of the assigned joints, sorted by id; for
+    // each ancestor a bit mask of the assigned joints beneath (or equal to) it.
+    m->anc_n.assign(V, 0);
+    m->anc.assign((size_t)AVT_ANC_MAX * V, 0);
+    int anc_max = 0;
+    for (int v = 0; v < V; ++v) {
+        unsigned mask[AVT_MAX_JOINTS] = {0};
+        for (size_t a = 0; a < assigned[v].size(); ++a)
+            for (int j = assigned[v][a].second; j != -1; j = desc->parent[j]) mask[j] |= 1u << a;
+        int n = 0;
+        for (int j = 0; j < J; ++j)
+            if (mask[j]) {
+                if (n >= AVT_ANC_MAX) { delete m; avt_set_error("avt_model_create: more than 16 ancestors on a vertex"); return 1; }
+                m->anc[(size_t)n * V + v] = (unsigned short)(j | (mask[j] << 8));
+                ++n;
+            }
+        m->anc_n[v] = (unsigned char)n;
+        anc_max = std::max(anc_max, n);
+    }
+    d.anc_max = anc_max;
+
+    // mesh SoA
+    m->mesh_soa.assign((size_t)3 * F, 0);
+    for (int f = 0; f < F; ++f)
+        for (int c = 0; c < 3; ++c) {
+            const int idx = desc->mesh[3 * f + c];
+            if (idx < 0 || idx >= V) { delete m; avt_set_error("avt_model_create: mesh index out of range"); return 1; }
+            m->mesh_soa[(size_t)c * F + f] = idx;
+        }
+
+    // GMM (GaussianMixture.cpp:12-77)
+    d.ncomps = desc->prior_ncomps > 0 ? desc->prior_ncomps : 0;
+    d.ndims = d.ncomps ? desc->prior_ndims : 0;
+    if (d.ncomps) {
+        const int n = d.ndims;
+        if (n != 3 * (J - 1)) { delete m; avt_set_error("avt_model_create: prior_ndims must be 3*(J-1)"); return 1; }
+        m->prior_mean.assign(desc->prior_mean, desc->prior_mean + (size_t)d.ncomps * n);
+        m->prior_prec.assign((size_t)d.ncomps * n * n, 0.0);
+        m->prior_L.assign((size_t)d.ncomps * n * n, 0.0);
+        m->prior_clog.assign(d.ncomps, 0.0);
+        const double log_sqrt_2_pi_n = n * 0.5 * std::log(2 * M_PI);
+        double minDet = std::numeric_limits<double>::max();
+        std::vector<double> L((size_t)n * n), Li((size_t)n * n);
+        for (int c = 0; c < d.ncomps; ++c) {
+            m->prior_clog[c] = std::log(desc->prior_weight[c]) - log_sqrt_2_pi_n;
+            if (!chol_lower(desc->prior_cov + (size_t)c * n * n, n, L.data())) {
+                delete m; avt_set_error("avt_model_create: prior covariance not positive definite (\"Decomposition failed!\")");
+                return 1;
+            }
+            std::fill(Li.begin(), Li.end(), 0.0);  // L^-1 by forward substitution
+            for (int col = 0; col < n; ++col)
+                for (int i = col; i < n; ++i) {
+                    double s = (i == col) ? 1.0 : 0.0;
+                    for (int k = col; k < i; ++k) s -= L[(size_t)i * n + k] * Li[(size_t)k * n + col];
+                    Li[(size_t)i * n + col] = s / L[(size_t)i * n + i];
+                }
+            double* prec = &m->prior_prec[(size_t)c * n * n];
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    double s = 0.0;
+                    for (int k = std::max(i, j); k < n; ++k) s += Li[(size_t)k * n + i] * Li[(size_t)k * n + j];
+                    prec[(size_t)i * n + j] = s;
+                }
+            if (!chol_lower(prec, n, &m->prior_L[(size_t)c * n * n])) {
+                delete m; avt_set_error("avt_model_create: precision factorisation failed");
+                return 1;
+            }
+            double det = 1.0;
+            for (int i = 0; i < n; ++i) det *= L[(size_t)i * n + i];
+            minDet = std::min(minDet, det);
+            m->prior_clog[c] -= std::log(det);
+        }
+        for (int c = 0; c < d.ncomps; ++c) m->prior_clog[c] += std::log(minDet);
+        // the solve kernel uses precision = Lp Lp^T recomposed from the factor the reference keeps (prec_cho)
+        for (int c = 0; c < d.ncomps; ++c) {
+            const double* Lp = &m->prior_L[(size_t)c * n * n];
+            double* prec = &m->prior_prec[(size_t)c * n * n];
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    double s = 0.0;
+                    for (int k = 0; k <= std::min(i, j); ++k) s += Lp[(size_t)i * n + k] * Lp[(size_t)j * n + k];
+                    prec[(size_t)i * n + j] = s;
+                }
+        }
+    }
+    *out = m;
+    return 0;
+}
+
+extern "C" void avt_model_destroy(avt_model* m) { delete m; }
+
+extern "C" int avt_model_dims(const avt_model* m, int* V, int* J, int* K, int* F, int* P) {
+    if (!m) { avt_set_error("avt_model_dims: null model"); return 1; }
+    if (V) *V = m->d.V;
+    if (J) *J = m->d.J;
+    if (K) *K = m->d.K;
+    if (F) *F = m->d.F;
+    if (P) *P = m->d.P;
+    return 0;
+}
+
+extern "C" int avt_model_main_joint(const avt_model* m, int* out) {
+    if (!m || !out) { avt_set_error("avt_model_main_joint: null argument"); return 1; }
+    std::copy(m->main_joint.begin(), m->main_joint.end(), out);
+    return 0;
+}
+
+extern "C" int avt_model_joint_regression(const avt_model* m, double* ijp, double* jsr_colmajor) {
+    if (!m) { avt_set_error("avt_model_joint_regression: null model"); return 1; }
+    const int J = m->d.J, K = m->d.K;
+    if (ijp) std::copy(m->jsr_base.begin(), m->jsr_base.end(), ijp);
+    if (jsr_colmajor)
+        for (int i = 0; i < 3 * J; ++i)
+            for (int k = 0; k < K; ++k) jsr_colmajor[(size_t)k * 3 * J + i] = m->jsr[(size_t)i * K + k];
+    return 0;
+}
+
+extern "C" void avt_options_default(avt_options* o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->beta_pose = 0.1; o->beta_shape = 1.0; o->nn_step = 20; o->max_iters_per_icp = 10; o->enable_occlusion = 1;
+    o->icp_iters = 1; o->num_threads = 4;
+    o->lm_lambda0 = 1e-3; o->lm_up = 4.0; o->lm_down = 1.0 / 3.0; o->lm_lambda_min = 1e-12; o->lm_lambda_max = 1e8;
+}
+
+extern "C" const char* avt_kernel_name(int k) {
+    static const char* names[AVT_K_COUNT] = {"lbs", "visibility", "bucket", "nn", "aggregate", "prepare", "eval", "reduce", "solve"};
+    return (k >= 0 && k < AVT_K_COUNT) ? names[k] : "?";
+}

@@ -1,0 +1,164 @@
+/* avt.h — C ABI of the MI355X-native SMPL-to-depth fitting engine (libavatar_hip.so).
+ *
+ * This is the drop-in boundary for the AvatarOptimizer hot path of sxyu/avatar.  The reference has no FFI:
+ * the path sits behind two C++ classes (`ark::Avatar`, `ark::AvatarOptimizer`).  Each entry point below
+ * names the reference interface it replaces (file:line relative to the reference tree); the C++ facade in
+ * include/ark/ re-creates those classes on top of this ABI.
+ *
+ * Conventions (identical to the reference on the host side of the ABI):
+ *   - everything is fp64; indices are int                                  (Avatar.h:19)
+ *   - clouds are column-major 3xN, point i at ptr + 3*i                     (AvatarOptimizer.cpp:901)
+ *   - rotations are column-major 3x3; quaternion coefficient order (x,y,z,w) (AvatarOptimizer.cpp:295-298)
+ *   - labels are ints in [0, num_parts)                                     (demo.cpp:236-243)
+ *   - caller owns every host buffer; the library owns all device memory; handles are opaque.
+ *   - every function returns 0 on success, non-zero on error; avt_last_error() describes the last failure
+ *     on the calling thread.  (The reference's `void` + std::exit(1) asserts live in the C++ facade.)
+ *   - a context is NOT thread-safe: one context per host thread / HIP stream   (Avatar.h:191 lifetimes)
+ */
+#ifndef AVT_H_
+#define AVT_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVT_MAX_JOINTS 32   /* SMPL: 24 */
+#define AVT_MAX_SHAPE 16    /* SMPL: 10 */
+#define AVT_MAX_ASSIGN 4    /* AvatarOptimizer.cpp:164 MAX_ASSIGN */
+#define AVT_MAX_PARTS 64
+
+typedef struct avt_model avt_model;
+typedef struct avt_ctx avt_ctx;
+
+/* Immutable model data, the fields of `struct AvatarModel` the path reads (Avatar.h:64-151, filled at
+ * AvatarModel.cpp:35-127).  All pointers are borrowed for the duration of avt_model_create only. */
+typedef struct avt_model_desc {
+    int num_points;             /* V  = weights.cols()            (Avatar.h:82)  */
+    int num_joints;             /* J  = parent.rows()             (Avatar.h:80)  */
+    int num_shape_keys;         /* K  = keyClouds.cols()          (Avatar.h:84)  */
+    int num_faces;              /* F  = mesh.cols()               (Avatar.h:86)  */
+    const double* base_cloud;   /* 3V, x1 y1 z1 x2 ...            (Avatar.h:113) */
+    const double* key_clouds;   /* 3V x K column-major            (Avatar.h:117) */
+    const int* parent;          /* J, parent[0] = -1, topo-sorted (Avatar.h:97, AvatarModel.cpp:41) */
+    const int* mesh;            /* 3 x F column-major             (Avatar.h:94)  */
+    /* LBS weights, J x V sparse, compressed column (one column per vertex)      (Avatar.h:142) */
+    const int* weights_colptr;  /* V+1 */
+    const int* weights_row;     /* nnz, joint ids, ascending within a column */
+    const double* weights_val;  /* nnz */
+    /* joint regressor, V x J sparse, compressed column (one column per joint)   (Avatar.h:124) */
+    const int* jreg_colptr;     /* J+1 */
+    const int* jreg_row;        /* nnz, vertex ids, ascending within a column */
+    const double* jreg_val;     /* nnz */
+    /* Gaussian-mixture pose prior, pose_prior.txt contents (GaussianMixture.cpp:20-58); ncomps<=0: none */
+    int prior_ncomps;
+    int prior_ndims;            /* must be 3*(J-1) */
+    const double* prior_weight; /* ncomps */
+    const double* prior_mean;   /* ncomps x ndims row-major */
+    const double* prior_cov;    /* ncomps x ndims x ndims, each matrix row-major as in the text file */
+} avt_model_desc;
+
+/* Knobs: the public data members of AvatarOptimizer (AvatarOptimizer.h:25-39) and the arguments of
+ * optimize() (AvatarOptimizer.h:17-19), plus the Gauss-Newton/LM step rule that replaces the reference's
+ * Ceres BFGS line search (AvatarOptimizer.cpp:1313-1341, :1486; see DESIGN.md "step rule"). */
+typedef struct avt_options {
+    double beta_pose;           /* betaPose, reference default 0.1; demos use 0.05 (demo.cpp:54-57) */
+    double beta_shape;          /* betaShape, reference default 1.0; demos use 0.12 */
+    int nn_step;                /* nnStep = 20; unused in the inverted NN mode the reference runs (:933,:1393) */
+    int max_iters_per_icp;      /* maxItersPerICP = 10: GN iterations per ICP iteration */
+    int enable_occlusion;       /* enableOcclusion = true: back-face visibility (AvatarOptimizer.cpp:1349-1367) */
+    int icp_iters;              /* optimize(..., icp_iters = 1, ...) */
+    int num_threads;            /* optimize(..., num_threads = 4): accepted, ignored on the GPU path */
+    int reserved0;
+    double lm_lambda0;          /* initial damping (relative to diag H); default 1e-3 */
+    double lm_up;               /* damping multiplier on a rejected step; default 4 */
+    double lm_down;             /* damping multiplier on an accepted step; default 1/3 */
+    double lm_lambda_min;       /* default 1e-12 */
+    double lm_lambda_max;       /* default 1e8 */
+} avt_options;
+
+typedef struct avt_stats {
+    double initial_cost;        /* 0.5*sum r^2 at entry to the last ICP iteration (data + priors) */
+    double final_cost;          /* same objective after the last accepted step */
+    double lambda;              /* damping at exit */
+    int num_correspondences;    /* ICP residual blocks in the last ICP iteration (totalResiduals, :1441-1451) */
+    int matched_model_points;   /* model points with >= 1 correspondence (caches, :1419-1431) */
+    int gn_iterations;          /* GN iterations executed over all ICP iterations */
+    int accepted_steps;
+} avt_stats;
+
+/* Per-kernel-class device timings (ms, HIP events on the context's stream) accumulated between
+ * avt_profile_begin / avt_profile_end.  Profiling inserts event records around every launch. */
+enum { AVT_K_LBS = 0, AVT_K_VISIBILITY, AVT_K_BUCKET, AVT_K_NN, AVT_K_AGGREGATE, AVT_K_PREPARE,
+       AVT_K_EVAL, AVT_K_REDUCE, AVT_K_SOLVE, AVT_K_COUNT };
+typedef struct avt_profile {
+    double ms[AVT_K_COUNT];
+    int launches[AVT_K_COUNT];
+} avt_profile;
+
+const char* avt_last_error(void);
+const char* avt_kernel_name(int kernel_class);
+void avt_options_default(avt_options* o);      /* reference defaults (AvatarOptimizer.h:28-39) + LM defaults */
+
+/* ---- model: replaces `AvatarModel::AvatarModel` data preparation (AvatarModel.cpp:74-127) and the
+ * pose-independent parts of `AvatarEvaluationCommonData` (AvatarOptimizer.cpp:187-245) and
+ * `GaussianMixture::load` factorisations (GaussianMixture.cpp:44-76). */
+int avt_model_create(const avt_model_desc* desc, avt_model** out);
+void avt_model_destroy(avt_model* m);
+int avt_model_dims(const avt_model* m, int* V, int* J, int* K, int* F, int* P);
+/* main (largest-weight) joint of every vertex: assignedJoints[v][0].second (Avatar.h:101) */
+int avt_model_main_joint(const avt_model* m, int* main_joint_V);
+/* initialJointPos (3xJ) and jointShapeReg (3J x K col-major) (AvatarModel.cpp:112-127) */
+int avt_model_joint_regression(const avt_model* m, double* initial_joint_pos_3xJ, double* joint_shape_reg_3JxK);
+
+/* ---- context: one HIP device + stream + persistent buffers.  `part_map` (>= J entries) and `num_parts`
+ * are the AvatarOptimizer ctor arguments (AvatarOptimizer.h:14, AvatarOptimizer.cpp:1213-1244). */
+int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* part_map,
+                   int max_points_per_frame, int max_frames, avt_ctx** out);
+void avt_ctx_destroy(avt_ctx* c);
+int avt_sync(avt_ctx* c);
+
+/* ---- Avatar::update() (Avatar.cpp:22-75) for `nframes` independent avatars.
+ * w: K x nframes, p: 3 x nframes, R: 9J x nframes (J column-major 3x3 blocks per frame).
+ * Outputs (any may be NULL): cloud 3V x nframes, joint_pos 3J x nframes, joint_trans 12J x nframes. */
+int avt_lbs_update(avt_ctx* c, int nframes, const double* w, const double* p, const double* R,
+                   double* cloud, double* joint_pos, double* joint_trans);
+
+/* ---- back-face visibility (AvatarOptimizer.cpp:1342-1367). visible: V bytes (0/1). */
+int avt_visibility(avt_ctx* c, const double* cloud_3xV, int enable_occlusion, unsigned char* visible);
+
+/* ---- findNN(..., invert=true) (AvatarOptimizer.cpp:841-907): for each data point the exact nearest
+ * visible model point of its own part; -1 where the part has no visible model point (:899). */
+int avt_nn(avt_ctx* c, const double* model_cloud_3xV, const unsigned char* visible,
+           const double* data_3xN, const int* labels, int N, int* model_idx_out);
+
+/* ---- AvatarOptimizer::optimize() (AvatarOptimizer.cpp:1246-1517), one frame.
+ * In/out: p (3), q (4 x J, xyzw), w (K).  The caller converts ava.r <-> q (AvatarOptimizer.cpp:1250-1254,
+ * :1494-1496; done by the C++ facade).  stats may be NULL. */
+int avt_optimize(avt_ctx* c, const double* data_3xN, const int* labels, int N, const avt_options* opt,
+                 double* p, double* q, double* w, avt_stats* stats);
+
+/* ---- batch of independent frames (one optimize() each).  frame f owns points
+ * [frame_offsets[f], frame_offsets[f+1]) of data/labels; p/q/w/stats are per-frame, frame-major. */
+int avt_optimize_batch(avt_ctx* c, int nframes, const double* data, const int* labels,
+                       const int* frame_offsets, const avt_options* opt,
+                       double* p, double* q, double* w, avt_stats* stats);
+
+/* ---- the same, split so that inputs can be resident in HBM before a timed region starts:
+ * upload (H2D + nothing else), run (asynchronous on the context's stream), download (syncs). */
+int avt_frames_upload(avt_ctx* c, int nframes, const double* data, const int* labels, const int* frame_offsets);
+int avt_state_upload(avt_ctx* c, int nframes, const double* p, const double* q, const double* w);
+int avt_optimize_resident(avt_ctx* c, const avt_options* opt);
+int avt_state_download(avt_ctx* c, double* p, double* q, double* w, avt_stats* stats);
+
+/* ---- introspection of the last optimize call (tests / diagnostics) */
+int avt_get_correspondences(avt_ctx* c, int frame, int* model_idx_out /* N of that frame */);
+int avt_get_cloud(avt_ctx* c, int frame, double* cloud_3xV);       /* ava.cloud after the final update() */
+int avt_get_normal_equations(avt_ctx* c, int frame, double* H /* P x P */, double* g /* P */, double* cost);
+
+int avt_profile_begin(avt_ctx* c);
+int avt_profile_end(avt_ctx* c, avt_profile* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVT_H_ */

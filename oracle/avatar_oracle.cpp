@@ -1,0 +1,1020 @@
+// avatar_oracle.cpp — CPU restatement of the sxyu/avatar AvatarOptimizer hot path.
+//
+// TEST INFRASTRUCTURE ONLY.  Nothing under avatar_amd/ may import, link or call this file; only tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and only as the checker / the timed CPU
+// baseline.  It is a plain scalar fp64 restatement (no Eigen, no Ceres, no nanoflann) of the algorithm in
+// the reference files cited per function (paths relative to the reference tree).
+//
+// PARITY STATUS.  The reference has no tests, golden vectors or fixtures for this path and
+// its sources need Eigen3/Ceres/OpenCV/Boost, none of which exist in this image, so it cannot be built
+// here.  What pins this oracle instead:
+//   * nearest-neighbour search: bit-exact against the reference's own vendored include/nanoflann.hpp,
+//     compiled from where it lies (oracle/nanoflann_ref.cpp -> oracle/_ref/), goldens in tests/golden/;
+//   * LBS / residual / Jacobians: closed-form known answers derivable from Avatar.cpp and finite
+//     differences through the reference's retraction, plus the independent forward model of the
+//     reference's own TEST_COMPARE_AUTO_DIFF design (AvatarOptimizer.cpp:742-818);
+//   * minimiser iterates: PARITY UNPINNED.  The reference minimises with Ceres 1.14 BFGS line search
+//     (AvatarOptimizer.cpp:1322-1326), a third-party dependency absent from the tree; north_star replaces
+//     that step rule with damped Gauss-Newton (LM).  The objective, residuals and analytic Jacobians are
+//     the reference's; the LM schedule restated here is this repo's (DESIGN.md "step rule").
+// Third-party closed forms restated from their published definitions: Eigen 3.3.4 Quaternion<->Matrix3,
+// AngleAxis<->Quaternion conversions and LLT; nanoflann v0x130 L2_Simple metric.
+//
+// Build: see oracle/Makefile (g++ -O2 -ffp-contract=off, x86-64 baseline = no FMA, as the reference build
+// CMakeLists.txt:37 has no -march flag).
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <thread>
+#include <vector>
+
+#include "../include/avt.h"  // data-layout structs only (avt_model_desc, avt_options, avt_stats)
+
+namespace {
+
+struct M3 {
+    double a[3][3];
+};
+struct V3 {
+    double v[3];
+};
+
+inline M3 m3_identity() {
+    M3 r{};
+    r.a[0][0] = r.a[1][1] = r.a[2][2] = 1.0;
+    return r;
+}
+inline M3 mul(const M3& A, const M3& B) {
+    M3 r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) r.a[i][j] = A.a[i][0] * B.a[0][j] + A.a[i][1] * B.a[1][j] + A.a[i][2] * B.a[2][j];
+    return r;
+}
+inline V3 mul(const M3& A, const V3& x) {
+    V3 r;
+    for (int i = 0; i < 3; ++i) r.v[i] = A.a[i][0] * x.v[0] + A.a[i][1] * x.v[1] + A.a[i][2] * x.v[2];
+    return r;
+}
+inline V3 add(const V3& a, const V3& b) { return V3{{a.v[0] + b.v[0], a.v[1] + b.v[1], a.v[2] + b.v[2]}}; }
+inline V3 sub(const V3& a, const V3& b) { return V3{{a.v[0] - b.v[0], a.v[1] - b.v[1], a.v[2] - b.v[2]}}; }
+inline V3 scale(const V3& a, double s) { return V3{{a.v[0] * s, a.v[1] * s, a.v[2] * s}}; }
+
+// Eigen 3.3.4 Quaternion::toRotationMatrix (published closed form); q = (x,y,z,w)
+inline M3 quat_to_rot(const double* q) {
+    const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+    const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+    const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+    const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    M3 r;
+    r.a[0][0] = 1 - (tyy + tzz); r.a[0][1] = txy - twz;       r.a[0][2] = txz + twy;
+    r.a[1][0] = txy + twz;       r.a[1][1] = 1 - (txx + tzz); r.a[1][2] = tyz - twx;
+    r.a[2][0] = txz - twy;       r.a[2][1] = tyz + twx;       r.a[2][2] = 1 - (txx + tyy);
+    return r;
+}
+
+// Eigen 3.3.4 Quaternion = Matrix3 (trace / largest-diagonal branch form)
+inline void rot_to_quat_raw(const M3& m, double* q) {
+    double t = m.a[0][0] + m.a[1][1] + m.a[2][2];
+    if (t > 0.0) {
+        t = std::sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m.a[2][1] - m.a[1][2]) * t;
+        q[1] = (m.a[0][2] - m.a[2][0]) * t;
+        q[2] = (m.a[1][0] - m.a[0][1]) * t;
+    } else {
+        int i = 0;
+        if (m.a[1][1] > m.a[0][0]) i = 1;
+        if (m.a[2][2] > m.a[i][i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(m.a[i][i] - m.a[j][j] - m.a[k][k] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (m.a[k][j] - m.a[j][k]) * t;
+        q[j] = (m.a[j][i] + m.a[i][j]) * t;
+        q[k] = (m.a[k][i] + m.a[i][k]) * t;
+    }
+}
+
+// Eigen 3.3.4 AngleAxis = Quaternion: angle in [0,pi], axis sign follows w
+inline void quat_to_angle_axis(const double* q, double* angle, double* axis) {
+    double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    if (n < std::numeric_limits<double>::epsilon()) {
+        // stableNorm(): scale by the max abs component
+        const double mx = std::max(std::fabs(q[0]), std::max(std::fabs(q[1]), std::fabs(q[2])));
+        if (mx > 0.0) {
+            const double a = q[0] / mx, b = q[1] / mx, c = q[2] / mx;
+            n = mx * std::sqrt(a * a + b * b + c * c);
+        } else {
+            n = 0.0;
+        }
+    }
+    if (n != 0.0) {
+        *angle = 2.0 * std::atan2(n, std::fabs(q[3]));
+        if (q[3] < 0) n = -n;
+        axis[0] = q[0] / n; axis[1] = q[1] / n; axis[2] = q[2] / n;
+    } else {
+        *angle = 0.0;
+        axis[0] = 1.0; axis[1] = 0.0; axis[2] = 0.0;
+    }
+}
+
+// Eigen 3.3.4 Quaternion = AngleAxis
+inline void angle_axis_to_quat(double angle, const double* axis, double* q) {
+    const double ha = 0.5 * angle;
+    q[3] = std::cos(ha);
+    const double s = std::sin(ha);
+    q[0] = s * axis[0]; q[1] = s * axis[1]; q[2] = s * axis[2];
+}
+
+// Eigen quaternion product a*b, (x,y,z,w) storage
+inline void quat_mul(const double* a, const double* b, double* r) {
+    const double w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    const double x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    const double y = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    const double z = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    r[0] = x; r[1] = y; r[2] = z; r[3] = w;
+}
+
+// Cholesky (LLT, lower) of a dense n x n row-major SPD matrix; returns false if not PD.
+bool cholesky_lower(const double* A, int n, double* L) {
+    std::fill(L, L + (size_t)n * n, 0.0);
+    for (int j = 0; j < n; ++j) {
+        double d = A[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+        if (!(d > 0.0)) return false;
+        const double ljj = std::sqrt(d);
+        L[(size_t)j * n + j] = ljj;
+        for (int i = j + 1; i < n; ++i) {
+            double s = A[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) s -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
+            L[(size_t)i * n + j] = s / ljj;
+        }
+    }
+    return true;
+}
+
+struct Ancestor {  // AvatarOptimizer.cpp:368-404
+    int jid;
+    int assign[AVT_MAX_ASSIGN];
+    double weight[AVT_MAX_ASSIGN];
+    int num_assign;
+};
+
+struct Gmm {  // GaussianMixture.h / GaussianMixture.cpp:12-77
+    int nComps = -1, nDims = 0;
+    std::vector<double> weight, mean, consts_log;
+    std::vector<std::vector<double>> prec_cho;  // lower-triangular L with cov^-1 = L L^T, row-major
+};
+
+}  // namespace
+
+struct orc_model {
+    int V, J, K, F, P;
+    std::vector<double> base, keys;  // 3V ; 3V x K col-major
+    std::vector<int> parent, mesh;
+    std::vector<int> wcol, wrow;
+    std::vector<double> wval;
+    // derived (AvatarModel.cpp:74-127)
+    std::vector<std::vector<std::pair<double, int>>> assigned;  // per vertex (weight, joint) desc
+    std::vector<double> initialJointPos;                        // 3J
+    std::vector<double> jointShapeReg;                          // 3J x K col-major
+    // derived (AvatarOptimizer.cpp:187-245)
+    std::vector<std::vector<Ancestor>> ancestor;
+    std::vector<double> S, Sp;  // per joint 3 x K row-major
+    Gmm prior;
+};
+
+namespace {
+
+void build_model_derived(orc_model& m, const avt_model_desc& d) {
+    const int V = m.V, J = m.J, K = m.K;
+    // assignedJoints: weights > 1e-12, sorted by std::greater<pair<double,int>> (AvatarModel.cpp:74-94)
+    m.assigned.assign(V, {});
+    for (int c = 0; c < V; ++c) {
+        for (int e = m.wcol[c]; e < m.wcol[c + 1]; ++e) {
+            if (m.wval[e] > 1e-12) m.assigned[c].push_back({m.wval[e], m.wrow[e]});
+        }
+        std::sort(m.assigned[c].begin(), m.assigned[c].end(), std::greater<std::pair<double, int>>());
+    }
+    // initialJointPos = baseCloud(3xV) * jointRegressor ; jointShapeReg col k = keyCloud_k * jointRegressor
+    m.initialJointPos.assign(3 * J, 0.0);
+    m.jointShapeReg.assign((size_t)3 * J * K, 0.0);
+    for (int j = 0; j < J; ++j) {
+        for (int e = d.jreg_colptr[j]; e < d.jreg_colptr[j + 1]; ++e) {
+            const int v = d.jreg_row[e];
+            const double wt = d.jreg_val[e];
+            for (int c = 0; c < 3; ++c) m.initialJointPos[3 * j + c] += m.base[3 * v + c] * wt;
+            for (int k = 0; k < K; ++k)
+                for (int c = 0; c < 3; ++c)
+                    m.jointShapeReg[(size_t)k * 3 * J + 3 * j + c] += m.keys[(size_t)k * 3 * V + 3 * v + c] * wt;
+        }
+    }
+    // ancestors (AvatarOptimizer.cpp:187-213)
+    m.ancestor.assign(V, {});
+    for (int pt = 0; pt < V; ++pt) {
+        auto& an = m.ancestor[pt];
+        for (auto& wj : m.assigned[pt]) {
+            const double weight = wj.first;
+            const int joint = wj.second;
+            Ancestor a{};
+            a.jid = joint; a.assign[0] = joint; a.weight[0] = weight; a.num_assign = 1;
+            an.push_back(a);
+            for (int j = m.parent[joint]; j != -1; j = m.parent[j]) {
+                Ancestor b{};
+                b.jid = j; b.assign[0] = joint; b.weight[0] = weight; b.num_assign = 1;
+                an.push_back(b);
+            }
+        }
+        // std::sort by jid is not stable in the reference; the merged (assign, weight) lists are sets whose
+        // order only permutes a <=4-term sum.  We use a stable sort (deterministic).
+        std::stable_sort(an.begin(), an.end(), [](const Ancestor& x, const Ancestor& y) { return x.jid < y.jid; });
+        size_t last = 0;
+        for (size_t i = 1; i < an.size(); ++i) {
+            if (an[last].jid == an[i].jid) {
+                for (int t = 0; t < an[i].num_assign; ++t) {
+                    if (an[last].num_assign >= AVT_MAX_ASSIGN) { std::fprintf(stderr, "oracle: >MAX_ASSIGN\n"); std::exit(1); }
+                    an[last].weight[an[last].num_assign] = an[i].weight[t];
+                    an[last].assign[an[last].num_assign++] = an[i].assign[t];
+                }
+            } else {
+                ++last;
+                if (last < i) an[last] = an[i];
+            }
+        }
+        if (!an.empty()) an.resize(last + 1);
+    }
+    // S, Sp (AvatarOptimizer.cpp:215-245), useJointShapeRegressor == true (AvatarModel.cpp:112)
+    m.S.assign((size_t)J * 3 * K, 0.0);
+    m.Sp.assign((size_t)J * 3 * K, 0.0);
+    for (int j = 0; j < J; ++j)
+        for (int c = 0; c < 3; ++c)
+            for (int k = 0; k < K; ++k) m.S[((size_t)j * 3 + c) * K + k] = m.jointShapeReg[(size_t)k * 3 * J + 3 * j + c];
+    for (int j = 1; j < J; ++j)
+        for (int e = 0; e < 3 * K; ++e) m.Sp[(size_t)j * 3 * K + e] = m.S[(size_t)j * 3 * K + e] - m.S[(size_t)m.parent[j] * 3 * K + e];
+
+    // GMM (GaussianMixture.cpp:12-77)
+    Gmm& g = m.prior;
+    g.nComps = d.prior_ncomps > 0 ? d.prior_ncomps : -1;
+    if (g.nComps > 0) {
+        const int n = g.nDims = d.prior_ndims;
+        const double log_sqrt_2_pi_n = n * 0.5 * std::log(2 * M_PI);
+        g.weight.assign(d.prior_weight, d.prior_weight + g.nComps);
+        g.mean.assign(d.prior_mean, d.prior_mean + (size_t)g.nComps * n);
+        g.consts_log.resize(g.nComps);
+        g.prec_cho.resize(g.nComps);
+        double minDet = std::numeric_limits<double>::max();
+        std::vector<double> L((size_t)n * n), Linv((size_t)n * n), prec((size_t)n * n);
+        for (int c = 0; c < g.nComps; ++c) {
+            g.consts_log[c] = std::log(g.weight[c]) - log_sqrt_2_pi_n;
+            const double* cov = d.prior_cov + (size_t)c * n * n;
+            if (!cholesky_lower(cov, n, L.data())) { std::fprintf(stderr, "oracle: Decomposition failed!\n"); std::exit(1); }
+            // cov^-1 = L^-T L^-1 (Eigen uses PartialPivLU .inverse(); same matrix up to rounding)
+            std::fill(Linv.begin(), Linv.end(), 0.0);
+            for (int col = 0; col < n; ++col) {
+                for (int i = col; i < n; ++i) {
+                    double s = (i == col) ? 1.0 : 0.0;
+                    for (int k = col; k < i; ++k) s -= L[(size_t)i * n + k] * Linv[(size_t)k * n + col];
+                    Linv[(size_t)i * n + col] = s / L[(size_t)i * n + i];
+                }
+            }
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    double s = 0.0;
+                    for (int k = std::max(i, j); k < n; ++k) s += Linv[(size_t)k * n + i] * Linv[(size_t)k * n + j];
+                    prec[(size_t)i * n + j] = s;
+                }
+            g.prec_cho[c].resize((size_t)n * n);
+            if (!cholesky_lower(prec.data(), n, g.prec_cho[c].data())) { std::fprintf(stderr, "oracle: prec chol failed\n"); std::exit(1); }
+            double det = 1.0;  // cov_cho.determinant() = prod diag(L)
+            for (int i = 0; i < n; ++i) det *= L[(size_t)i * n + i];
+            minDet = std::min(det, minDet);
+            g.consts_log[c] -= std::log(det);
+        }
+        for (int c = 0; c < g.nComps; ++c) g.consts_log[c] += std::log(minDet);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Avatar::update()  (Avatar.cpp:22-75, Util.h:191-199)
+// ------------------------------------------------------------------------------------------------
+void avatar_update(const orc_model& m, const double* w, const double* p, const double* Rcm /*9J col-major*/,
+                   double* cloud, double* jointPosOut, double* jointTransOut) {
+    const int V = m.V, J = m.J, K = m.K;
+    std::vector<double> shaped(3 * V);
+    for (int i = 0; i < 3 * V; ++i) {
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) s += m.keys[(size_t)k * 3 * V + i] * w[k];
+        shaped[i] = s + m.base[i];
+    }
+    std::vector<double> jp(3 * J);
+    for (int i = 0; i < 3 * J; ++i) {
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) s += m.jointShapeReg[(size_t)k * 3 * J + i] * w[k];
+        jp[i] = m.initialJointPos[i] + s;
+    }
+    std::vector<M3> R(J);
+    std::vector<V3> t(J);
+    auto loadR = [&](int i) {
+        M3 r;
+        for (int c = 0; c < 3; ++c)
+            for (int rr = 0; rr < 3; ++rr) r.a[rr][c] = Rcm[9 * i + 3 * c + rr];
+        return r;
+    };
+    R[0] = loadR(0);
+    t[0] = V3{{p[0], p[1], p[2]}};
+    for (int i = 1; i < J; ++i) {
+        const int pa = m.parent[i];
+        M3 ri = loadR(i);
+        V3 ti{{jp[3 * i] - jp[3 * pa], jp[3 * i + 1] - jp[3 * pa + 1], jp[3 * i + 2] - jp[3 * pa + 2]}};
+        R[i] = mul(R[pa], ri);                // mulAffine: b.left = a.left * b.left
+        t[i] = add(t[pa], mul(R[pa], ti));    //            b.right = a.right + a.left * b.right
+    }
+    for (int i = 0; i < J; ++i) {
+        V3 jinit{{jp[3 * i], jp[3 * i + 1], jp[3 * i + 2]}};
+        for (int c = 0; c < 3; ++c) jp[3 * i + c] = t[i].v[c];
+        t[i] = sub(t[i], mul(R[i], jinit));
+    }
+    if (jointPosOut) std::memcpy(jointPosOut, jp.data(), sizeof(double) * 3 * J);
+    if (jointTransOut) {
+        for (int i = 0; i < J; ++i) {
+            for (int c = 0; c < 3; ++c)
+                for (int rr = 0; rr < 3; ++rr) jointTransOut[12 * i + 3 * c + rr] = R[i].a[rr][c];
+            for (int rr = 0; rr < 3; ++rr) jointTransOut[12 * i + 9 + rr] = t[i].v[rr];
+        }
+    }
+    if (cloud) {
+        for (int v = 0; v < V; ++v) {
+            double pt[12] = {0};  // column-major 3x4
+            for (int e = m.wcol[v]; e < m.wcol[v + 1]; ++e) {
+                const int j = m.wrow[e];
+                const double wt = m.wval[e];
+                for (int c = 0; c < 3; ++c)
+                    for (int rr = 0; rr < 3; ++rr) pt[3 * c + rr] += R[j].a[rr][c] * wt;
+                for (int rr = 0; rr < 3; ++rr) pt[9 + rr] += t[j].v[rr] * wt;
+            }
+            const double* x = &shaped[3 * v];
+            for (int rr = 0; rr < 3; ++rr)
+                cloud[3 * v + rr] = pt[rr] * x[0] + pt[3 + rr] * x[1] + pt[6 + rr] * x[2] + pt[9 + rr];
+        }
+    }
+}
+
+// back-face visibility (AvatarOptimizer.cpp:1342-1367)
+void visibility(const orc_model& m, const double* cloud, int enable, unsigned char* vis) {
+    if (!enable) {
+        std::fill(vis, vis + m.V, (unsigned char)1);
+        return;
+    }
+    std::fill(vis, vis + m.V, (unsigned char)0);
+    for (int f = 0; f < m.F; ++f) {
+        const int i1 = m.mesh[3 * f], i2 = m.mesh[3 * f + 1], i3 = m.mesh[3 * f + 2];
+        const double* p1 = cloud + 3 * i1;
+        const double* p2 = cloud + 3 * i2;
+        const double* p3 = cloud + 3 * i3;
+        const double ax = p2[0] - p1[0], ay = p2[1] - p1[1];
+        const double bx = p1[0] - p3[0], by = p1[1] - p3[1];
+        const double z = ax * by - ay * bx;  // ((p2-p1) x (p1-p3)).z
+        if (z > 1e-4) vis[i1] = vis[i2] = vis[i3] = 1;
+    }
+}
+
+// part buckets of the model (AvatarOptimizer.cpp:1227-1243)
+void model_part_indices(const orc_model& m, const int* part_map, int num_parts, std::vector<std::vector<int>>& out) {
+    out.assign(num_parts, {});
+    for (int i = 0; i < m.V; ++i) {
+        const int mainJoint = m.assigned[i][0].second;
+        out[part_map[mainJoint]].push_back(i);
+    }
+}
+
+// findNN(..., invert=true) (AvatarOptimizer.cpp:841-907) with the KD-tree replaced by an ordered exhaustive
+// scan using nanoflann's metric arithmetic ((d0*d0)+d1*d1)+d2*d2 and strict '<' (nanoflann.hpp:432-440,
+// :175-199).  Equal to the KD-tree result whenever no two candidates are at exactly equal distance.
+void find_nn(const orc_model& m, const std::vector<std::vector<int>>& partIdx, const double* modelCloud,
+             const unsigned char* vis, const double* data, const int* labels, int N, int* out) {
+    const int numParts = (int)partIdx.size();
+    std::vector<std::vector<int>> newIdx(numParts);
+    std::vector<std::vector<double>> partCloud(numParts);
+    for (int q = 0; q < numParts; ++q) {
+        for (int k : partIdx[q]) {
+            if (!vis[k]) continue;
+            newIdx[q].push_back(k);
+            partCloud[q].push_back(modelCloud[3 * k]);
+            partCloud[q].push_back(modelCloud[3 * k + 1]);
+            partCloud[q].push_back(modelCloud[3 * k + 2]);
+        }
+    }
+    for (int i = 0; i < N; ++i) {
+        const int q = labels[i];
+        if (q < 0 || q >= numParts || newIdx[q].empty()) { out[i] = -1; continue; }
+        const double* a = data + 3 * i;
+        const double* pc = partCloud[q].data();
+        const int n = (int)newIdx[q].size();
+        double best = std::numeric_limits<double>::max();
+        int bi = -1;
+        for (int c = 0; c < n; ++c) {
+            double r = 0.0;
+            const double d0 = a[0] - pc[3 * c];     r += d0 * d0;
+            const double d1 = a[1] - pc[3 * c + 1]; r += d1 * d1;
+            const double d2 = a[2] - pc[3 * c + 2]; r += d2 * d2;
+            if (r < best) { best = r; bi = c; }
+        }
+        out[i] = newIdx[q][bi];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// AvatarEvaluationCommonData + AvatarCostFunctorCache  (AvatarOptimizer.cpp:249-347, :505-582)
+// ------------------------------------------------------------------------------------------------
+struct Common {
+    const orc_model& m;
+    int nJS;  // numJointSpaces = J + 1
+    std::vector<M3> _R;
+    std::vector<V3> _t;
+    std::vector<double> shapedCloud;   // 3V (root-subtracted)
+    std::vector<double> jointPosInit;  // 3J
+    std::vector<double> jointVecInit;  // 3J
+    std::vector<double> localJacobian; // J x (4x3 row-major)
+    std::vector<double> H;             // J x 3 x K
+    explicit Common(const orc_model& mm) : m(mm), nJS(mm.J + 1) {
+        _R.resize((size_t)nJS * nJS);
+        _t.resize((size_t)nJS * nJS);
+        shapedCloud.resize(3 * m.V);
+        jointPosInit.resize(3 * m.J);
+        jointVecInit.resize(3 * m.J);
+        localJacobian.resize((size_t)m.J * 12);
+        H.assign((size_t)m.J * 3 * m.K, 0.0);
+    }
+    M3& R(int ja, int j) { return _R[(size_t)nJS * (ja + 1) + j + 1]; }
+    V3& t(int ja, int j) { return _t[(size_t)nJS * (ja + 1) + j + 1]; }
+
+    void CalcShape(const double* w) {  // :249-281
+        const int V = m.V, J = m.J, K = m.K;
+        for (int i = 0; i < 3 * V; ++i) {
+            double s = 0.0;
+            for (int k = 0; k < K; ++k) s += m.keys[(size_t)k * 3 * V + i] * w[k];
+            shapedCloud[i] = s + m.base[i];
+        }
+        for (int i = 0; i < 3 * J; ++i) {
+            double s = 0.0;
+            for (int k = 0; k < K; ++k) s += m.jointShapeReg[(size_t)k * 3 * J + i] * w[k];
+            jointPosInit[i] = m.initialJointPos[i] + s;
+        }
+        const double off[3] = {jointPosInit[0], jointPosInit[1], jointPosInit[2]};
+        for (int v = 0; v < V; ++v)
+            for (int c = 0; c < 3; ++c) shapedCloud[3 * v + c] -= off[c];
+        for (int j = 0; j < J; ++j)
+            for (int c = 0; c < 3; ++c) jointPosInit[3 * j + c] -= off[c];
+        jointVecInit = jointPosInit;
+        for (int i = J - 1; i >= 1; --i)
+            for (int c = 0; c < 3; ++c) jointVecInit[3 * i + c] -= jointVecInit[3 * m.parent[i] + c];
+        // NB: the loop above runs children-first on a topologically sorted tree, so parents are still
+        // absolute when subtracted — identical to the reference.
+    }
+
+    void Prepare(const double* p, const double* q /*4J*/, const double* w) {  // :283-325
+        const int J = m.J, K = m.K;
+        CalcShape(w);
+        for (int c = 0; c < 3; ++c) jointVecInit[c] = p[c];
+        for (int i = 0; i < J; ++i) {
+            const double* x = q + 4 * i;
+            double* lj = &localJacobian[(size_t)i * 12];
+            lj[0] = x[3];  lj[1] = x[2];  lj[2] = -x[1];
+            lj[3] = -x[2]; lj[4] = x[3];  lj[5] = x[0];
+            lj[6] = x[1];  lj[7] = -x[0]; lj[8] = x[3];
+            lj[9] = -x[0]; lj[10] = -x[1]; lj[11] = -x[2];
+        }
+        R(-1, -1) = m3_identity();
+        t(-1, -1) = V3{{0, 0, 0}};
+        for (int i = 0; i < J; ++i) {
+            R(i, i) = m3_identity();
+            const M3 rot = quat_to_rot(q + 4 * i);
+            t(i, i) = V3{{0, 0, 0}};
+            const int pa = m.parent[i];
+            const V3 jv{{jointVecInit[3 * i], jointVecInit[3 * i + 1], jointVecInit[3 * i + 2]}};
+            for (int j = pa;; j = m.parent[j]) {
+                R(j, i) = mul(R(j, pa), rot);
+                t(j, i) = add(mul(R(j, pa), jv), t(j, pa));
+                if (j == -1) break;
+            }
+        }
+        for (int j = 1; j < J; ++j) {
+            const M3& Rp = R(-1, m.parent[j]);
+            for (int c = 0; c < 3; ++c)
+                for (int k = 0; k < K; ++k) {
+                    double s = 0.0;
+                    for (int e = 0; e < 3; ++e) s += Rp.a[c][e] * m.Sp[((size_t)j * 3 + e) * K + k];
+                    H[((size_t)j * 3 + c) * K + k] = s + H[((size_t)m.parent[j] * 3 + c) * K + k];
+                }
+        }
+    }
+
+    // AvatarCostFunctorCache::updateData (:505-582).  Outputs: x (3), per-ancestor 3x3 row-major blocks,
+    // 3xK row-major shape block.
+    void pointData(const double* q, int pointId, bool jac, double* x, double* blocks, double* shapeBlock) {
+        const int K = m.K, V = m.V;
+        const V3 ppi{{shapedCloud[3 * pointId], shapedCloud[3 * pointId + 1], shapedCloud[3 * pointId + 2]}};
+        V3 resid{{0, 0, 0}};
+        for (auto& as : m.assigned[pointId]) {
+            const int k = as.second;
+            const V3 jk{{jointPosInit[3 * k], jointPosInit[3 * k + 1], jointPosInit[3 * k + 2]}};
+            resid = add(resid, scale(add(mul(R(-1, k), sub(ppi, jk)), t(-1, k)), as.first));
+        }
+        x[0] = resid.v[0]; x[1] = resid.v[1]; x[2] = resid.v[2];
+        if (!jac) return;
+        const auto& anc = m.ancestor[pointId];
+        for (size_t i = 0; i < anc.size(); ++i) {
+            const Ancestor& an = anc[i];
+            const int j = an.jid;
+            V3 v{{0, 0, 0}};
+            for (int a = 0; a < an.num_assign; ++a) {
+                const int k = an.assign[a];
+                const V3 jk{{jointPosInit[3 * k], jointPosInit[3 * k + 1], jointPosInit[3 * k + 2]}};
+                v = add(v, scale(add(mul(R(j, k), sub(ppi, jk)), t(j, k)), an.weight[a]));
+            }
+            const double* qq = q + 4 * j;
+            const double u0 = qq[0] * 2, u1 = qq[1] * 2, u2 = qq[2] * 2, ww = qq[3] * 2;
+            const double v0 = v.v[0], v1 = v.v[1], v2 = v.v[2];
+            double dRot[3][4];
+            dRot[0][0] = u1 * v1 + v2 * u2;
+            dRot[0][1] = ww * v2 + u0 * v1 - 2 * u1 * v0;
+            dRot[0][2] = -ww * v1 - 2 * v0 * u2 + u0 * v2;
+            dRot[0][3] = u1 * v2 - v1 * u2;
+            dRot[1][0] = -ww * v2 - 2 * u0 * v1 + v0 * u1;
+            dRot[1][1] = v2 * u2 + u0 * v0;
+            dRot[1][2] = ww * v0 + u1 * v2 - 2 * v1 * u2;
+            dRot[1][3] = v0 * u2 - u0 * v2;
+            dRot[2][0] = ww * v1 + v0 * u2 - 2 * u0 * v2;
+            dRot[2][1] = -ww * v0 - 2 * u1 * v2 + v1 * u2;
+            dRot[2][2] = u0 * v0 + v1 * u1;
+            dRot[2][3] = u0 * v1 - v0 * u1;
+            const M3& Rp = R(-1, m.parent[j]);
+            const double* lj = &localJacobian[(size_t)j * 12];
+            double tmp[3][4];
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 4; ++c) tmp[r][c] = Rp.a[r][0] * dRot[0][c] + Rp.a[r][1] * dRot[1][c] + Rp.a[r][2] * dRot[2][c];
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c)
+                    blocks[i * 9 + r * 3 + c] = tmp[r][0] * lj[c] + tmp[r][1] * lj[3 + c] + tmp[r][2] * lj[6 + c] + tmp[r][3] * lj[9 + c];
+        }
+        for (int e = 0; e < 3 * K; ++e) shapeBlock[e] = 0.0;
+        for (auto& as : m.assigned[pointId]) {
+            const int j = as.second;
+            const M3& Rj = R(-1, j);
+            for (int r = 0; r < 3; ++r)
+                for (int k = 0; k < K; ++k) {
+                    double s = 0.0;
+                    for (int e = 0; e < 3; ++e)
+                        s += Rj.a[r][e] * (m.keys[(size_t)k * 3 * V + 3 * pointId + e] - m.S[((size_t)j * 3 + e) * K + k]);
+                    shapeBlock[r * K + k] += (s + H[((size_t)j * 3 + r) * K + k]) * as.first;
+                }
+        }
+    }
+};
+
+// smplParams from quaternions (AvatarOptimizer.cpp:664-669)
+void pose_params(const orc_model& m, const double* q, double* x) {
+    for (int i = 0; i < m.J - 1; ++i) {
+        double ang, ax[3];
+        quat_to_angle_axis(q + 4 * (i + 1), &ang, ax);
+        x[3 * i] = ax[0] * ang; x[3 * i + 1] = ax[1] * ang; x[3 * i + 2] = ax[2] * ang;
+    }
+}
+
+// GaussianMixture::residual (GaussianMixture.cpp:95-114); out has nDims+1 entries
+int gmm_residual(const Gmm& g, const double* x, double* out) {
+    const int n = g.nDims;
+    double bestProb = std::numeric_limits<double>::max();
+    int best = -1;
+    std::vector<double> r(n + 1), d(n);
+    for (int c = 0; c < g.nComps; ++c) {
+        const double* L = g.prec_cho[c].data();
+        for (int i = 0; i < n; ++i) d[i] = x[i] - g.mean[(size_t)c * n + i];
+        double sq = 0.0;
+        for (int i = 0; i < n; ++i) {  // (L^T d)_i = sum_{k>=i} L[k][i] d[k]
+            double s = 0.0;
+            for (int k = i; k < n; ++k) s += L[(size_t)k * n + i] * d[k];
+            r[i] = s * std::sqrt(0.5);
+            sq += r[i] * r[i];
+        }
+        r[n] = 0.0;
+        const double pr = sq - g.consts_log[c];
+        if (pr < bestProb) {
+            bestProb = pr;
+            r[n] = std::sqrt(-g.consts_log[c]);
+            std::copy(r.begin(), r.end(), out);
+            best = c;
+        }
+    }
+    return best;
+}
+
+struct EvalOut {
+    double cost = 0.0;
+    std::vector<double> g, H;  // P ; P x P row-major (full symmetric)
+    int comp = -1;
+};
+
+struct Corr {
+    std::vector<int> matched;               // model points with >=1 correspondence, ascending
+    std::vector<std::vector<int>> lists;    // data indices per matched model point (ascending i)
+    size_t total = 0;
+};
+
+void build_corr(const orc_model& m, const int* idx, int N, Corr& c) {
+    std::vector<std::vector<int>> all(m.V);
+    for (int i = 0; i < N; ++i)
+        if (idx[i] >= 0) all[idx[i]].push_back(i);
+    c.matched.clear(); c.lists.clear(); c.total = 0;
+    for (int v = 0; v < m.V; ++v)
+        if (!all[v].empty()) {
+            c.total += all[v].size();
+            c.matched.push_back(v);
+            c.lists.push_back(std::move(all[v]));
+        }
+}
+
+// One cost/Jacobian evaluation with the reference's problem structure (AvatarOptimizer.cpp:1405-1474):
+// one 3-residual block per (model point, data point) pair, pose prior, shape prior; accumulated into the
+// Gauss-Newton normal equations H = J^T J, g = J^T r and cost = 1/2 sum r^2.
+//   aggregate == 0: every residual block accumulated separately (reference structure);
+//   aggregate == 1: blocks sharing a model point folded as c*J^T J and J^T(c*x - sum d) (exact algebra).
+void evaluate(const orc_model& m, Common& cm, const double* p, const double* q, const double* w, const Corr& corr,
+              const double* data, double betaPose, double betaShape, bool wantJac, int aggregate, int nthreads,
+              EvalOut& out) {
+    const int J = m.J, K = m.K, P = m.P;
+    cm.Prepare(p, q, w);
+    out.g.assign(P, 0.0);
+    out.H.assign((size_t)P * P, 0.0);
+    const size_t M = corr.matched.size();
+    nthreads = std::max(1, std::min<int>(nthreads, (int)std::max<size_t>(1, M / 64)));
+    std::vector<double> costs(nthreads, 0.0);
+    std::vector<std::vector<double>> gs(nthreads), Hs(nthreads);
+    auto worker = [&](int tid) {
+        std::vector<double>& g = gs[tid];
+        std::vector<double>& H = Hs[tid];
+        g.assign(P, 0.0);
+        if (wantJac) H.assign((size_t)P * P, 0.0);
+        double cost = 0.0;
+        std::vector<double> blocks(9 * (size_t)J), shapeBlock(3 * (size_t)K);
+        std::vector<int> cols(P);
+        std::vector<double> Jc(3 * (size_t)P);
+        const size_t lo = M * tid / nthreads, hi = M * (tid + 1) / nthreads;
+        for (size_t ci = lo; ci < hi; ++ci) {
+            const int pt = corr.matched[ci];
+            double x[3];
+            cm.pointData(q, pt, wantJac, x, blocks.data(), shapeBlock.data());
+            const auto& lst = corr.lists[ci];
+            int nc = 0;
+            if (wantJac) {
+                for (int c = 0; c < 3; ++c) {
+                    cols[nc] = c;
+                    for (int r = 0; r < 3; ++r) Jc[(size_t)r * P + nc] = (r == c) ? 1.0 : 0.0;
+                    ++nc;
+                }
+                const auto& anc = m.ancestor[pt];
+                for (size_t a = 0; a < anc.size(); ++a)
+                    for (int c = 0; c < 3; ++c) {
+                        cols[nc] = 3 + 3 * anc[a].jid + c;
+                        for (int r = 0; r < 3; ++r) Jc[(size_t)r * P + nc] = blocks[a * 9 + r * 3 + c];
+                        ++nc;
+                    }
+                for (int k = 0; k < K; ++k) {
+                    cols[nc] = 3 + 3 * J + k;
+                    for (int r = 0; r < 3; ++r) Jc[(size_t)r * P + nc] = shapeBlock[r * K + k];
+                    ++nc;
+                }
+            }
+            if (!aggregate) {
+                for (int di : lst) {
+                    const double r3[3] = {x[0] - data[3 * di], x[1] - data[3 * di + 1], x[2] - data[3 * di + 2]};
+                    cost += r3[0] * r3[0] + r3[1] * r3[1] + r3[2] * r3[2];
+                    if (!wantJac) continue;
+                    for (int a = 0; a < nc; ++a) {
+                        const double ja0 = Jc[a], ja1 = Jc[(size_t)P + a], ja2 = Jc[2 * (size_t)P + a];
+                        g[cols[a]] += ja0 * r3[0] + ja1 * r3[1] + ja2 * r3[2];
+                        double* Hrow = &H[(size_t)cols[a] * P];
+                        for (int b = a; b < nc; ++b)
+                            Hrow[cols[b]] += ja0 * Jc[b] + ja1 * Jc[(size_t)P + b] + ja2 * Jc[2 * (size_t)P + b];
+                    }
+                }
+            } else {
+                double s[3] = {0, 0, 0};
+                for (int di : lst) {
+                    const double r3[3] = {x[0] - data[3 * di], x[1] - data[3 * di + 1], x[2] - data[3 * di + 2]};
+                    cost += r3[0] * r3[0] + r3[1] * r3[1] + r3[2] * r3[2];
+                    s[0] += data[3 * di]; s[1] += data[3 * di + 1]; s[2] += data[3 * di + 2];
+                }
+                if (wantJac) {
+                    const double cnt = (double)lst.size();
+                    const double r3[3] = {cnt * x[0] - s[0], cnt * x[1] - s[1], cnt * x[2] - s[2]};
+                    for (int a = 0; a < nc; ++a) {
+                        const double ja0 = Jc[a], ja1 = Jc[(size_t)P + a], ja2 = Jc[2 * (size_t)P + a];
+                        g[cols[a]] += ja0 * r3[0] + ja1 * r3[1] + ja2 * r3[2];
+                        double* Hrow = &H[(size_t)cols[a] * P];
+                        const double c0 = cnt * ja0, c1 = cnt * ja1, c2 = cnt * ja2;
+                        for (int b = a; b < nc; ++b)
+                            Hrow[cols[b]] += c0 * Jc[b] + c1 * Jc[(size_t)P + b] + c2 * Jc[2 * (size_t)P + b];
+                    }
+                }
+            }
+        }
+        costs[tid] = cost;
+    };
+    if (nthreads == 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker, t);
+        for (auto& th : pool) th.join();
+    }
+    double cost = 0.0;
+    for (int t = 0; t < nthreads; ++t) {
+        cost += costs[t];
+        for (int i = 0; i < P; ++i) out.g[i] += gs[t][i];
+        if (wantJac)
+            for (size_t i = 0; i < (size_t)P * P; ++i) out.H[i] += Hs[t][i];
+    }
+    // prior weights rescaled by sqrt(totalResiduals)/15 (:1457-1458)
+    const double sbp = betaPose * std::sqrt((double)corr.total) / 15.0;
+    const double sbs = betaShape * std::sqrt((double)corr.total) / 15.0;
+    out.comp = -1;
+    if (betaPose > 0.0 && m.prior.nComps > 0) {  // :1465, AvatarPosePriorCostFunctor :647-696
+        const int n = m.prior.nDims;
+        std::vector<double> xs(n), res(n + 1);
+        pose_params(m, q, xs.data());
+        const int comp = gmm_residual(m.prior, xs.data(), res.data());
+        out.comp = comp;
+        for (int i = 0; i <= n; ++i) {
+            res[i] *= sbp;
+            cost += res[i] * res[i];
+        }
+        if (wantJac) {
+            const double* L = m.prior.prec_cho[comp].data();
+            const double sc = 0.707106781186548 * sbp;  // literal constant of the reference (:684)
+            // J[r][a] = L[a][r]*sc for r,a < n (joint i's 3 columns are tangent cols 6+3i..), last row 0
+            for (int a = 0; a < n; ++a) {
+                double s = 0.0;
+                for (int r = 0; r <= a; ++r) s += (L[(size_t)a * n + r] * sc) * res[r];
+                out.g[6 + a] += s;
+                for (int b = a; b < n; ++b) {
+                    double h = 0.0;
+                    for (int r = 0; r <= a; ++r) h += (L[(size_t)a * n + r] * sc) * (L[(size_t)b * n + r] * sc);
+                    out.H[(size_t)(6 + a) * P + 6 + b] += h;
+                }
+            }
+        }
+    }
+    if (betaShape > 0.0) {  // :1469, AvatarShapePriorCostFunctor :700-726
+        for (int k = 0; k < K; ++k) {
+            const double r = w[k] * sbs;
+            cost += r * r;
+            if (wantJac) {
+                out.g[3 + 3 * J + k] += sbs * r;
+                out.H[(size_t)(3 + 3 * J + k) * P + 3 + 3 * J + k] += sbs * sbs;
+            }
+        }
+    }
+    out.cost = 0.5 * cost;
+    if (wantJac)
+        for (int a = 0; a < P; ++a)
+            for (int b = a + 1; b < P; ++b) out.H[(size_t)b * P + a] = out.H[(size_t)a * P + b];
+}
+
+// FakeQuaternionParameterization::Plus (:123-143) + plain addition for p and w
+void retract(const orc_model& m, const double* p, const double* q, const double* w, const double* delta, double* p2,
+             double* q2, double* w2) {
+    for (int c = 0; c < 3; ++c) p2[c] = p[c] + delta[c];
+    for (int j = 0; j < m.J; ++j) {
+        const double* d = delta + 3 + 3 * j;
+        const double nd = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        if (nd > 0.0) {
+            const double s = std::sin(nd) / nd;
+            const double dq[4] = {s * d[0], s * d[1], s * d[2], std::cos(nd)};
+            quat_mul(dq, q + 4 * j, q2 + 4 * j);
+        } else {
+            for (int c = 0; c < 4; ++c) q2[4 * j + c] = q[4 * j + c];
+        }
+    }
+    for (int k = 0; k < m.K; ++k) w2[k] = w[k] + delta[3 + 3 * m.J + k];
+}
+
+// solve (H + lambda*diag(H)) delta = -g by Cholesky; false if not positive definite
+bool lm_solve(const double* H, const double* g, int P, double lambda, double* delta) {
+    std::vector<double> A((size_t)P * P), L((size_t)P * P), y(P);
+    for (int i = 0; i < P; ++i)
+        for (int j = 0; j < P; ++j) A[(size_t)i * P + j] = H[(size_t)i * P + j];
+    for (int i = 0; i < P; ++i) A[(size_t)i * P + i] = H[(size_t)i * P + i] + lambda * H[(size_t)i * P + i];
+    if (!cholesky_lower(A.data(), P, L.data())) return false;
+    for (int i = 0; i < P; ++i) {
+        double s = -g[i];
+        for (int k = 0; k < i; ++k) s -= L[(size_t)i * P + k] * y[k];
+        y[i] = s / L[(size_t)i * P + i];
+    }
+    for (int i = P - 1; i >= 0; --i) {
+        double s = y[i];
+        for (int k = i + 1; k < P; ++k) s -= L[(size_t)k * P + i] * delta[k];
+        delta[i] = s / L[(size_t)i * P + i];
+    }
+    return true;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C API (ctypes)
+// ================================================================================================
+extern "C" {
+
+orc_model* orc_model_create(const avt_model_desc* d) {
+    orc_model* m = new orc_model();
+    m->V = d->num_points; m->J = d->num_joints; m->K = d->num_shape_keys; m->F = d->num_faces;
+    m->P = 3 + 3 * m->J + m->K;
+    m->base.assign(d->base_cloud, d->base_cloud + 3 * (size_t)m->V);
+    m->keys.assign(d->key_clouds, d->key_clouds + 3 * (size_t)m->V * m->K);
+    m->parent.assign(d->parent, d->parent + m->J);
+    m->mesh.assign(d->mesh, d->mesh + 3 * (size_t)m->F);
+    m->wcol.assign(d->weights_colptr, d->weights_colptr + m->V + 1);
+    m->wrow.assign(d->weights_row, d->weights_row + m->wcol[m->V]);
+    m->wval.assign(d->weights_val, d->weights_val + m->wcol[m->V]);
+    build_model_derived(*m, *d);
+    return m;
+}
+void orc_model_destroy(orc_model* m) { delete m; }
+
+void orc_model_joint_regression(const orc_model* m, double* ijp, double* jsr) {
+    std::memcpy(ijp, m->initialJointPos.data(), sizeof(double) * 3 * m->J);
+    std::memcpy(jsr, m->jointShapeReg.data(), sizeof(double) * 3 * (size_t)m->J * m->K);
+}
+void orc_model_main_joint(const orc_model* m, int* out) {
+    for (int v = 0; v < m->V; ++v) out[v] = m->assigned[v][0].second;
+}
+int orc_model_num_ancestors(const orc_model* m, int point) { return (int)m->ancestor[point].size(); }
+void orc_model_ancestors(const orc_model* m, int point, int* jids) {
+    for (size_t i = 0; i < m->ancestor[point].size(); ++i) jids[i] = m->ancestor[point][i].jid;
+}
+
+void orc_update(const orc_model* m, const double* w, const double* p, const double* R, double* cloud, double* jointPos,
+                double* jointTrans) {
+    avatar_update(*m, w, p, R, cloud, jointPos, jointTrans);
+}
+void orc_visibility(const orc_model* m, const double* cloud, int enable, unsigned char* vis) {
+    visibility(*m, cloud, enable, vis);
+}
+void orc_nn(const orc_model* m, int num_parts, const int* part_map, const double* modelCloud, const unsigned char* vis,
+            const double* data, const int* labels, int N, int* out) {
+    std::vector<std::vector<int>> partIdx;
+    model_part_indices(*m, part_map, num_parts, partIdx);
+    find_nn(*m, partIdx, modelCloud, vis, data, labels, N, out);
+}
+
+// rotation <-> quaternion as optimize() does it (AvatarOptimizer.cpp:1250-1254, :1494-1496)
+void orc_rot_to_quat(const double* Rcm, double* q) {
+    M3 r;
+    for (int c = 0; c < 3; ++c)
+        for (int rr = 0; rr < 3; ++rr) r.a[rr][c] = Rcm[3 * c + rr];
+    double raw[4], ang, ax[3];
+    rot_to_quat_raw(r, raw);
+    quat_to_angle_axis(raw, &ang, ax);
+    angle_axis_to_quat(ang, ax, q);
+}
+void orc_quat_to_rot(const double* q, double* Rcm) {
+    const M3 r = quat_to_rot(q);
+    for (int c = 0; c < 3; ++c)
+        for (int rr = 0; rr < 3; ++rr) Rcm[3 * c + rr] = r.a[rr][c];
+}
+void orc_retract(const orc_model* m, const double* p, const double* q, const double* w, const double* delta, double* p2,
+                 double* q2, double* w2) {
+    retract(*m, p, q, w, delta, p2, q2, w2);
+}
+
+// model-point position + dense 3xP Jacobian row block (row-major) at (p,q,w); for FD / known-answer tests
+void orc_point_jacobian(const orc_model* m, const double* p, const double* q, const double* w, int point, double* x,
+                        double* Jdense) {
+    Common cm(*m);
+    cm.Prepare(p, q, w);
+    std::vector<double> blocks(9 * (size_t)m->J), sb(3 * (size_t)m->K);
+    cm.pointData(q, point, true, x, blocks.data(), sb.data());
+    const int P = m->P;
+    std::fill(Jdense, Jdense + 3 * (size_t)P, 0.0);
+    for (int c = 0; c < 3; ++c) Jdense[(size_t)c * P + c] = 1.0;
+    const auto& anc = m->ancestor[point];
+    for (size_t a = 0; a < anc.size(); ++a)
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) Jdense[(size_t)r * P + 3 + 3 * anc[a].jid + c] = blocks[a * 9 + r * 3 + c];
+    for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < m->K; ++k) Jdense[(size_t)r * P + 3 + 3 * m->J + k] = sb[r * m->K + k];
+}
+
+// all model-point positions through the optimiser's forward model (updateData :505-514)
+void orc_points(const orc_model* m, const double* p, const double* q, const double* w, double* cloud) {
+    Common cm(*m);
+    cm.Prepare(p, q, w);
+    for (int v = 0; v < m->V; ++v) cm.pointData(q, v, false, cloud + 3 * v, nullptr, nullptr);
+}
+
+// pose-prior residual (nDims+1, unscaled) and chosen component (GaussianMixture.cpp:95-114)
+int orc_pose_prior_residual(const orc_model* m, const double* q, double* x_out, double* res_out) {
+    if (m->prior.nComps <= 0) return -1;
+    std::vector<double> x(m->prior.nDims);
+    pose_params(*m, q, x.data());
+    if (x_out) std::copy(x.begin(), x.end(), x_out);
+    return gmm_residual(m->prior, x.data(), res_out);
+}
+void orc_prior_factors(const orc_model* m, int comp, double* prec_cho, double* consts_log) {
+    std::copy(m->prior.prec_cho[comp].begin(), m->prior.prec_cho[comp].end(), prec_cho);
+    *consts_log = m->prior.consts_log[comp];
+}
+
+// cost, gradient and GN normal equations for given correspondences
+void orc_evaluate(const orc_model* m, const double* p, const double* q, const double* w, const int* corr_idx,
+                  const double* data, int N, double betaPose, double betaShape, int aggregate, int nthreads,
+                  double* cost, double* g, double* H, int* comp) {
+    Common cm(*m);
+    Corr corr;
+    build_corr(*m, corr_idx, N, corr);
+    EvalOut eo;
+    evaluate(*m, cm, p, q, w, corr, data, betaPose, betaShape, true, aggregate, nthreads, eo);
+    *cost = eo.cost;
+    if (g) std::copy(eo.g.begin(), eo.g.end(), g);
+    if (H) std::copy(eo.H.begin(), eo.H.end(), H);
+    if (comp) *comp = eo.comp;
+}
+
+// AvatarOptimizer::optimize() (AvatarOptimizer.cpp:1246-1517) with the Ceres BFGS solve (:1486) replaced by
+// the damped Gauss-Newton schedule of DESIGN.md "step rule".
+//   trace_cost (optional): icp_iters*(max_iters+1) doubles: cost at entry then after every GN iteration
+//   trace_acc  (optional): icp_iters*max_iters ints: 1 accepted / 0 rejected / -1 Cholesky failure
+//   corr_out   (optional): N ints: correspondences of the last ICP iteration
+//   cloud_out  (optional): 3V doubles: ava.cloud after the final update()
+int orc_optimize(const orc_model* m, int num_parts, const int* part_map, const double* data, const int* labels, int N,
+                 const avt_options* o, int aggregate, int nthreads, double* p, double* q, double* w, avt_stats* st,
+                 double* trace_cost, int* trace_acc, int* corr_out, double* cloud_out) {
+    const int V = m->V, J = m->J, K = m->K, P = m->P;
+    std::vector<std::vector<int>> partIdx;
+    model_part_indices(*m, part_map, num_parts, partIdx);
+    Common cm(*m);
+    std::vector<double> cloud(3 * (size_t)V), Rcm(9 * (size_t)J);
+    std::vector<unsigned char> vis(V);
+    std::vector<int> idx(N);
+    std::vector<double> p2(3), q2(4 * (size_t)J), w2(K), delta(P);
+    auto do_update = [&]() {
+        for (int j = 0; j < J; ++j) orc_quat_to_rot(q + 4 * j, &Rcm[9 * (size_t)j]);
+        avatar_update(*m, w, p, Rcm.data(), cloud.data(), nullptr, nullptr);
+    };
+    do_update();  // precondition of optimize(): ava.cloud is current (:1356,:1390)
+    double lambda = o->lm_lambda0;
+    avt_stats s{};
+    for (int icp = 0; icp < o->icp_iters; ++icp) {
+        visibility(*m, cloud.data(), o->enable_occlusion, vis.data());
+        find_nn(*m, partIdx, cloud.data(), vis.data(), data, labels, N, idx.data());
+        Corr corr;
+        build_corr(*m, idx.data(), N, corr);
+        s.num_correspondences = (int)corr.total;
+        s.matched_model_points = (int)corr.matched.size();
+        EvalOut cur, tr;
+        evaluate(*m, cm, p, q, w, corr, data, o->beta_pose, o->beta_shape, true, aggregate, nthreads, cur);
+        s.initial_cost = cur.cost;
+        if (trace_cost) trace_cost[(size_t)icp * (o->max_iters_per_icp + 1)] = cur.cost;
+        for (int it = 0; it < o->max_iters_per_icp; ++it) {
+            int acc = 0;
+            if (corr.total > 0 && lm_solve(cur.H.data(), cur.g.data(), P, lambda, delta.data())) {
+                retract(*m, p, q, w, delta.data(), p2.data(), q2.data(), w2.data());
+                evaluate(*m, cm, p2.data(), q2.data(), w2.data(), corr, data, o->beta_pose, o->beta_shape, true, aggregate,
+                         nthreads, tr);
+                if (tr.cost < cur.cost) {
+                    acc = 1;
+                    std::copy(p2.begin(), p2.end(), p);
+                    std::copy(q2.begin(), q2.end(), q);
+                    std::copy(w2.begin(), w2.end(), w);
+                    std::swap(cur, tr);
+                    lambda = std::max(lambda * o->lm_down, o->lm_lambda_min);
+                    ++s.accepted_steps;
+                } else {
+                    lambda = std::min(lambda * o->lm_up, o->lm_lambda_max);
+                }
+            } else {
+                acc = -1;
+                lambda = std::min(lambda * o->lm_up, o->lm_lambda_max);
+            }
+            ++s.gn_iterations;
+            if (trace_acc) trace_acc[(size_t)icp * o->max_iters_per_icp + it] = acc;
+            if (trace_cost) trace_cost[(size_t)icp * (o->max_iters_per_icp + 1) + it + 1] = cur.cost;
+        }
+        s.final_cost = cur.cost;
+        do_update();  // :1494-1497
+    }
+    s.lambda = lambda;
+    if (st) *st = s;
+    if (corr_out) std::copy(idx.begin(), idx.end(), corr_out);
+    if (cloud_out) std::copy(cloud.begin(), cloud.end(), cloud_out);
+    return 0;
+}
+
+}  // extern "C"
