@@ -244,7 +244,9 @@ class Context:
         _check(self._lib.avt_get_normal_equations(self.h, C.c_int(frame), dptr(H), dptr(g), C.byref(cost)))
         return H, g, cost.value
 
-    def profile_begin(self):
+    def profile_begin(self, classes=None):
+        mask = 0xffffffff if classes is None else sum(1 << capi.AVT_K_NAMES.index(c) for c in classes)
+        _check(self._lib.avt_profile_select(self.h, C.c_uint(mask)))
         _check(self._lib.avt_profile_begin(self.h))
 
     def profile_end(self):

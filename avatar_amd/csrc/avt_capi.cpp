@@ -39,7 +39,7 @@ int choose_G(int nframes) { return std::max(2, std::min(64, 512 / std::max(1, nf
 hipEvent_t next_event(avt_ctx* c) {
     if (c->event_pool_used == c->event_pool.size()) {
         hipEvent_t e;
-        hipEventCreate(&e);
+        (void)hipEventCreate(&e);
         c->event_pool.push_back(e);
     }
     return c->event_pool[c->event_pool_used++];
@@ -49,11 +49,13 @@ struct ProfScope {
     avt_ctx* c;
     int cls;
     hipEvent_t a, b;
+    bool on;
     ProfScope(avt_ctx* c_, int cls_) : c(c_), cls(cls_) {
-        if (c->profiling) { a = next_event(c); b = next_event(c); hipEventRecord(a, c->stream); }
+        on = c->profiling && ((c->prof_mask >> cls_) & 1u);
+        if (on) { a = next_event(c); b = next_event(c); (void)hipEventRecord(a, c->stream); }
     }
     ~ProfScope() {
-        if (c->profiling) { hipEventRecord(b, c->stream); c->prof_events.push_back({cls, {a, b}}); }
+        if (on) { (void)hipEventRecord(b, c->stream); c->prof_events.push_back({cls, {a, b}}); }
     }
 };
 
@@ -177,6 +179,7 @@ int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* par
     c->device = device;
     c->model = m;
     c->profiling = false;
+    c->prof_mask = 0xffffffffu;
     c->event_pool_used = 0;
     c->nframes = 0;
     c->ran_icp_iters = 0;
@@ -397,6 +400,12 @@ int avt_profile_begin(avt_ctx* c) {
     c->profiling = true;
     c->prof_events.clear();
     c->event_pool_used = 0;
+    return 0;
+}
+
+int avt_profile_select(avt_ctx* c, unsigned mask) {
+    if (!c) { avt_set_error("avt_profile_select: null context"); return 1; }
+    c->prof_mask = mask;
     return 0;
 }
 

@@ -151,6 +151,7 @@ struct avt_ctx {
     int nframes;                     // frames currently resident
     std::vector<int> frame_N, frame_off;
     bool profiling;
+    unsigned prof_mask;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
     std::vector<hipEvent_t> event_pool;
     size_t event_pool_used;

@@ -156,6 +156,8 @@ int avt_get_cloud(avt_ctx* c, int frame, double* cloud_3xV);       /* ava.cloud 
 int avt_get_normal_equations(avt_ctx* c, int frame, double* H /* P x P */, double* g /* P */, double* cost);
 
 int avt_profile_begin(avt_ctx* c);
+/* restrict event insertion to the kernel classes in `mask` (bit k = class k); default: all classes */
+int avt_profile_select(avt_ctx* c, unsigned mask);
 int avt_profile_end(avt_ctx* c, avt_profile* out);
 
 #ifdef __cplusplus
