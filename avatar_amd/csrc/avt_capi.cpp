@@ -2,11 +2,14 @@
 // sequence of AvatarOptimizer::optimize() (AvatarOptimizer.cpp:1246-1517).  Compiled with hipcc (host only).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "avt_internal.h"
 
 int avt_solve_set_attributes();
+int avt_eval_set_attributes();
 
 #define HIP_OK(expr)                                                                          \
     do {                                                                                      \
@@ -34,7 +37,7 @@ int dev_upload(avt_ctx* c, T** p, const std::vector<T>& v) {
     return 0;
 }
 
-int choose_G(int nframes) { return std::max(2, std::min(64, 512 / std::max(1, nframes))); }
+int choose_G(int nframes) { return std::max(2, std::min(128, 512 / std::max(1, nframes))); }
 
 hipEvent_t next_event(avt_ctx* c) {
     if (c->event_pool_used == c->event_pool.size()) {
@@ -66,13 +69,9 @@ int check_launch(const char* what) {
 }
 
 // the launch sequence of one optimize() over the resident frames
-int run_optimize(avt_ctx* c, const avt_options* o) {
+void enqueue_optimize(avt_ctx* c, const avt_options* o) {
     const int nf = c->nframes;
-    if (nf <= 0) { avt_set_error("avt_optimize: no frames resident"); return 1; }
-    if (o->max_iters_per_icp < 0 || o->max_iters_per_icp > 62 || o->icp_iters < 0) { avt_set_error("avt_optimize: bad iteration counts"); return 1; }
-    c->fb.G = choose_G(nf);
     c->ran_icp_iters = 0;
-    c->ran_max_iters = o->max_iters_per_icp;
     { ProfScope ps(c, AVT_K_BUCKET); launch_bucket(c, nf); }
     { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 1); }   // ava.update() precondition (:1356)
     for (int icp = 0; icp < o->icp_iters; ++icp) {
@@ -92,7 +91,37 @@ int run_optimize(avt_ctx* c, const avt_options* o) {
         { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 1); }   // :1494-1497
         c->ran_icp_iters++;
     }
-    return check_launch("optimize launch sequence");
+}
+
+int run_optimize(avt_ctx* c, const avt_options* o) {
+    const int nf = c->nframes;
+    if (nf <= 0) { avt_set_error("avt_optimize: no frames resident"); return 1; }
+    if (o->max_iters_per_icp < 0 || o->max_iters_per_icp > 62 || o->icp_iters < 0) { avt_set_error("avt_optimize: bad iteration counts"); return 1; }
+    c->fb.G = choose_G(nf);
+    c->ran_max_iters = o->max_iters_per_icp;
+    if (!c->use_graph || c->profiling) {
+        enqueue_optimize(c, o);
+        return check_launch("optimize launch sequence");
+    }
+    // The launch sequence depends only on (nframes, grid sizes, options): capture it once, replay it afterwards.
+    char key[256];
+    snprintf(key, sizeof key, "%d|%d|%d|%d|%d|%.17g|%.17g|%.17g|%.17g|%.17g|%.17g|%.17g", nf, c->launch_maxN, o->icp_iters,
+             o->max_iters_per_icp, o->enable_occlusion, o->beta_pose, o->beta_shape, o->lm_lambda0, o->lm_up, o->lm_down,
+             o->lm_lambda_min, o->lm_lambda_max);
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        enqueue_optimize(c, o);
+        HIP_OK(hipStreamEndCapture(c->stream, &graph));
+        HIP_OK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        HIP_OK(hipGraphDestroy(graph));
+        it = c->graphs.emplace(key, exec).first;
+    }
+    HIP_OK(hipGraphLaunch(it->second, c->stream));
+    c->ran_icp_iters = o->icp_iters;
+    return 0;
 }
 
 int upload_frames(avt_ctx* c, int nframes, const double* data, const int* labels, const int* offs) {
@@ -100,6 +129,10 @@ int upload_frames(avt_ctx* c, int nframes, const double* data, const int* labels
     c->nframes = nframes;
     c->frame_N.assign(nframes, 0);
     c->frame_off.assign(offs, offs + nframes + 1);
+    int mx = 0;
+    for (int f = 0; f < nframes; ++f) mx = std::max(mx, offs[f + 1] - offs[f]);
+    c->launch_maxN = std::min(c->fb.max_points, ((mx + 2047) / 2048) * 2048);
+    if (c->launch_maxN < mx) c->launch_maxN = mx;
     for (int f = 0; f < nframes; ++f) {
         const int N = offs[f + 1] - offs[f];
         if (N < 0 || N > c->fb.max_points) { avt_set_error("frames: a frame has more points than max_points_per_frame"); return 1; }
@@ -184,8 +217,10 @@ int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* par
     c->nframes = 0;
     c->ran_icp_iters = 0;
     c->ran_max_iters = 0;
+    c->launch_maxN = 0;
+    c->use_graph = getenv("AVT_NO_GRAPH") == nullptr;
     HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    if (avt_solve_set_attributes()) { avt_set_error("avt_ctx_create: hipFuncSetAttribute failed"); return 1; }
+    if (avt_solve_set_attributes() || avt_eval_set_attributes()) { avt_set_error("avt_ctx_create: hipFuncSetAttribute failed"); return 1; }
     DeviceModel& dm = c->dm;
     dm.d = m->d;
     dm.d.num_parts = num_parts;
@@ -206,7 +241,7 @@ int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* par
     }
     if (dev_upload(c, &dm.shape_planes, m->shape_planes) || dev_upload(c, &dm.lbs_w, m->lbs_w) || dev_upload(c, &dm.lbs_j, m->lbs_j) ||
         dev_upload(c, &dm.asg_w, m->asg_w) || dev_upload(c, &dm.asg_j, m->asg_j) || dev_upload(c, &dm.anc_n, m->anc_n) ||
-        dev_upload(c, &dm.anc, m->anc) || dev_upload(c, &dm.mesh, m->mesh_soa) || dev_upload(c, &dm.parent, m->parent) ||
+        dev_upload(c, &dm.anc, m->anc) || dev_upload(c, &dm.mesh, m->mesh_soa) || dev_upload(c, &dm.parent, m->parent) || dev_upload(c, &dm.jlevel, m->jlevel) ||
         dev_upload(c, &dm.jsr_base, m->jsr_base) || dev_upload(c, &dm.jsr, m->jsr) || dev_upload(c, &dm.S, m->S) ||
         dev_upload(c, &dm.Sp, m->Sp) || dev_upload(c, &dm.prior_mean, m->prior_mean) || dev_upload(c, &dm.prior_prec, m->prior_prec) ||
         dev_upload(c, &dm.prior_L, m->prior_L) || dev_upload(c, &dm.prior_clog, m->prior_clog) || dev_upload(c, &dm.part_of_vertex, pov) ||
@@ -220,24 +255,24 @@ int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* par
     fb.const_blocks = (max_points + 255) / 256;
     const size_t FN = (size_t)max_frames * max_points, FV = (size_t)max_frames * V;
     const AvtDims& d = dm.d;
-    // eval workgroups over all frames: nf*choose_G(nf) <= max(min(64*nf, 512), 2*nf)
-    const size_t part_cap = std::max<size_t>(std::min<size_t>((size_t)64 * max_frames, 512), (size_t)2 * max_frames);
+    // eval workgroups over all frames: nf*choose_G(nf) <= max(min(128*nf, 512), 2*nf)
+    const size_t part_cap = std::max<size_t>(std::min<size_t>((size_t)128 * max_frames, 512), (size_t)2 * max_frames);
     char* cntsum = nullptr;
     if (dev_alloc(c, &fb.data_raw, FN * 3) || dev_alloc(c, &fb.labels_raw, FN) || dev_alloc(c, &fb.dx, FN) || dev_alloc(c, &fb.dy, FN) ||
-        dev_alloc(c, &fb.dz, FN) || dev_alloc(c, &fb.dorig, FN) || dev_alloc(c, &fb.part_off, (size_t)max_frames * (num_parts + 1)) ||
+        dev_alloc(c, &fb.dz, FN) || dev_alloc(c, &fb.dorig, FN) || dev_alloc(c, &fb.part_off, (size_t)max_frames * (num_parts + 1)) || dev_alloc(c, &fb.part_cnt, (size_t)max_frames * 2 * (AVT_MAX_PARTS + 1)) ||
         dev_alloc(c, &fb.corr, FN) || dev_alloc(c, &fb.corr_sorted, FN) || dev_alloc(c, &fb.cloud, FV * 3) || dev_alloc(c, &fb.pcx, FV) ||
         dev_alloc(c, &fb.pcy, FV) || dev_alloc(c, &fb.pcz, FV) || dev_alloc(c, &fb.visible, FV) ||
         dev_alloc(c, &cntsum, FV * (sizeof(int) + 3 * sizeof(long long)) + 64) || dev_alloc(c, &fb.matched, FV) || dev_alloc(c, &fb.mcnt, FV) ||
         dev_alloc(c, &fb.mdbar, FV * 3) || dev_alloc(c, &fb.const_part, (size_t)max_frames * fb.const_blocks) ||
         dev_alloc(c, &fb.x, (size_t)max_frames * 2 * d.xsize) || dev_alloc(c, &fb.prep, (size_t)max_frames * 2 * d.prep_size) ||
-        dev_alloc(c, &fb.partial, part_cap * d.NPAIR * 256) || dev_alloc(c, &fb.tiles, (size_t)max_frames * d.NPAIR * 256) ||
-        dev_alloc(c, &fb.Hfin, (size_t)max_frames * 2 * (d.P + 1) * d.P) || dev_alloc(c, &fb.ctl, (size_t)max_frames) ||
+        dev_alloc(c, &fb.partial, part_cap * d.NPAIR * 256) || dev_alloc(c, &fb.Hraw, (size_t)max_frames * 2 * d.HS * d.HS) ||
+        dev_alloc(c, &fb.prior, (size_t)max_frames * 2 * AVT_MAX_COMPS * AVT_PRIOR_STRIDE) || dev_alloc(c, &fb.ctl, (size_t)max_frames) ||
         dev_alloc(c, &fb.jointpos, (size_t)max_frames * 3 * J) || dev_alloc(c, &fb.jointtrans, (size_t)max_frames * 12 * J) ||
-        dev_alloc(c, &fb.trace, (size_t)max_frames * (64 + 2 + 3 * AVT_MAX_JOINTS)))
+        dev_alloc(c, &fb.trace, (size_t)max_frames * 64))
         return 1;
     fb.fsum = (long long*)cntsum;                                   // 8-byte aligned first
     fb.cnt = (int*)(cntsum + FV * 3 * sizeof(long long));
-    HIP_OK(hipMemset(fb.trace, 0, (size_t)max_frames * (64 + 2 + 3 * AVT_MAX_JOINTS) * sizeof(double)));
+    HIP_OK(hipMemset(fb.trace, 0, (size_t)max_frames * 64 * sizeof(double)));
     HIP_OK(hipMemset(fb.ctl, 0, (size_t)max_frames * sizeof(AvtFrameCtl)));
     HIP_OK(hipDeviceSynchronize());
     *out = c;
@@ -250,6 +285,7 @@ void avt_ctx_destroy(avt_ctx* c) {
     hipStreamSynchronize(c->stream);
     for (void* p : c->allocs) hipFree(p);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
+    for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
     hipStreamDestroy(c->stream);
     delete c;
 }
@@ -385,13 +421,23 @@ int avt_get_normal_equations(avt_ctx* c, int frame, double* H, double* g, double
     if (!c || frame < 0 || frame >= c->nframes) { avt_set_error("avt_get_normal_equations: bad argument"); return 1; }
     const AvtDims& d = c->dm.d;
     HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
     AvtFrameCtl ctl;
     HIP_OK(hipMemcpy(&ctl, c->fb.ctl + frame, sizeof(ctl), hipMemcpyDeviceToHost));
-    std::vector<double> buf((size_t)(d.P + 1) * d.P);
-    HIP_OK(hipMemcpy(buf.data(), c->fb.Hfin + ((size_t)frame * 2 + ctl.cur_slot) * buf.size(), buf.size() * sizeof(double), hipMemcpyDeviceToHost));
-    if (H) std::copy(buf.begin(), buf.begin() + (size_t)d.P * d.P, H);
-    if (g) std::copy(buf.begin() + (size_t)d.P * d.P, buf.end(), g);
+    std::vector<double> buf((size_t)d.HS * d.HS);
+    HIP_OK(hipMemcpy(buf.data(), c->fb.Hraw + ((size_t)frame * 2 + ctl.cur_slot) * buf.size(), buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int r = 0; r < d.P; ++r) {
+        if (H) for (int q = 0; q < d.P; ++q) H[(size_t)r * d.P + q] = buf[(size_t)r * d.HS + q];
+        if (g) g[r] = buf[(size_t)d.P * d.HS + r];
+    }
     if (cost) *cost = ctl.cost_cur;
+    return 0;
+}
+
+int avt_debug_trace(avt_ctx* c, int frame, double* out64) {
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy(out64, c->fb.trace + (size_t)frame * 64, 64 * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -37,23 +37,34 @@ __device__ __forceinline__ void quat_to_rot(const double* q, double* R) {
 // Forward kinematics shared by Avatar::update (Avatar.cpp:41-64) and PrepareForEvaluation
 // (AvatarOptimizer.cpp:303-315): world rotation Rw[j] = Rw[parent]*rot[j], origin o[j] = o[parent] +
 // Rw[parent]*(jp[j]-jp[parent]), root at p.  All arrays live in LDS; must be called by every thread of the
-// block (contains barriers).  rot[J][9], jp[J][3] are inputs.
+// block (contains barriers).  rot[J][9], jp[J][3] are inputs; lvl[J+1] is LDS scratch.  Joints are processed
+// one tree level per barrier (SMPL: 9 levels instead of 24 sequential joints).
 __device__ __forceinline__ void fk_chain(int J, const int* __restrict__ parent, const double* rot, const double* jp,
-                                         const double* p, double* Rw, double* o) {
+                                         const double* p, double* Rw, double* o, int* lvl) {
     const int t = threadIdx.x;
-    for (int j = 0; j < J; ++j) {
-        if (t < 12) {
+    if (t == 0) {
+        int mx = 0;
+        lvl[0] = 0;
+        for (int j = 1; j < J; ++j) { lvl[j] = lvl[parent[j]] + 1; mx = max(mx, lvl[j]); }
+        lvl[J] = mx;
+    }
+    __syncthreads();
+    const int nl = lvl[J];
+    for (int L = 0; L <= nl; ++L) {
+        for (int idx = t; idx < 12 * J; idx += blockDim.x) {
+            const int j = idx / 12, e = idx % 12;
+            if (lvl[j] != L) continue;
             if (j == 0) {
-                if (t < 9) Rw[t] = rot[t];
-                else o[t - 9] = p[t - 9];
+                if (e < 9) Rw[e] = rot[e];
+                else o[e - 9] = p[e - 9];
             } else {
                 const int pa = parent[j];
                 const double* Rp = Rw + 9 * pa;
-                if (t < 9) {
-                    const int r = t / 3, c = t % 3;
-                    Rw[9 * j + t] = Rp[3 * r] * rot[9 * j + c] + Rp[3 * r + 1] * rot[9 * j + 3 + c] + Rp[3 * r + 2] * rot[9 * j + 6 + c];
+                if (e < 9) {
+                    const int r = e / 3, c = e % 3;
+                    Rw[9 * j + e] = Rp[3 * r] * rot[9 * j + c] + Rp[3 * r + 1] * rot[9 * j + 3 + c] + Rp[3 * r + 2] * rot[9 * j + 6 + c];
                 } else {
-                    const int r = t - 9;
+                    const int r = e - 9;
                     const double d0 = jp[3 * j] - jp[3 * pa], d1 = jp[3 * j + 1] - jp[3 * pa + 1], d2 = jp[3 * j + 2] - jp[3 * pa + 2];
                     o[3 * j + r] = o[3 * pa + r] + (Rp[3 * r] * d0 + Rp[3 * r + 1] * d1 + Rp[3 * r + 2] * d2);
                 }

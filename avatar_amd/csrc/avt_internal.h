@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -13,6 +14,8 @@
 #define AVT_EVAL_ROWS (3 * AVT_EVAL_PTS)
 #define AVT_EVAL_RS 50        // LDS row stride (doubles) of the transposed Jacobian tile: conflict-free b64 reads
 #define AVT_MAX_TILES 8       // ceil((P+1)/16) <= 8  (J<=32, K<=16)
+#define AVT_MAX_COMPS 16      // GMM components
+#define AVT_PRIOR_STRIDE (2 + 3 * AVT_MAX_JOINTS)   // doubles per (frame, component) of prior scratch
 #define AVT_FIX_SCALE 1099511627776.0  // 2^40 fixed-point scale of the centred correspondence sums
 
 // ---- per-frame state block (doubles), double-buffered: slot 0/1 --------------------------------
@@ -26,6 +29,8 @@ struct AvtDims {
     int num_parts;
     int anc_max;             // actual max #ancestors in this model
     int ncomps, ndims;       // GMM
+    int nlevels;             // depth of the kinematic tree + 1
+    int HS;                  // row stride of the dense normal-equation block: 4*ceil((P+1)/4)
 };
 
 // prep block layout (doubles), one per frame per slot: what an evaluation needs about the skeleton state
@@ -79,6 +84,7 @@ struct DeviceModel {
     unsigned short* anc;  // [AVT_ANC_MAX][V]
     int* mesh;            // [3][F] SoA
     int* parent;          // [J]
+    int* jlevel;          // [J] tree level of each joint (root = 0)
     double* jsr_base;     // [3J] initialJointPos
     double* jsr;          // [3J][K] row-major jointShapeReg
     double* S;            // [J][3][K]
@@ -105,6 +111,7 @@ struct FrameBuffers {
     double* dx; double* dy; double* dz;
     int* dorig;           // original index of sorted point
     int* part_off;        // [max_frames][num_parts+1] offsets (relative to frame segment)
+    int* part_cnt;        // [max_frames][2][AVT_MAX_PARTS+1] label histogram | scatter cursors
     int* corr;            // [max_frames*max_points] model idx per ORIGINAL data index (-1 none)
     int* corr_sorted;     // per sorted position
     // model-side per frame
@@ -123,8 +130,8 @@ struct FrameBuffers {
     double* x;            // [max_frames][2][xsize]
     double* prep;         // [max_frames][2][prep_size]
     double* partial;      // [max_frames][G][NPAIR][256]
-    double* tiles;        // [max_frames][NPAIR][256]  reduced raw (data-term) tiles of the last evaluation
-    double* Hfin;         // [max_frames][2][(P+1)*P]   finalised H (P x P) + g (P) per slot
+    double* Hraw;         // [max_frames][2][HS*HS] reduced data-term [J|r]^T W [J|r] (full symmetric) per state slot
+    double* prior;        // [max_frames][2][AVT_MAX_COMPS][AVT_PRIOR_STRIDE] GMM scores / Prec*(x-mu) per state slot
     AvtFrameCtl* ctl;     // [max_frames]
     double* jointpos;     // [max_frames][3J]
     double* jointtrans;   // [max_frames][12J]
@@ -135,7 +142,7 @@ struct avt_model {
     AvtDims d;
     // host copies (used by avt_ctx_create to build the device model and by accessors)
     std::vector<double> shape_planes, lbs_w, asg_w, jsr_base, jsr, S, Sp;
-    std::vector<int> lbs_j, asg_j, mesh_soa, parent, main_joint;
+    std::vector<int> lbs_j, asg_j, mesh_soa, parent, main_joint, jlevel;
     std::vector<unsigned char> anc_n;
     std::vector<unsigned short> anc;
     std::vector<double> prior_mean, prior_prec, prior_L, prior_clog;
@@ -157,6 +164,9 @@ struct avt_ctx {
     size_t event_pool_used;
     std::vector<void*> allocs;
     int ran_icp_iters, ran_max_iters;
+    int launch_maxN;                 // max points per frame of the resident batch, rounded up to 2048 (grid sizing)
+    bool use_graph;                  // replay the optimize() launch sequence as a hipGraph (AVT_NO_GRAPH=1 disables)
+    std::map<std::string, hipGraphExec_t> graphs;
 };
 
 void avt_set_error(const std::string& s);

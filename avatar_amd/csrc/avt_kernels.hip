@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
     __shared__ double s_rot[AVT_MAX_JOINTS * 9], s_Rw[AVT_MAX_JOINTS * 9], s_o[AVT_MAX_JOINTS * 3], s_jp[AVT_MAX_JOINTS * 3];
     __shared__ double s_T[AVT_MAX_JOINTS * 12];  // jointTrans, column-major 3x4 per joint (Avatar.h:215)
     __shared__ double s_w[AVT_MAX_SHAPE], s_p[3];
-    __shared__ int s_parent[AVT_MAX_JOINTS];
+    __shared__ int s_parent[AVT_MAX_JOINTS], s_lvl[AVT_MAX_JOINTS + 1];
 
     const double* xs = nullptr;
     if (from_state) xs = fb.x + ((size_t)f * 2 + fb.ctl[f].cur_slot) * d.xsize;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
         s_jp[t] = dm.jsr_base[t] + s;
     }
     __syncthreads();
-    fk_chain(J, s_parent, s_rot, s_jp, s_p, s_Rw, s_o);
+    fk_chain(J, s_parent, s_rot, s_jp, s_p, s_Rw, s_o, s_lvl);
     // jointPos_i <- t_i ; t_i -= R_i * jPosInit   (Avatar.cpp:59-64)
     if (t < 3 * J) {
         const int j = t / 3, r = t % 3;
@@ -135,65 +135,83 @@ void launch_visibility(avt_ctx* c, int nframes, int enable) {
 }
 
 // =================================================================================================
-// Data bucketing by body-part label (the data-side counterpart of AvatarOptimizer.cpp:1274-1293): a stable
-// counting sort, one workgroup per frame.  Within a part the original index order is preserved, which the
-// ordered nearest-neighbour scan and the ordered correspondence lists rely on.
+// Data bucketing by body-part label (the data-side counterpart of AvatarOptimizer.cpp:1274-1293): a
+// two-pass counting sort over many workgroups.  Pass 1 histograms labels (LDS atomics, then one global atomic
+// per (workgroup, part)); pass 2 reserves a range per (workgroup, part) and scatters.  The order of points
+// INSIDE a part bucket is not deterministic, and nothing downstream depends on it: the nearest neighbour of a
+// point does not depend on its neighbours, the correspondence sums are order-independent integer atomics and
+// every floating-point reduction over data points runs in original index order.
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_bucket(DeviceModel dm, FrameBuffers fb) {
-    const int f = blockIdx.x, t = threadIdx.x;
-    const int np = dm.d.num_parts;
+#define BUCKET_TILE 2048
+
+__global__ __launch_bounds__(256) void k_bucket_count(DeviceModel dm, FrameBuffers fb) {
+    const int f = blockIdx.y, t = threadIdx.x, np = dm.d.num_parts;
+    const int N = fb.ctl[f].N;
+    const int s0 = blockIdx.x * BUCKET_TILE;
+    if (s0 >= N) return;
+    __shared__ int hist[AVT_MAX_PARTS + 1];
+    if (t <= np) hist[t] = 0;
+    __syncthreads();
+    const int* lab = fb.labels_raw + (size_t)f * fb.max_points;
+#pragma unroll
+    for (int u = 0; u < BUCKET_TILE / 256; ++u) {
+        const int i = s0 + u * 256 + t;
+        if (i < N) {
+            int q = lab[i];
+            if (q < 0 || q >= np) q = np;
+            atomicAdd(&hist[q], 1);
+        }
+    }
+    __syncthreads();
+    if (t <= np && hist[t]) atomicAdd(fb.part_cnt + (size_t)f * 2 * (AVT_MAX_PARTS + 1) + t, hist[t]);
+}
+
+__global__ __launch_bounds__(256) void k_bucket_scatter(DeviceModel dm, FrameBuffers fb) {
+    const int f = blockIdx.y, t = threadIdx.x, np = dm.d.num_parts;
     AvtFrameCtl& ctl = fb.ctl[f];
     const int N = ctl.N;
+    const int s0 = blockIdx.x * BUCKET_TILE;
     const size_t base = (size_t)f * fb.max_points;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* hist = (int*)smem;                 // [np+1][256] (row np = invalid labels)
-    int* tot = hist + (size_t)(np + 1) * 256;   // [np+2]
-    const int chunk = (N + 255) / 256;
-    const int lo = min(N, t * chunk), hi = min(N, lo + chunk);
-    for (int q = 0; q <= np; ++q) hist[q * 256 + t] = 0;
-    const int* lab = fb.labels_raw + base;
-    for (int i = lo; i < hi; ++i) {
-        int q = lab[i];
-        if (q < 0 || q >= np) q = np;
-        hist[q * 256 + t] += 1;
-    }
-    __syncthreads();
-    // per-part exclusive scan across the 256 thread columns: wave w takes parts w, w+4, ...
-    for (int q = wave_id(); q <= np; q += 4) {
-        const int l = lane_id();
-        int v0 = hist[q * 256 + 4 * l], v1 = hist[q * 256 + 4 * l + 1], v2 = hist[q * 256 + 4 * l + 2], v3 = hist[q * 256 + 4 * l + 3];
-        const int s = v0 + v1 + v2 + v3;
-        const int incl = wave_incl_scan(s);
-        const int ex = incl - s;
-        hist[q * 256 + 4 * l] = ex;
-        hist[q * 256 + 4 * l + 1] = ex + v0;
-        hist[q * 256 + 4 * l + 2] = ex + v0 + v1;
-        hist[q * 256 + 4 * l + 3] = ex + v0 + v1 + v2;
-        if (l == 63) tot[q] = incl;
-    }
-    __syncthreads();
+    __shared__ int hist[AVT_MAX_PARTS + 1], poff[AVT_MAX_PARTS + 2], bbase[AVT_MAX_PARTS + 1];
+    int* pcnt = fb.part_cnt + (size_t)f * 2 * (AVT_MAX_PARTS + 1);
+    int* cursor = pcnt + (AVT_MAX_PARTS + 1);
+    if (t <= np) hist[t] = 0;
     if (t == 0) {
         int acc = 0;
-        int* po = fb.part_off + (size_t)f * (np + 1);
-        for (int q = 0; q < np; ++q) {
-            const int n = tot[q];
-            tot[q] = acc;
-            po[q] = acc;
-            acc += n;
-        }
-        po[np] = acc;
-        tot[np] = acc;  // invalid labels go after all parts
-        if (N > 0) {
-            ctl.centre[0] = fb.data_raw[3 * base];
-            ctl.centre[1] = fb.data_raw[3 * base + 1];
-            ctl.centre[2] = fb.data_raw[3 * base + 2];
-        }
+        for (int q = 0; q <= np; ++q) { poff[q] = acc; acc += pcnt[q]; }
+        poff[np + 1] = acc;
     }
     __syncthreads();
-    for (int i = lo; i < hi; ++i) {
-        int q = lab[i];
-        if (q < 0 || q >= np) q = np;
-        const int pos = tot[q] + hist[q * 256 + t]++;
+    if (blockIdx.x == 0) {
+        if (t <= np) fb.part_off[(size_t)f * (np + 1) + t] = poff[t];
+        if (t < 3 && N > 0) ctl.centre[t] = fb.data_raw[3 * base + t];
+    }
+    if (s0 >= N) return;
+    const int* lab = fb.labels_raw + base;
+    int qs[BUCKET_TILE / 256];
+#pragma unroll
+    for (int u = 0; u < BUCKET_TILE / 256; ++u) {
+        const int i = s0 + u * 256 + t;
+        int q = -1;
+        if (i < N) {
+            q = lab[i];
+            if (q < 0 || q >= np) q = np;
+            atomicAdd(&hist[q], 1);
+        }
+        qs[u] = q;
+    }
+    __syncthreads();
+    if (t <= np) {
+        bbase[t] = hist[t] ? poff[t] + atomicAdd(cursor + t, hist[t]) : 0;
+        hist[t] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < BUCKET_TILE / 256; ++u) {
+        const int i = s0 + u * 256 + t;
+        const int q = qs[u];
+        if (q < 0) continue;
+        const int pos = bbase[q] + atomicAdd(&hist[q], 1);
         fb.dx[base + pos] = fb.data_raw[3 * (base + i)];
         fb.dy[base + pos] = fb.data_raw[3 * (base + i) + 1];
         fb.dz[base + pos] = fb.data_raw[3 * (base + i) + 2];
@@ -203,9 +221,11 @@ __global__ __launch_bounds__(256) void k_bucket(DeviceModel dm, FrameBuffers fb)
 }
 
 void launch_bucket(avt_ctx* c, int nframes) {
-    const int np = c->dm.d.num_parts;
-    const size_t lds = ((size_t)(np + 1) * 256 + np + 2) * sizeof(int);
-    hipLaunchKernelGGL(k_bucket, dim3(nframes), dim3(256), lds, c->stream, c->dm, c->fb);
+    const int maxN = c->launch_maxN;
+    const int nb = std::max(1, (maxN + BUCKET_TILE - 1) / BUCKET_TILE);
+    (void)hipMemsetAsync(c->fb.part_cnt, 0, (size_t)nframes * 2 * (AVT_MAX_PARTS + 1) * sizeof(int), c->stream);
+    hipLaunchKernelGGL(k_bucket_count, dim3(nb, nframes), dim3(256), 0, c->stream, c->dm, c->fb);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(nb, nframes), dim3(256), 0, c->stream, c->dm, c->fb);
 }
 
 // =================================================================================================
@@ -265,24 +285,25 @@ __global__ __launch_bounds__(1024) void k_finalize(DeviceModel dm, FrameBuffers 
 }
 
 // 0.5*sum_i |d_i - dbar_m(i)|^2: the part of the data cost that does not depend on the parameters once the
-// correspondences are fixed.  Deterministic two-level reduction (block partials, summed in order by the
-// solve kernel).
+// correspondences are fixed.  Deterministic two-level reduction in original data order (block partials,
+// summed in a fixed order by the solve kernel).
 __global__ __launch_bounds__(256) void k_cost_const(DeviceModel dm, FrameBuffers fb) {
     const int f = blockIdx.y, t = threadIdx.x, V = dm.d.V;
     const AvtFrameCtl& ctl = fb.ctl[f];
     const int N = ctl.N;
     const size_t base = (size_t)f * fb.max_points;
-    const int s = blockIdx.x * 256 + t;
+    const int i = blockIdx.x * 256 + t;      // ORIGINAL data index: the reduction order is fixed
     double acc = 0.0;
-    if (s < N) {
-        const int m = fb.corr_sorted[base + s];
+    if (i < N) {
+        const int m = fb.corr[base + i];
         if (m >= 0) {
             const int c = fb.cnt[(size_t)f * V + m];
             const long long* fs = fb.fsum + (size_t)f * 3 * V;
             const double mx = ctl.centre[0] + ((double)fs[m] / AVT_FIX_SCALE) / (double)c;
             const double my = ctl.centre[1] + ((double)fs[(size_t)V + m] / AVT_FIX_SCALE) / (double)c;
             const double mz = ctl.centre[2] + ((double)fs[2 * (size_t)V + m] / AVT_FIX_SCALE) / (double)c;
-            const double ex = fb.dx[base + s] - mx, ey = fb.dy[base + s] - my, ez = fb.dz[base + s] - mz;
+            const double* dp = fb.data_raw + 3 * (base + i);
+            const double ex = dp[0] - mx, ey = dp[1] - my, ez = dp[2] - mz;
             acc = ex * ex + ey * ey + ez * ez;
         }
     }
@@ -296,8 +317,7 @@ __global__ __launch_bounds__(256) void k_cost_const(DeviceModel dm, FrameBuffers
 void launch_finalize(avt_ctx* c, int nframes, const avt_options* o) {
     hipLaunchKernelGGL(k_finalize, dim3(nframes), dim3(1024), 0, c->stream, c->dm, c->fb, o->beta_pose, o->beta_shape,
                        o->lm_lambda0, c->ran_icp_iters == 0 ? 1 : 0);
-    int maxN = 0;
-    for (int f = 0; f < nframes; ++f) maxN = std::max(maxN, c->frame_N[f]);
+    const int maxN = c->launch_maxN;
     const int nb = (maxN + 255) / 256;
     hipMemsetAsync(c->fb.const_part, 0, (size_t)nframes * c->fb.const_blocks * sizeof(double), c->stream);
     if (nb > 0) hipLaunchKernelGGL(k_cost_const, dim3(nb, nframes), dim3(256), 0, c->stream, c->dm, c->fb);

@@ -1,0 +1,491 @@
+// avt_lm.hip — the Gauss-Newton / Levenberg-Marquardt step kernels (gfx950, wave64):
+//   k_reduce : fixed-order reduction of k_eval's partial MFMA tiles into the dense symmetric data-term system
+//              [J|r]^T W [J|r] of the trial point, plus one workgroup per GMM component evaluating the pose prior
+//              (GaussianMixture::residual, GaussianMixture.cpp:95-114);
+//   k_solve  : one workgroup per frame — LM accept/reject, prior assembly (AvatarOptimizer.cpp:647-726,
+//              :1457-1458), damped LDL^T solve held in registers, quaternion retraction
+//              (FakeQuaternionParameterization::Plus, :123-143) and the skeleton tables of the next trial point
+//              (PrepareForEvaluation, :283-325).  The whole inner loop runs without host synchronisation.
+//
+// Everything in k_solve is latency-bound (an 85-long pivot chain), so it is organised around the dependency
+// chain: no divide / sqrt on the chain (v_rcp_f64 + cubic Newton), one barrier per 4 pivots, the diagonal 4x4
+// block factored redundantly by every lane instead of being published, back-substitution by cross-lane
+// v_readlane instead of LDS round trips, and no global load inside any sequential loop.
+#include "avt_device.h"
+
+#ifdef AVT_TIMING
+#define TPROBE(i) do { if (threadIdx.x == 0) fb.trace[(size_t)blockIdx.x * 64 + 40 + (i)] = (double)clock64(); } while (0)
+#else
+#define TPROBE(i) do {} while (0)
+#endif
+
+// -------------------------------------------------------------------------------------------------
+// skeleton tables of a state x=(p,q,w) -> prep block in global memory.  Called by all 256 threads.
+// -------------------------------------------------------------------------------------------------
+struct PrepScratch {
+    double rot[AVT_MAX_JOINTS * 9], Rw[AVT_MAX_JOINTS * 9], o[AVT_MAX_JOINTS * 3], jp[AVT_MAX_JOINTS * 3];
+    double H[AVT_MAX_JOINTS * 3 * AVT_MAX_SHAPE], Sp[AVT_MAX_JOINTS * 3 * AVT_MAX_SHAPE];
+    double w[AVT_MAX_SHAPE], p[3];
+    int parent[AVT_MAX_JOINTS], level[AVT_MAX_JOINTS];
+};
+
+__device__ void compute_prep(const DeviceModel& dm, const double* __restrict__ x, double* __restrict__ prep, PrepScratch& s) {
+    const AvtDims d = dm.d;
+    const int J = d.J, K = d.K, t = threadIdx.x;
+    const double* q = x + 3;
+    if (t < J) { s.parent[t] = dm.parent[t]; s.level[t] = dm.jlevel[t]; quat_to_rot(q + 4 * t, s.rot + 9 * t); }
+    if (t < 3) s.p[t] = x[t];
+    if (t < K) s.w[t] = x[3 + 4 * J + t];
+    for (int e = t; e < 3 * J * K; e += 256) s.Sp[e] = dm.Sp[e];
+    __syncthreads();
+    // CalcShape (AvatarOptimizer.cpp:249-281): jointPosInit = base + jointShapeReg*w
+    if (t < 3 * J) {
+        double a = 0.0;
+        for (int k = 0; k < K; ++k) a += dm.jsr[(size_t)t * K + k] * s.w[k];
+        s.jp[t] = dm.jsr_base[t] + a;
+    }
+    __syncthreads();
+    // one tree level per barrier: world rotation/origin (:303-315) and H[j] = R(-1,parent j) Sp[j] + H[parent j]
+    // (:318-324) of every joint of the level in parallel
+    const int per = 12 + 3 * K;
+    for (int L = 0; L < d.nlevels; ++L) {
+        for (int idx = t; idx < J * per; idx += 256) {
+            const int j = idx / per, e = idx - j * per;
+            if (s.level[j] != L) continue;
+            const int pa = s.parent[j];
+            if (e < 12) {
+                if (j == 0) {
+                    if (e < 9) s.Rw[e] = s.rot[e];
+                    else s.o[e - 9] = s.p[e - 9];
+                } else {
+                    const double* Rp = s.Rw + 9 * pa;
+                    if (e < 9) {
+                        const int r = e / 3, c = e % 3;
+                        s.Rw[9 * j + e] = Rp[3 * r] * s.rot[9 * j + c] + Rp[3 * r + 1] * s.rot[9 * j + 3 + c] + Rp[3 * r + 2] * s.rot[9 * j + 6 + c];
+                    } else {
+                        const int r = e - 9;
+                        const double d0 = s.jp[3 * j] - s.jp[3 * pa], d1 = s.jp[3 * j + 1] - s.jp[3 * pa + 1], d2 = s.jp[3 * j + 2] - s.jp[3 * pa + 2];
+                        s.o[3 * j + r] = s.o[3 * pa + r] + (Rp[3 * r] * d0 + Rp[3 * r + 1] * d1 + Rp[3 * r + 2] * d2);
+                    }
+                }
+            } else {
+                const int e2 = e - 12, r = e2 / K, k = e2 - r * K;
+                double v = 0.0;
+                if (j > 0) {
+                    const double* Rp = s.Rw + 9 * pa;
+                    const double* Sp = s.Sp + j * 3 * K;
+                    v = (Rp[3 * r] * Sp[k] + Rp[3 * r + 1] * Sp[K + k] + Rp[3 * r + 2] * Sp[2 * K + k]) + s.H[pa * 3 * K + e2];
+                }
+                s.H[j * 3 * K + e2] = v;
+            }
+        }
+        __syncthreads();
+    }
+    const double off0 = s.jp[0], off1 = s.jp[1], off2 = s.jp[2];
+    for (int e = t; e < 9 * J; e += 256) prep[prep_off_Rw(d) + e] = s.Rw[e];
+    for (int e = t; e < 3 * J; e += 256) {
+        prep[prep_off_o(d) + e] = s.o[e];
+        const int c = e % 3;
+        prep[prep_off_Jh(d) + e] = s.jp[e] - (c == 0 ? off0 : (c == 1 ? off1 : off2));   // root at origin (:270-272)
+    }
+    for (int e = t; e < 3 * J * K; e += 256) {  // G[j] = H[j] - Rw[j]*S[j]  (shape block of :568-580)
+        const int j = e / (3 * K), r = (e / K) % 3, k = e % K;
+        const double* Rj = s.Rw + 9 * j;
+        const double* S = dm.S + (size_t)j * 3 * K;
+        prep[prep_off_G(d) + e] = s.H[e] - (Rj[3 * r] * S[k] + Rj[3 * r + 1] * S[K + k] + Rj[3 * r + 2] * S[2 * K + k]);
+    }
+    for (int e = t; e < 4 * J; e += 256) prep[prep_off_q(d) + e] = q[e];
+    if (t < K) prep[prep_off_w(d) + t] = s.w[t];
+    if (t < 3) prep[prep_off_off(d) + t] = (t == 0 ? off0 : (t == 1 ? off1 : off2));
+}
+
+// =================================================================================================
+// k_reduce.  grid (NPAIR + ncomps, nframes), block 256.
+//   blocks 0..NPAIR-1: Hraw[f][try][r][c] = sum_g partial[f][g][pair][e], g ascending (deterministic); the tile is
+//     written to both triangles of the dense (HS x HS) symmetric block; row/column P carry J^T r and sum c|r|^2.
+//   blocks NPAIR..: GMM pose prior at the trial point, one workgroup per component: smplParams
+//     (AvatarOptimizer.cpp:664-669), score = ||rho_c||^2 - consts_log_c (GaussianMixture.cpp:95-114) and
+//     Prec_c (x - mu_c) for the gradient; k_solve picks the minimising component.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_reduce(DeviceModel dm, FrameBuffers fb) {
+    const AvtDims d = dm.d;
+    const int f = blockIdx.y, t = threadIdx.x, NPAIR = d.NPAIR, NT = d.NT, P = d.P, HS = d.HS;
+    const int try_slot = 1 - fb.ctl[f].cur_slot;
+    if ((int)blockIdx.x < NPAIR) {
+        int p = blockIdx.x, ti = 0;
+        while (p >= NT - ti) { p -= NT - ti; ++ti; }
+        const int tj = ti + p;
+        const double* part = fb.partial + ((size_t)f * fb.G * NPAIR + blockIdx.x) * 256 + t;
+        // 16 independent loads in flight per lane, summed in ascending g (same order as a plain loop)
+        const size_t st = (size_t)NPAIR * 256;
+        double a = 0.0;
+        int g = 0;
+        for (; g + 16 <= fb.G; g += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = __builtin_nontemporal_load(part + (size_t)(g + u) * st);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a += v[u];
+        }
+        for (; g < fb.G; ++g) a += part[(size_t)g * st];
+        const int r = ti * 16 + ((t >> 4) & 3) + 4 * (t >> 6), c = tj * 16 + (t & 15);
+        if (r <= P && c <= P) {
+            double* H = fb.Hraw + ((size_t)f * 2 + try_slot) * HS * HS;
+            H[(size_t)r * HS + c] = a;
+            if (ti != tj) H[(size_t)c * HS + r] = a;
+        }
+        return;
+    }
+    // ---- pose prior, one workgroup per GMM component c = blockIdx.x - NPAIR --------------------------------
+    const int n = d.ndims, C = d.ncomps, J = d.J;
+    const int c = blockIdx.x - NPAIR;
+    if (c >= C) return;
+    double* po = fb.prior + (((size_t)f * 2 + try_slot) * AVT_MAX_COMPS + c) * AVT_PRIOR_STRIDE;
+    __shared__ double s_x[AVT_MAX_JOINTS * 3], s_q[AVT_MAX_JOINTS * 3];
+    const double* x = fb.x + ((size_t)f * 2 + try_slot) * d.xsize;
+    if (t < J - 1) {  // Eigen AngleAxis(Quaternion): angle in [0,pi], axis sign follows w
+        const double* q = x + 3 + 4 * (t + 1);
+        double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+        if (nrm < 2.220446049250313e-16) {
+            const double mx = fmax(fabs(q[0]), fmax(fabs(q[1]), fabs(q[2])));
+            if (mx > 0.0) { const double a = q[0] / mx, b = q[1] / mx, cc = q[2] / mx; nrm = mx * sqrt(a * a + b * b + cc * cc); }
+            else nrm = 0.0;
+        }
+        double ang = 0.0, ax0 = 1.0, ax1 = 0.0, ax2 = 0.0;
+        if (nrm != 0.0) {
+            ang = 2.0 * atan2(nrm, fabs(q[3]));
+            if (q[3] < 0) nrm = -nrm;
+            ax0 = q[0] / nrm; ax1 = q[1] / nrm; ax2 = q[2] / nrm;
+        }
+        const double* mu = dm.prior_mean + (size_t)c * n;
+        s_x[3 * t] = ax0 * ang - mu[3 * t]; s_x[3 * t + 1] = ax1 * ang - mu[3 * t + 1]; s_x[3 * t + 2] = ax2 * ang - mu[3 * t + 2];
+    }
+    __syncthreads();
+    // y = Prec_c (x - mu_c): 4 lanes per row, 64 rows per pass
+    for (int a0 = 0; a0 < n; a0 += 64) {
+        const int a = a0 + (t >> 2), sub = t & 3;
+        double sacc = 0.0;
+        if (a < n) {
+            const double* Pr = dm.prior_prec + ((size_t)c * n + a) * n;
+            for (int b = sub; b < n; b += 4) sacc += Pr[b] * s_x[b];
+        }
+        sacc += __shfl_xor(sacc, 1, 64);
+        sacc += __shfl_xor(sacc, 2, 64);
+        if (a < n && sub == 0) { s_q[a] = sacc; po[2 + a] = sacc; }
+    }
+    __syncthreads();
+    if (t < 64) {  // ||rho||^2 = 1/2 d^T Prec d  (rho = L^T d sqrt(1/2), Prec = L L^T)
+        double sacc = 0.0;
+        for (int a = t; a < n; a += 64) sacc += s_x[a] * s_q[a];
+        sacc = wave_sum(sacc);
+        if (t == 0) po[0] = 0.5 * sacc - dm.prior_clog[c];
+    }
+}
+
+// reciprocal off the slow path: v_rcp_f64 (~2^-26 relative) + one cubic Newton step (error e^3)
+__device__ __forceinline__ double fast_rcp(double d) {
+    const double r0 = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, r0, 1.0);
+    const double t2 = fma(e, e, e);
+    return fma(r0, t2, r0);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// =================================================================================================
+// k_solve.  grid (nframes), block 256.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, int mode, double lm_up, double lm_down,
+                                               double lm_min, double lm_max) {
+    const AvtDims d = dm.d;
+    const int J = d.J, K = d.K, P = d.P, HS = d.HS;
+    const int f = blockIdx.x, t = threadIdx.x;
+    AvtFrameCtl& ctl = fb.ctl[f];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int LD = HS + 1;                                  // odd leading dimension
+    double* Lf = (double*)smem;                             // [HS][LD] unit-lower factor (row P = D^-1 L^-1 rhs)
+    double* s_raw = Lf + (size_t)HS * LD;                   // [2][HS][4] current block column, raw (double-buffered)
+    double* s_delta = s_raw + 2 * (size_t)HS * 4;           // [HS]
+    PrepScratch* ps = (PrepScratch*)(s_delta + HS);
+    __shared__ int s_failv[2];   // alternating per round: written in round kb, read after the next barrier
+    const int xs = d.xsize;
+    double* x0 = fb.x + ((size_t)f * 2) * xs;
+
+    if (mode == SOLVE_INIT) {
+        // trial point := current point; sum the constant part of the data cost
+        const int cur = ctl.cur_slot, tr = 1 - cur;
+        for (int e = t; e < xs; e += 256) x0[(size_t)tr * xs + e] = x0[(size_t)cur * xs + e];
+        double a = 0.0;
+        if (t < 64) {
+            for (int e = t; e < fb.const_blocks; e += 64) a += fb.const_part[(size_t)f * fb.const_blocks + e];
+            a = wave_sum(a);
+        }
+        __syncthreads();
+        if (t == 0) { ctl.cost_const = 0.5 * a; ctl.try_valid = 1; }
+        compute_prep(dm, x0 + (size_t)tr * xs, fb.prep + ((size_t)f * 2 + tr) * d.prep_size, *ps);
+        return;
+    }
+    TPROBE(0);
+    // ---- a. objective of the trial point + LM decision (uniform work, done redundantly by every lane) -----
+    const int cur0 = ctl.cur_slot, try0 = 1 - cur0;
+    const int try_valid = ctl.try_valid, comp_cur0 = ctl.comp_cur;
+    const double sbp = ctl.sbp, sbs = ctl.sbs, cost_cur0 = ctl.cost_cur, cost_const = ctl.cost_const;
+    double lambda = ctl.lambda;
+    const double* Htry = fb.Hraw + ((size_t)f * 2 + try0) * HS * HS;
+    const double* xt = x0 + (size_t)try0 * xs;
+    double cost = 0.5 * Htry[(size_t)P * HS + P] + cost_const;
+    int comp_try = -1;
+    if (sbp > 0.0 && d.ncomps > 0) {
+        // best component: strict '<' in ascending component order (GaussianMixture.cpp:103)
+        double best = 1.7976931348623157e308;
+        for (int c = 0; c < d.ncomps; ++c) {
+            const double pr = fb.prior[(((size_t)f * 2 + try0) * AVT_MAX_COMPS + c) * AVT_PRIOR_STRIDE];
+            if (pr < best) { best = pr; comp_try = c; }
+        }
+        cost += 0.5 * sbp * sbp * best;
+    }
+    if (sbs > 0.0) {
+        double a = 0.0;
+        for (int k = 0; k < K; ++k) { const double r = xt[3 + 4 * J + k] * sbs; a += r * r; }
+        cost += 0.5 * a;
+    }
+    int cur = cur0;
+    bool accepted = false;
+    if (mode == SOLVE_FIRST) {
+        accepted = true;
+        cur = try0;
+    } else if (try_valid) {
+        if (cost < cost_cur0) { accepted = true; cur = try0; lambda = fmax(lambda * lm_down, lm_min); }
+        else lambda = fmin(lambda * lm_up, lm_max);
+    }
+    const double cost_cur = accepted ? cost : cost_cur0;
+    const int comp = accepted ? comp_try : comp_cur0;
+    __syncthreads();   // every lane has read the control block before lane 0 rewrites it
+    if (t == 0) {
+        ctl.cur_slot = cur;
+        ctl.cost_cur = cost_cur;
+        ctl.comp_cur = comp;
+        int it = ctl.gn_iterations;
+        if (mode == SOLVE_FIRST) ctl.cost_initial = cost;
+        else { it += 1; ctl.gn_iterations = it; if (accepted) ctl.accepted += 1; }
+        if (it < 40) fb.trace[(size_t)f * 64 + it] = cost_cur;
+        if (mode == SOLVE_LAST) ctl.lambda = lambda;
+    }
+    if (mode == SOLVE_LAST) return;
+    TPROBE(1);
+
+    // ---- b. the damped system of the current point, straight into registers --------------------------------
+    // Thread t owns the 4x4 block (bi >= bj) of the bordered (P+1)x(P+1) matrix [[H + lambda diag H, .],[-g^T, .]]
+    // (row P carries the rhs so D^-1 L^-1 (-g) falls out of the factorisation as row P of the unit-lower factor).
+    const int NB = HS >> 2;
+    int bi = -1, bj = -1;
+    if (t < NB * (NB + 1) / 2) {
+        int r0 = 0, rem = t;
+        while (rem > r0) { rem -= r0 + 1; ++r0; }
+        bi = r0; bj = rem;
+    }
+    const double* Hc = fb.Hraw + ((size_t)f * 2 + cur) * HS * HS;
+    const double* xc = x0 + (size_t)cur * xs;
+    const double* pri = fb.prior + (((size_t)f * 2 + cur) * AVT_MAX_COMPS + (comp >= 0 ? comp : 0)) * AVT_PRIOR_STRIDE;
+    const bool use_pose = sbp > 0.0 && d.ncomps > 0 && comp >= 0;
+    const int n = d.ndims;
+    const double sc = 0.707106781186548 * sbp;          // literal constant (AvatarOptimizer.cpp:684)
+    const double sc2 = sc * sc;
+    const double gs = sc * sbp * 0.7071067811865476;    // J^T r = sc*sbp*sqrt(1/2) * Prec (x - mu)
+    const double* Pr = dm.prior_prec + (size_t)(comp >= 0 ? comp : 0) * n * n;
+    double a4[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int row = 4 * bi + r, col = 4 * bj + c;
+            double v = (row == col) ? 1.0 : 0.0;
+            if (bi >= 0 && row <= P && col < P) {
+                v = Hc[(size_t)row * HS + col];
+                const int pc = col - 6, sk = col - (3 + 3 * J);
+                if (row < P) {
+                    const int pr_ = row - 6;
+                    if (use_pose && pr_ >= 0 && pr_ < n && pc >= 0 && pc < n) v += sc2 * Pr[(size_t)pr_ * n + pc];
+                    if (row == col) {
+                        if (sbs > 0.0 && sk >= 0) v += sbs * sbs;
+                        v += lambda * v;
+                    }
+                } else {  // rhs row: -(J^T r) including the priors
+                    if (use_pose && pc >= 0 && pc < n) v += gs * pri[2 + pc];
+                    if (sbs > 0.0 && sk >= 0) v += sbs * (xc[3 + 4 * J + sk] * sbs);
+                    v = -v;
+                }
+            }
+            a4[r][c] = v;
+        }
+    TPROBE(2);
+
+    // ---- c. register-blocked LDL^T, four pivots per barrier ---------------------------------------------------
+    if (t == 0) { s_failv[0] = 0; s_failv[1] = 0; }
+    if (bj == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s_raw[((size_t)(4 * bi + r)) * 4 + c] = a4[r][c];
+    }
+    bool fail = false;
+    for (int kb = 0; kb < NB; ++kb) {
+        __syncthreads();
+        if (kb > 0 && s_failv[(kb - 1) & 1]) { fail = true; break; }
+        if (bj < kb) continue;                      // this lane's block is final (it still meets every barrier)
+        const double* raw = s_raw + (size_t)(kb & 1) * HS * 4;
+        // the (updated) diagonal block, factored redundantly by every lane: D = Ld diag(dv) Ld^T
+        const double* Dr = raw + (size_t)(4 * kb) * 4;
+        double D00 = Dr[0], D10 = Dr[4], D11 = Dr[5], D20 = Dr[8], D21 = Dr[9], D22 = Dr[10], D30 = Dr[12], D31 = Dr[13],
+               D32 = Dr[14], D33 = Dr[15];
+        const bool real1 = 4 * kb + 1 < P, real2 = 4 * kb + 2 < P, real3 = 4 * kb + 3 < P;   // 4*kb < P always
+        bool ok = D00 > 0.0;
+        const double r0 = fast_rcp(D00);
+        const double l10 = D10 * r0, l20 = D20 * r0, l30 = D30 * r0;
+        D11 = fma(-l10, D10, D11); D21 = fma(-l20, D10, D21); D31 = fma(-l30, D10, D31);
+        D22 = fma(-l20, D20, D22); D32 = fma(-l30, D20, D32); D33 = fma(-l30, D30, D33);
+        ok = ok && (!real1 || D11 > 0.0);
+        const double r1 = fast_rcp(D11);
+        const double l21 = D21 * r1, l31 = D31 * r1;
+        D22 = fma(-l21, D21, D22); D32 = fma(-l31, D21, D32); D33 = fma(-l31, D31, D33);
+        ok = ok && (!real2 || D22 > 0.0);
+        const double r2 = fast_rcp(D22);
+        const double l32 = D32 * r2;
+        D33 = fma(-l32, D32, D33);
+        ok = ok && (!real3 || D33 > 0.0);
+        const double r3 = fast_rcp(D33);
+        if (!ok) s_failv[kb & 1] = 1;               // same verdict in every lane that reaches here
+        if (bj == kb) {
+            // my block belongs to this block column: W = A Ld^-T (row-wise forward substitution), L = W D^-1
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double w0 = a4[r][0];
+                const double w1 = fma(-w0, l10, a4[r][1]);
+                const double w2 = fma(-w1, l21, fma(-w0, l20, a4[r][2]));
+                const double w3 = fma(-w2, l32, fma(-w1, l31, fma(-w0, l30, a4[r][3])));
+                double* Lrow = Lf + (size_t)(4 * bi + r) * LD + 4 * kb;
+                Lrow[0] = w0 * r0; Lrow[1] = w1 * r1; Lrow[2] = w2 * r2; Lrow[3] = w3 * r3;
+            }
+        } else {
+            // trailing block: A_ij -= W_i (W_j D^-1)^T with W from the raw block-column rows of bi and bj
+            double Wi[4][4], Lj[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double* ar = raw + (size_t)(4 * bi + r) * 4;
+                const double w0 = ar[0];
+                const double w1 = fma(-w0, l10, ar[1]);
+                const double w2 = fma(-w1, l21, fma(-w0, l20, ar[2]));
+                const double w3 = fma(-w2, l32, fma(-w1, l31, fma(-w0, l30, ar[3])));
+                Wi[r][0] = w0; Wi[r][1] = w1; Wi[r][2] = w2; Wi[r][3] = w3;
+                const double* br = raw + (size_t)(4 * bj + r) * 4;
+                const double u0 = br[0];
+                const double u1 = fma(-u0, l10, br[1]);
+                const double u2 = fma(-u1, l21, fma(-u0, l20, br[2]));
+                const double u3 = fma(-u2, l32, fma(-u1, l31, fma(-u0, l30, br[3])));
+                Lj[r][0] = u0 * r0; Lj[r][1] = u1 * r1; Lj[r][2] = u2 * r2; Lj[r][3] = u3 * r3;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    double v = a4[r][cc];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v = fma(-Wi[r][c], Lj[cc][c], v);
+                    a4[r][cc] = v;
+                }
+            if (bj == kb + 1) {                     // publish the next block column, raw
+                double* nxt = s_raw + (size_t)((kb + 1) & 1) * HS * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) nxt[(size_t)(4 * bi + r) * 4 + cc] = a4[r][cc];
+            }
+        }
+    }
+    __syncthreads();
+    if (s_failv[0] || s_failv[1]) fail = true;
+    TPROBE(3);
+    const bool ok = !fail;
+    const int ntry = 1 - cur;
+    double* xn = x0 + (size_t)ntry * xs;
+    if (ok) {
+        // ---- back substitution L^T delta = w (w = row P of Lf) by wave 0.  Lane l keeps w[l], w[l+64] and the
+        // running sums acc[l] = sum_{k>i} L[k][l] delta_k in registers; values cross lanes by v_readlane.
+        if (t < 64) {
+            const double w0 = (t < P) ? Lf[(size_t)P * LD + t] : 0.0;
+            const double w1 = (t + 64 < P) ? Lf[(size_t)P * LD + t + 64] : 0.0;
+            double acc0 = 0.0, acc1 = 0.0, dl0 = 0.0, dl1 = 0.0;
+            double n0 = (t < P - 1) ? Lf[(size_t)(P - 1) * LD + t] : 0.0;
+            double n1 = (t + 64 < P - 1) ? Lf[(size_t)(P - 1) * LD + t + 64] : 0.0;
+            for (int i = P - 1; i >= 0; --i) {
+                const double c0 = n0, c1 = n1;
+                if (i > 0) {                                  // prefetch row i-1 of the factor
+                    n0 = (t < i - 1) ? Lf[(size_t)(i - 1) * LD + t] : 0.0;
+                    n1 = (t + 64 < i - 1) ? Lf[(size_t)(i - 1) * LD + t + 64] : 0.0;
+                }
+                double di;
+                if (i < 64) { di = readlane_f64(w0, i) - readlane_f64(acc0, i); if (t == i) dl0 = di; }
+                else { di = readlane_f64(w1, i - 64) - readlane_f64(acc1, i - 64); if (t == i - 64) dl1 = di; }
+                acc0 = fma(c0, di, acc0);                     // c0/c1 are zero at and above the diagonal
+                acc1 = fma(c1, di, acc1);
+            }
+            if (t < P) s_delta[t] = dl0;
+            if (t + 64 < P) s_delta[t + 64] = dl1;
+        }
+        __syncthreads();
+        TPROBE(4);
+        // retraction (FakeQuaternionParameterization::Plus, :123-143)
+        if (t < 3) xn[t] = xc[t] + s_delta[t];
+        if (t < K) xn[3 + 4 * J + t] = xc[3 + 4 * J + t] + s_delta[3 + 3 * J + t];
+        if (t < J) {
+            const double* dl = s_delta + 3 + 3 * t;
+            const double* q = xc + 3 + 4 * t;
+            const double nd = sqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
+            double* qo = xn + 3 + 4 * t;
+            if (nd > 0.0) {
+                const double sdd = sin(nd) / nd;
+                const double a0 = sdd * dl[0], a1 = sdd * dl[1], a2 = sdd * dl[2], a3 = cos(nd);
+                qo[3] = a3 * q[3] - a0 * q[0] - a1 * q[1] - a2 * q[2];
+                qo[0] = a3 * q[0] + a0 * q[3] + a1 * q[2] - a2 * q[1];
+                qo[1] = a3 * q[1] + a1 * q[3] + a2 * q[0] - a0 * q[2];
+                qo[2] = a3 * q[2] + a2 * q[3] + a0 * q[1] - a1 * q[0];
+            } else {
+                qo[0] = q[0]; qo[1] = q[1]; qo[2] = q[2]; qo[3] = q[3];
+            }
+        }
+    } else {
+        for (int e = t; e < xs; e += 256) xn[e] = xc[e];
+        lambda = fmin(lambda * lm_up, lm_max);
+    }
+    if (t == 0) { ctl.lambda = lambda; ctl.try_valid = ok ? 1 : 0; }
+    __syncthreads();
+    __threadfence_block();
+    TPROBE(5);
+    // ---- d. skeleton tables of the new trial point ----------------------------------------------------
+    compute_prep(dm, xn, fb.prep + ((size_t)f * 2 + ntry) * d.prep_size, *ps);
+    TPROBE(6);
+}
+
+static size_t solve_lds_bytes(const AvtDims& d) {
+    const int HS = d.HS, LD = HS + 1;
+    return sizeof(double) * ((size_t)HS * LD + 2 * (size_t)HS * 4 + HS) + sizeof(PrepScratch) + 64;
+}
+
+void launch_reduce(avt_ctx* c, int nframes) {
+    const AvtDims& d = c->dm.d;
+    hipLaunchKernelGGL(k_reduce, dim3(d.NPAIR + std::max(0, d.ncomps), nframes), dim3(256), 0, c->stream, c->dm, c->fb);
+}
+
+void launch_solve(avt_ctx* c, int nframes, int mode, const avt_options* o) {
+    const AvtDims& d = c->dm.d;
+    hipLaunchKernelGGL(k_solve, dim3(nframes), dim3(256), solve_lds_bytes(d), c->stream, c->dm, c->fb, mode, o->lm_up, o->lm_down,
+                       o->lm_lambda_min, o->lm_lambda_max);
+}
+
+int avt_solve_set_attributes() {
+    return hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess;
+}

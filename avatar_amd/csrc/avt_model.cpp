@@ -42,6 +42,10 @@ extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
         avt_set_error("avt_model_create: unsupported dimensions (J<=32, K<=16)");
         return 1;
     }
+    if (3 + 3 * J + K > 87) {  // the register-blocked LDL^T of k_solve maps one 4x4 block per lane of a 256-thread workgroup
+        avt_set_error("avt_model_create: 3+3J+K must be <= 87 in this build (SMPL: 85)");
+        return 1;
+    }
     if (desc->parent[0] != -1) { avt_set_error("avt_model_create: parent[0] must be -1 (AvatarModel.cpp:41)"); return 1; }
     for (int j = 1; j < J; ++j)
         if (desc->parent[j] < 0 || desc->parent[j] >= j) { avt_set_error("avt_model_create: parent[] must be topologically sorted"); return 1; }
@@ -54,6 +58,10 @@ extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
     d.prep_size = prep_total(d);
     d.num_parts = 0;
     m->parent.assign(desc->parent, desc->parent + J);
+    m->jlevel.assign(J, 0);
+    d.nlevels = 1;
+    for (int j = 1; j < J; ++j) { m->jlevel[j] = m->jlevel[desc->parent[j]] + 1; d.nlevels = std::max(d.nlevels, m->jlevel[j] + 1); }
+    d.HS = 4 * ((d.P + 4) / 4);
 
     // shape planes
     m->shape_planes.assign((size_t)(K + 1) * 3 * V, 0.0);
@@ -145,6 +153,7 @@ extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
 
     // GMM (GaussianMixture.cpp:12-77)
     d.ncomps = desc->prior_ncomps > 0 ? desc->prior_ncomps : 0;
+    if (d.ncomps > AVT_MAX_COMPS) { delete m; avt_set_error("avt_model_create: more than 16 GMM components"); return 1; }
     d.ndims = d.ncomps ? desc->prior_ndims : 0;
     if (d.ncomps) {
         const int n = d.ndims;

@@ -21,16 +21,19 @@
 
 #define NN_TILE 1024
 
+#define NN_QPB 64   // queries per workgroup: 4 lanes cooperate on one query
+
 __global__ __launch_bounds__(256) void k_nn(DeviceModel dm, FrameBuffers fb) {
     const int f = blockIdx.y, t = threadIdx.x;
     const int V = dm.d.V, np = dm.d.num_parts;
     const AvtFrameCtl& ctl = fb.ctl[f];
     const int* po = fb.part_off + (size_t)f * (np + 1);
     const int nvalid = po[np];  // bucketed points with a valid label
-    const int s0 = blockIdx.x * 256;
+    const int s0 = blockIdx.x * NN_QPB;
     if (s0 >= nvalid) return;
     const size_t base = (size_t)f * fb.max_points;
-    const int s = s0 + t;
+    const int sub = t & 3;
+    const int s = s0 + (t >> 2);
     const bool active = s < nvalid;
 
     __shared__ double c_x[NN_TILE], c_y[NN_TILE], c_z[NN_TILE];
@@ -40,14 +43,14 @@ __global__ __launch_bounds__(256) void k_nn(DeviceModel dm, FrameBuffers fb) {
         int lo = 0, hi = np - 1;
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (po[mid] <= s0) lo = mid; else hi = mid - 1; }
         s_qlo = lo;
-        const int last = min(s0 + 255, nvalid - 1);
+        const int last = min(s0 + NN_QPB - 1, nvalid - 1);
         lo = 0; hi = np - 1;
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (po[mid] <= last) lo = mid; else hi = mid - 1; }
         s_qhi = lo;
     }
     __syncthreads();
     const int qlo = s_qlo, qhi = s_qhi;
-    // my part: walk up from qlo (a workgroup rarely spans more than 2-3 parts)
+    // my part: walk up from qlo (a workgroup rarely spans more than 2 parts)
     int q = qlo;
     if (active) while (q < qhi && po[q + 1] <= s) ++q;
     const int my_b = dm.part_start[q], my_e = dm.part_start[q + 1];
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(256) void k_nn(DeviceModel dm, FrameBuffers fb) {
     const double* pcz = fb.pcz + (size_t)f * V;
     const unsigned char* vis = fb.visible + (size_t)f * V;
     double best = 1.7976931348623157e308;  // numeric_limits<double>::max(), KNNResultSet::init
-    int bi = -1;
+    int bi = 0x7fffffff;
     for (int tb = cb; tb < ce; tb += NN_TILE) {
         const int tn = min(NN_TILE, ce - tb);
         __syncthreads();
@@ -74,7 +77,8 @@ __global__ __launch_bounds__(256) void k_nn(DeviceModel dm, FrameBuffers fb) {
         __syncthreads();
         if (active) {
             const int b = max(my_b, tb) - tb, e = min(my_e, tb + tn) - tb;
-            for (int c = b; c < e; ++c) {
+            // lane `sub` of the query's 4-lane group scans candidates b+sub, b+sub+4, ... in ascending order
+            for (int c = b + sub; c < e; c += 4) {
                 const double d0 = a0 - c_x[c];
                 const double d1 = a1 - c_y[c];
                 const double d2 = a2 - c_z[c];
@@ -85,8 +89,16 @@ __global__ __launch_bounds__(256) void k_nn(DeviceModel dm, FrameBuffers fb) {
             }
         }
     }
-    if (!active) return;
-    const int m = bi >= 0 ? dm.part_vertices[bi] : -1;
+    // combine the 4 sub-scans: smallest distance, ties to the lowest candidate position — exactly the winner of
+    // one ascending scan with strict '<'
+#pragma unroll
+    for (int m = 1; m <= 2; m <<= 1) {
+        const double ob = __shfl_xor(best, m, 64);
+        const int oi = __shfl_xor(bi, m, 64);
+        if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (!active || sub != 0) return;
+    const int m = bi != 0x7fffffff ? dm.part_vertices[bi] : -1;
     fb.corr_sorted[base + s] = m;
     fb.corr[base + fb.dorig[base + s]] = m;
     if (m >= 0) {
@@ -106,8 +118,7 @@ void launch_nn(avt_ctx* c, int nframes) {
     // cnt and fsum are adjacent: one memset clears both for the frames in use
     hipMemsetAsync(c->fb.cnt, 0, (size_t)nframes * V * sizeof(int), c->stream);
     hipMemsetAsync(c->fb.fsum, 0, (size_t)nframes * 3 * V * sizeof(long long), c->stream);
-    int maxN = 0;
-    for (int f = 0; f < nframes; ++f) maxN = std::max(maxN, c->frame_N[f]);
-    const int nb = (maxN + 255) / 256;
+    const int maxN = c->launch_maxN;
+    const int nb = (maxN + NN_QPB - 1) / NN_QPB;
     if (nb > 0) hipLaunchKernelGGL(k_nn, dim3(nb, nframes), dim3(256), 0, c->stream, c->dm, c->fb);
 }

@@ -153,6 +153,7 @@ int avt_state_download(avt_ctx* c, double* p, double* q, double* w, avt_stats* s
 /* ---- introspection of the last optimize call (tests / diagnostics) */
 int avt_get_correspondences(avt_ctx* c, int frame, int* model_idx_out /* N of that frame */);
 int avt_get_cloud(avt_ctx* c, int frame, double* cloud_3xV);       /* ava.cloud after the final update() */
+/* data-term Gauss-Newton normal equations J^T J (P x P) and J^T r (P) at the current point + its objective */
 int avt_get_normal_equations(avt_ctx* c, int frame, double* H /* P x P */, double* g /* P */, double* cost);
 
 int avt_profile_begin(avt_ctx* c);
