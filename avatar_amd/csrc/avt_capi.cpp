@@ -10,6 +10,7 @@
 
 int avt_solve_set_attributes();
 int avt_eval_set_attributes();
+void avt_eval_report_occupancy(const AvtDims& d);
 
 #define HIP_OK(expr)                                                                          \
     do {                                                                                      \
@@ -275,6 +276,7 @@ int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* par
     HIP_OK(hipMemset(fb.trace, 0, (size_t)max_frames * 64 * sizeof(double)));
     HIP_OK(hipMemset(fb.ctl, 0, (size_t)max_frames * sizeof(AvtFrameCtl)));
     HIP_OK(hipDeviceSynchronize());
+    if (getenv("AVT_DEBUG")) avt_eval_report_occupancy(dm.d);
     *out = c;
     return 0;
 }

@@ -30,6 +30,28 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 #define TPROBE(i) do {} while (0)
 #endif
 
+// upper-triangular tile pairs of the 6x6 tile grid, in the order k_reduce / k_solve decode them
+__device__ constexpr int PAIR6_TI[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+__device__ constexpr int PAIR6_TJ[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
+
+// one batch (48 rows) of the [J|r]^T [J|r] contraction for wave W: pairs W, W+4, W+8, ... ; A and B operands are the
+// same kind of fragment (lane l: column tile*16 + (l&15), row k0 + (l>>4)), so 6 LDS reads feed up to 6 MFMAs.
+template <int W, int MAXPW>
+__device__ __forceinline__ void mfma_batch6(const double* __restrict__ s_Jt, int ln, v4f64 (&acc)[MAXPW]) {
+    const double* base = s_Jt + (size_t)(ln & 15) * AVT_EVAL_RS + (ln >> 4);
+#pragma unroll
+    for (int k0 = 0; k0 < AVT_EVAL_ROWS; k0 += 4) {
+        double fr[6];
+#pragma unroll
+        for (int ti = 0; ti < 6; ++ti) fr[ti] = base[(size_t)ti * 16 * AVT_EVAL_RS + k0];
+#pragma unroll
+        for (int i = 0; i < MAXPW; ++i) {
+            const int p = W + 4 * i;
+            if (p < 21) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[PAIR6_TI[p < 21 ? p : 0]], fr[PAIR6_TJ[p < 21 ? p : 0]], acc[i], 0, 0, 0);
+        }
+    }
+}
+
 // =================================================================================================
 // k_eval.  grid (G, nframes), block 256 = 4 waves.  Workgroup g of frame f owns a contiguous slice of the
 // frame's matched model points and walks it in batches of 16 points (48 rows of the augmented matrix).
@@ -42,7 +64,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 //     are the same kind of fragment: A[i][k] = Jt[ti*16+i][k], B[k][j] = Jt[tj*16+j][k]).
 // =================================================================================================
 template <int NT_MAX>
-__global__ __launch_bounds__(256) void k_eval(DeviceModel dm, FrameBuffers fb) {
+__global__ __launch_bounds__(256, 2) void k_eval(DeviceModel dm, FrameBuffers fb) {
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, V = d.V, P = d.P, NT = d.NT, NPAIR = d.NPAIR;
     const int f = blockIdx.y, g = blockIdx.x, G = gridDim.x, t = threadIdx.x;
@@ -60,10 +82,14 @@ __global__ __launch_bounds__(256) void k_eval(DeviceModel dm, FrameBuffers fb) {
     double* s_xhat = s_D + 16 * NSH;                              // [16][3]
     double* s_xk = s_xhat + 48;                                   // [16][4][3]
     double* s_aw = s_xk + 192;                                    // [16][4]
-    int* s_aj = (int*)(s_aw + 64);                                // [16][4]
+    double* s_T = s_aw + 64;                                      // [16][9]  blended rotation per point
+    double* s_Gs = s_T + 144;                                     // [16][3K] blended shape table per point
+    int* s_aj = (int*)(s_Gs + 16 * 3 * K);                        // [16][4]
+    int* s_par = s_aj + 64;                                       // [J]
 
     const double* prep = fb.prep + ((size_t)f * 2 + try_slot) * d.prep_size;
     for (int e = t; e < d.prep_size; e += 256) s_prep[e] = prep[e];
+    if (t < J) s_par[t] = dm.parent[t];
     const double* Rw = s_prep + prep_off_Rw(d);
     const double* oo = s_prep + prep_off_o(d);
     const double* Jh = s_prep + prep_off_Jh(d);
@@ -93,41 +119,91 @@ __global__ __launch_bounds__(256) void k_eval(DeviceModel dm, FrameBuffers fb) {
     const double* mcnt = fb.mcnt + (size_t)f * V;
     const double* mdbar = fb.mdbar + (size_t)f * 3 * V;
 
+#ifdef AVT_TIMING
+    long long tacc[6] = {0, 0, 0, 0, 0, 0}; long long tlast = clock64();
+#define EPROBE(k) do { const long long _n = clock64(); tacc[k] += _n - tlast; tlast = _n; } while (0)
+#else
+#define EPROBE(k) do {} while (0)
+#endif
+    // ---- software pipeline: the global loads of batch b+1 are issued while batch b is in its Jacobian / MFMA
+    // phases; the matched-vertex id travels one batch further ahead (it addresses every other load).
+    double pD[AVT_MAX_SHAPE + 1];      // slot < 3: component `slot` of the K key clouds + base cloud of my point
+    double p_aw = 0.0, p_sc = 0.0, p_db = 0.0;
+    int p_aj = 0, p_nanc = 0;
+    unsigned p_aword = 0u;
+    auto fetch = [&](int b0n, int mm) {
+        const int idxn = b0n + pi;
+        const bool vn = idxn < hi;
+        const int m = vn ? mm : 0;
+        if (slot < 3) {
+#pragma unroll
+            for (int k = 0; k <= AVT_MAX_SHAPE; ++k)
+                if (k <= K) pD[k] = dm.shape_planes[((size_t)k * 3 + slot) * V + m];
+            p_db = vn ? mdbar[(size_t)slot * V + idxn] : 0.0;
+        }
+        if (slot < 4) { p_aw = vn ? dm.asg_w[(size_t)slot * V + m] : 0.0; p_aj = dm.asg_j[(size_t)slot * V + m]; }
+        p_nanc = vn ? (int)dm.anc_n[m] : 0;
+        p_aword = (unsigned)dm.anc[(size_t)slot * V + m];
+        p_sc = vn ? mcnt[idxn] : 0.0;
+    };
+    int m_nxt = (lo + AVT_EVAL_PTS + pi < hi) ? matched[lo + AVT_EVAL_PTS + pi] : 0;
+    if (lo < hi) fetch(lo, (lo + pi < hi) ? matched[lo + pi] : 0);
+
     for (int b0 = lo; b0 < hi; b0 += AVT_EVAL_PTS) {
         const int idx = b0 + pi;
         const bool valid = idx < hi;
-        const int m = valid ? matched[idx] : 0;
+        // consume the prefetched registers of this batch
+        const double sc = p_sc;
+        const int nanc = p_nanc;
+        const unsigned aword = (slot < nanc) ? p_aword : 0u;
         __syncthreads();  // previous batch's MFMA reads are done (also covers the prep load on the first pass)
-        // clear the tile, fetch this batch's model data
+        EPROBE(0);
         for (int e = t; e < NT * 16 * RS; e += 256) s_Jt[e] = 0.0;
-        for (int e = slot; e < NSH; e += 16) s_D[pi * NSH + e] = valid ? dm.shape_planes[(size_t)e * V + m] : 0.0;
-        if (slot < 4) {
-            s_aw[pi * 4 + slot] = valid ? dm.asg_w[(size_t)slot * V + m] : 0.0;
-            s_aj[pi * 4 + slot] = valid ? dm.asg_j[(size_t)slot * V + m] : 0;
-        }
-        const int nanc = valid ? (int)dm.anc_n[m] : 0;
-        const unsigned aword = (slot < nanc) ? (unsigned)dm.anc[(size_t)slot * V + m] : 0u;
-        const double sc = valid ? mcnt[idx] : 0.0;
-        __syncthreads();
-        // shaped rest position, root-subtracted (CalcShape, :249-272)
         if (slot < 3) {
+            // shaped rest position, root-subtracted (CalcShape, :249-272)
             double a = 0.0;
-            for (int k = 0; k < K; ++k) a += s_D[pi * NSH + 3 * k + slot] * ww[k];
-            s_xhat[pi * 3 + slot] = (a + s_D[pi * NSH + 3 * K + slot]) - off[slot];
+#pragma unroll
+            for (int k = 0; k < AVT_MAX_SHAPE; ++k)
+                if (k < K) { s_D[pi * NSH + 3 * k + slot] = pD[k]; a += pD[k] * ww[k]; }
+            double bse = pD[0];
+#pragma unroll
+            for (int k = 1; k <= AVT_MAX_SHAPE; ++k)
+                if (k == K) bse = pD[k];
+            s_D[pi * NSH + 3 * K + slot] = bse;
+            s_xhat[pi * 3 + slot] = (a + bse) - off[slot];
         }
+        if (slot < 4) { s_aw[pi * 4 + slot] = p_aw; s_aj[pi * 4 + slot] = p_aj; }
         __syncthreads();
-        // x_k = R(-1,k)(x^ - J^_k) + t(-1,k) for the <=4 assigned joints (:508-514)
+        EPROBE(1);
+        const double* aw = s_aw + pi * 4;
+        const int* aj = s_aj + pi * 4;
+        // x_k = R(-1,k)(x^ - J^_k) + t(-1,k) for the <=4 assigned joints (:508-514); blended rotation T = sum a_k Rw_k
+        // and blended shape table Gs = sum a_k G_k for the shape block (:568-580)
         if (slot < 4) {
-            const int k = s_aj[pi * 4 + slot];
+            const int k = aj[slot];
             const double* R = Rw + 9 * k;
             const double e0 = s_xhat[pi * 3] - Jh[3 * k], e1 = s_xhat[pi * 3 + 1] - Jh[3 * k + 1], e2 = s_xhat[pi * 3 + 2] - Jh[3 * k + 2];
             double* xk = s_xk + (pi * 4 + slot) * 3;
             xk[0] = (R[0] * e0 + R[1] * e1 + R[2] * e2) + oo[3 * k];
             xk[1] = (R[3] * e0 + R[4] * e1 + R[5] * e2) + oo[3 * k + 1];
             xk[2] = (R[6] * e0 + R[7] * e1 + R[8] * e2) + oo[3 * k + 2];
+        } else if (slot < 13) {
+            const int e9 = slot - 4;
+            s_T[pi * 9 + e9] = ((aw[0] * Rw[9 * aj[0] + e9] + aw[1] * Rw[9 * aj[1] + e9]) + aw[2] * Rw[9 * aj[2] + e9]) + aw[3] * Rw[9 * aj[3] + e9];
         }
+        for (int e = slot; e < 3 * K; e += 16)
+            s_Gs[pi * 3 * K + e] = ((aw[0] * Gm[aj[0] * 3 * K + e] + aw[1] * Gm[aj[1] * 3 * K + e]) + aw[2] * Gm[aj[2] * 3 * K + e]) + aw[3] * Gm[aj[3] * 3 * K + e];
         __syncthreads();
-        const double* aw = s_aw + pi * 4;
+        EPROBE(2);
+        // issue the next batch's loads now: they land while this batch does its Jacobian and MFMA phases
+        const double db = p_db;
+        {
+            const int b0n = b0 + AVT_EVAL_PTS;
+            const int mm = m_nxt;
+            m_nxt = (b0n + AVT_EVAL_PTS + pi < hi) ? matched[b0n + AVT_EVAL_PTS + pi] : 0;
+            if (b0n < hi) fetch(b0n, mm);
+        }
+        EPROBE(3);
         const double* xk = s_xk + pi * 12;
         if (slot < nanc) {
             const int j = aword & 0xff;
@@ -165,7 +241,7 @@ __global__ __launch_bounds__(256) void k_eval(DeviceModel dm, FrameBuffers fb) {
             double Rp[9];
             if (j == 0) { Rp[0] = 1; Rp[1] = 0; Rp[2] = 0; Rp[3] = 0; Rp[4] = 1; Rp[5] = 0; Rp[6] = 0; Rp[7] = 0; Rp[8] = 1; }
             else {
-                const double* src = Rw + 9 * dm.parent[j];
+                const double* src = Rw + 9 * s_par[j];
 #pragma unroll
                 for (int e = 0; e < 9; ++e) Rp[e] = src[e];
             }
@@ -182,49 +258,54 @@ __global__ __launch_bounds__(256) void k_eval(DeviceModel dm, FrameBuffers fb) {
                     s_Jt[(size_t)(3 + 3 * j + c) * RS + pi * 3 + r] = sc * bl;
                 }
         }
-        // shape block (:568-580), residual column and the identity root-translation block (:476-481)
-        for (int e = slot; e < 3 * K + 6; e += 16) {
-            if (e < 3 * K) {
-                const int r = e / K, k = e % K;
-                double a = 0.0;
+        // shape block (:568-580): (sum a_k Rw_k) D + sum a_k G_k
+        for (int e = slot; e < 3 * K; e += 16) {
+            const int r = e / K, k = e - r * K;
+            const double* Tr = s_T + pi * 9 + 3 * r;
+            const double* Dk = s_D + pi * NSH + 3 * k;
+            const double a = (Tr[0] * Dk[0] + Tr[1] * Dk[1] + Tr[2] * Dk[2]) + s_Gs[pi * 3 * K + e];
+            s_Jt[(size_t)(3 + 3 * J + k) * RS + pi * 3 + r] = sc * a;
+        }
+        if (slot < 3) {          // residual column: sqrt(c) (x_m - dbar_m)
+            double xm = 0.0;
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    const double wt = aw[s4];
-                    if (wt != 0.0) {
-                        const int jj = s_aj[pi * 4 + s4];
-                        const double* R = Rw + 9 * jj;
-                        const double* Dk = s_D + pi * NSH + 3 * k;
-                        a += ((R[3 * r] * Dk[0] + R[3 * r + 1] * Dk[1] + R[3 * r + 2] * Dk[2]) + Gm[(jj * 3 + r) * K + k]) * wt;
-                    }
-                }
-                s_Jt[(size_t)(3 + 3 * J + k) * RS + pi * 3 + r] = sc * a;
-            } else if (e < 3 * K + 3) {
-                const int r = e - 3 * K;
-                double xm = 0.0;
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) xm += aw[s4] * xk[3 * s4 + r];
-                const double db = valid ? mdbar[(size_t)r * V + idx] : 0.0;
-                s_Jt[(size_t)P * RS + pi * 3 + r] = sc * (xm - db);
-            } else {
-                const int r = e - 3 * K - 3;
-                s_Jt[(size_t)r * RS + pi * 3 + r] = sc;
-            }
+            for (int s4 = 0; s4 < 4; ++s4) xm += aw[s4] * xk[3 * s4 + slot];
+            s_Jt[(size_t)P * RS + pi * 3 + slot] = sc * (xm - db);
+        } else if (slot < 6) {   // identity root-translation block (:476-481)
+            const int r = slot - 3;
+            s_Jt[(size_t)r * RS + pi * 3 + r] = sc;
         }
         __syncthreads();
+        EPROBE(4);
         // MFMA phase: 12 k-steps of 4 rows
+        if constexpr (NT_MAX == 6) {
+            // SMPL shape (P+1 <= 96): straight-line code per wave, fragments fetched once per k-step and shared by
+            // the wave's tile pairs; no exec-mask branches between the matrix instructions.
+            switch (wv) {
+                case 0: mfma_batch6<0, MAXPW>(s_Jt, ln, acc); break;
+                case 1: mfma_batch6<1, MAXPW>(s_Jt, ln, acc); break;
+                case 2: mfma_batch6<2, MAXPW>(s_Jt, ln, acc); break;
+                default: mfma_batch6<3, MAXPW>(s_Jt, ln, acc); break;
+            }
+        } else {
 #pragma unroll 1
-        for (int k0 = 0; k0 < AVT_EVAL_ROWS; k0 += 4) {
-            const int rowoff = k0 + (ln >> 4);
+            for (int k0 = 0; k0 < AVT_EVAL_ROWS; k0 += 4) {
+                const int rowoff = k0 + (ln >> 4);
 #pragma unroll
-            for (int i = 0; i < MAXPW; ++i) {
-                if (pr_ti[i] >= 0) {
-                    const double a = s_Jt[(size_t)(pr_ti[i] * 16 + (ln & 15)) * RS + rowoff];
-                    const double bq = s_Jt[(size_t)(pr_tj[i] * 16 + (ln & 15)) * RS + rowoff];
-                    acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc[i], 0, 0, 0);
+                for (int i = 0; i < MAXPW; ++i) {
+                    if (pr_ti[i] >= 0) {
+                        const double a = s_Jt[(size_t)(pr_ti[i] * 16 + (ln & 15)) * RS + rowoff];
+                        const double bq = s_Jt[(size_t)(pr_tj[i] * 16 + (ln & 15)) * RS + rowoff];
+                        acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc[i], 0, 0, 0);
+                    }
                 }
             }
         }
     }
+#ifdef AVT_TIMING
+    EPROBE(5);
+    if (t == 0 && f == 0 && g == 0) for (int k = 0; k < 6; ++k) fb.trace[48 + k] = (double)tacc[k];
+#endif
     // partial tiles out: element (row = (ln>>4) + 4*reg, col = ln&15) of pair p at [p][reg*64 + ln]
     double* part = fb.partial + (((size_t)f * fb.G + g) * NPAIR) * 256;
 #pragma unroll
@@ -239,20 +320,26 @@ __global__ __launch_bounds__(256) void k_eval(DeviceModel dm, FrameBuffers fb) {
 
 static size_t eval_lds_bytes(const AvtDims& d) {
     const int NSH = 3 * (d.K + 1);
-    return sizeof(double) * ((size_t)d.prep_size + (size_t)d.NT * 16 * AVT_EVAL_RS + 16 * NSH + 48 + 192 + 64) + sizeof(int) * 64;
+    return sizeof(double) * ((size_t)d.prep_size + (size_t)d.NT * 16 * AVT_EVAL_RS + 16 * NSH + 48 + 192 + 64 + 144 + 16 * 3 * d.K) +
+           sizeof(int) * (64 + AVT_MAX_JOINTS);
 }
 
 void launch_eval(avt_ctx* c, int nframes) {
     const AvtDims& d = c->dm.d;
     dim3 grid(c->fb.G, nframes);
     const size_t lds = eval_lds_bytes(d);
-    if (d.NT <= 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<6>), grid, dim3(256), lds, c->stream, c->dm, c->fb);
+    if (d.NT == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<6>), grid, dim3(256), lds, c->stream, c->dm, c->fb);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<AVT_MAX_TILES>), grid, dim3(256), lds, c->stream, c->dm, c->fb);
 }
 
+void avt_eval_report_occupancy(const AvtDims& d) {
+    int nb = -1;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_eval<6>, 256, eval_lds_bytes(d));
+    fprintf(stderr, "[avt] k_eval<6>: dynamic LDS %zu B, occupancy query -> %d blocks/CU (%s)\n", eval_lds_bytes(d), nb, hipGetErrorString(e));
+}
+
 int avt_eval_set_attributes() {
-    hipError_t e = hipFuncSetAttribute((const void*)k_eval<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-    if (e != hipSuccess) return 1;
-    e = hipFuncSetAttribute((const void*)k_eval<AVT_MAX_TILES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-    return e != hipSuccess;
+    // k_eval<6> needs < 64 KB of dynamic LDS: leave its attribute alone (raising the cap costs residency);
+    // the generic shape may need more.
+    return hipFuncSetAttribute((const void*)k_eval<AVT_MAX_TILES>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess;
 }

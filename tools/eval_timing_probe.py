@@ -1,0 +1,18 @@
+import sys, numpy as np, ctypes as C
+sys.path.insert(0,'/root/repo')
+from avatar_amd import api, synth, capi
+from avatar_amd.capi import Options
+F=int(sys.argv[1]) if len(sys.argv)>1 else 64
+smpl=synth.load_model(0); gm=api.AvatarModel(smpl)
+frs=[synth.make_frame(smpl,s%8) for s in range(F)]; pm=synth.identity_part_map()
+ctx=api.Context(gm,24,pm,60000,F)
+p0=np.array([f['start'][1] for f in frs]); q0=np.array([api.rot_to_quat(f['start'][2]) for f in frs]); w0=np.array([f['start'][0] for f in frs])
+opt=Options.demo()
+for i in range(3):
+    ctx.optimize_batch([f['data'] for f in frs],[f['labels'] for f in frs],opt,p0,q0,w0)
+lib=capi.load_library(); buf=np.zeros(64)
+lib.avt_debug_trace.argtypes=[C.c_void_p,C.c_int,C.POINTER(C.c_double)]
+lib.avt_debug_trace(ctx.h,0,buf.ctypes.data_as(C.POINTER(C.c_double)))
+names=['wait_prev+top','zero+gload','xhat','xk','jac+shape','mfma(+tail)']
+t=buf[48:54]; print('F',F,'eval block0 cycles per phase:'); [print('  %-14s %10.0f  %5.1f%%'%(n,v,100*v/t.sum())) for n,v in zip(names,t)]; print('  total',t.sum(), 'cycles =', t.sum()/2.4e3,'us @2.4GHz')
+s=buf[40:47]; print('solve probes deltas', np.diff(s))
