@@ -35,6 +35,120 @@ def algorithmic_bytes_per_gn_iter(N, V, K, P):
     return 24 * N + 4 * N + 24 * V * (K + 1) + 48 * V + 24 * V + 8 * P * (P + 1)
 
 
+PMC_FILES = {1: "profiles/r01_pmc_single_frame.json", 64: "profiles/r01_pmc_64_frames.json"}
+KERNEL_SYMBOL = {"eval": "_Z6k_evalILi6EEv11DeviceModel12FrameBuffers.kd", "solve": "_Z7k_solve11DeviceModel12FrameBuffersidddd.kd",
+                 "reduce": "_Z8k_reduce11DeviceModel12FrameBuffers.kd", "nn": "_Z4k_nn11DeviceModel12FrameBuffers.kd"}
+
+
+def pmc_traffic(frames, kernel_class):
+    """HBM bytes per launch of `kernel_class` from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+    same command (tools/pmc_summary.py applies the gfx950 corrections of MI355X_MICROARCH.md §HBM); None if not measured."""
+    path = os.path.join(ROOT, PMC_FILES.get(frames, ""))
+    try:
+        d = json.load(open(path))
+        return int(d["kernels"][KERNEL_SYMBOL[kernel_class]]["hbm_bytes"])
+    except Exception:
+        return None
+
+
+def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, rank, world, local_rank, dense):
+    """Times `steps` optimize() calls over F resident frames on this rank; returns the per-config result dict."""
+    V, J, K, P = gm.numPoints(), gm.numJoints(), gm.numShapeKeys(), gm.arrays.P
+    pm = synth.identity_part_map()
+    uniq = min(F, 8)     # a handful of distinct frames are rendered per rank, the rest of the batch reuses them
+    frames = [synth.make_frame(smpl, rank * uniq + s, dense=dense) for s in range(uniq)]
+    frs = [frames[f % uniq] for f in range(F)]
+    maxN = max(len(fr["labels"]) for fr in frs)
+    ctx = api.Context(gm, 24, pm, maxN, F, device=local_rank)
+    opt = Options.demo(icp_iters=args.icp_iters)
+    p0 = np.array([fr["start"][1] for fr in frs])
+    q0 = np.array([api.rot_to_quat(fr["start"][2]) for fr in frs])
+    w0 = np.array([fr["start"][0] for fr in frs])
+    ctx.frames_upload([fr["data"] for fr in frs], [fr["labels"] for fr in frs])   # inputs resident in HBM
+
+    def step():
+        ctx.state_upload(p0, q0, w0)      # reset to the tracking start state (109 doubles per frame)
+        ctx.optimize_resident(opt)        # asynchronous on the context's stream (one hipGraph replay)
+
+    # which kernel class dominates this configuration (one instrumented, untimed step)
+    for _ in range(max(1, warmup)):
+        step()
+    ctx.sync()
+    ctx.profile_begin()
+    step()
+    ctx.sync()
+    prof = ctx.profile_end()
+    dominant = max(prof, key=lambda k: prof[k][0])
+    for _ in range(warmup):
+        step()
+    ctx.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    # timed region; HIP events only around the dominant kernel class, on the stream it is launched on
+    ctx.profile_begin(classes=[dominant])
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.sync()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    prof_timed = ctx.profile_end()
+    elapsed = t1 - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+        dist.barrier()
+    # the same K steps once more WITHOUT any event records: `value` must not carry instrumentation overhead
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.sync()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed_clean = t1 - t0
+    if world > 1:
+        te = torch.tensor([elapsed_clean], dtype=torch.float64, device="cuda")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed_clean = float(te.item())
+        dist.barrier()
+    p, q, w, st = ctx.state_download()
+    gn_per_step = F * opt.icp_iters * opt.max_iters_per_icp
+    res = {"value": world * gn_per_step * steps / elapsed_clean, "elapsed": elapsed_clean, "elapsed_with_events": elapsed,
+           "steps": steps, "F": F}
+    tot = sum(v[0] for v in prof.values())
+    res["kernels"] = {k: {"ms": round(v[0], 5), "launches": v[1], "share": round(v[0] / tot, 4)} for k, v in prof.items() if v[1]}
+    Nmean = float(np.mean([len(fr["labels"]) for fr in frs]))
+    M = float(np.mean([s.matched_model_points for s in st]))
+    bytes_launch = F * algorithmic_bytes_per_gn_iter(Nmean, V, K, P)
+    avg_ms = prof_timed[dominant][0] / max(1, prof_timed[dominant][1])      # live, over the (event-instrumented) timed region
+    achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
+    res["roofline"] = {"kernel": "k_" + dominant, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(F, dominant),
+                       "avg_launch_us": round(avg_ms * 1e3, 3), "launches_timed": prof_timed[dominant][1],
+                       "algorithmic_bytes_per_launch": int(bytes_launch),
+                       "note": "achieved = frames x SURVEY 8(d) bytes per GN iteration / mean launch time of the dominant kernel class; "
+                               "traffic = HBM bytes per launch from committed rocprofv3 PMC passes (profiles/)"}
+    ev = prof["eval"]
+    ev_ms = ev[0] / max(1, ev[1])
+    tfl = F * 3.0 * M * P * (P + 1) / (ev_ms * 1e-3) / 1e12 if ev_ms > 0 else 0.0
+    res["eval_kernel"] = {"avg_launch_us_with_events": round(ev_ms * 1e3, 3), "jtj_tflops_f64": round(tfl, 4), "mfma_peak_tflops": FP64_MFMA_PEAK_TFLOPS,
+                          "mfma_frac": round(tfl / FP64_MFMA_PEAK_TFLOPS, 6)}
+    res["points_per_frame"] = int(Nmean)
+    res["matched_model_points"] = int(M)
+    res["final_cost_frame0"] = st[0].final_cost
+    res["accepted_steps_frame0"] = st[0].accepted_steps
+    res["frames0"] = frs[0]
+    res["opt"] = opt
+    res["start0"] = (p0[0], q0[0], w0[0])
+    del ctx
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -44,6 +158,7 @@ def main():
     ap.add_argument("--dense", action="store_true", help="120k-point stress frames (configs[4])")
     ap.add_argument("--icp-iters", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-throughput-config", action="store_true", help="skip the secondary 64-frames-per-GPU measurement")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
 
@@ -61,112 +176,62 @@ def main():
 
     smpl = synth.load_model(0)
     gm = api.AvatarModel(smpl)
-    V, J, K, P = gm.numPoints(), gm.numJoints(), gm.numShapeKeys(), gm.arrays.P
-    pm = synth.identity_part_map()
+    P = gm.arrays.P
     F = args.frames
-    # distinct seeds per frame and rank; only a handful of distinct frames are rendered, the rest reuse them
-    uniq = min(F, 8)
-    frames = [synth.make_frame(smpl, rank * uniq + s, dense=args.dense) for s in range(uniq)]
-    frs = [frames[f % uniq] for f in range(F)]
-    maxN = max(len(fr["labels"]) for fr in frs)
-    ctx = api.Context(gm, 24, pm, maxN, F, device=local_rank)
-    opt = Options.demo(icp_iters=args.icp_iters)
-    p0 = np.array([fr["start"][1] for fr in frs])
-    q0 = np.array([api.rot_to_quat(fr["start"][2]) for fr in frs])
-    w0 = np.array([fr["start"][0] for fr in frs])
-    ctx.frames_upload([fr["data"] for fr in frs], [fr["labels"] for fr in frs])   # inputs resident in HBM
-
-    def step():
-        ctx.state_upload(p0, q0, w0)      # reset to the tracking start state (109 doubles per frame)
-        ctx.optimize_resident(opt)        # asynchronous on the context's stream
-
-    for _ in range(args.warmup):
-        step()
-    ctx.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    # timed region: HIP events only around the dominant kernel class (known from the previous profile; refined below)
-    ctx.profile_begin(classes=["eval"])
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.sync()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    prof_timed = ctx.profile_end()
-    elapsed = t1 - t0
-    if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-        dist.barrier()
-    p, q, w, st = ctx.state_download()
-    gn_per_step = F * opt.icp_iters * opt.max_iters_per_icp
-    value = world * gn_per_step * args.steps / elapsed
-
-    # one extra, fully instrumented step (not timed for `value`): per-kernel-class device time
-    ctx.profile_begin()
-    step()
-    ctx.sync()
-    prof = ctx.profile_end()
+    r = measure(api, synth, Options, torch, dist, smpl, gm, args, F, args.steps, args.warmup, rank, world, local_rank, args.dense)
+    r2 = None
+    if F == 1 and not args.dense and not args.no_throughput_config:
+        r2 = measure(api, synth, Options, torch, dist, smpl, gm, args, 64, max(5, args.steps // 5), 2, rank, world, local_rank, False)
     if rank == 0:
-        tot = sum(v[0] for v in prof.values())
-        kernels = {k: {"ms": round(v[0], 5), "launches": v[1], "share": round(v[0] / tot, 4)} for k, v in prof.items() if v[1]}
-        dominant = max(prof, key=lambda k: prof[k][0])
-        Nmean = float(np.mean([len(fr["labels"]) for fr in frs]))
-        bytes_launch = F * algorithmic_bytes_per_gn_iter(Nmean, V, K, P)
-        if dominant == "eval" and prof_timed["eval"][1]:
-            avg_ms = prof_timed["eval"][0] / prof_timed["eval"][1]          # live, over the timed region
-        else:
-            avg_ms = prof[dominant][0] / max(1, prof[dominant][1])
-        achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
-        roofline = {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                    "avg_launch_us": round(avg_ms * 1e3, 3), "bytes_per_launch": int(bytes_launch)}
-        M = float(np.mean([s.matched_model_points for s in st]))
-        ev_ms = prof_timed["eval"][0] / max(1, prof_timed["eval"][1])
-        eval_tflops = F * 3.0 * M * P * (P + 1) / (ev_ms * 1e-3) / 1e12 if ev_ms > 0 else 0.0
+        opt = r["opt"]
         out = {
             "metric": "Gauss-Newton iterations/sec (30k-pt cloud, 10 shape + 24-joint pose)",
-            "value": round(value, 2), "unit": "GN iterations/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "value": round(r["value"], 2), "unit": "GN iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(r["elapsed"] / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("dense 120k-pt stress frame" if args.dense else "1 synthetic smplsynth cloud (~30k pts)")
                        + f", {F} frame(s)/GPU, icp_iters={opt.icp_iters}, maxItersPerICP={opt.max_iters_per_icp}, P={P}",
-                       "frames_per_gpu": F, "points_per_frame": int(Nmean), "matched_model_points": int(M),
+                       "frames_per_gpu": F, "points_per_frame": r["points_per_frame"], "matched_model_points": r["matched_model_points"],
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
-            "roofline": roofline,
-            "eval_kernel": {"avg_launch_us": round(ev_ms * 1e3, 3), "jtj_tflops_f64": round(eval_tflops, 4),
-                            "mfma_peak_tflops": FP64_MFMA_PEAK_TFLOPS, "mfma_frac": round(eval_tflops / FP64_MFMA_PEAK_TFLOPS, 6)},
-            "kernels": kernels,
-            "final_cost_frame0": st[0].final_cost, "accepted_steps_frame0": st[0].accepted_steps,
+            "roofline": r["roofline"], "eval_kernel": r["eval_kernel"], "kernels": r["kernels"],
+            "ms_per_step_with_event_records": round(r["elapsed_with_events"] / args.steps * 1e3, 4),
+            "final_cost_frame0": r["final_cost_frame0"], "accepted_steps_frame0": r["accepted_steps_frame0"],
         }
-        if not args.no_cpu_baseline and world >= 1:
+        if r2 is not None:
+            out["throughput_config"] = {
+                "workload": "BASELINE configs[2]: 64 independent ~30k-pt frames per GPU, same optimize()", "value": round(r2["value"], 2),
+                "unit": "GN iterations/s", "steps": r2["steps"], "ms_per_step": round(r2["elapsed"] / r2["steps"] * 1e3, 4),
+                "roofline": r2["roofline"], "eval_kernel": r2["eval_kernel"], "kernels": r2["kernels"]}
+        if not args.no_cpu_baseline:
             from oracle import oracle as orc
             om = orc.OracleModel(smpl)
-            fr = frs[0]
+            fr = r["frames0"]
+            p0, q0, w0 = r["start0"]
+            pm = synth.identity_part_map()
             ncpu = os.cpu_count() or 1
 
             def cpu_rate(aggregate, nthreads, budget):
                 reps, tt = 0, 0.0
                 while tt < budget:
                     a = time.perf_counter()
-                    om.optimize(pm, 24, fr["data"], fr["labels"], opt, p0[0], q0[0], w0[0], aggregate=aggregate, nthreads=nthreads)
+                    om.optimize(pm, 24, fr["data"], fr["labels"], opt, p0, q0, w0, aggregate=aggregate, nthreads=nthreads)
                     tt += time.perf_counter() - a
                     reps += 1
                 return reps * opt.icp_iters * opt.max_iters_per_icp / tt, reps
 
             v1, reps = cpu_rate(1, 1, args.cpu_seconds * 0.6)
             vlit, _ = cpu_rate(0, 1, args.cpu_seconds * 0.2)
-            vall, _ = cpu_rate(1, ncpu, args.cpu_seconds * 0.2)
+            vall, _ = cpu_rate(1, min(ncpu, 32), args.cpu_seconds * 0.2)
             out["cpu_baseline"] = {
                 "value": round(v1, 2), "unit": "GN iterations/s", "cores": 1, "kind": "port",
-                "sample": f"{reps} x optimize() of frame 0 ({len(fr['labels'])} pts, 10 GN iterations), CPU restatement of the "
-                          f"sxyu/avatar algorithm (not Ceres), aggregated normal equations, 1 thread",
-                "per_residual_block_1thread": round(vlit, 2), "aggregated_all_cores": round(vall, 2), "host_cores": ncpu,
+                "sample": f"{reps} x optimize() of frame 0 ({len(fr['labels'])} pts, 10 GN iterations): CPU restatement of the "
+                          f"sxyu/avatar algorithm (oracle/, not Ceres), same LM schedule, aggregated normal equations, 1 thread",
+                "reference_structure_per_residual_block_1thread": round(vlit, 2),
+                "aggregated_%d_threads" % min(ncpu, 32): round(vall, 2), "host_cores": ncpu,
             }
-            out["speedup_vs_cpu_port"] = round(value / v1, 1)
+            out["speedup_vs_cpu_port"] = round(r["value"] / v1, 1)
+            if r2 is not None:
+                out["throughput_config"]["speedup_vs_cpu_port"] = round(r2["value"] / v1, 1)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
