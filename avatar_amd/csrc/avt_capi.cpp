@@ -242,7 +242,7 @@ int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* par
     }
     if (dev_upload(c, &dm.shape_planes, m->shape_planes) || dev_upload(c, &dm.lbs_w, m->lbs_w) || dev_upload(c, &dm.lbs_j, m->lbs_j) ||
         dev_upload(c, &dm.asg_w, m->asg_w) || dev_upload(c, &dm.asg_j, m->asg_j) || dev_upload(c, &dm.anc_n, m->anc_n) ||
-        dev_upload(c, &dm.anc, m->anc) || dev_upload(c, &dm.mesh, m->mesh_soa) || dev_upload(c, &dm.parent, m->parent) || dev_upload(c, &dm.jlevel, m->jlevel) ||
+        dev_upload(c, &dm.anc, m->anc) || dev_upload(c, &dm.mesh, m->mesh_soa) || dev_upload(c, &dm.parent, m->parent) || dev_upload(c, &dm.jlevel, m->jlevel) || dev_upload(c, &dm.fk_items, m->fk_items) || dev_upload(c, &dm.fk_level_off, m->fk_level_off) ||
         dev_upload(c, &dm.jsr_base, m->jsr_base) || dev_upload(c, &dm.jsr, m->jsr) || dev_upload(c, &dm.S, m->S) ||
         dev_upload(c, &dm.Sp, m->Sp) || dev_upload(c, &dm.prior_mean, m->prior_mean) || dev_upload(c, &dm.prior_prec, m->prior_prec) ||
         dev_upload(c, &dm.prior_L, m->prior_L) || dev_upload(c, &dm.prior_clog, m->prior_clog) || dev_upload(c, &dm.part_of_vertex, pov) ||

@@ -85,6 +85,8 @@ struct DeviceModel {
     int* mesh;            // [3][F] SoA
     int* parent;          // [J]
     int* jlevel;          // [J] tree level of each joint (root = 0)
+    int* fk_items;        // [J*(12+3K)] per-level work items of compute_prep: (joint << 8) | entry, grouped by level
+    int* fk_level_off;    // [nlevels+1] offsets into fk_items
     double* jsr_base;     // [3J] initialJointPos
     double* jsr;          // [3J][K] row-major jointShapeReg
     double* S;            // [J][3][K]
@@ -142,7 +144,7 @@ struct avt_model {
     AvtDims d;
     // host copies (used by avt_ctx_create to build the device model and by accessors)
     std::vector<double> shape_planes, lbs_w, asg_w, jsr_base, jsr, S, Sp;
-    std::vector<int> lbs_j, asg_j, mesh_soa, parent, main_joint, jlevel;
+    std::vector<int> lbs_j, asg_j, mesh_soa, parent, main_joint, jlevel, fk_items, fk_level_off;
     std::vector<unsigned char> anc_n;
     std::vector<unsigned short> anc;
     std::vector<double> prior_mean, prior_prec, prior_L, prior_clog;

@@ -26,32 +26,39 @@ struct PrepScratch {
     double rot[AVT_MAX_JOINTS * 9], Rw[AVT_MAX_JOINTS * 9], o[AVT_MAX_JOINTS * 3], jp[AVT_MAX_JOINTS * 3];
     double H[AVT_MAX_JOINTS * 3 * AVT_MAX_SHAPE], Sp[AVT_MAX_JOINTS * 3 * AVT_MAX_SHAPE];
     double w[AVT_MAX_SHAPE], p[3];
-    int parent[AVT_MAX_JOINTS], level[AVT_MAX_JOINTS];
+    int parent[AVT_MAX_JOINTS], level[AVT_MAX_JOINTS + 2];
+    unsigned short items[AVT_MAX_JOINTS * (12 + 3 * AVT_MAX_SHAPE)];
 };
 
 __device__ void compute_prep(const DeviceModel& dm, const double* __restrict__ x, double* __restrict__ prep, PrepScratch& s) {
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, t = threadIdx.x;
     const double* q = x + 3;
-    if (t < J) { s.parent[t] = dm.parent[t]; s.level[t] = dm.jlevel[t]; quat_to_rot(q + 4 * t, s.rot + 9 * t); }
+    const double* w = x + 3 + 4 * J;
+    // everything that comes from global memory is requested up front, in one round trip
+    if (t < J) { s.parent[t] = dm.parent[t]; quat_to_rot(q + 4 * t, s.rot + 9 * t); }
     if (t < 3) s.p[t] = x[t];
-    if (t < K) s.w[t] = x[3 + 4 * J + t];
+    if (t < K) s.w[t] = w[t];
+    if (t <= d.nlevels) s.level[t] = dm.fk_level_off[t];
     for (int e = t; e < 3 * J * K; e += 256) s.Sp[e] = dm.Sp[e];
-    __syncthreads();
     // CalcShape (AvatarOptimizer.cpp:249-281): jointPosInit = base + jointShapeReg*w
     if (t < 3 * J) {
         double a = 0.0;
-        for (int k = 0; k < K; ++k) a += dm.jsr[(size_t)t * K + k] * s.w[k];
+        for (int k = 0; k < K; ++k) a += dm.jsr[(size_t)t * K + k] * w[k];
         s.jp[t] = dm.jsr_base[t] + a;
     }
+    // per-level work items (joint, entry), at most one per lane and level for SMPL
+    const int per = 12 + 3 * K;
+    const int nitems = J * per;
+    for (int e = t; e < nitems; e += 256) s.items[e] = (unsigned short)dm.fk_items[e];
     __syncthreads();
     // one tree level per barrier: world rotation/origin (:303-315) and H[j] = R(-1,parent j) Sp[j] + H[parent j]
     // (:318-324) of every joint of the level in parallel
-    const int per = 12 + 3 * K;
     for (int L = 0; L < d.nlevels; ++L) {
-        for (int idx = t; idx < J * per; idx += 256) {
-            const int j = idx / per, e = idx - j * per;
-            if (s.level[j] != L) continue;
+        const int lo = s.level[L], hi = s.level[L + 1];
+        for (int idx = lo + t; idx < hi; idx += 256) {
+            const int item = s.items[idx];
+            const int j = item >> 8, e = item & 0xff;
             const int pa = s.parent[j];
             if (e < 12) {
                 if (j == 0) {
@@ -182,6 +189,8 @@ __global__ __launch_bounds__(256) void k_reduce(DeviceModel dm, FrameBuffers fb)
     }
 }
 
+typedef double d2 __attribute__((ext_vector_type(2)));
+
 // reciprocal off the slow path: v_rcp_f64 (~2^-26 relative) + one cubic Newton step (error e^3)
 __device__ __forceinline__ double fast_rcp(double d) {
     const double r0 = __builtin_amdgcn_rcp(d);
@@ -196,6 +205,34 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+// Back substitution L^T delta = w for a compile-time size, fully unrolled: lane indices of the v_readlane broadcasts
+// and all LDS offsets are immediates, so the factor rows are fetched far ahead of the 85-step dependency chain.
+template <int PP>
+__device__ __forceinline__ void backsub_unrolled(const double* __restrict__ Lf, int LD, int t, double* __restrict__ s_delta) {
+    const double w0 = (t < PP) ? Lf[(size_t)PP * LD + t] : 0.0;
+    const double w1 = (t + 64 < PP) ? Lf[(size_t)PP * LD + t + 64] : 0.0;
+    double acc0 = 0.0, acc1 = 0.0, dl0 = 0.0, dl1 = 0.0;
+    const double* col0 = Lf + t;
+    const double* col1 = Lf + t + 64;
+#pragma unroll
+    for (int i = PP - 1; i >= 0; --i) {
+        const double c0 = (t < i) ? col0[(size_t)i * LD] : 0.0;
+        double di;
+        if (i >= 64) {
+            const double c1 = (t + 64 < i) ? col1[(size_t)i * LD] : 0.0;
+            di = readlane_f64(w1, i - 64) - readlane_f64(acc1, i - 64);
+            if (t == i - 64) dl1 = di;
+            acc1 = fma(c1, di, acc1);
+        } else {
+            di = readlane_f64(w0, i) - readlane_f64(acc0, i);
+            if (t == i) dl0 = di;
+        }
+        acc0 = fma(c0, di, acc0);
+    }
+    if (t < PP) s_delta[t] = dl0;
+    if (t + 64 < PP) s_delta[t + 64] = dl1;
+}
+
 // =================================================================================================
 // k_solve.  grid (nframes), block 256.
 // =================================================================================================
@@ -208,8 +245,10 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int LD = HS + 1;                                  // odd leading dimension
     double* Lf = (double*)smem;                             // [HS][LD] unit-lower factor (row P = D^-1 L^-1 rhs)
-    double* s_raw = Lf + (size_t)HS * LD;                   // [2][HS][4] current block column, raw (double-buffered)
-    double* s_delta = s_raw + 2 * (size_t)HS * 4;           // [HS]
+    // current block column, raw, double-buffered: [2][NB][18]: a 4x4 block is 16 doubles + 2 of padding (144 B), so
+    // lanes reading different row blocks spread over the LDS banks instead of colliding on two bank groups
+    double* s_raw = Lf + (size_t)HS * LD;
+    double* s_delta = s_raw + 2 * (size_t)(HS / 4) * 18;    // [HS]
     PrepScratch* ps = (PrepScratch*)(s_delta + HS);
     __shared__ int s_failv[2];   // alternating per round: written in round kb, read after the next barrier
     const int xs = d.xsize;
@@ -330,35 +369,70 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) s_raw[((size_t)(4 * bi + r)) * 4 + c] = a4[r][c];
+            for (int c = 0; c < 4; ++c) s_raw[(size_t)bi * 18 + r * 4 + c] = a4[r][c];
     }
+#ifdef AVT_TIMING
+    long long lacc[5] = {0, 0, 0, 0, 0}; long long llast = clock64();
+#define LPROBE(k) do { const long long _n = clock64(); lacc[k] += _n - llast; llast = _n; } while (0)
+#else
+#define LPROBE(k) do {} while (0)
+#endif
     bool fail = false;
     for (int kb = 0; kb < NB; ++kb) {
+#if !(defined(AVT_EXP) && AVT_EXP == 4)
         __syncthreads();
+#endif
+        LPROBE(0);
+#ifdef AVT_TIMING
+        if (t == 251 && kb < 22) fb.trace[(size_t)f * 64 + 8 + kb] = (double)llast;
+#endif
         if (kb > 0 && s_failv[(kb - 1) & 1]) { fail = true; break; }
+#if defined(AVT_EXP) && AVT_EXP == 1
+        continue;
+#endif
         if (bj < kb) continue;                      // this lane's block is final (it still meets every barrier)
-        const double* raw = s_raw + (size_t)(kb & 1) * HS * 4;
+        const double* raw = s_raw + (size_t)(kb & 1) * NB * 18;
+        // all LDS traffic of the round is issued up front as 16-byte reads: the diagonal block and, for trailing
+        // blocks, the raw block-column rows of bi and bj (the factorisation chain below hides their latency)
+        const d2* rawv = (const d2*)raw;
+        d2 Dv[4][2], Av[4][2], Bv[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { Dv[r][0] = rawv[kb * 9 + r * 2]; Dv[r][1] = rawv[kb * 9 + r * 2 + 1]; }
+        const bool trailing = bj > kb;
+        if (trailing) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Av[r][0] = rawv[bi * 9 + r * 2]; Av[r][1] = rawv[bi * 9 + r * 2 + 1];
+                Bv[r][0] = rawv[bj * 9 + r * 2]; Bv[r][1] = rawv[bj * 9 + r * 2 + 1];
+            }
+        }
         // the (updated) diagonal block, factored redundantly by every lane: D = Ld diag(dv) Ld^T
-        const double* Dr = raw + (size_t)(4 * kb) * 4;
-        double D00 = Dr[0], D10 = Dr[4], D11 = Dr[5], D20 = Dr[8], D21 = Dr[9], D22 = Dr[10], D30 = Dr[12], D31 = Dr[13],
-               D32 = Dr[14], D33 = Dr[15];
+        double D00 = Dv[0][0].x, D10 = Dv[1][0].x, D11 = Dv[1][0].y, D20 = Dv[2][0].x, D21 = Dv[2][0].y, D22 = Dv[2][1].x,
+               D30 = Dv[3][0].x, D31 = Dv[3][0].y, D32 = Dv[3][1].x, D33 = Dv[3][1].y;
         const bool real1 = 4 * kb + 1 < P, real2 = 4 * kb + 2 < P, real3 = 4 * kb + 3 < P;   // 4*kb < P always
-        bool ok = D00 > 0.0;
+        // (pivot checks are combined branch-free at the end: no control flow inside the dependency chain)
+        const double P0 = D00;
         const double r0 = fast_rcp(D00);
         const double l10 = D10 * r0, l20 = D20 * r0, l30 = D30 * r0;
         D11 = fma(-l10, D10, D11); D21 = fma(-l20, D10, D21); D31 = fma(-l30, D10, D31);
         D22 = fma(-l20, D20, D22); D32 = fma(-l30, D20, D32); D33 = fma(-l30, D30, D33);
-        ok = ok && (!real1 || D11 > 0.0);
+        const double P1 = D11;
         const double r1 = fast_rcp(D11);
         const double l21 = D21 * r1, l31 = D31 * r1;
         D22 = fma(-l21, D21, D22); D32 = fma(-l31, D21, D32); D33 = fma(-l31, D31, D33);
-        ok = ok && (!real2 || D22 > 0.0);
+        const double P2 = D22;
         const double r2 = fast_rcp(D22);
         const double l32 = D32 * r2;
         D33 = fma(-l32, D32, D33);
-        ok = ok && (!real3 || D33 > 0.0);
+        const double P3 = D33;
         const double r3 = fast_rcp(D33);
-        if (!ok) s_failv[kb & 1] = 1;               // same verdict in every lane that reaches here
+        const int bad = (int)!(P0 > 0.0) | ((int)real1 & (int)!(P1 > 0.0)) | ((int)real2 & (int)!(P2 > 0.0)) | ((int)real3 & (int)!(P3 > 0.0));
+        if (bad) s_failv[kb & 1] = 1;               // same verdict in every lane that reaches here
+        LPROBE(1);
+#if defined(AVT_EXP) && AVT_EXP == 3
+        asm volatile("" :: "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(l10), "v"(l20), "v"(l30), "v"(l21), "v"(l31), "v"(l32));
+        continue;
+#endif
         if (bj == kb) {
             // my block belongs to this block column: W = A Ld^-T (row-wise forward substitution), L = W D^-1
 #pragma unroll
@@ -375,19 +449,18 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
             double Wi[4][4], Lj[4][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double* ar = raw + (size_t)(4 * bi + r) * 4;
-                const double w0 = ar[0];
-                const double w1 = fma(-w0, l10, ar[1]);
-                const double w2 = fma(-w1, l21, fma(-w0, l20, ar[2]));
-                const double w3 = fma(-w2, l32, fma(-w1, l31, fma(-w0, l30, ar[3])));
+                const double w0 = Av[r][0].x;
+                const double w1 = fma(-w0, l10, Av[r][0].y);
+                const double w2 = fma(-w1, l21, fma(-w0, l20, Av[r][1].x));
+                const double w3 = fma(-w2, l32, fma(-w1, l31, fma(-w0, l30, Av[r][1].y)));
                 Wi[r][0] = w0; Wi[r][1] = w1; Wi[r][2] = w2; Wi[r][3] = w3;
-                const double* br = raw + (size_t)(4 * bj + r) * 4;
-                const double u0 = br[0];
-                const double u1 = fma(-u0, l10, br[1]);
-                const double u2 = fma(-u1, l21, fma(-u0, l20, br[2]));
-                const double u3 = fma(-u2, l32, fma(-u1, l31, fma(-u0, l30, br[3])));
+                const double u0 = Bv[r][0].x;
+                const double u1 = fma(-u0, l10, Bv[r][0].y);
+                const double u2 = fma(-u1, l21, fma(-u0, l20, Bv[r][1].x));
+                const double u3 = fma(-u2, l32, fma(-u1, l31, fma(-u0, l30, Bv[r][1].y)));
                 Lj[r][0] = u0 * r0; Lj[r][1] = u1 * r1; Lj[r][2] = u2 * r2; Lj[r][3] = u3 * r3;
             }
+            LPROBE(2);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -397,15 +470,20 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
                     for (int c = 0; c < 4; ++c) v = fma(-Wi[r][c], Lj[cc][c], v);
                     a4[r][cc] = v;
                 }
+            LPROBE(3);
             if (bj == kb + 1) {                     // publish the next block column, raw
-                double* nxt = s_raw + (size_t)((kb + 1) & 1) * HS * 4;
+                d2* nxt = (d2*)(s_raw + (size_t)((kb + 1) & 1) * NB * 18);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) nxt[(size_t)(4 * bi + r) * 4 + cc] = a4[r][cc];
+                for (int r = 0; r < 4; ++r) {
+                    nxt[bi * 9 + r * 2] = (d2){a4[r][0], a4[r][1]};
+                    nxt[bi * 9 + r * 2 + 1] = (d2){a4[r][2], a4[r][3]};
+                }
             }
         }
     }
+#ifdef AVT_TIMING
+    if (t == 251) for (int k = 0; k < 5; ++k) fb.trace[(size_t)f * 64 + 56 + k] = (double)lacc[k];
+#endif
     __syncthreads();
     if (s_failv[0] || s_failv[1]) fail = true;
     TPROBE(3);
@@ -416,25 +494,23 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
         // ---- back substitution L^T delta = w (w = row P of Lf) by wave 0.  Lane l keeps w[l], w[l+64] and the
         // running sums acc[l] = sum_{k>i} L[k][l] delta_k in registers; values cross lanes by v_readlane.
         if (t < 64) {
-            const double w0 = (t < P) ? Lf[(size_t)P * LD + t] : 0.0;
-            const double w1 = (t + 64 < P) ? Lf[(size_t)P * LD + t + 64] : 0.0;
-            double acc0 = 0.0, acc1 = 0.0, dl0 = 0.0, dl1 = 0.0;
-            double n0 = (t < P - 1) ? Lf[(size_t)(P - 1) * LD + t] : 0.0;
-            double n1 = (t + 64 < P - 1) ? Lf[(size_t)(P - 1) * LD + t + 64] : 0.0;
-            for (int i = P - 1; i >= 0; --i) {
-                const double c0 = n0, c1 = n1;
-                if (i > 0) {                                  // prefetch row i-1 of the factor
-                    n0 = (t < i - 1) ? Lf[(size_t)(i - 1) * LD + t] : 0.0;
-                    n1 = (t + 64 < i - 1) ? Lf[(size_t)(i - 1) * LD + t + 64] : 0.0;
+            if (P == 85) backsub_unrolled<85>(Lf, LD, t, s_delta);
+            else {
+                const double w0 = (t < P) ? Lf[(size_t)P * LD + t] : 0.0;
+                const double w1 = (t + 64 < P) ? Lf[(size_t)P * LD + t + 64] : 0.0;
+                double acc0 = 0.0, acc1 = 0.0, dl0 = 0.0, dl1 = 0.0;
+                for (int i = P - 1; i >= 0; --i) {
+                    const double c0 = (t < i) ? Lf[(size_t)i * LD + t] : 0.0;
+                    const double c1 = (t + 64 < i) ? Lf[(size_t)i * LD + t + 64] : 0.0;
+                    double di;
+                    if (i < 64) { di = readlane_f64(w0, i) - readlane_f64(acc0, i); if (t == i) dl0 = di; }
+                    else { di = readlane_f64(w1, i - 64) - readlane_f64(acc1, i - 64); if (t == i - 64) dl1 = di; }
+                    acc0 = fma(c0, di, acc0);
+                    acc1 = fma(c1, di, acc1);
                 }
-                double di;
-                if (i < 64) { di = readlane_f64(w0, i) - readlane_f64(acc0, i); if (t == i) dl0 = di; }
-                else { di = readlane_f64(w1, i - 64) - readlane_f64(acc1, i - 64); if (t == i - 64) dl1 = di; }
-                acc0 = fma(c0, di, acc0);                     // c0/c1 are zero at and above the diagonal
-                acc1 = fma(c1, di, acc1);
+                if (t < P) s_delta[t] = dl0;
+                if (t + 64 < P) s_delta[t + 64] = dl1;
             }
-            if (t < P) s_delta[t] = dl0;
-            if (t + 64 < P) s_delta[t + 64] = dl1;
         }
         __syncthreads();
         TPROBE(4);
@@ -472,7 +548,7 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
 
 static size_t solve_lds_bytes(const AvtDims& d) {
     const int HS = d.HS, LD = HS + 1;
-    return sizeof(double) * ((size_t)HS * LD + 2 * (size_t)HS * 4 + HS) + sizeof(PrepScratch) + 64;
+    return sizeof(double) * ((size_t)HS * LD + 2 * (size_t)(HS / 4) * 18 + HS) + sizeof(PrepScratch) + 64;
 }
 
 void launch_reduce(avt_ctx* c, int nframes) {

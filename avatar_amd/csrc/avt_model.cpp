@@ -62,6 +62,15 @@ extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
     d.nlevels = 1;
     for (int j = 1; j < J; ++j) { m->jlevel[j] = m->jlevel[desc->parent[j]] + 1; d.nlevels = std::max(d.nlevels, m->jlevel[j] + 1); }
     d.HS = 4 * ((d.P + 4) / 4);
+    // per-level work lists for the forward-kinematics / shape-table pass (entries 0..11: 3x3 rotation + origin,
+    // 12..12+3K-1: the joint's accumulated shape table)
+    m->fk_level_off.assign(d.nlevels + 1, 0);
+    for (int L = 0; L < d.nlevels; ++L) {
+        for (int j = 0; j < J; ++j)
+            if (m->jlevel[j] == L)
+                for (int e = 0; e < 12 + 3 * K; ++e) m->fk_items.push_back((j << 8) | e);
+        m->fk_level_off[L + 1] = (int)m->fk_items.size();
+    }
 
     // shape planes
     m->shape_planes.assign((size_t)(K + 1) * 3 * V, 0.0);
