@@ -120,6 +120,9 @@ struct FrameBuffers {
     double* cloud;        // [max_frames][3V] xyz interleaved (ava.cloud)
     double* pcx; double* pcy; double* pcz;   // [max_frames][V] cloud in part-sorted order; invisible -> +inf
     unsigned char* visible;                  // [max_frames][V]
+    double* vcx; double* vcy; double* vcz;   // [max_frames][V] visible model points, compacted per part segment
+    int* vcid;                               // [max_frames][V] vertex id of each compacted candidate
+    int* vcount;                             // [max_frames][num_parts] visible candidates per part
     // correspondence aggregation
     int* cnt;             // [max_frames][V]
     long long* fsum;      // [max_frames][3][V] fixed-point centred sums

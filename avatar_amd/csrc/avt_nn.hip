@@ -21,9 +21,11 @@
 
 #define NN_TILE 1024
 
-#define NN_QPB 64   // queries per workgroup: 4 lanes cooperate on one query
 
+// LANES lanes cooperate on one query (4: low-latency single-frame shape; 1: throughput shape for large batches)
+template <int LANES>
 __global__ __launch_bounds__(256) void k_nn(DeviceModel dm, FrameBuffers fb) {
+    constexpr int NN_QPB = 256 / LANES;
     const int f = blockIdx.y, t = threadIdx.x;
     const int V = dm.d.V, np = dm.d.num_parts;
     const AvtFrameCtl& ctl = fb.ctl[f];
@@ -32,8 +34,8 @@ __global__ __launch_bounds__(256) void k_nn(DeviceModel dm, FrameBuffers fb) {
     const int s0 = blockIdx.x * NN_QPB;
     if (s0 >= nvalid) return;
     const size_t base = (size_t)f * fb.max_points;
-    const int sub = t & 3;
-    const int s = s0 + (t >> 2);
+    const int sub = t % LANES;
+    const int s = s0 + t / LANES;
     const bool active = s < nvalid;
 
     __shared__ double c_x[NN_TILE], c_y[NN_TILE], c_z[NN_TILE];
@@ -53,15 +55,14 @@ __global__ __launch_bounds__(256) void k_nn(DeviceModel dm, FrameBuffers fb) {
     // my part: walk up from qlo (a workgroup rarely spans more than 2 parts)
     int q = qlo;
     if (active) while (q < qhi && po[q + 1] <= s) ++q;
-    const int my_b = dm.part_start[q], my_e = dm.part_start[q + 1];
+    const int my_b = dm.part_start[q], my_e = my_b + fb.vcount[(size_t)f * np + q];   // visible candidates of my part
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     if (active) { a0 = fb.dx[base + s]; a1 = fb.dy[base + s]; a2 = fb.dz[base + s]; }
 
-    const int cb = dm.part_start[qlo], ce = dm.part_start[qhi + 1];
-    const double* pcx = fb.pcx + (size_t)f * V;
-    const double* pcy = fb.pcy + (size_t)f * V;
-    const double* pcz = fb.pcz + (size_t)f * V;
-    const unsigned char* vis = fb.visible + (size_t)f * V;
+    const int cb = dm.part_start[qlo], ce = dm.part_start[qhi] + fb.vcount[(size_t)f * np + qhi];
+    const double* pcx = fb.vcx + (size_t)f * V;
+    const double* pcy = fb.vcy + (size_t)f * V;
+    const double* pcz = fb.vcz + (size_t)f * V;
     double best = 1.7976931348623157e308;  // numeric_limits<double>::max(), KNNResultSet::init
     int bi = 0x7fffffff;
     for (int tb = cb; tb < ce; tb += NN_TILE) {
@@ -69,8 +70,7 @@ __global__ __launch_bounds__(256) void k_nn(DeviceModel dm, FrameBuffers fb) {
         __syncthreads();
         for (int e = t; e < tn; e += 256) {
             const int pos = tb + e;
-            const bool vz = vis[dm.part_vertices[pos]] != 0;
-            c_x[e] = vz ? pcx[pos] : AVT_INF;   // invisible candidates can never win: inf < best is false
+            c_x[e] = pcx[pos];
             c_y[e] = pcy[pos];
             c_z[e] = pcz[pos];
         }
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_nn(DeviceModel dm, FrameBuffers fb) {
         if (active) {
             const int b = max(my_b, tb) - tb, e = min(my_e, tb + tn) - tb;
             // lane `sub` of the query's 4-lane group scans candidates b+sub, b+sub+4, ... in ascending order
-            for (int c = b + sub; c < e; c += 4) {
+            for (int c = b + sub; c < e; c += LANES) {
                 const double d0 = a0 - c_x[c];
                 const double d1 = a1 - c_y[c];
                 const double d2 = a2 - c_z[c];
@@ -92,25 +92,58 @@ __global__ __launch_bounds__(256) void k_nn(DeviceModel dm, FrameBuffers fb) {
     // combine the 4 sub-scans: smallest distance, ties to the lowest candidate position — exactly the winner of
     // one ascending scan with strict '<'
 #pragma unroll
-    for (int m = 1; m <= 2; m <<= 1) {
+    for (int m = 1; m < LANES; m <<= 1) {
         const double ob = __shfl_xor(best, m, 64);
         const int oi = __shfl_xor(bi, m, 64);
         if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
     if (!active || sub != 0) return;
-    const int m = bi != 0x7fffffff ? dm.part_vertices[bi] : -1;
+    const int m = bi != 0x7fffffff ? fb.vcid[(size_t)f * V + bi] : -1;
     fb.corr_sorted[base + s] = m;
     fb.corr[base + fb.dorig[base + s]] = m;
     if (m >= 0) {
+        // integer atomics: the per-vertex count and fixed-point coordinate sums are order-independent
         atomicAdd(fb.cnt + (size_t)f * V + m, 1);
         unsigned long long* fs = (unsigned long long*)(fb.fsum + (size_t)f * 3 * V);
-        const long long q0 = __double2ll_rn((a0 - ctl.centre[0]) * AVT_FIX_SCALE);
-        const long long q1 = __double2ll_rn((a1 - ctl.centre[1]) * AVT_FIX_SCALE);
-        const long long q2 = __double2ll_rn((a2 - ctl.centre[2]) * AVT_FIX_SCALE);
-        atomicAdd(fs + m, (unsigned long long)q0);
-        atomicAdd(fs + (size_t)V + m, (unsigned long long)q1);
-        atomicAdd(fs + 2 * (size_t)V + m, (unsigned long long)q2);
+        atomicAdd(fs + m, (unsigned long long)__double2ll_rn((a0 - ctl.centre[0]) * AVT_FIX_SCALE));
+        atomicAdd(fs + (size_t)V + m, (unsigned long long)__double2ll_rn((a1 - ctl.centre[1]) * AVT_FIX_SCALE));
+        atomicAdd(fs + 2 * (size_t)V + m, (unsigned long long)__double2ll_rn((a2 - ctl.centre[2]) * AVT_FIX_SCALE));
     }
+}
+
+// Visible model points of every part, compacted in ascending vertex order inside the part's segment of the
+// part-sorted arrays (exactly the per-part clouds findNN builds at AvatarOptimizer.cpp:860-878).  grid (parts, frames).
+__global__ __launch_bounds__(256) void k_compact(DeviceModel dm, FrameBuffers fb) {
+    const int f = blockIdx.y, q = blockIdx.x, t = threadIdx.x, V = dm.d.V, np = dm.d.num_parts;
+    const int b = dm.part_start[q], e = dm.part_start[q + 1];
+    __shared__ int s_wcnt[4];
+    __shared__ int s_run;
+    if (t == 0) s_run = 0;
+    __syncthreads();
+    const unsigned char* vis = fb.visible + (size_t)f * V;
+    for (int c0 = b; c0 < e; c0 += 256) {
+        const int pos = c0 + t;
+        int v = -1;
+        bool keep = false;
+        if (pos < e) { v = dm.part_vertices[pos]; keep = vis[v] != 0; }
+        const unsigned long long bal = __ballot(keep);
+        const int rank = __popcll(bal & ((1ull << lane_id()) - 1ull));
+        if (lane_id() == 0) s_wcnt[wave_id()] = __popcll(bal);
+        __syncthreads();
+        int off = s_run;
+        for (int w = 0; w < wave_id(); ++w) off += s_wcnt[w];
+        if (keep) {
+            const size_t o = (size_t)f * V + b + off + rank;
+            fb.vcx[o] = fb.pcx[(size_t)f * V + pos];
+            fb.vcy[o] = fb.pcy[(size_t)f * V + pos];
+            fb.vcz[o] = fb.pcz[(size_t)f * V + pos];
+            fb.vcid[o] = v;
+        }
+        __syncthreads();
+        if (t == 0) s_run += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        __syncthreads();
+    }
+    if (t == 0) fb.vcount[(size_t)f * np + q] = s_run;
 }
 
 void launch_nn(avt_ctx* c, int nframes) {
@@ -119,6 +152,9 @@ void launch_nn(avt_ctx* c, int nframes) {
     hipMemsetAsync(c->fb.cnt, 0, (size_t)nframes * V * sizeof(int), c->stream);
     hipMemsetAsync(c->fb.fsum, 0, (size_t)nframes * 3 * V * sizeof(long long), c->stream);
     const int maxN = c->launch_maxN;
-    const int nb = (maxN + NN_QPB - 1) / NN_QPB;
-    if (nb > 0) hipLaunchKernelGGL(k_nn, dim3(nb, nframes), dim3(256), 0, c->stream, c->dm, c->fb);
+    if (maxN <= 0) return;
+    hipLaunchKernelGGL(k_compact, dim3(c->dm.d.num_parts, nframes), dim3(256), 0, c->stream, c->dm, c->fb);
+    // few queries: 4 lanes per query (more workgroups, shorter scans); many: one lane per query
+    if (!getenv("AVT_NN1")) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn<4>), dim3((maxN + 63) / 64, nframes), dim3(256), 0, c->stream, c->dm, c->fb);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn<1>), dim3((maxN + 255) / 256, nframes), dim3(256), 0, c->stream, c->dm, c->fb);
 }

@@ -96,7 +96,7 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
     prof_timed = ctx.profile_end()
     elapsed = t1 - t0
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        te = torch.tensor([elapsed], dtype=torch.float64, device=("cuda" if args.backend == "nccl" else "cpu"))
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
         dist.barrier()
@@ -112,7 +112,7 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
     t1 = time.perf_counter()
     elapsed_clean = t1 - t0
     if world > 1:
-        te = torch.tensor([elapsed_clean], dtype=torch.float64, device="cuda")
+        te = torch.tensor([elapsed_clean], dtype=torch.float64, device=("cuda" if args.backend == "nccl" else "cpu"))
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed_clean = float(te.item())
         dist.barrier()
@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-throughput-config", action="store_true", help="skip the secondary 64-frames-per-GPU measurement")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -167,9 +168,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
+    if os.environ.get("AVT_BENCH_SHARE_GPU0"):      # dry run of the N>1 code path on a single-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend, init_method="env://")
 
     from avatar_amd import api, synth
     from avatar_amd.capi import Options
