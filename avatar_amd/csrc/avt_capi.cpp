@@ -73,8 +73,10 @@ int check_launch(const char* what) {
 void enqueue_optimize(avt_ctx* c, const avt_options* o) {
     const int nf = c->nframes;
     c->ran_icp_iters = 0;
+    const int vis_init = o->enable_occlusion ? 0 : 1;
+    c->lbs_cleared = true;
     { ProfScope ps(c, AVT_K_BUCKET); launch_bucket(c, nf); }
-    { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 1); }   // ava.update() precondition (:1356)
+    { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 1, vis_init); }   // ava.update() precondition (:1356)
     for (int icp = 0; icp < o->icp_iters; ++icp) {
         { ProfScope ps(c, AVT_K_VISIBILITY); launch_visibility(c, nf, o->enable_occlusion); }
         { ProfScope ps(c, AVT_K_NN); launch_nn(c, nf); }
@@ -89,9 +91,10 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o) {
             { ProfScope ps(c, AVT_K_REDUCE); launch_reduce(c, nf); }
         }
         if (o->max_iters_per_icp > 0) { ProfScope ps(c, AVT_K_SOLVE); launch_solve(c, nf, SOLVE_LAST, o); }
-        { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 1); }   // :1494-1497
+        { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 1, vis_init); }   // :1494-1497
         c->ran_icp_iters++;
     }
+    c->lbs_cleared = false;
 }
 
 int run_optimize(avt_ctx* c, const avt_options* o) {
@@ -220,6 +223,7 @@ int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* par
     c->ran_max_iters = 0;
     c->launch_maxN = 0;
     c->use_graph = getenv("AVT_NO_GRAPH") == nullptr;
+    c->lbs_cleared = false;
     HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (avt_solve_set_attributes() || avt_eval_set_attributes()) { avt_set_error("avt_ctx_create: hipFuncSetAttribute failed"); return 1; }
     DeviceModel& dm = c->dm;
@@ -312,7 +316,7 @@ int avt_lbs_update(avt_ctx* c, int nframes, const double* w, const double* p, co
     HIP_OK(hipMemcpyAsync(dw, w, (size_t)nframes * d.K * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipMemcpyAsync(dp, p, (size_t)nframes * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipMemcpyAsync(dR, R, (size_t)nframes * 9 * d.J * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nframes, nullptr, dw, dp, dR, 0); }
+    { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nframes, nullptr, dw, dp, dR, 0, -1); }
     if (check_launch("k_lbs")) return 1;
     if (cloud) HIP_OK(hipMemcpyAsync(cloud, c->fb.cloud, (size_t)nframes * 3 * d.V * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (joint_pos) HIP_OK(hipMemcpyAsync(joint_pos, c->fb.jointpos, (size_t)nframes * 3 * d.J * sizeof(double), hipMemcpyDeviceToHost, c->stream));

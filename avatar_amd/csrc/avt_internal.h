@@ -131,6 +131,7 @@ struct FrameBuffers {
     double* mdbar;        // [max_frames][3][V] mean data point per compacted entry
     double* const_part;   // [max_frames][const_blocks]
     int const_blocks;
+    int const_used;       // blocks written by the last k_cost_const launch
     // optimiser state
     double* x;            // [max_frames][2][xsize]
     double* prep;         // [max_frames][2][prep_size]
@@ -170,6 +171,7 @@ struct avt_ctx {
     std::vector<void*> allocs;
     int ran_icp_iters, ran_max_iters;
     int launch_maxN;                 // max points per frame of the resident batch, rounded up to 2048 (grid sizing)
+    bool lbs_cleared;                // the preceding k_lbs reset visibility / correspondence bookkeeping
     bool use_graph;                  // replay the optimize() launch sequence as a hipGraph (AVT_NO_GRAPH=1 disables)
     std::map<std::string, hipGraphExec_t> graphs;
 };
@@ -179,7 +181,7 @@ void avt_set_error(const std::string& s);
 // kernel launch wrappers (avt_kernels.hip / avt_nn.hip)
 enum { SOLVE_INIT = 0, SOLVE_FIRST = 1, SOLVE_NORMAL = 2, SOLVE_LAST = 3 };
 void launch_lbs(avt_ctx* c, int nframes, const double* x_state_or_null, const double* w, const double* p, const double* R,
-                int from_state);
+                int from_state, int vis_init /* -1: leave bookkeeping alone; 0/1: reset it, visibility flags to this value */);
 void launch_visibility(avt_ctx* c, int nframes, int enable);
 void launch_bucket(avt_ctx* c, int nframes);
 void launch_nn(avt_ctx* c, int nframes);

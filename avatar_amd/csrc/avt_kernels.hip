@@ -11,7 +11,7 @@
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, const double* __restrict__ w_in,
                                              const double* __restrict__ p_in, const double* __restrict__ R_in,
-                                             int from_state) {
+                                             int from_state, int vis_init) {
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, V = d.V;
     const int f = blockIdx.y, t = threadIdx.x;
@@ -90,6 +90,14 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
     const double cz = pt[2] * sx + pt[5] * sy + pt[8] * sz + pt[11];
     double* cl = fb.cloud + (size_t)f * 3 * V + 3 * (size_t)v;
     cl[0] = cx; cl[1] = cy; cl[2] = cz;
+    if (vis_init >= 0) {
+        // this launch also resets the per-vertex bookkeeping of the next ICP iteration (saves four memset nodes):
+        // visibility flags (0, or 1 when occlusion is off), correspondence counts and fixed-point sums
+        fb.visible[(size_t)f * V + v] = (unsigned char)vis_init;
+        fb.cnt[(size_t)f * V + v] = 0;
+        long long* fs = fb.fsum + (size_t)f * 3 * V;
+        fs[v] = 0; fs[(size_t)V + v] = 0; fs[2 * (size_t)V + v] = 0;
+    }
     if (dm.part_pos) {
         const int pp = dm.part_pos[v];
         fb.pcx[(size_t)f * V + pp] = cx;
@@ -98,9 +106,9 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
     }
 }
 
-void launch_lbs(avt_ctx* c, int nframes, const double*, const double* w, const double* p, const double* R, int from_state) {
+void launch_lbs(avt_ctx* c, int nframes, const double*, const double* w, const double* p, const double* R, int from_state, int vis_init) {
     dim3 grid((c->dm.d.V + 255) / 256, nframes);
-    hipLaunchKernelGGL(k_lbs, grid, dim3(256), 0, c->stream, c->dm, c->fb, w, p, R, from_state);
+    hipLaunchKernelGGL(k_lbs, grid, dim3(256), 0, c->stream, c->dm, c->fb, w, p, R, from_state, vis_init);
 }
 
 // =================================================================================================
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(256) void k_visibility(DeviceModel dm, FrameBuffers
 
 void launch_visibility(avt_ctx* c, int nframes, int enable) {
     const int V = c->dm.d.V;
-    hipMemsetAsync(c->fb.visible, enable ? 0 : 1, (size_t)nframes * V, c->stream);
+    if (!c->lbs_cleared) (void)hipMemsetAsync(c->fb.visible, enable ? 0 : 1, (size_t)nframes * V, c->stream);
     if (enable) {
         dim3 grid((c->dm.d.F + 255) / 256, nframes);
         hipLaunchKernelGGL(k_visibility, grid, dim3(256), 0, c->stream, c->dm, c->fb);
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(256) void k_cost_const(DeviceModel dm, FrameBuffers
     acc = wave_sum(acc);
     if (lane_id() == 0) s_part[wave_id()] = acc;
     __syncthreads();
-    if (t == 0) fb.const_part[(size_t)f * fb.const_blocks + blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    if (t == 0) fb.const_part[(size_t)f * fb.const_blocks + blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);   // every block of the grid writes
 }
 
 void launch_finalize(avt_ctx* c, int nframes, const avt_options* o) {
@@ -319,6 +327,6 @@ void launch_finalize(avt_ctx* c, int nframes, const avt_options* o) {
                        o->lm_lambda0, c->ran_icp_iters == 0 ? 1 : 0);
     const int maxN = c->launch_maxN;
     const int nb = (maxN + 255) / 256;
-    hipMemsetAsync(c->fb.const_part, 0, (size_t)nframes * c->fb.const_blocks * sizeof(double), c->stream);
+    c->fb.const_used = nb;
     if (nb > 0) hipLaunchKernelGGL(k_cost_const, dim3(nb, nframes), dim3(256), 0, c->stream, c->dm, c->fb);
 }

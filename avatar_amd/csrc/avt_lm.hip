@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
         for (int e = t; e < xs; e += 256) x0[(size_t)tr * xs + e] = x0[(size_t)cur * xs + e];
         double a = 0.0;
         if (t < 64) {
-            for (int e = t; e < fb.const_blocks; e += 64) a += fb.const_part[(size_t)f * fb.const_blocks + e];
+            for (int e = t; e < fb.const_used; e += 64) a += fb.const_part[(size_t)f * fb.const_blocks + e];
             a = wave_sum(a);
         }
         __syncthreads();

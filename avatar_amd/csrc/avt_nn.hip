@@ -149,8 +149,10 @@ __global__ __launch_bounds__(256) void k_compact(DeviceModel dm, FrameBuffers fb
 void launch_nn(avt_ctx* c, int nframes) {
     const int V = c->dm.d.V;
     // cnt and fsum are adjacent: one memset clears both for the frames in use
-    hipMemsetAsync(c->fb.cnt, 0, (size_t)nframes * V * sizeof(int), c->stream);
-    hipMemsetAsync(c->fb.fsum, 0, (size_t)nframes * 3 * V * sizeof(long long), c->stream);
+    if (!c->lbs_cleared) {   // stand-alone avt_nn(): no preceding k_lbs cleared the bookkeeping
+        (void)hipMemsetAsync(c->fb.cnt, 0, (size_t)nframes * V * sizeof(int), c->stream);
+        (void)hipMemsetAsync(c->fb.fsum, 0, (size_t)nframes * 3 * V * sizeof(long long), c->stream);
+    }
     const int maxN = c->launch_maxN;
     if (maxN <= 0) return;
     hipLaunchKernelGGL(k_compact, dim3(c->dm.d.num_parts, nframes), dim3(256), 0, c->stream, c->dm, c->fb);
