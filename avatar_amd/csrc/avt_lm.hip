@@ -208,18 +208,22 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // Back substitution L^T delta = w for a compile-time size, fully unrolled: lane indices of the v_readlane broadcasts
 // and all LDS offsets are immediates, so the factor rows are fetched far ahead of the 85-step dependency chain.
 template <int PP>
-__device__ __forceinline__ void backsub_unrolled(const double* __restrict__ Lf, int LD, int t, double* __restrict__ s_delta) {
-    const double w0 = (t < PP) ? Lf[(size_t)PP * LD + t] : 0.0;
-    const double w1 = (t + 64 < PP) ? Lf[(size_t)PP * LD + t + 64] : 0.0;
+__device__ __forceinline__ void backsub_unrolled(const double* __restrict__ Lblk, int NB, int t, double* __restrict__ s_delta) {
+    // element (i, l) of the unit-lower factor lives at Lblk[((l>>2)*NB + (i>>2))*18 + (i&3)*4 + (l&3)]: the lane-dependent
+    // part (column l = t or t+64) is a base pointer, the row-dependent part a compile-time offset
+    const double* col0 = Lblk + ((size_t)(t >> 2) * NB) * 18 + (t & 3);
+    const double* col1 = Lblk + ((size_t)((t + 64) >> 2) * NB) * 18 + (t & 3);
+    constexpr int PO = (PP >> 2) * 18 + (PP & 3) * 4;
+    const double w0 = (t < PP) ? col0[PO] : 0.0;
+    const double w1 = (t + 64 < PP) ? col1[PO] : 0.0;
     double acc0 = 0.0, acc1 = 0.0, dl0 = 0.0, dl1 = 0.0;
-    const double* col0 = Lf + t;
-    const double* col1 = Lf + t + 64;
 #pragma unroll
     for (int i = PP - 1; i >= 0; --i) {
-        const double c0 = (t < i) ? col0[(size_t)i * LD] : 0.0;
+        const int io = (i >> 2) * 18 + (i & 3) * 4;
+        const double c0 = (t < i) ? col0[io] : 0.0;
         double di;
         if (i >= 64) {
-            const double c1 = (t + 64 < i) ? col1[(size_t)i * LD] : 0.0;
+            const double c1 = (t + 64 < i) ? col1[io] : 0.0;
             di = readlane_f64(w1, i - 64) - readlane_f64(acc1, i - 64);
             if (t == i - 64) dl1 = di;
             acc1 = fma(c1, di, acc1);
@@ -243,14 +247,15 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
     const int f = blockIdx.x, t = threadIdx.x;
     AvtFrameCtl& ctl = fb.ctl[f];
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int LD = HS + 1;                                  // odd leading dimension
-    double* Lf = (double*)smem;                             // [HS][LD] unit-lower factor (row P = D^-1 L^-1 rhs)
-    // current block column, raw, double-buffered: [2][NB][18]: a 4x4 block is 16 doubles + 2 of padding (144 B), so
-    // lanes reading different row blocks spread over the LDS banks instead of colliding on two bank groups
-    double* s_raw = Lf + (size_t)HS * LD;
-    double* s_delta = s_raw + 2 * (size_t)(HS / 4) * 18;    // [HS]
-    PrepScratch* ps = (PrepScratch*)(s_delta + HS);
-    __shared__ int s_failv[2];   // alternating per round: written in round kb, read after the next barrier
+    const int NBk = HS >> 2;                                // 4-row blocks covering rows 0..P (22 for SMPL)
+    // unit-lower factor, block layout [pivot block kb][row block bi][18]: a 4x4 block is 16 doubles + 2 of padding
+    // (144 B), so lanes reading different blocks spread over the LDS banks; row P carries D^-1 L^-1 rhs
+    double* Lblk = (double*)smem;
+    double* s_W = Lblk + (size_t)NBk * NBk * 18;            // [NB][18]  W = A_panel Ld^-T of the current pivot block
+    double* s_D = s_W + (size_t)NBk * 18;                   // [18]      updated diagonal block of the next pivot block
+    double* s_delta = s_D + 18;                             // [HS]
+    PrepScratch* ps = (PrepScratch*)(s_delta + HS + 2);
+    __shared__ int s_fail;
     const int xs = d.xsize;
     double* x0 = fb.x + ((size_t)f * 2) * xs;
 
@@ -363,13 +368,19 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
         }
     TPROBE(2);
 
-    // ---- c. register-blocked LDL^T, four pivots per barrier ---------------------------------------------------
-    if (t == 0) { s_failv[0] = 0; s_failv[1] = 0; }
-    if (bj == 0) {
+    // ---- c. register-blocked LDL^T, four pivots per round, two barriers per round -----------------------------------
+    //  (1) the lanes owning the pivot block column (bj == kb) read the updated diagonal block, factor it
+    //      (D = Ld diag(d) Ld^T), solve their own 4x4 block W = A Ld^-T, L = W diag(d)^-1 and publish W and L;
+    //  (2) every trailing lane (bj > kb) reads W of its row block and L of its column block: A -= W L^T;
+    //      the owner of the next diagonal block publishes it.
+    // Nothing is recomputed: per round a trailing lane issues 16 LDS reads and 64 FMAs.
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    if (t == 0) s_fail = 0;
+    if (bi == 0 && bj == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) s_raw[(size_t)bi * 18 + r * 4 + c] = a4[r][c];
+            for (int c = 0; c < 4; ++c) s_D[r * 4 + c] = a4[r][c];
     }
 #ifdef AVT_TIMING
     long long lacc[5] = {0, 0, 0, 0, 0}; long long llast = clock64();
@@ -379,105 +390,69 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
 #endif
     bool fail = false;
     for (int kb = 0; kb < NB; ++kb) {
-#if !(defined(AVT_EXP) && AVT_EXP == 4)
-        __syncthreads();
-#endif
+        __syncthreads();                                    // B1: diagonal block kb is visible
         LPROBE(0);
-#ifdef AVT_TIMING
-        if (t == 251 && kb < 22) fb.trace[(size_t)f * 64 + 8 + kb] = (double)llast;
-#endif
-        if (kb > 0 && s_failv[(kb - 1) & 1]) { fail = true; break; }
-#if defined(AVT_EXP) && AVT_EXP == 1
-        continue;
-#endif
-        if (bj < kb) continue;                      // this lane's block is final (it still meets every barrier)
-        const double* raw = s_raw + (size_t)(kb & 1) * NB * 18;
-        // all LDS traffic of the round is issued up front as 16-byte reads: the diagonal block and, for trailing
-        // blocks, the raw block-column rows of bi and bj (the factorisation chain below hides their latency)
-        const d2* rawv = (const d2*)raw;
-        d2 Dv[4][2], Av[4][2], Bv[4][2];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { Dv[r][0] = rawv[kb * 9 + r * 2]; Dv[r][1] = rawv[kb * 9 + r * 2 + 1]; }
-        const bool trailing = bj > kb;
-        if (trailing) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                Av[r][0] = rawv[bi * 9 + r * 2]; Av[r][1] = rawv[bi * 9 + r * 2 + 1];
-                Bv[r][0] = rawv[bj * 9 + r * 2]; Bv[r][1] = rawv[bj * 9 + r * 2 + 1];
-            }
-        }
-        // the (updated) diagonal block, factored redundantly by every lane: D = Ld diag(dv) Ld^T
-        double D00 = Dv[0][0].x, D10 = Dv[1][0].x, D11 = Dv[1][0].y, D20 = Dv[2][0].x, D21 = Dv[2][0].y, D22 = Dv[2][1].x,
-               D30 = Dv[3][0].x, D31 = Dv[3][0].y, D32 = Dv[3][1].x, D33 = Dv[3][1].y;
-        const bool real1 = 4 * kb + 1 < P, real2 = 4 * kb + 2 < P, real3 = 4 * kb + 3 < P;   // 4*kb < P always
-        // (pivot checks are combined branch-free at the end: no control flow inside the dependency chain)
-        const double P0 = D00;
-        const double r0 = fast_rcp(D00);
-        const double l10 = D10 * r0, l20 = D20 * r0, l30 = D30 * r0;
-        D11 = fma(-l10, D10, D11); D21 = fma(-l20, D10, D21); D31 = fma(-l30, D10, D31);
-        D22 = fma(-l20, D20, D22); D32 = fma(-l30, D20, D32); D33 = fma(-l30, D30, D33);
-        const double P1 = D11;
-        const double r1 = fast_rcp(D11);
-        const double l21 = D21 * r1, l31 = D31 * r1;
-        D22 = fma(-l21, D21, D22); D32 = fma(-l31, D21, D32); D33 = fma(-l31, D31, D33);
-        const double P2 = D22;
-        const double r2 = fast_rcp(D22);
-        const double l32 = D32 * r2;
-        D33 = fma(-l32, D32, D33);
-        const double P3 = D33;
-        const double r3 = fast_rcp(D33);
-        const int bad = (int)!(P0 > 0.0) | ((int)real1 & (int)!(P1 > 0.0)) | ((int)real2 & (int)!(P2 > 0.0)) | ((int)real3 & (int)!(P3 > 0.0));
-        if (bad) s_failv[kb & 1] = 1;               // same verdict in every lane that reaches here
-        LPROBE(1);
-#if defined(AVT_EXP) && AVT_EXP == 3
-        asm volatile("" :: "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(l10), "v"(l20), "v"(l30), "v"(l21), "v"(l31), "v"(l32));
-        continue;
-#endif
         if (bj == kb) {
-            // my block belongs to this block column: W = A Ld^-T (row-wise forward substitution), L = W D^-1
+            const d2v* Dq = (const d2v*)s_D;
+            const d2v q0 = Dq[0], q2 = Dq[2], q4 = Dq[4], q5 = Dq[5], q6 = Dq[6], q7 = Dq[7];
+            const double D00 = q0.x, D10 = q2.x;
+            double D11 = q2.y, D20 = q4.x, D21 = q4.y, D22 = q5.x, D30 = q6.x, D31 = q6.y, D32 = q7.x, D33 = q7.y;
+            const bool real1 = 4 * kb + 1 < P, real2 = 4 * kb + 2 < P, real3 = 4 * kb + 3 < P;   // 4*kb < P always
+            const double P0 = D00;
+            const double r0 = fast_rcp(D00);
+            const double l10 = D10 * r0, l20 = D20 * r0, l30 = D30 * r0;
+            D11 = fma(-l10, D10, D11); D21 = fma(-l20, D10, D21); D31 = fma(-l30, D10, D31);
+            D22 = fma(-l20, D20, D22); D32 = fma(-l30, D20, D32); D33 = fma(-l30, D30, D33);
+            const double P1 = D11;
+            const double r1 = fast_rcp(D11);
+            const double l21 = D21 * r1, l31 = D31 * r1;
+            D22 = fma(-l21, D21, D22); D32 = fma(-l31, D21, D32); D33 = fma(-l31, D31, D33);
+            const double P2 = D22;
+            const double r2 = fast_rcp(D22);
+            const double l32 = D32 * r2;
+            D33 = fma(-l32, D32, D33);
+            const double P3 = D33;
+            const double r3 = fast_rcp(D33);
+            const int bad = (int)!(P0 > 0.0) | ((int)real1 & (int)!(P1 > 0.0)) | ((int)real2 & (int)!(P2 > 0.0)) | ((int)real3 & (int)!(P3 > 0.0));
+            if (bad) s_fail = 1;
+            d2v* Wo = (d2v*)(s_W + (size_t)bi * 18);
+            d2v* Lo = (d2v*)(Lblk + ((size_t)kb * NB + bi) * 18);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double w0 = a4[r][0];
                 const double w1 = fma(-w0, l10, a4[r][1]);
                 const double w2 = fma(-w1, l21, fma(-w0, l20, a4[r][2]));
                 const double w3 = fma(-w2, l32, fma(-w1, l31, fma(-w0, l30, a4[r][3])));
-                double* Lrow = Lf + (size_t)(4 * bi + r) * LD + 4 * kb;
-                Lrow[0] = w0 * r0; Lrow[1] = w1 * r1; Lrow[2] = w2 * r2; Lrow[3] = w3 * r3;
+                Wo[2 * r] = (d2v){w0, w1}; Wo[2 * r + 1] = (d2v){w2, w3};
+                Lo[2 * r] = (d2v){w0 * r0, w1 * r1}; Lo[2 * r + 1] = (d2v){w2 * r2, w3 * r3};
             }
-        } else {
-            // trailing block: A_ij -= W_i (W_j D^-1)^T with W from the raw block-column rows of bi and bj
-            double Wi[4][4], Lj[4][4];
+        }
+        LPROBE(1);
+        __syncthreads();                                    // B2: W and L of pivot block kb are visible
+        LPROBE(2);
+        if (s_fail) { fail = true; break; }
+        if (bj > kb) {
+            const d2v* Wi = (const d2v*)(s_W + (size_t)bi * 18);
+            const d2v* Lj = (const d2v*)(Lblk + ((size_t)kb * NB + bj) * 18);
+            d2v wv[4][2], lv[4][2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double w0 = Av[r][0].x;
-                const double w1 = fma(-w0, l10, Av[r][0].y);
-                const double w2 = fma(-w1, l21, fma(-w0, l20, Av[r][1].x));
-                const double w3 = fma(-w2, l32, fma(-w1, l31, fma(-w0, l30, Av[r][1].y)));
-                Wi[r][0] = w0; Wi[r][1] = w1; Wi[r][2] = w2; Wi[r][3] = w3;
-                const double u0 = Bv[r][0].x;
-                const double u1 = fma(-u0, l10, Bv[r][0].y);
-                const double u2 = fma(-u1, l21, fma(-u0, l20, Bv[r][1].x));
-                const double u3 = fma(-u2, l32, fma(-u1, l31, fma(-u0, l30, Bv[r][1].y)));
-                Lj[r][0] = u0 * r0; Lj[r][1] = u1 * r1; Lj[r][2] = u2 * r2; Lj[r][3] = u3 * r3;
-            }
-            LPROBE(2);
+            for (int r = 0; r < 4; ++r) { wv[r][0] = Wi[2 * r]; wv[r][1] = Wi[2 * r + 1]; lv[r][0] = Lj[2 * r]; lv[r][1] = Lj[2 * r + 1]; }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
                     double v = a4[r][cc];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v = fma(-Wi[r][c], Lj[cc][c], v);
+                    v = fma(-wv[r][0].x, lv[cc][0].x, v);
+                    v = fma(-wv[r][0].y, lv[cc][0].y, v);
+                    v = fma(-wv[r][1].x, lv[cc][1].x, v);
+                    v = fma(-wv[r][1].y, lv[cc][1].y, v);
                     a4[r][cc] = v;
                 }
             LPROBE(3);
-            if (bj == kb + 1) {                     // publish the next block column, raw
-                d2* nxt = (d2*)(s_raw + (size_t)((kb + 1) & 1) * NB * 18);
+            if (bi == kb + 1 && bj == kb + 1) {             // publish the next diagonal block
+                d2v* Do = (d2v*)s_D;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    nxt[bi * 9 + r * 2] = (d2){a4[r][0], a4[r][1]};
-                    nxt[bi * 9 + r * 2 + 1] = (d2){a4[r][2], a4[r][3]};
-                }
+                for (int r = 0; r < 4; ++r) { Do[2 * r] = (d2v){a4[r][0], a4[r][1]}; Do[2 * r + 1] = (d2v){a4[r][2], a4[r][3]}; }
             }
         }
     }
@@ -485,7 +460,6 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
     if (t == 251) for (int k = 0; k < 5; ++k) fb.trace[(size_t)f * 64 + 56 + k] = (double)lacc[k];
 #endif
     __syncthreads();
-    if (s_failv[0] || s_failv[1]) fail = true;
     TPROBE(3);
     const bool ok = !fail;
     const int ntry = 1 - cur;
@@ -494,14 +468,15 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
         // ---- back substitution L^T delta = w (w = row P of Lf) by wave 0.  Lane l keeps w[l], w[l+64] and the
         // running sums acc[l] = sum_{k>i} L[k][l] delta_k in registers; values cross lanes by v_readlane.
         if (t < 64) {
-            if (P == 85) backsub_unrolled<85>(Lf, LD, t, s_delta);
+            if (P == 85) backsub_unrolled<85>(Lblk, NB, t, s_delta);
             else {
-                const double w0 = (t < P) ? Lf[(size_t)P * LD + t] : 0.0;
-                const double w1 = (t + 64 < P) ? Lf[(size_t)P * LD + t + 64] : 0.0;
+                auto Lat = [&](int i, int l) { return Lblk[((size_t)(l >> 2) * NB + (i >> 2)) * 18 + (i & 3) * 4 + (l & 3)]; };
+                const double w0 = (t < P) ? Lat(P, t) : 0.0;
+                const double w1 = (t + 64 < P) ? Lat(P, t + 64) : 0.0;
                 double acc0 = 0.0, acc1 = 0.0, dl0 = 0.0, dl1 = 0.0;
                 for (int i = P - 1; i >= 0; --i) {
-                    const double c0 = (t < i) ? Lf[(size_t)i * LD + t] : 0.0;
-                    const double c1 = (t + 64 < i) ? Lf[(size_t)i * LD + t + 64] : 0.0;
+                    const double c0 = (t < i) ? Lat(i, t) : 0.0;
+                    const double c1 = (t + 64 < i) ? Lat(i, t + 64) : 0.0;
                     double di;
                     if (i < 64) { di = readlane_f64(w0, i) - readlane_f64(acc0, i); if (t == i) dl0 = di; }
                     else { di = readlane_f64(w1, i - 64) - readlane_f64(acc1, i - 64); if (t == i - 64) dl1 = di; }
@@ -547,8 +522,8 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
 }
 
 static size_t solve_lds_bytes(const AvtDims& d) {
-    const int HS = d.HS, LD = HS + 1;
-    return sizeof(double) * ((size_t)HS * LD + 2 * (size_t)(HS / 4) * 18 + HS) + sizeof(PrepScratch) + 64;
+    const int HS = d.HS, NB = HS / 4;
+    return sizeof(double) * ((size_t)NB * NB * 18 + (size_t)NB * 18 + 18 + HS + 2) + sizeof(PrepScratch) + 64;
 }
 
 void launch_reduce(avt_ctx* c, int nframes) {

@@ -17,18 +17,45 @@
 #include <limits>
 #include <vector>
 
-extern "C" int avt_synth_render_cloud(int V, int F, const double* cloud /*3xV*/, const int* mesh /*3xF*/,
-                                      const int* vertex_part /*V*/, double fx, double fy, double cx, double cy,
-                                      int width, int height, int capacity, double* out_xyz /*3 x capacity*/,
-                                      int* out_labels) {
+static void rasterise(int V, int F, const double* cloud, const int* mesh, const int* vertex_part, double fx, double fy, double cx,
+                      double cy, int width, int height, std::vector<float>& zbuf, std::vector<int>& lab);
+
+// the same render as avt_synth_render_cloud, returned as images the way the reference's perception front-end hands
+// them to the tracker loop (demo.cpp:215-250): xyz map (H x W x 3 float32, camera coordinates, y NOT yet negated)
+// and body-part mask (H x W uint8, 255 = background).  Returns the number of foreground pixels.
+extern "C" int avt_synth_render_images(int V, int F, const double* cloud, const int* mesh, const int* vertex_part, double fx,
+                                       double fy, double cx, double cy, int width, int height, float* xyz_out,
+                                       unsigned char* mask_out) {
+    std::vector<float> zbuf;
+    std::vector<int> lab;
+    rasterise(V, F, cloud, mesh, vertex_part, fx, fy, cx, cy, width, height, zbuf, lab);
+    int count = 0;
+    const float ffx = (float)fx, ffy = (float)fy, fcx = (float)cx, fcy = (float)cy;
+    for (int r = 0; r < height; ++r)
+        for (int col = 0; col < width; ++col) {
+            const size_t o = (size_t)r * width + col;
+            float* q = xyz_out + 3 * o;
+            if (lab[o] < 0) { q[0] = q[1] = q[2] = 0.f; mask_out[o] = 255; continue; }
+            const float depth = zbuf[o];
+            q[0] = ((float)col - fcx) * depth / ffx;
+            q[1] = ((float)r - fcy) * depth / ffy;
+            q[2] = depth;
+            mask_out[o] = (unsigned char)lab[o];
+            ++count;
+        }
+    return count;
+}
+
+static void rasterise(int V, int F, const double* cloud, const int* mesh, const int* vertex_part, double fx, double fy, double cx,
+                      double cy, int width, int height, std::vector<float>& zbuf, std::vector<int>& lab) {
     std::vector<float> px(V), py(V);
     for (int i = 0; i < V; ++i) {  // AvatarRenderer.cpp:11-24 (y flipped on projection)
         const double* p = cloud + 3 * i;
         px[i] = (float)(p[0] * fx / p[2] + cx);
         py[i] = (float)(-p[1] * fy / p[2] + cy);
     }
-    std::vector<float> zbuf((size_t)width * height, std::numeric_limits<float>::infinity());
-    std::vector<int> lab((size_t)width * height, -1);
+    zbuf.assign((size_t)width * height, std::numeric_limits<float>::infinity());
+    lab.assign((size_t)width * height, -1);
     for (int f = 0; f < F; ++f) {
         const int ia = mesh[3 * f], ib = mesh[3 * f + 1], ic = mesh[3 * f + 2];
         const double* a = cloud + 3 * ia; const double* b = cloud + 3 * ib; const double* c = cloud + 3 * ic;
@@ -64,6 +91,15 @@ extern "C" int avt_synth_render_cloud(int V, int F, const double* cloud /*3xV*/,
             }
         }
     }
+}
+
+extern "C" int avt_synth_render_cloud(int V, int F, const double* cloud /*3xV*/, const int* mesh /*3xF*/,
+                                      const int* vertex_part /*V*/, double fx, double fy, double cx, double cy,
+                                      int width, int height, int capacity, double* out_xyz /*3 x capacity*/,
+                                      int* out_labels) {
+    std::vector<float> zbuf;
+    std::vector<int> lab;
+    rasterise(V, F, cloud, mesh, vertex_part, fx, fy, cx, cy, width, height, zbuf, lab);
     int count = 0;
     const float ffx = (float)fx, ffy = (float)fy, fcx = (float)cx, fcy = (float)cy;
     for (int r = 0; r < height; ++r)

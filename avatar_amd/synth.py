@@ -544,6 +544,26 @@ def render_cloud(model, verts, part_map, res_scale=1):
     return xyz[:n].copy(), lab[:n].copy()
 
 
+def render_images(model, verts, part_map):
+    """XYZ map (H,W,3) float32 (camera coordinates, y down) + part mask (H,W) uint8 (255 = background) of the posed
+    vertices, the inputs of the reference's tracker loop (demo.cpp:215-250)."""
+    import ctypes as C
+    lib = _render_lib()
+    mesh = np.ascontiguousarray(model["f"], np.int32)
+    vp = np.ascontiguousarray(np.asarray(part_map, np.int32)[main_joint(model)])
+    cloud = np.ascontiguousarray(verts, np.float64)
+    k = K4A_INTRIN
+    W, H = k["width"], k["height"]
+    xyz = np.empty((H, W, 3), np.float32); mask = np.empty((H, W), np.uint8)
+    dp = C.POINTER(C.c_double); ip = C.POINTER(C.c_int)
+    lib.avt_synth_render_images.restype = C.c_int
+    n = lib.avt_synth_render_images(
+        C.c_int(verts.shape[0]), C.c_int(mesh.shape[0]), cloud.ctypes.data_as(dp), mesh.ctypes.data_as(ip), vp.ctypes.data_as(ip),
+        C.c_double(k["fx"]), C.c_double(k["fy"]), C.c_double(k["cx"]), C.c_double(k["cy"]), C.c_int(W), C.c_int(H),
+        xyz.ctypes.data_as(C.POINTER(C.c_float)), mask.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return xyz, mask, n
+
+
 def identity_part_map(J=NUM_JOINTS):
     """numParts = J, partMap = identity: the documented benchmark choice."""
     return np.arange(J, dtype=np.int32)

@@ -17,6 +17,6 @@ names=['wait_prev+top','zero+gload','xhat','xk','jac+shape','mfma(+tail)']
 t=buf[48:54]; print('F',F,'eval block0 cycles per phase:'); [print('  %-14s %10.0f  %5.1f%%'%(n,v,100*v/t.sum())) for n,v in zip(names,t)]; print('  total',t.sum(), 'cycles =', t.sum()/2.4e3,'us @2.4GHz')
 s=buf[40:47]; print('solve probes deltas', np.diff(s))
 
-l=buf[56:61]; print('LDLT thread251 cycles: barrier_wait %.0f  read+factor %.0f  W/L %.0f  update %.0f  (sum %.0f over 21 rounds)'%(l[0],l[1],l[2],l[3],l[:4].sum()))
+l=buf[56:61]; print('LDLT wave3 cycles: B1 wait(+publish D) %.0f | panel phase %.0f | B2 wait %.0f | trailing %.0f | (sum %.0f over 22 rounds)'%(l[0],l[1],l[2],l[3],l[:4].sum()))
 
 r=buf[8:30]; print('per-round cycles (thread 251):', np.diff(r).astype(int))
