@@ -442,6 +442,7 @@ int avt_get_normal_equations(avt_ctx* c, int frame, double* H, double* g, double
 }
 
 int avt_debug_trace(avt_ctx* c, int frame, double* out64) {
+    if (!c || !out64 || frame < 0 || frame >= c->fb.max_frames) { avt_set_error("avt_debug_trace: bad argument"); return 1; }
     HIP_OK(hipSetDevice(c->device));
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipMemcpy(out64, c->fb.trace + (size_t)frame * 64, 64 * sizeof(double), hipMemcpyDeviceToHost));

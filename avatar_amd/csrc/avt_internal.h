@@ -189,4 +189,3 @@ void launch_finalize(avt_ctx* c, int nframes, const avt_options* o);
 void launch_eval(avt_ctx* c, int nframes);
 void launch_reduce(avt_ctx* c, int nframes);
 void launch_solve(avt_ctx* c, int nframes, int mode, const avt_options* o);
-void launch_nn_single(avt_ctx* c);  // avt_nn(): uses frame 0 buffers with caller-provided cloud/visible

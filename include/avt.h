@@ -156,6 +156,10 @@ int avt_get_cloud(avt_ctx* c, int frame, double* cloud_3xV);       /* ava.cloud 
 /* data-term Gauss-Newton normal equations J^T J (P x P) and J^T r (P) at the current point + its objective */
 int avt_get_normal_equations(avt_ctx* c, int frame, double* H /* P x P */, double* g /* P */, double* cost);
 
+/* diagnostics: 64 doubles per frame (objective after every GN iteration; with -DAVT_TIMING builds also in-kernel
+ * s_memtime probes, see tools/kernel_timing_probe.py) */
+int avt_debug_trace(avt_ctx* c, int frame, double* out64);
+
 int avt_profile_begin(avt_ctx* c);
 /* restrict event insertion to the kernel classes in `mask` (bit k = class k); default: all classes */
 int avt_profile_select(avt_ctx* c, unsigned mask);

@@ -1,0 +1,104 @@
+"""More GPU parity cases: full-size / dense frames, other part maps and knobs, ragged batches, determinism and
+size-independent properties (translation equivariance, monotone objective)."""
+import numpy as np
+import pytest
+
+from avatar_amd import synth
+from avatar_amd.capi import Options
+
+pytestmark = pytest.mark.gpu
+
+
+def _start(fr):
+    from avatar_amd import api
+    w0, p0, R0 = fr["start"]
+    return p0, api.rot_to_quat(R0), w0
+
+
+def _check(ctx, ref, p, q, w, n, tol=1e-6):
+    assert np.array_equal(ctx.correspondences(0, n), ref["corr"])
+    assert np.abs(ctx.cloud(0) - ref["cloud"]).max() < tol
+    assert np.abs(p[0] - ref["p"]).max() < tol and np.abs(w[0] - ref["w"]).max() < 10 * tol
+    dq = np.minimum(np.abs(q[0] - ref["q"]).max(1), np.abs(q[0] + ref["q"]).max(1))
+    assert dq.max() < tol
+
+
+def test_dense_120k_frame_matches_oracle(smpl, omodel, gmodel):
+    """BASELINE configs[4]: the 2560x1440 render (~150k points)."""
+    from avatar_amd import api
+    fr = synth.make_frame(smpl, 0, dense=True)
+    assert len(fr["labels"]) > 100000
+    pm = synth.identity_part_map()
+    p0, q0, w0 = _start(fr)
+    opt = Options.demo()
+    ctx = api.Context(gmodel, 24, pm, len(fr["labels"]), 1)
+    p, q, w, st = ctx.optimize_batch([fr["data"]], [fr["labels"]], opt, p0[None], q0[None], w0[None])
+    ref = omodel.optimize(pm, 24, fr["data"], fr["labels"], opt, p0, q0, w0, aggregate=1)
+    _check(ctx, ref, p, q, w, len(fr["labels"]))
+    assert st[0].num_correspondences == ref["stats"].num_correspondences
+
+
+def test_coarse_part_map_and_reference_default_betas(smpl, omodel, gmodel):
+    from avatar_amd import api
+    coarse = np.array([0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 2, 3, 3, 3, 3, 4, 5, 4, 5, 4, 5, 4, 5], np.int32)
+    fr = synth.make_frame(smpl, 13, part_map=coarse)
+    p0, q0, w0 = _start(fr)
+    opt = Options.reference_defaults()          # betaPose 0.1, betaShape 1.0 (AvatarOptimizer.h:28)
+    opt.icp_iters = 2
+    ctx = api.Context(gmodel, 6, coarse, len(fr["labels"]), 1)
+    p, q, w, st = ctx.optimize_batch([fr["data"]], [fr["labels"]], opt, p0[None], q0[None], w0[None])
+    ref = omodel.optimize(coarse, 6, fr["data"], fr["labels"], opt, p0, q0, w0, aggregate=1)
+    _check(ctx, ref, p, q, w, len(fr["labels"]))
+
+
+def test_model_without_pose_prior(smpl):
+    from avatar_amd import api
+    from oracle import oracle as orc
+    m2 = {k: v for k, v in smpl.items() if not k.startswith("prior_")}
+    gm, om = api.AvatarModel(m2), orc.OracleModel(m2)
+    fr = synth.make_frame(smpl, 14)
+    pm = synth.identity_part_map()
+    p0, q0, w0 = _start(fr)
+    opt = Options.demo(max_iters_per_icp=6)
+    ctx = api.Context(gm, 24, pm, len(fr["labels"]), 1)
+    p, q, w, st = ctx.optimize_batch([fr["data"]], [fr["labels"]], opt, p0[None], q0[None], w0[None])
+    ref = om.optimize(pm, 24, fr["data"], fr["labels"], opt, p0, q0, w0, aggregate=1)
+    _check(ctx, ref, p, q, w, len(fr["labels"]))
+
+
+def test_ragged_batch_with_empty_frame_and_determinism(smpl, omodel, gmodel):
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    frs = [synth.make_frame(smpl, s) for s in (15, 16)]
+    datas = [frs[0]["data"], np.zeros((0, 3)), frs[1]["data"][:777]]
+    labs = [frs[0]["labels"], np.zeros(0, np.int32), frs[1]["labels"][:777]]
+    starts = [_start(frs[0]), _start(frs[0]), _start(frs[1])]
+    opt = Options.demo(max_iters_per_icp=5)
+    ctx = api.Context(gmodel, 24, pm, 60000, 3)
+    args = (datas, labs, opt, np.array([s[0] for s in starts]), np.array([s[1] for s in starts]), np.array([s[2] for s in starts]))
+    p1, q1, w1, st1 = ctx.optimize_batch(*args)
+    p2, q2, w2, st2 = ctx.optimize_batch(*args)
+    # bit-wise reproducible run to run (fixed-order reductions, integer atomics)
+    assert np.array_equal(p1, p2) and np.array_equal(q1, q2) and np.array_equal(w1, w2)
+    # the empty frame is left untouched
+    assert st1[1].num_correspondences == 0 and np.array_equal(p1[1], starts[1][0]) and np.array_equal(w1[1], starts[1][2])
+    for f in (0, 2):
+        ref = omodel.optimize(pm, 24, datas[f], labs[f], opt, *starts[f], aggregate=1)
+        assert np.abs(p1[f] - ref["p"]).max() < 1e-6 and np.abs(w1[f] - ref["w"]).max() < 1e-5
+
+
+def test_translation_equivariance_and_monotone_cost(smpl, gmodel):
+    """Size-independent properties at full size: shifting the data and the start by t shifts the fit by t (the model
+    enters only through p + R(...)); the LM objective never increases."""
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    fr = synth.make_frame(smpl, 17)
+    p0, q0, w0 = _start(fr)
+    opt = Options.demo()
+    ctx = api.Context(gmodel, 24, pm, len(fr["labels"]), 1)
+    p, q, w, st = ctx.optimize_batch([fr["data"]], [fr["labels"]], opt, p0[None], q0[None], w0[None])
+    assert st[0].final_cost <= st[0].initial_cost
+    t = np.array([0.25, -0.125, 0.5])          # exactly representable shift
+    pt, qt, wt, stt = ctx.optimize_batch([fr["data"] + t], [fr["labels"]], opt, (p0 + t)[None], q0[None], w0[None])
+    assert np.abs(pt[0] - t - p[0]).max() < 1e-7 and np.abs(wt[0] - w[0]).max() < 1e-6
+    assert np.abs(qt[0] - q[0]).max() < 1e-7

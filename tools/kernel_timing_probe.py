@@ -1,3 +1,4 @@
+"""In-kernel phase timing (s_memtime) of k_eval / k_solve.  Needs a -DAVT_TIMING build: make -C avatar_amd/csrc EXTRA=-DAVT_TIMING (after touching avt_solve.hip avt_lm.hip).  Usage: python tools/kernel_timing_probe.py [frames]"""
 import sys, numpy as np, ctypes as C
 sys.path.insert(0,'/root/repo')
 from avatar_amd import api, synth, capi
@@ -11,7 +12,7 @@ opt=Options.demo()
 for i in range(3):
     ctx.optimize_batch([f['data'] for f in frs],[f['labels'] for f in frs],opt,p0,q0,w0)
 lib=capi.load_library(); buf=np.zeros(64)
-lib.avt_debug_trace.argtypes=[C.c_void_p,C.c_int,C.POINTER(C.c_double)]
+
 lib.avt_debug_trace(ctx.h,0,buf.ctypes.data_as(C.POINTER(C.c_double)))
 names=['wait_prev+top','zero+gload','xhat','xk','jac+shape','mfma(+tail)']
 t=buf[48:54]; print('F',F,'eval block0 cycles per phase:'); [print('  %-14s %10.0f  %5.1f%%'%(n,v,100*v/t.sum())) for n,v in zip(names,t)]; print('  total',t.sum(), 'cycles =', t.sum()/2.4e3,'us @2.4GHz')
