@@ -70,8 +70,9 @@ int check_launch(const char* what) {
 }
 
 // the launch sequence of one optimize() over the resident frames
-void enqueue_optimize(avt_ctx* c, const avt_options* o) {
-    const int nf = c->nframes;
+void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStream_t stream) {
+    c->fb.f0 = f0;
+    c->cur_stream = stream;
     c->ran_icp_iters = 0;
     const int vis_init = o->enable_occlusion ? 0 : 1;
     c->lbs_cleared = true;
@@ -95,21 +96,27 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o) {
         c->ran_icp_iters++;
     }
     c->lbs_cleared = false;
+    c->fb.f0 = 0;
+    c->cur_stream = c->stream;
 }
 
 int run_optimize(avt_ctx* c, const avt_options* o) {
     const int nf = c->nframes;
     if (nf <= 0) { avt_set_error("avt_optimize: no frames resident"); return 1; }
     if (o->max_iters_per_icp < 0 || o->max_iters_per_icp > 62 || o->icp_iters < 0) { avt_set_error("avt_optimize: bad iteration counts"); return 1; }
-    c->fb.G = choose_G(nf);
     c->ran_max_iters = o->max_iters_per_icp;
+    // Large batches run as two frame groups on two streams: the latency-bound single-workgroup-per-frame kernels of
+    // one group (k_solve, k_finalize, k_reduce) overlap the throughput kernels (k_eval, k_nn) of the other.
+    const bool two_groups = c->use_graph && !c->profiling && nf >= 32 && !getenv("AVT_ONE_GROUP");
+    const int nfA = two_groups ? (nf + 1) / 2 : nf;
+    c->fb.G = choose_G(nfA);
     if (!c->use_graph || c->profiling) {
-        enqueue_optimize(c, o);
+        enqueue_optimize(c, o, 0, nf, c->stream);
         return check_launch("optimize launch sequence");
     }
     // The launch sequence depends only on (nframes, grid sizes, options): capture it once, replay it afterwards.
     char key[256];
-    snprintf(key, sizeof key, "%d|%d|%d|%d|%d|%.17g|%.17g|%.17g|%.17g|%.17g|%.17g|%.17g", nf, c->launch_maxN, o->icp_iters,
+    snprintf(key, sizeof key, "%d|%d|%d|%d|%d|%d|%.17g|%.17g|%.17g|%.17g|%.17g|%.17g|%.17g", nf, (int)two_groups, c->launch_maxN, o->icp_iters,
              o->max_iters_per_icp, o->enable_occlusion, o->beta_pose, o->beta_shape, o->lm_lambda0, o->lm_up, o->lm_down,
              o->lm_lambda_min, o->lm_lambda_max);
     auto it = c->graphs.find(key);
@@ -117,7 +124,16 @@ int run_optimize(avt_ctx* c, const avt_options* o) {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        enqueue_optimize(c, o);
+        if (two_groups) {
+            HIP_OK(hipEventRecord(c->ev_fork, c->stream));
+            HIP_OK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            enqueue_optimize(c, o, 0, nfA, c->stream);
+            enqueue_optimize(c, o, nfA, nf - nfA, c->stream2);
+            HIP_OK(hipEventRecord(c->ev_join, c->stream2));
+            HIP_OK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        } else {
+            enqueue_optimize(c, o, 0, nf, c->stream);
+        }
         HIP_OK(hipStreamEndCapture(c->stream, &graph));
         HIP_OK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         HIP_OK(hipGraphDestroy(graph));
@@ -225,6 +241,10 @@ int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* par
     c->use_graph = getenv("AVT_NO_GRAPH") == nullptr;
     c->lbs_cleared = false;
     HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_OK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    c->cur_stream = c->stream;
     if (avt_solve_set_attributes() || avt_eval_set_attributes()) { avt_set_error("avt_ctx_create: hipFuncSetAttribute failed"); return 1; }
     DeviceModel& dm = c->dm;
     dm.d = m->d;
@@ -261,7 +281,11 @@ int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* par
     const size_t FN = (size_t)max_frames * max_points, FV = (size_t)max_frames * V;
     const AvtDims& d = dm.d;
     // eval workgroups over all frames: nf*choose_G(nf) <= max(min(128*nf, 512), 2*nf)
-    const size_t part_cap = std::max<size_t>(std::min<size_t>((size_t)128 * max_frames, 512), (size_t)2 * max_frames);
+    size_t part_cap = 0;
+    for (int nf = 1; nf <= max_frames; ++nf) {
+        part_cap = std::max(part_cap, (size_t)nf * choose_G(nf));
+        if (nf >= 32) part_cap = std::max(part_cap, (size_t)nf * choose_G((nf + 1) / 2));
+    }
     char* cntsum = nullptr;
     if (dev_alloc(c, &fb.data_raw, FN * 3) || dev_alloc(c, &fb.labels_raw, FN) || dev_alloc(c, &fb.dx, FN) || dev_alloc(c, &fb.dy, FN) ||
         dev_alloc(c, &fb.dz, FN) || dev_alloc(c, &fb.dorig, FN) || dev_alloc(c, &fb.part_off, (size_t)max_frames * (num_parts + 1)) || dev_alloc(c, &fb.part_cnt, (size_t)max_frames * 2 * (AVT_MAX_PARTS + 1)) ||
@@ -293,6 +317,9 @@ void avt_ctx_destroy(avt_ctx* c) {
     for (void* p : c->allocs) hipFree(p);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
     for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
+    hipEventDestroy(c->ev_fork);
+    hipEventDestroy(c->ev_join);
+    hipStreamDestroy(c->stream2);
     hipStreamDestroy(c->stream);
     delete c;
 }

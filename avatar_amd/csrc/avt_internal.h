@@ -106,6 +106,7 @@ struct DeviceModel {
 struct FrameBuffers {
     int max_frames, max_points;   // per frame
     int G;                        // eval blocks per frame
+    int f0;                       // first frame of the frame group a launch covers (grid frame index is relative to it)
     // raw inputs
     double* data_raw;     // [max_frames*max_points][3]
     int* labels_raw;      // [max_frames*max_points]
@@ -157,6 +158,9 @@ struct avt_model {
 struct avt_ctx {
     int device;
     hipStream_t stream;
+    hipStream_t stream2;             // second branch of the two-group pipeline (large batches)
+    hipEvent_t ev_fork, ev_join;
+    hipStream_t cur_stream;          // stream the launch wrappers enqueue on
     const avt_model* model;
     DeviceModel dm;
     FrameBuffers fb;

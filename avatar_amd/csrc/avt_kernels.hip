@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
                                              int from_state, int vis_init) {
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, V = d.V;
-    const int f = blockIdx.y, t = threadIdx.x;
+    const int f = blockIdx.y + fb.f0, t = threadIdx.x;
     __shared__ double s_rot[AVT_MAX_JOINTS * 9], s_Rw[AVT_MAX_JOINTS * 9], s_o[AVT_MAX_JOINTS * 3], s_jp[AVT_MAX_JOINTS * 3];
     __shared__ double s_T[AVT_MAX_JOINTS * 12];  // jointTrans, column-major 3x4 per joint (Avatar.h:215)
     __shared__ double s_w[AVT_MAX_SHAPE], s_p[3];
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
 
 void launch_lbs(avt_ctx* c, int nframes, const double*, const double* w, const double* p, const double* R, int from_state, int vis_init) {
     dim3 grid((c->dm.d.V + 255) / 256, nframes);
-    hipLaunchKernelGGL(k_lbs, grid, dim3(256), 0, c->stream, c->dm, c->fb, w, p, R, from_state, vis_init);
+    hipLaunchKernelGGL(k_lbs, grid, dim3(256), 0, c->cur_stream, c->dm, c->fb, w, p, R, from_state, vis_init);
 }
 
 // =================================================================================================
@@ -117,7 +117,7 @@ void launch_lbs(avt_ctx* c, int nframes, const double*, const double* w, const d
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_visibility(DeviceModel dm, FrameBuffers fb) {
     const int F = dm.d.F, V = dm.d.V;
-    const int f = blockIdx.y;
+    const int f = blockIdx.y + fb.f0;
     const int face = blockIdx.x * 256 + threadIdx.x;
     if (face >= F) return;
     const int i1 = dm.mesh[face], i2 = dm.mesh[(size_t)F + face], i3 = dm.mesh[2 * (size_t)F + face];
@@ -135,10 +135,10 @@ __global__ __launch_bounds__(256) void k_visibility(DeviceModel dm, FrameBuffers
 
 void launch_visibility(avt_ctx* c, int nframes, int enable) {
     const int V = c->dm.d.V;
-    if (!c->lbs_cleared) (void)hipMemsetAsync(c->fb.visible, enable ? 0 : 1, (size_t)nframes * V, c->stream);
+    if (!c->lbs_cleared) (void)hipMemsetAsync(c->fb.visible + (size_t)c->fb.f0 * V, enable ? 0 : 1, (size_t)nframes * V, c->cur_stream);
     if (enable) {
         dim3 grid((c->dm.d.F + 255) / 256, nframes);
-        hipLaunchKernelGGL(k_visibility, grid, dim3(256), 0, c->stream, c->dm, c->fb);
+        hipLaunchKernelGGL(k_visibility, grid, dim3(256), 0, c->cur_stream, c->dm, c->fb);
     }
 }
 
@@ -153,7 +153,7 @@ void launch_visibility(avt_ctx* c, int nframes, int enable) {
 #define BUCKET_TILE 2048
 
 __global__ __launch_bounds__(256) void k_bucket_count(DeviceModel dm, FrameBuffers fb) {
-    const int f = blockIdx.y, t = threadIdx.x, np = dm.d.num_parts;
+    const int f = blockIdx.y + fb.f0, t = threadIdx.x, np = dm.d.num_parts;
     const int N = fb.ctl[f].N;
     const int s0 = blockIdx.x * BUCKET_TILE;
     if (s0 >= N) return;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_bucket_count(DeviceModel dm, FrameBuffe
 }
 
 __global__ __launch_bounds__(256) void k_bucket_scatter(DeviceModel dm, FrameBuffers fb) {
-    const int f = blockIdx.y, t = threadIdx.x, np = dm.d.num_parts;
+    const int f = blockIdx.y + fb.f0, t = threadIdx.x, np = dm.d.num_parts;
     AvtFrameCtl& ctl = fb.ctl[f];
     const int N = ctl.N;
     const int s0 = blockIdx.x * BUCKET_TILE;
@@ -231,9 +231,9 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(DeviceModel dm, FrameBuf
 void launch_bucket(avt_ctx* c, int nframes) {
     const int maxN = c->launch_maxN;
     const int nb = std::max(1, (maxN + BUCKET_TILE - 1) / BUCKET_TILE);
-    (void)hipMemsetAsync(c->fb.part_cnt, 0, (size_t)nframes * 2 * (AVT_MAX_PARTS + 1) * sizeof(int), c->stream);
-    hipLaunchKernelGGL(k_bucket_count, dim3(nb, nframes), dim3(256), 0, c->stream, c->dm, c->fb);
-    hipLaunchKernelGGL(k_bucket_scatter, dim3(nb, nframes), dim3(256), 0, c->stream, c->dm, c->fb);
+    (void)hipMemsetAsync(c->fb.part_cnt + (size_t)c->fb.f0 * 2 * (AVT_MAX_PARTS + 1), 0, (size_t)nframes * 2 * (AVT_MAX_PARTS + 1) * sizeof(int), c->cur_stream);
+    hipLaunchKernelGGL(k_bucket_count, dim3(nb, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(nb, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
 }
 
 // =================================================================================================
@@ -244,7 +244,7 @@ void launch_bucket(avt_ctx* c, int nframes) {
 // =================================================================================================
 __global__ __launch_bounds__(1024) void k_finalize(DeviceModel dm, FrameBuffers fb, double beta_pose, double beta_shape,
                                                    double lambda0, int first_icp) {
-    const int f = blockIdx.x, t = threadIdx.x, V = dm.d.V;
+    const int f = blockIdx.x + fb.f0, t = threadIdx.x, V = dm.d.V;
     AvtFrameCtl& ctl = fb.ctl[f];
     __shared__ int s_wave_m[16], s_wave_t[16];
     const int chunk = (V + 1023) / 1024;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(1024) void k_finalize(DeviceModel dm, FrameBuffers 
 // correspondences are fixed.  Deterministic two-level reduction in original data order (block partials,
 // summed in a fixed order by the solve kernel).
 __global__ __launch_bounds__(256) void k_cost_const(DeviceModel dm, FrameBuffers fb) {
-    const int f = blockIdx.y, t = threadIdx.x, V = dm.d.V;
+    const int f = blockIdx.y + fb.f0, t = threadIdx.x, V = dm.d.V;
     const AvtFrameCtl& ctl = fb.ctl[f];
     const int N = ctl.N;
     const size_t base = (size_t)f * fb.max_points;
@@ -323,10 +323,10 @@ __global__ __launch_bounds__(256) void k_cost_const(DeviceModel dm, FrameBuffers
 }
 
 void launch_finalize(avt_ctx* c, int nframes, const avt_options* o) {
-    hipLaunchKernelGGL(k_finalize, dim3(nframes), dim3(1024), 0, c->stream, c->dm, c->fb, o->beta_pose, o->beta_shape,
+    hipLaunchKernelGGL(k_finalize, dim3(nframes), dim3(1024), 0, c->cur_stream, c->dm, c->fb, o->beta_pose, o->beta_shape,
                        o->lm_lambda0, c->ran_icp_iters == 0 ? 1 : 0);
     const int maxN = c->launch_maxN;
     const int nb = (maxN + 255) / 256;
     c->fb.const_used = nb;
-    if (nb > 0) hipLaunchKernelGGL(k_cost_const, dim3(nb, nframes), dim3(256), 0, c->stream, c->dm, c->fb);
+    if (nb > 0) hipLaunchKernelGGL(k_cost_const, dim3(nb, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
 }

@@ -14,7 +14,7 @@
 #include "avt_device.h"
 
 #ifdef AVT_TIMING
-#define TPROBE(i) do { if (threadIdx.x == 0) fb.trace[(size_t)blockIdx.x * 64 + 40 + (i)] = (double)clock64(); } while (0)
+#define TPROBE(i) do { if (threadIdx.x == 0) fb.trace[(size_t)(blockIdx.x + fb.f0) * 64 + 40 + (i)] = (double)clock64(); } while (0)
 #else
 #define TPROBE(i) do {} while (0)
 #endif
@@ -116,7 +116,7 @@ __device__ void compute_prep(const DeviceModel& dm, const double* __restrict__ x
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_reduce(DeviceModel dm, FrameBuffers fb) {
     const AvtDims d = dm.d;
-    const int f = blockIdx.y, t = threadIdx.x, NPAIR = d.NPAIR, NT = d.NT, P = d.P, HS = d.HS;
+    const int f = blockIdx.y + fb.f0, t = threadIdx.x, NPAIR = d.NPAIR, NT = d.NT, P = d.P, HS = d.HS;
     const int try_slot = 1 - fb.ctl[f].cur_slot;
     if ((int)blockIdx.x < NPAIR) {
         int p = blockIdx.x, ti = 0;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
                                                double lm_min, double lm_max) {
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, P = d.P, HS = d.HS;
-    const int f = blockIdx.x, t = threadIdx.x;
+    const int f = blockIdx.x + fb.f0, t = threadIdx.x;
     AvtFrameCtl& ctl = fb.ctl[f];
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NBk = HS >> 2;                                // 4-row blocks covering rows 0..P (22 for SMPL)
@@ -528,12 +528,12 @@ static size_t solve_lds_bytes(const AvtDims& d) {
 
 void launch_reduce(avt_ctx* c, int nframes) {
     const AvtDims& d = c->dm.d;
-    hipLaunchKernelGGL(k_reduce, dim3(d.NPAIR + std::max(0, d.ncomps), nframes), dim3(256), 0, c->stream, c->dm, c->fb);
+    hipLaunchKernelGGL(k_reduce, dim3(d.NPAIR + std::max(0, d.ncomps), nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
 }
 
 void launch_solve(avt_ctx* c, int nframes, int mode, const avt_options* o) {
     const AvtDims& d = c->dm.d;
-    hipLaunchKernelGGL(k_solve, dim3(nframes), dim3(256), solve_lds_bytes(d), c->stream, c->dm, c->fb, mode, o->lm_up, o->lm_down,
+    hipLaunchKernelGGL(k_solve, dim3(nframes), dim3(256), solve_lds_bytes(d), c->cur_stream, c->dm, c->fb, mode, o->lm_up, o->lm_down,
                        o->lm_lambda_min, o->lm_lambda_max);
 }
 

@@ -26,7 +26,7 @@
 template <int LANES>
 __global__ __launch_bounds__(256) void k_nn(DeviceModel dm, FrameBuffers fb) {
     constexpr int NN_QPB = 256 / LANES;
-    const int f = blockIdx.y, t = threadIdx.x;
+    const int f = blockIdx.y + fb.f0, t = threadIdx.x;
     const int V = dm.d.V, np = dm.d.num_parts;
     const AvtFrameCtl& ctl = fb.ctl[f];
     const int* po = fb.part_off + (size_t)f * (np + 1);
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_nn(DeviceModel dm, FrameBuffers fb) {
 // Visible model points of every part, compacted in ascending vertex order inside the part's segment of the
 // part-sorted arrays (exactly the per-part clouds findNN builds at AvatarOptimizer.cpp:860-878).  grid (parts, frames).
 __global__ __launch_bounds__(256) void k_compact(DeviceModel dm, FrameBuffers fb) {
-    const int f = blockIdx.y, q = blockIdx.x, t = threadIdx.x, V = dm.d.V, np = dm.d.num_parts;
+    const int f = blockIdx.y + fb.f0, q = blockIdx.x, t = threadIdx.x, V = dm.d.V, np = dm.d.num_parts;
     const int b = dm.part_start[q], e = dm.part_start[q + 1];
     __shared__ int s_wcnt[4];
     __shared__ int s_run;
@@ -150,13 +150,13 @@ void launch_nn(avt_ctx* c, int nframes) {
     const int V = c->dm.d.V;
     // cnt and fsum are adjacent: one memset clears both for the frames in use
     if (!c->lbs_cleared) {   // stand-alone avt_nn(): no preceding k_lbs cleared the bookkeeping
-        (void)hipMemsetAsync(c->fb.cnt, 0, (size_t)nframes * V * sizeof(int), c->stream);
-        (void)hipMemsetAsync(c->fb.fsum, 0, (size_t)nframes * 3 * V * sizeof(long long), c->stream);
+        (void)hipMemsetAsync(c->fb.cnt + (size_t)c->fb.f0 * V, 0, (size_t)nframes * V * sizeof(int), c->cur_stream);
+        (void)hipMemsetAsync(c->fb.fsum + (size_t)c->fb.f0 * 3 * V, 0, (size_t)nframes * 3 * V * sizeof(long long), c->cur_stream);
     }
     const int maxN = c->launch_maxN;
     if (maxN <= 0) return;
-    hipLaunchKernelGGL(k_compact, dim3(c->dm.d.num_parts, nframes), dim3(256), 0, c->stream, c->dm, c->fb);
+    hipLaunchKernelGGL(k_compact, dim3(c->dm.d.num_parts, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
     // few queries: 4 lanes per query (more workgroups, shorter scans); many: one lane per query
-    if (!getenv("AVT_NN1")) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn<4>), dim3((maxN + 63) / 64, nframes), dim3(256), 0, c->stream, c->dm, c->fb);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn<1>), dim3((maxN + 255) / 256, nframes), dim3(256), 0, c->stream, c->dm, c->fb);
+    if (!getenv("AVT_NN1")) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn<4>), dim3((maxN + 63) / 64, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn<1>), dim3((maxN + 255) / 256, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
 }

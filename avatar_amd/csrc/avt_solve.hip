@@ -25,7 +25,7 @@
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 #ifdef AVT_TIMING
-#define TPROBE(i) do { if (threadIdx.x == 0) fb.trace[(size_t)blockIdx.x * 64 + 40 + (i)] = (double)clock64(); } while (0)
+#define TPROBE(i) do { if (threadIdx.x == 0) fb.trace[(size_t)(blockIdx.x + fb.f0) * 64 + 40 + (i)] = (double)clock64(); } while (0)
 #else
 #define TPROBE(i) do {} while (0)
 #endif
@@ -67,7 +67,7 @@ template <int NT_MAX>
 __global__ __launch_bounds__(256, 2) void k_eval(DeviceModel dm, FrameBuffers fb) {
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, V = d.V, P = d.P, NT = d.NT, NPAIR = d.NPAIR;
-    const int f = blockIdx.y, g = blockIdx.x, G = gridDim.x, t = threadIdx.x;
+    const int f = blockIdx.y + fb.f0, g = blockIdx.x, G = gridDim.x, t = threadIdx.x;
     const AvtFrameCtl& ctl = fb.ctl[f];
     const int M = ctl.M;
     const int try_slot = 1 - ctl.cur_slot;
@@ -328,8 +328,8 @@ void launch_eval(avt_ctx* c, int nframes) {
     const AvtDims& d = c->dm.d;
     dim3 grid(c->fb.G, nframes);
     const size_t lds = eval_lds_bytes(d);
-    if (d.NT == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<6>), grid, dim3(256), lds, c->stream, c->dm, c->fb);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<AVT_MAX_TILES>), grid, dim3(256), lds, c->stream, c->dm, c->fb);
+    if (d.NT == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<6>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<AVT_MAX_TILES>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb);
 }
 
 void avt_eval_report_occupancy(const AvtDims& d) {
