@@ -209,6 +209,31 @@ class Context:
         _check(self._lib.avt_frames_upload(self.h, C.c_int(F), dptr(data), iptr(lab), iptr(offs)))
         self._F = F
 
+    def render_frames(self, w, p, R, intrin=None, res_scale=1):
+        """Synthesise depth frames of posed avatars on the GPU, resident in this context.
+        w (F,K), p (F,3), R (F,J,3,3). Returns the number of points of every frame."""
+        from . import synth
+        k = dict(synth.K4A_INTRIN) if intrin is None else dict(intrin)
+        m = self.model
+        w = np.ascontiguousarray(np.atleast_2d(w), np.float64); p = np.ascontiguousarray(np.atleast_2d(p), np.float64)
+        R = np.asarray(R, np.float64).reshape(-1, m.numJoints(), 3, 3)
+        F = w.shape[0]
+        Rcm = np.ascontiguousarray(np.transpose(R, (0, 1, 3, 2)))
+        n = np.zeros(F, np.int32)
+        _check(self._lib.avt_synth_render_frames(self.h, C.c_int(F), dptr(w), dptr(p), dptr(Rcm), C.c_double(k["fx"] * res_scale),
+                                                 C.c_double(k["fy"] * res_scale), C.c_double(k["cx"] * res_scale),
+                                                 C.c_double(k["cy"] * res_scale), C.c_int(k["width"] * res_scale),
+                                                 C.c_int(k["height"] * res_scale), iptr(n)))
+        self._F = F
+        self._N = n
+        return n
+
+    def frame_download(self, frame):
+        n = int(self._N[frame])
+        data = np.empty((n, 3)); lab = np.empty(n, np.int32)
+        _check(self._lib.avt_frames_download(self.h, C.c_int(frame), dptr(data), iptr(lab)))
+        return data, lab
+
     def state_upload(self, p, q, w):
         F = self._F
         p = np.ascontiguousarray(np.asarray(p, np.float64).reshape(F, 3)); q = np.ascontiguousarray(np.asarray(q, np.float64).reshape(F, -1))

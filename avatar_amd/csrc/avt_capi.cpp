@@ -10,6 +10,8 @@
 
 int avt_solve_set_attributes();
 int avt_eval_set_attributes();
+int avt_render_enqueue(avt_ctx* c, int nframes, const int* d_vertex_part, unsigned long long* d_zkey, unsigned char* d_label, int* d_block,
+                       double fx, double fy, double cx, double cy, int width, int height);
 void avt_eval_report_occupancy(const AvtDims& d);
 
 #define HIP_OK(expr)                                                                          \
@@ -390,6 +392,63 @@ int avt_nn(avt_ctx* c, const double* model_cloud, const unsigned char* visible, 
     if (check_launch("k_nn")) return 1;
     HIP_OK(hipMemcpyAsync(out, c->fb.corr, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int avt_synth_render_frames(avt_ctx* c, int nframes, const double* w, const double* p, const double* R, double fx, double fy, double cx,
+                            double cy, int width, int height, int* points_per_frame) {
+    if (!c || !w || !p || !R || width <= 0 || height <= 0) { avt_set_error("avt_synth_render_frames: bad argument"); return 1; }
+    const AvtDims& d = c->dm.d;
+    if (nframes <= 0 || nframes > c->fb.max_frames) { avt_set_error("avt_synth_render_frames: nframes out of range"); return 1; }
+    HIP_OK(hipSetDevice(c->device));
+    // pose the ground-truth avatars (Avatar::update) for all frames
+    double* dw = c->fb.prep;
+    double* dp = dw + (size_t)nframes * d.K;
+    double* dR = dp + (size_t)nframes * 3;
+    HIP_OK(hipMemcpyAsync(dw, w, (size_t)nframes * d.K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(dp, p, (size_t)nframes * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(dR, R, (size_t)nframes * 9 * d.J * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    launch_lbs(c, nframes, nullptr, dw, dp, dR, 0, -1);
+    // rasterise in chunks of frames (8 bytes of z-buffer key per pixel)
+    const size_t npix = (size_t)width * height;
+    const int chunk = std::max(1, std::min(nframes, (int)((256ull << 20) / (npix * 9 + 64))));
+    const int nb = (int)((npix + 255) / 256);
+    unsigned long long* zkey = nullptr; unsigned char* label = nullptr; int* block = nullptr;
+    HIP_OK(hipMalloc((void**)&zkey, npix * chunk * sizeof(unsigned long long)));
+    HIP_OK(hipMalloc((void**)&label, npix * chunk));
+    HIP_OK(hipMalloc((void**)&block, (size_t)nb * chunk * sizeof(int)));
+    int rc = 0;
+    for (int f0 = 0; f0 < nframes && !rc; f0 += chunk) {
+        c->fb.f0 = f0;
+        rc = avt_render_enqueue(c, std::min(chunk, nframes - f0), c->dm.part_of_vertex, zkey, label, block, fx, fy, cx, cy, width, height);
+    }
+    c->fb.f0 = 0;
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(zkey); hipFree(label); hipFree(block);
+    if (rc || e != hipSuccess) { avt_set_error("avt_synth_render_frames: render launch failed"); return 1; }
+    std::vector<AvtFrameCtl> ctl(nframes);
+    HIP_OK(hipMemcpy(ctl.data(), c->fb.ctl, ctl.size() * sizeof(AvtFrameCtl), hipMemcpyDeviceToHost));
+    c->nframes = nframes;
+    c->frame_N.assign(nframes, 0);
+    c->frame_off.assign(nframes + 1, 0);
+    int mx = 0;
+    for (int f = 0; f < nframes; ++f) {
+        if (ctl[f].T > c->fb.max_points) { avt_set_error("avt_synth_render_frames: a rendered frame has more points than max_points_per_frame"); return 1; }
+        c->frame_N[f] = ctl[f].N;
+        c->frame_off[f + 1] = c->frame_off[f] + ctl[f].N;
+        mx = std::max(mx, ctl[f].N);
+        if (points_per_frame) points_per_frame[f] = ctl[f].N;
+    }
+    c->launch_maxN = std::min(c->fb.max_points, ((mx + 2047) / 2048) * 2048);
+    return 0;
+}
+
+int avt_frames_download(avt_ctx* c, int frame, double* data_3xN, int* labels) {
+    if (!c || frame < 0 || frame >= c->nframes) { avt_set_error("avt_frames_download: bad argument"); return 1; }
+    HIP_OK(hipSetDevice(c->device));
+    const size_t N = c->frame_N[frame];
+    if (data_3xN) HIP_OK(hipMemcpy(data_3xN, c->fb.data_raw + (size_t)frame * c->fb.max_points * 3, N * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (labels) HIP_OK(hipMemcpy(labels, c->fb.labels_raw + (size_t)frame * c->fb.max_points, N * sizeof(int), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -55,16 +55,19 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
     """Times `steps` optimize() calls over F resident frames on this rank; returns the per-config result dict."""
     V, J, K, P = gm.numPoints(), gm.numJoints(), gm.numShapeKeys(), gm.arrays.P
     pm = synth.identity_part_map()
-    uniq = min(F, 8)     # a handful of distinct frames are rendered per rank, the rest of the batch reuses them
-    frames = [synth.make_frame(smpl, rank * uniq + s, dense=dense) for s in range(uniq)]
-    frs = [frames[f % uniq] for f in range(F)]
-    maxN = max(len(fr["labels"]) for fr in frs)
-    ctx = api.Context(gm, 24, pm, maxN, F, device=local_rank)
+    # F distinct synthetic frames (seed = global frame id), rendered on the GPU straight into the resident buffers
+    # (avt_synth_render_frames: depth + part render of the ground-truth avatar, back-projection, y flip)
+    gts = [synth.sample_ground_truth(smpl, rank * F + f) for f in range(F)]
+    starts = [synth.perturb_start(*gts[f], rank * F + f) for f in range(F)]
+    ctx = api.Context(gm, 24, pm, 200000 if dense else 65536, F, device=local_rank)
     opt = Options.demo(icp_iters=args.icp_iters)
-    p0 = np.array([fr["start"][1] for fr in frs])
-    q0 = np.array([api.rot_to_quat(fr["start"][2]) for fr in frs])
-    w0 = np.array([fr["start"][0] for fr in frs])
-    ctx.frames_upload([fr["data"] for fr in frs], [fr["labels"] for fr in frs])   # inputs resident in HBM
+    npts = ctx.render_frames(np.array([g[0] for g in gts]), np.array([g[1] for g in gts]), np.array([g[2] for g in gts]),
+                             res_scale=2 if dense else 1)                      # inputs resident in HBM
+    p0 = np.array([s[1] for s in starts])
+    q0 = np.array([api.rot_to_quat(s[2]) for s in starts])
+    w0 = np.array([s[0] for s in starts])
+    d0, l0 = ctx.frame_download(0)
+    frs = [{"data": d0, "labels": l0}]
 
     def step():
         ctx.state_upload(p0, q0, w0)      # reset to the tracking start state (109 doubles per frame)
@@ -122,7 +125,7 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
            "steps": steps, "F": F}
     tot = sum(v[0] for v in prof.values())
     res["kernels"] = {k: {"ms": round(v[0], 5), "launches": v[1], "share": round(v[0] / tot, 4)} for k, v in prof.items() if v[1]}
-    Nmean = float(np.mean([len(fr["labels"]) for fr in frs]))
+    Nmean = float(np.mean(npts))
     M = float(np.mean([s.matched_model_points for s in st]))
     bytes_launch = F * algorithmic_bytes_per_gn_iter(Nmean, V, K, P)
     avg_ms = prof_timed[dominant][0] / max(1, prof_timed[dominant][1])      # live, over the (event-instrumented) timed region

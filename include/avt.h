@@ -150,6 +150,15 @@ int avt_state_upload(avt_ctx* c, int nframes, const double* p, const double* q, 
 int avt_optimize_resident(avt_ctx* c, const avt_options* opt);
 int avt_state_download(avt_ctx* c, double* p, double* q, double* w, avt_stats* stats);
 
+/* ---- synthetic-frame generator on the GPU: AvatarRenderer::renderDepth / renderPartMask
+ * (AvatarRenderer.cpp:72-101, :174-202) of `nframes` posed avatars + back-projection (Calibration.cpp:68-74, y negated as
+ * optim.cpp:116-119), written straight into the context's resident frame buffers (as if by avt_frames_upload).
+ * w: K x nframes, p: 3 x nframes, R: 9J x nframes; points_per_frame (nframes ints, may be NULL) receives N of each frame.
+ * avt_frames_download copies one resident frame back (data 3 x N doubles, labels N ints). */
+int avt_synth_render_frames(avt_ctx* c, int nframes, const double* w, const double* p, const double* R, double fx, double fy,
+                            double cx, double cy, int width, int height, int* points_per_frame);
+int avt_frames_download(avt_ctx* c, int frame, double* data_3xN, int* labels);
+
 /* ---- introspection of the last optimize call (tests / diagnostics) */
 int avt_get_correspondences(avt_ctx* c, int frame, int* model_idx_out /* N of that frame */);
 int avt_get_cloud(avt_ctx* c, int frame, double* cloud_3xV);       /* ava.cloud after the final update() */
