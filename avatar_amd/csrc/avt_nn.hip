@@ -77,12 +77,31 @@ __global__ __launch_bounds__(256) void k_nn(DeviceModel dm, FrameBuffers fb) {
         __syncthreads();
         if (active) {
             const int b = max(my_b, tb) - tb, e = min(my_e, tb + tn) - tb;
-            // lane `sub` of the query's 4-lane group scans candidates b+sub, b+sub+4, ... in ascending order
-            for (int c = b + sub; c < e; c += LANES) {
+            // lane `sub` of the query's LANES-lane group scans candidates b+sub, b+sub+LANES, ... in ascending order;
+            // four candidates per trip are evaluated independently (ILP) and compared in order (same strict-'<' result)
+            int c = b + sub;
+            for (; c + 3 * LANES < e; c += 4 * LANES) {
+                double r[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cu = c + u * LANES;
+                    const double d0 = a0 - c_x[cu];
+                    const double d1 = a1 - c_y[cu];
+                    const double d2 = a2 - c_z[cu];
+                    double ru = d0 * d0;          // (0 + d0*d0) == d0*d0 exactly
+                    ru = ru + d1 * d1;
+                    ru = ru + d2 * d2;
+                    r[u] = ru;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (r[u] < best) { best = r[u]; bi = tb + c + u * LANES; }
+            }
+            for (; c < e; c += LANES) {
                 const double d0 = a0 - c_x[c];
                 const double d1 = a1 - c_y[c];
                 const double d2 = a2 - c_z[c];
-                double r = d0 * d0;          // (0 + d0*d0) == d0*d0 exactly
+                double r = d0 * d0;
                 r = r + d1 * d1;
                 r = r + d2 * d2;
                 if (r < best) { best = r; bi = tb + c; }
@@ -97,17 +116,44 @@ __global__ __launch_bounds__(256) void k_nn(DeviceModel dm, FrameBuffers fb) {
         const int oi = __shfl_xor(bi, m, 64);
         if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
-    if (!active || sub != 0) return;
-    const int m = bi != 0x7fffffff ? fb.vcid[(size_t)f * V + bi] : -1;
-    fb.corr_sorted[base + s] = m;
-    fb.corr[base + fb.dorig[base + s]] = m;
+    // ---- correspondence bookkeeping.  Neighbouring pixels usually hit the same model vertex, so runs of equal
+    // vertices among the wave's consecutive queries are merged first (segmented inclusive scan over the query lanes,
+    // integer adds: order-independent) and only the last lane of each run issues the global atomics.
+    const bool qlane = active && sub == 0;
+    const int m = (qlane && bi != 0x7fffffff) ? fb.vcid[(size_t)f * V + bi] : -1;
+    if (qlane) {
+        fb.corr_sorted[base + s] = m;
+        fb.corr[base + fb.dorig[base + s]] = m;
+    }
+    int cnt = (m >= 0) ? 1 : 0;
+    long long s0q = 0, s1q = 0, s2q = 0;
     if (m >= 0) {
-        // integer atomics: the per-vertex count and fixed-point coordinate sums are order-independent
-        atomicAdd(fb.cnt + (size_t)f * V + m, 1);
+        s0q = __double2ll_rn((a0 - ctl.centre[0]) * AVT_FIX_SCALE);
+        s1q = __double2ll_rn((a1 - ctl.centre[1]) * AVT_FIX_SCALE);
+        s2q = __double2ll_rn((a2 - ctl.centre[2]) * AVT_FIX_SCALE);
+    }
+    const int ql = lane_id() / LANES;                     // index of my query among the wave's 64/LANES queries
+    const int mprev = __shfl_up(m, LANES, 64);
+    bool head = (ql == 0) || (mprev != m);
+#pragma unroll
+    for (int dq = 1; dq < 64 / LANES; dq <<= 1) {
+        const int d = dq * LANES;
+        const int c_up = __shfl_up(cnt, d, 64);
+        const long long a_up = __shfl_up(s0q, d, 64), b_up = __shfl_up(s1q, d, 64), e_up = __shfl_up(s2q, d, 64);
+        const int h_up = __shfl_up((int)head, d, 64);
+        if (ql >= dq) {
+            if (!head) { cnt += c_up; s0q += a_up; s1q += b_up; s2q += e_up; }
+            head = head || (h_up != 0);
+        }
+    }
+    const int mnext = __shfl_down(m, LANES, 64);
+    const bool tail = (ql == 64 / LANES - 1) || (mnext != m);
+    if (sub == 0 && m >= 0 && tail) {
+        atomicAdd(fb.cnt + (size_t)f * V + m, cnt);
         unsigned long long* fs = (unsigned long long*)(fb.fsum + (size_t)f * 3 * V);
-        atomicAdd(fs + m, (unsigned long long)__double2ll_rn((a0 - ctl.centre[0]) * AVT_FIX_SCALE));
-        atomicAdd(fs + (size_t)V + m, (unsigned long long)__double2ll_rn((a1 - ctl.centre[1]) * AVT_FIX_SCALE));
-        atomicAdd(fs + 2 * (size_t)V + m, (unsigned long long)__double2ll_rn((a2 - ctl.centre[2]) * AVT_FIX_SCALE));
+        atomicAdd(fs + m, (unsigned long long)s0q);
+        atomicAdd(fs + (size_t)V + m, (unsigned long long)s1q);
+        atomicAdd(fs + 2 * (size_t)V + m, (unsigned long long)s2q);
     }
 }
 
@@ -157,6 +203,6 @@ void launch_nn(avt_ctx* c, int nframes) {
     if (maxN <= 0) return;
     hipLaunchKernelGGL(k_compact, dim3(c->dm.d.num_parts, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
     // few queries: 4 lanes per query (more workgroups, shorter scans); many: one lane per query
-    if (!getenv("AVT_NN1")) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn<4>), dim3((maxN + 63) / 64, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
+    if ((long long)nframes * maxN <= 400000) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn<4>), dim3((maxN + 63) / 64, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn<1>), dim3((maxN + 255) / 256, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
 }
