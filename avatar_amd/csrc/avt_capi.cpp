@@ -40,7 +40,11 @@ int dev_upload(avt_ctx* c, T** p, const std::vector<T>& v) {
     return 0;
 }
 
-int choose_G(int nframes) { return std::max(2, std::min(128, 512 / std::max(1, nframes))); }
+int choose_G(int nframes) {
+    const int g = std::max(2, std::min(128, 512 / std::max(1, nframes)));
+    if (const char* e = getenv("AVT_G")) return std::max(1, std::min(g, atoi(e)));   // tuning knob, never above the allocation
+    return g;
+}
 
 hipEvent_t next_event(avt_ctx* c) {
     if (c->event_pool_used == c->event_pool.size()) {
@@ -83,7 +87,7 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
     for (int icp = 0; icp < o->icp_iters; ++icp) {
         { ProfScope ps(c, AVT_K_VISIBILITY); launch_visibility(c, nf, o->enable_occlusion); }
         { ProfScope ps(c, AVT_K_NN); launch_nn(c, nf); }
-        { ProfScope ps(c, AVT_K_AGGREGATE); launch_finalize(c, nf, o); }
+        { ProfScope ps(c, AVT_K_AGGREGATE); launch_finalize(c, nf, o); launch_records(c, nf); }
         { ProfScope ps(c, AVT_K_PREPARE); launch_solve(c, nf, SOLVE_INIT, o); }
         { ProfScope ps(c, AVT_K_EVAL); launch_eval(c, nf); }
         { ProfScope ps(c, AVT_K_REDUCE); launch_reduce(c, nf); }
@@ -297,7 +301,7 @@ int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* par
         dev_alloc(c, &cntsum, FV * (sizeof(int) + 3 * sizeof(long long)) + 64) || dev_alloc(c, &fb.matched, FV) || dev_alloc(c, &fb.mcnt, FV) ||
         dev_alloc(c, &fb.mdbar, FV * 3) || dev_alloc(c, &fb.const_part, (size_t)max_frames * fb.const_blocks) ||
         dev_alloc(c, &fb.x, (size_t)max_frames * 2 * d.xsize) || dev_alloc(c, &fb.prep, (size_t)max_frames * 2 * d.prep_size) ||
-        dev_alloc(c, &fb.partial, part_cap * d.NPAIR * 256) || dev_alloc(c, &fb.Hraw, (size_t)max_frames * 2 * d.HS * d.HS) ||
+        dev_alloc(c, &fb.rec, (size_t)max_frames * d.nb_max * 4 * d.rec_quad) || dev_alloc(c, &fb.partial, part_cap * d.NPAIR * 256) || dev_alloc(c, &fb.Hraw, (size_t)max_frames * 2 * d.HS * d.HS) ||
         dev_alloc(c, &fb.prior, (size_t)max_frames * 2 * AVT_MAX_COMPS * AVT_PRIOR_STRIDE) || dev_alloc(c, &fb.ctl, (size_t)max_frames) ||
         dev_alloc(c, &fb.jointpos, (size_t)max_frames * 3 * J) || dev_alloc(c, &fb.jointtrans, (size_t)max_frames * 12 * J) ||
         dev_alloc(c, &fb.trace, (size_t)max_frames * 64))

@@ -1,0 +1,402 @@
+// avt_eval.hip — data term of one Gauss-Newton / LM evaluation (gfx950, wave64):
+//   k_records : once per ICP iteration, gathers everything an evaluation needs about each matched model point
+//               (shape planes, mean data point, sqrt(count), assigned joints/weights, ancestor words) into
+//               contiguous per-wave records, so that k_eval streams them with two 16-byte loads per lane;
+//   k_eval    : residual + analytic Jacobian rows per matched model point (AvatarCostFunctorCache::updateData,
+//               AvatarOptimizer.cpp:505-582) staged in LDS and contracted on the fp64 matrix cores
+//               (v_mfma_f64_16x16x4_f64) into per-workgroup partial tiles of [J | r]^T W [J | r]; extra
+//               workgroups of the same grid evaluate the GMM pose prior (avt_prior.h), one component each.
+//   (k_reduce / k_solve: avt_lm.hip.)
+//
+// Algebra used (exact, only the summation order differs from the reference's per-residual-block form):
+// all residual blocks matched to model point m share one Jacobian block J_m (AvatarOptimizer.cpp:1445-1449),
+// so with c_m = #matches and dbar_m their mean data point,
+//   J^T J = sum_m c_m J_m^T J_m,  J^T r = sum_m c_m J_m^T (x_m - dbar_m),
+//   sum_i |x_m - d_i|^2 = c_m |x_m - dbar_m|^2 + sum_i |d_i - dbar_m|^2   (2nd term: k_cost_const).
+// Each matched point therefore contributes 3 rows sqrt(c_m) [J_m | x_m - dbar_m] to an augmented matrix
+// A (3M x (P+1)); A^T A holds H, g and the data cost at once.
+//
+// Rotation block in closed form.  The reference builds, per ancestor joint j of a point, the 3x3 block
+//   R(-1,parent j) * dRot(q_j, v_j) * localJacobian(q_j)                      (AvatarOptimizer.cpp:524-566)
+// with v_j = sum_{k under j} a_k (R(j,k)(x^-J^_k) + t(j,k)).  For a unit quaternion, dRot(q,v)*localJacobian(q)
+// is the derivative of R(dq*q) v at dq = (delta,1), i.e. -2 [R(q) v]_x, and R(-1,parent j) [y]_x =
+// [R(-1,parent j) y]_x R(-1,parent j).  With l_j = R(-1,j) v_j = sum_{k under j} a_k x_k - (sum a_k) o_j (x_k the
+// point carried by assigned joint k, o_j the world origin of joint j) the block is
+//   B_j = -2 [l_j]_x R(-1,parent j),
+// which needs neither q_j nor the (J+1)^2 relative-transform tables of :303-315.  It equals the reference's
+// expression up to rounding (|q_j| = 1 is maintained by the retraction; tests compare against the oracle,
+// which evaluates the reference's formula literally).
+#include <algorithm>
+
+#include "avt_device.h"
+#include "avt_prior.h"
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef double d2v __attribute__((ext_vector_type(2)));
+
+#ifdef AVT_TIMING
+#define EPROBE(k) do { const long long _n = clock64(); tacc[k] += _n - tlast; tlast = _n; } while (0)
+#else
+#define EPROBE(k) do {} while (0)
+#endif
+
+// LDS operations of one wave execute in order; this only stops the compiler from moving accesses across
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// -------------------------------------------------------------------------------------------------
+// Matched-point records.  Frame f, batch b (16 matched points), wave quad w (4 points) -> rec_quad doubles:
+//   double field F of point p4 at [F*4 + p4], F = 0..3K+2: shape plane k*3+c (k = K: base cloud);
+//   3K+3..3K+5: mean data point; 3K+6: sqrt(count); 3K+7..3K+10: assigned weights;
+//   then 20 int fields at int index [I*4 + p4]: I = 0..3 assigned joints, 4..19 ancestor words (0 = no ancestor).
+// Points past M in the last batch are written as zeros (sqrt(count) = 0 silences their rows).
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_records(DeviceModel dm, FrameBuffers fb) {
+    const AvtDims d = dm.d;
+    const int f = blockIdx.y + fb.f0, b = blockIdx.x, t = threadIdx.x, V = d.V, K = d.K;
+    const int M = fb.ctl[f].M;
+    if (b * AVT_EVAL_PTS >= M) return;
+    const int wv = t >> 6, ln = t & 63;
+    const int ND = 3 * K + 11, RQ = d.rec_quad;
+    double* R = fb.rec + (((size_t)f * d.nb_max + b) * 4 + wv) * RQ;
+    for (int e = ln; e < ND * 4; e += 64) {
+        const int field = e >> 2, pos = b * AVT_EVAL_PTS + wv * 4 + (e & 3);
+        double v = 0.0;
+        if (pos < M) {
+            const int m = fb.matched[(size_t)f * V + pos];
+            if (field < 3 * (K + 1)) v = dm.shape_planes[(size_t)field * V + m];
+            else if (field < 3 * K + 6) v = fb.mdbar[((size_t)f * 3 + (field - 3 * (K + 1))) * V + pos];
+            else if (field == 3 * K + 6) v = fb.mcnt[(size_t)f * V + pos];
+            else v = dm.asg_w[(size_t)(field - (3 * K + 7)) * V + m];
+        }
+        R[e] = v;
+    }
+    int* RI = (int*)(R + ND * 4);
+    for (int e = ln; e < 80; e += 64) {
+        const int ifield = e >> 2, pos = b * AVT_EVAL_PTS + wv * 4 + (e & 3);
+        int v = 0;
+        if (pos < M) {
+            const int m = fb.matched[(size_t)f * V + pos];
+            if (ifield < 4) v = dm.asg_j[(size_t)ifield * V + m];
+            else if (ifield - 4 < (int)dm.anc_n[m]) v = (int)dm.anc[(size_t)(ifield - 4) * V + m];
+        }
+        RI[e] = v;
+    }
+}
+
+void launch_records(avt_ctx* c, int nframes) {
+    hipLaunchKernelGGL(k_records, dim3(c->dm.d.nb_max, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
+}
+
+// upper-triangular tile pairs of the 6x6 tile grid, in the order k_reduce / k_solve decode them
+__device__ constexpr int PAIR6_TI[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+__device__ constexpr int PAIR6_TJ[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
+
+// SMPL shape (6 column tiles, 21 tile pairs, 12 k-steps per batch = 252 matrix instructions): wave W owns pairs
+// W, W+4, .., W+16 and k-steps 3W..3W+2 of the last pair (5,5), 63 instructions per wave and batch.  A and B
+// operands are the same kind of fragment (lane l: column tile*16 + (l&15), row k0 + (l>>4)), so 6 LDS reads per
+// k-step feed all of them; straight-line code, no exec-mask branches between the matrix instructions.
+template <int W>
+__device__ __forceinline__ void mfma_batch6(const double* __restrict__ s_Jt, int ln, v4f64 (&acc)[6]) {
+    const double* base = s_Jt + (size_t)(ln & 15) * AVT_EVAL_RS + (ln >> 4);
+#pragma unroll
+    for (int ks = 0; ks < AVT_EVAL_ROWS / 4; ++ks) {
+        double fr[6];
+#pragma unroll
+        for (int ti = 0; ti < 6; ++ti) fr[ti] = base[(size_t)ti * 16 * AVT_EVAL_RS + 4 * ks];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int p = W + 4 * i;
+            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[PAIR6_TI[p]], fr[PAIR6_TJ[p]], acc[i], 0, 0, 0);
+        }
+        if (ks / 3 == W) acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[5], fr[5], acc[5], 0, 0, 0);
+    }
+}
+
+// =================================================================================================
+// k_eval.  1-D grid of nframes*G + nframes*ncomps workgroups of 256 threads = 4 waves (1-D on purpose: the hardware
+// deals workgroups to shader engines by linear id, and a 2-D grid whose x extent is a multiple of 16 would send all
+// the short-lived prior workgroups to one half of the chip and all the evaluation workgroups to the other).
+// Workgroup g of frame f walks batches g, g+G, ... of
+// the frame's matched-point records (16 points = 48 rows of the augmented matrix per batch; wave w owns points
+// 4w..4w+3, lane = (point, slot) with 16 slots per point).
+//   Per batch, wave-local (no workgroup barrier): records registers -> LDS, next batch's records requested,
+//     own 12 rows of the tile zeroed, shaped rest position, the <= 4 carried points x_k, then one lane per
+//     (point, ancestor) writes B_j scaled by sqrt(c_m); shape block, residual column, translation block.
+//   The tile is stored transposed [column][row] with row stride 50 doubles (MFMA operand fetch = 16 columns x 4
+//     rows per ds_read_b64, conflict-free per half-wave).
+//   MFMA phase between two workgroup barriers: the upper-triangular 16x16 output tiles accumulate in registers
+//     over all batches of the workgroup and leave as NPAIR partial tiles (reduced in fixed order by k_reduce).
+// CJ/CK != 0: dimensions fixed at compile time (SMPL: 24 joints, 10 shape keys); 0: taken from the model.
+// =================================================================================================
+template <int CJ, int CK>
+__global__ __launch_bounds__(256, 2) void k_eval(DeviceModel dm, FrameBuffers fb, int nframes) {
+    constexpr bool FIXED = CJ != 0;
+    const AvtDims d = dm.d;
+    const int J = FIXED ? CJ : d.J, K = FIXED ? CK : d.K, P = 3 + 3 * J + K;
+    const int NT = FIXED ? (3 + 3 * CJ + CK + 16) / 16 : d.NT, NPAIR = NT * (NT + 1) / 2;
+    static_assert(!FIXED || (3 + 3 * CJ + CK + 16) / 16 == 6, "fixed-shape path is written for 6 column tiles");
+    constexpr int RS = AVT_EVAL_RS;
+    constexpr int MAXPW = FIXED ? 6 : (AVT_MAX_TILES * (AVT_MAX_TILES + 1) / 2 + 3) / 4;
+    const int G = fb.G, t = threadIdx.x;
+    const int id = blockIdx.x;
+    if (id >= nframes * G) {   // trailing workgroups: pose prior of the trial point, one (frame, GMM component) each
+        const int id2 = id - nframes * G, fp = id2 / d.ncomps + fb.f0;
+        prior_component(dm, fb, fp, id2 % d.ncomps, 1 - fb.ctl[fp].cur_slot);
+        return;
+    }
+    const int f = id / G + fb.f0, g = id % G;
+    const AvtFrameCtl& ctl = fb.ctl[f];
+    const int wv = t >> 6, ln = t & 63, p4 = ln >> 4, slot = ln & 15, pi = wv * 4 + p4;
+    const int ND = 3 * K + 11, RQ = 12 * K + 84, RQ2 = RQ / 2;
+    constexpr int NPF = FIXED ? (12 * CK + 84 + 127) / 128 : (12 * AVT_MAX_SHAPE + 84 + 127) / 128;
+
+    // the first batch's records do not depend on anything else this kernel loads: request them first
+    const d2v* recf = (const d2v*)(fb.rec + (size_t)f * d.nb_max * 4 * RQ);
+    d2v pf[NPF];
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) pf[i] = (d2v){0.0, 0.0};
+    auto prefetch = [&](int b) {
+        const d2v* src = recf + ((size_t)b * 4 + wv) * RQ2;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int idx = ln + 64 * i;
+            pf[i] = (idx < RQ2) ? __builtin_nontemporal_load(src + idx) : (d2v){0.0, 0.0};
+        }
+    };
+    if (g < d.nb_max) prefetch(g);
+    const int M = ctl.M;
+    const int try_slot = 1 - ctl.cur_slot;
+    const int nb = (M + AVT_EVAL_PTS - 1) / AVT_EVAL_PTS;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* s_prep = (double*)smem;                               // prep_size
+    double* s_Jt = s_prep + d.prep_size;                          // [NT*16][RS]
+    double* s_rec = s_Jt + (size_t)NT * 16 * RS;                  // [4 waves][RQ]
+    double* s_xhat = s_rec + 4 * RQ;                              // [16][3]
+    double* s_xk = s_xhat + 48;                                   // [16][4][3]
+    double* s_T = s_xk + 192;                                     // [16][9]  blended rotation per point
+    int* s_par = (int*)(s_T + 144);                               // [J]
+
+    const double* prep = fb.prep + ((size_t)f * 2 + try_slot) * d.prep_size;
+    for (int e = t; e < d.prep_size; e += 256) s_prep[e] = prep[e];
+    if (t < J) s_par[t] = dm.parent[t];
+    const double* Rw = s_prep;                                    // prep_off_Rw = 0
+    const double* oo = s_prep + 9 * J;
+    const double* Jh = s_prep + 12 * J;
+    const double* Gm = s_prep + 15 * J;
+    const double* ww = s_prep + 19 * J + 3 * J * K;
+    const double* off = ww + K;
+
+    // generic shapes: static round-robin deal of whole tile pairs to the waves
+    int pr_ti[MAXPW], pr_tj[MAXPW];
+    if constexpr (!FIXED) {
+#pragma unroll
+        for (int i = 0; i < MAXPW; ++i) {
+            int p = wv + 4 * i, ti = 0;
+            if (p < NPAIR) {
+                while (p >= NT - ti) { p -= NT - ti; ++ti; }
+                pr_ti[i] = ti; pr_tj[i] = ti + p;
+            } else { pr_ti[i] = -1; pr_tj[i] = -1; }
+        }
+    }
+    v4f64 acc[MAXPW];
+#pragma unroll
+    for (int i = 0; i < MAXPW; ++i) acc[i] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+#ifdef AVT_TIMING
+    long long tacc[6] = {0, 0, 0, 0, 0, 0}; long long tlast = clock64(); const long long wall0 = wall_clock64();
+#endif
+    const double* R = s_rec + (size_t)wv * RQ;
+    const int* RI = (const int*)(R + ND * 4);
+    for (int b = g; b < nb; b += G) {
+        __syncthreads();  // previous batch's MFMA reads are done (also covers the prep staging on the first pass)
+        EPROBE(0);
+        // ---- wave-local from here to the next barrier ------------------------------------------------------
+        {
+            d2v* R2 = (d2v*)(s_rec + (size_t)wv * RQ);
+#pragma unroll
+            for (int i = 0; i < NPF; ++i) {
+                const int idx = ln + 64 * i;
+                if (idx < RQ2) R2[idx] = pf[i];
+            }
+        }
+        if (b + G < nb) prefetch(b + G);
+        if (ln < 48) {   // zero my wave's 12 rows of every column: 8 columns x 6 double2 per pass
+            d2v* z = (d2v*)(s_Jt + (size_t)(ln / 6) * RS + wv * 12 + 2 * (ln % 6));
+#pragma unroll
+            for (int pass = 0; pass < 2 * AVT_MAX_TILES; ++pass)
+                if (pass < 2 * NT) z[pass * 4 * RS] = (d2v){0.0, 0.0};
+        }
+        wave_sync();
+        EPROBE(1);
+        if (slot < 3) {   // shaped rest position, root-subtracted (CalcShape, :249-272)
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < (FIXED ? CK : AVT_MAX_SHAPE); ++k)
+                if (k < K) a += R[(3 * k + slot) * 4 + p4] * ww[k];
+            s_xhat[pi * 3 + slot] = (a + R[(3 * K + slot) * 4 + p4]) - off[slot];
+        }
+        wave_sync();
+        const double sc = R[(3 * K + 6) * 4 + p4];
+        double aw[4];
+        int aj[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { aw[a] = R[(3 * K + 7 + a) * 4 + p4]; aj[a] = RI[a * 4 + p4]; }
+        // x_k = R(-1,k)(x^ - J^_k) + t(-1,k) for the <=4 assigned joints (:508-514); blended rotation T = sum a_k Rw_k
+        if (slot < 4) {
+            const int k = aj[slot];
+            const double* Rk = Rw + 9 * k;
+            const double e0 = s_xhat[pi * 3] - Jh[3 * k], e1 = s_xhat[pi * 3 + 1] - Jh[3 * k + 1], e2 = s_xhat[pi * 3 + 2] - Jh[3 * k + 2];
+            double* xk = s_xk + (pi * 4 + slot) * 3;
+            xk[0] = (Rk[0] * e0 + Rk[1] * e1 + Rk[2] * e2) + oo[3 * k];
+            xk[1] = (Rk[3] * e0 + Rk[4] * e1 + Rk[5] * e2) + oo[3 * k + 1];
+            xk[2] = (Rk[6] * e0 + Rk[7] * e1 + Rk[8] * e2) + oo[3 * k + 2];
+        } else if (slot < 13) {
+            const int e9 = slot - 4;
+            s_T[pi * 9 + e9] = ((aw[0] * Rw[9 * aj[0] + e9] + aw[1] * Rw[9 * aj[1] + e9]) + aw[2] * Rw[9 * aj[2] + e9]) + aw[3] * Rw[9 * aj[3] + e9];
+        }
+        wave_sync();
+        EPROBE(2);
+        const double* xk = s_xk + pi * 12;
+        const int aword = RI[(4 + slot) * 4 + p4];
+        if (aword != 0) {   // rotation block of ancestor j: -2 sqrt(c) [l_j]_x R(-1,parent j)
+            const int j = aword & 0xff;
+            const unsigned mask = (unsigned)aword >> 8;
+            double X0 = 0.0, X1 = 0.0, X2 = 0.0, cj = 0.0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                if (mask & (1u << a)) {
+                    X0 += aw[a] * xk[3 * a]; X1 += aw[a] * xk[3 * a + 1]; X2 += aw[a] * xk[3 * a + 2];
+                    cj += aw[a];
+                }
+            const double m2 = -2.0 * sc;
+            const double L0 = m2 * (X0 - cj * oo[3 * j]), L1 = m2 * (X1 - cj * oo[3 * j + 1]), L2 = m2 * (X2 - cj * oo[3 * j + 2]);
+            double Rp[9];
+            if (j == 0) { Rp[0] = 1; Rp[1] = 0; Rp[2] = 0; Rp[3] = 0; Rp[4] = 1; Rp[5] = 0; Rp[6] = 0; Rp[7] = 0; Rp[8] = 1; }
+            else {
+                const double* src = Rw + 9 * s_par[j];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) Rp[e] = src[e];
+            }
+            double* o0 = s_Jt + (size_t)(3 + 3 * j) * RS + pi * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                o0[c * RS] = L1 * Rp[6 + c] - L2 * Rp[3 + c];
+                o0[c * RS + 1] = L2 * Rp[c] - L0 * Rp[6 + c];
+                o0[c * RS + 2] = L0 * Rp[3 + c] - L1 * Rp[c];
+            }
+        }
+        // shape block (:568-580): (sum a_k Rw_k) D_k + sum a_k G_k
+#pragma unroll
+        for (int it = 0; it < (3 * (FIXED ? CK : AVT_MAX_SHAPE) + 15) / 16; ++it) {
+            const int e = slot + 16 * it;
+            if (e < 3 * K) {
+                const int r = e / K, k = e - r * K;
+                const double* Tr = s_T + pi * 9 + 3 * r;
+                const double gs = ((aw[0] * Gm[aj[0] * 3 * K + e] + aw[1] * Gm[aj[1] * 3 * K + e]) + aw[2] * Gm[aj[2] * 3 * K + e]) + aw[3] * Gm[aj[3] * 3 * K + e];
+                const double a = (Tr[0] * R[(3 * k) * 4 + p4] + Tr[1] * R[(3 * k + 1) * 4 + p4] + Tr[2] * R[(3 * k + 2) * 4 + p4]) + gs;
+                s_Jt[(size_t)(3 + 3 * J + k) * RS + pi * 3 + r] = sc * a;
+            }
+        }
+        if (slot < 3) {          // residual column: sqrt(c) (x_m - dbar_m)
+            double xm = 0.0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) xm += aw[a] * xk[3 * a + slot];
+            s_Jt[(size_t)P * RS + pi * 3 + slot] = sc * (xm - R[(3 * K + 3 + slot) * 4 + p4]);
+        } else if (slot < 6) {   // identity root-translation block (:476-481)
+            const int r = slot - 3;
+            s_Jt[(size_t)r * RS + pi * 3 + r] = sc;
+        }
+        EPROBE(3);
+        __syncthreads();
+        EPROBE(4);
+        // MFMA phase: 12 k-steps of 4 rows
+        if constexpr (FIXED) {
+            switch (wv) {
+                case 0: mfma_batch6<0>(s_Jt, ln, acc); break;
+                case 1: mfma_batch6<1>(s_Jt, ln, acc); break;
+                case 2: mfma_batch6<2>(s_Jt, ln, acc); break;
+                default: mfma_batch6<3>(s_Jt, ln, acc); break;
+            }
+        } else {
+#pragma unroll 1
+            for (int k0 = 0; k0 < AVT_EVAL_ROWS; k0 += 4) {
+                const int rowoff = k0 + (ln >> 4);
+#pragma unroll
+                for (int i = 0; i < MAXPW; ++i) {
+                    if (pr_ti[i] >= 0) {
+                        const double a = s_Jt[(size_t)(pr_ti[i] * 16 + (ln & 15)) * RS + rowoff];
+                        const double bq = s_Jt[(size_t)(pr_tj[i] * 16 + (ln & 15)) * RS + rowoff];
+                        acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+#ifdef AVT_TIMING
+    EPROBE(5);
+    if (t == 0 && f == 0 && g == 0) { for (int k = 0; k < 6; ++k) fb.trace[48 + k] = (double)tacc[k]; fb.trace[54] = (double)(wall_clock64() - wall0); }
+    if (t == 0 && g < 8) {   // where and when this workgroup ran (tools/eval_block_timeline.py)
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        double* tr = fb.trace + (size_t)f * 64 + 12 + 3 * g;
+        tr[0] = (double)wall0; tr[1] = (double)wall_clock64(); tr[2] = (double)((xcc & 0xf) * 65536 + (hw & 0xffff));
+    }
+#endif
+    if constexpr (FIXED) {   // the four waves' shares of pair (5,5) are summed in wave order by wave 0
+        __syncthreads();
+        if (wv > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_Jt[(wv - 1) * 256 + r * 64 + ln] = acc[5][r];
+        }
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[5][r] += s_Jt[w * 256 + r * 64 + ln];
+        }
+    }
+    // partial tiles out: element (row = (ln>>4) + 4*reg, col = ln&15) of pair p at [p][reg*64 + ln]
+    double* part = fb.partial + (((size_t)f * G + g) * NPAIR) * 256;
+#pragma unroll
+    for (int i = 0; i < MAXPW; ++i) {
+        const int p = wv + 4 * i;
+        if (p < NPAIR) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(size_t)p * 256 + r * 64 + ln] = acc[i][r];
+        }
+    }
+}
+
+static size_t eval_lds_bytes(const AvtDims& d) {
+    return sizeof(double) * ((size_t)d.prep_size + (size_t)d.NT * 16 * AVT_EVAL_RS + 4 * (size_t)d.rec_quad + 48 + 192 + 144) +
+           sizeof(int) * AVT_MAX_JOINTS;
+}
+
+static bool eval_fixed_shape(const AvtDims& d) { return d.J == 24 && d.K == 10; }
+
+void launch_eval(avt_ctx* c, int nframes) {
+    const AvtDims& d = c->dm.d;
+    dim3 grid((unsigned)nframes * (c->fb.G + std::max(0, d.ncomps)));
+    const size_t lds = eval_lds_bytes(d);
+    if (eval_fixed_shape(d)) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<24, 10>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, nframes);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<0, 0>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, nframes);
+}
+
+void avt_eval_report_occupancy(const AvtDims& d) {
+    int nb = -1;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_eval<24, 10>, 256, eval_lds_bytes(d));
+    fprintf(stderr, "[avt] k_eval<24,10>: dynamic LDS %zu B, occupancy query -> %d blocks/CU (%s)\n", eval_lds_bytes(d), nb, hipGetErrorString(e));
+}
+
+int avt_eval_set_attributes() {
+    // the fixed-shape kernel needs < 64 KB of dynamic LDS: leave its attribute alone (raising the cap costs residency);
+    // the generic shape may need more.
+    return hipFuncSetAttribute((const void*)k_eval<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess;
+}

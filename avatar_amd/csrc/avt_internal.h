@@ -31,6 +31,8 @@ struct AvtDims {
     int ncomps, ndims;       // GMM
     int nlevels;             // depth of the kinematic tree + 1
     int HS;                  // row stride of the dense normal-equation block: 4*ceil((P+1)/4)
+    int rec_quad;            // doubles per 4-point matched-point record (avt_eval.hip): 12K + 84
+    int nb_max;              // eval batches a frame can have: ceil(V/16)
 };
 
 // prep block layout (doubles), one per frame per slot: what an evaluation needs about the skeleton state
@@ -136,6 +138,7 @@ struct FrameBuffers {
     // optimiser state
     double* x;            // [max_frames][2][xsize]
     double* prep;         // [max_frames][2][prep_size]
+    double* rec;          // [max_frames][nb_max][4][rec_quad] matched-point records (k_records)
     double* partial;      // [max_frames][G][NPAIR][256]
     double* Hraw;         // [max_frames][2][HS*HS] reduced data-term [J|r]^T W [J|r] (full symmetric) per state slot
     double* prior;        // [max_frames][2][AVT_MAX_COMPS][AVT_PRIOR_STRIDE] GMM scores / Prec*(x-mu) per state slot
@@ -191,5 +194,6 @@ void launch_bucket(avt_ctx* c, int nframes);
 void launch_nn(avt_ctx* c, int nframes);
 void launch_finalize(avt_ctx* c, int nframes, const avt_options* o);
 void launch_eval(avt_ctx* c, int nframes);
+void launch_records(avt_ctx* c, int nframes);
 void launch_reduce(avt_ctx* c, int nframes);
 void launch_solve(avt_ctx* c, int nframes, int mode, const avt_options* o);

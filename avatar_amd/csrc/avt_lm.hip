@@ -1,7 +1,6 @@
 // avt_lm.hip — the Gauss-Newton / Levenberg-Marquardt step kernels (gfx950, wave64):
 //   k_reduce : fixed-order reduction of k_eval's partial MFMA tiles into the dense symmetric data-term system
-//              [J|r]^T W [J|r] of the trial point, plus one workgroup per GMM component evaluating the pose prior
-//              (GaussianMixture::residual, GaussianMixture.cpp:95-114);
+//              [J|r]^T W [J|r] of the trial point;
 //   k_solve  : one workgroup per frame — LM accept/reject, prior assembly (AvatarOptimizer.cpp:647-726,
 //              :1457-1458), damped LDL^T solve held in registers, quaternion retraction
 //              (FakeQuaternionParameterization::Plus, :123-143) and the skeleton tables of the next trial point
@@ -52,6 +51,9 @@ __device__ void compute_prep(const DeviceModel& dm, const double* __restrict__ x
     const int nitems = J * per;
     for (int e = t; e < nitems; e += 256) s.items[e] = (unsigned short)dm.fk_items[e];
     __syncthreads();
+#ifdef AVT_TIMING
+    if (threadIdx.x == 0) prep[d.prep_size - 1] = (double)clock64();
+#endif
     // one tree level per barrier: world rotation/origin (:303-315) and H[j] = R(-1,parent j) Sp[j] + H[parent j]
     // (:318-324) of every joint of the level in parallel
     for (int L = 0; L < d.nlevels; ++L) {
@@ -88,6 +90,9 @@ __device__ void compute_prep(const DeviceModel& dm, const double* __restrict__ x
         }
         __syncthreads();
     }
+#ifdef AVT_TIMING
+    if (threadIdx.x == 0) prep[d.prep_size - 2] = (double)clock64();
+#endif
     const double off0 = s.jp[0], off1 = s.jp[1], off2 = s.jp[2];
     for (int e = t; e < 9 * J; e += 256) prep[prep_off_Rw(d) + e] = s.Rw[e];
     for (int e = t; e < 3 * J; e += 256) {
@@ -107,18 +112,16 @@ __device__ void compute_prep(const DeviceModel& dm, const double* __restrict__ x
 }
 
 // =================================================================================================
-// k_reduce.  grid (NPAIR + ncomps, nframes), block 256.
-//   blocks 0..NPAIR-1: Hraw[f][try][r][c] = sum_g partial[f][g][pair][e], g ascending (deterministic); the tile is
-//     written to both triangles of the dense (HS x HS) symmetric block; row/column P carry J^T r and sum c|r|^2.
-//   blocks NPAIR..: GMM pose prior at the trial point, one workgroup per component: smplParams
-//     (AvatarOptimizer.cpp:664-669), score = ||rho_c||^2 - consts_log_c (GaussianMixture.cpp:95-114) and
-//     Prec_c (x - mu_c) for the gradient; k_solve picks the minimising component.
+// k_reduce.  grid (NPAIR, nframes), block 256.
+//   Hraw[f][try][r][c] = sum_g partial[f][g][pair][e], g ascending (deterministic); the tile is written to both
+//   triangles of the dense (HS x HS) symmetric block; row/column P carry J^T r and sum c|r|^2.
+//   (The GMM pose prior of the trial point is evaluated by extra workgroups of k_eval, avt_prior.h.)
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_reduce(DeviceModel dm, FrameBuffers fb) {
     const AvtDims d = dm.d;
     const int f = blockIdx.y + fb.f0, t = threadIdx.x, NPAIR = d.NPAIR, NT = d.NT, P = d.P, HS = d.HS;
     const int try_slot = 1 - fb.ctl[f].cur_slot;
-    if ((int)blockIdx.x < NPAIR) {
+    {
         int p = blockIdx.x, ti = 0;
         while (p >= NT - ti) { p -= NT - ti; ++ti; }
         const int tj = ti + p;
@@ -141,51 +144,6 @@ __global__ __launch_bounds__(256) void k_reduce(DeviceModel dm, FrameBuffers fb)
             H[(size_t)r * HS + c] = a;
             if (ti != tj) H[(size_t)c * HS + r] = a;
         }
-        return;
-    }
-    // ---- pose prior, one workgroup per GMM component c = blockIdx.x - NPAIR --------------------------------
-    const int n = d.ndims, C = d.ncomps, J = d.J;
-    const int c = blockIdx.x - NPAIR;
-    if (c >= C) return;
-    double* po = fb.prior + (((size_t)f * 2 + try_slot) * AVT_MAX_COMPS + c) * AVT_PRIOR_STRIDE;
-    __shared__ double s_x[AVT_MAX_JOINTS * 3], s_q[AVT_MAX_JOINTS * 3];
-    const double* x = fb.x + ((size_t)f * 2 + try_slot) * d.xsize;
-    if (t < J - 1) {  // Eigen AngleAxis(Quaternion): angle in [0,pi], axis sign follows w
-        const double* q = x + 3 + 4 * (t + 1);
-        double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
-        if (nrm < 2.220446049250313e-16) {
-            const double mx = fmax(fabs(q[0]), fmax(fabs(q[1]), fabs(q[2])));
-            if (mx > 0.0) { const double a = q[0] / mx, b = q[1] / mx, cc = q[2] / mx; nrm = mx * sqrt(a * a + b * b + cc * cc); }
-            else nrm = 0.0;
-        }
-        double ang = 0.0, ax0 = 1.0, ax1 = 0.0, ax2 = 0.0;
-        if (nrm != 0.0) {
-            ang = 2.0 * atan2(nrm, fabs(q[3]));
-            if (q[3] < 0) nrm = -nrm;
-            ax0 = q[0] / nrm; ax1 = q[1] / nrm; ax2 = q[2] / nrm;
-        }
-        const double* mu = dm.prior_mean + (size_t)c * n;
-        s_x[3 * t] = ax0 * ang - mu[3 * t]; s_x[3 * t + 1] = ax1 * ang - mu[3 * t + 1]; s_x[3 * t + 2] = ax2 * ang - mu[3 * t + 2];
-    }
-    __syncthreads();
-    // y = Prec_c (x - mu_c): 4 lanes per row, 64 rows per pass
-    for (int a0 = 0; a0 < n; a0 += 64) {
-        const int a = a0 + (t >> 2), sub = t & 3;
-        double sacc = 0.0;
-        if (a < n) {
-            const double* Pr = dm.prior_prec + ((size_t)c * n + a) * n;
-            for (int b = sub; b < n; b += 4) sacc += Pr[b] * s_x[b];
-        }
-        sacc += __shfl_xor(sacc, 1, 64);
-        sacc += __shfl_xor(sacc, 2, 64);
-        if (a < n && sub == 0) { s_q[a] = sacc; po[2 + a] = sacc; }
-    }
-    __syncthreads();
-    if (t < 64) {  // ||rho||^2 = 1/2 d^T Prec d  (rho = L^T d sqrt(1/2), Prec = L L^T)
-        double sacc = 0.0;
-        for (int a = t; a < n; a += 64) sacc += s_x[a] * s_q[a];
-        sacc = wave_sum(sacc);
-        if (t == 0) po[0] = 0.5 * sacc - dm.prior_clog[c];
     }
 }
 
@@ -383,7 +341,7 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
             for (int c = 0; c < 4; ++c) s_D[r * 4 + c] = a4[r][c];
     }
 #ifdef AVT_TIMING
-    long long lacc[5] = {0, 0, 0, 0, 0}; long long llast = clock64();
+    long long lacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long llast = clock64();
 #define LPROBE(k) do { const long long _n = clock64(); lacc[k] += _n - llast; llast = _n; } while (0)
 #else
 #define LPROBE(k) do {} while (0)
@@ -396,6 +354,9 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
             const d2v* Dq = (const d2v*)s_D;
             const d2v q0 = Dq[0], q2 = Dq[2], q4 = Dq[4], q5 = Dq[5], q6 = Dq[6], q7 = Dq[7];
             const double D00 = q0.x, D10 = q2.x;
+#ifdef AVT_TIMING
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); LPROBE(5);
+#endif
             double D11 = q2.y, D20 = q4.x, D21 = q4.y, D22 = q5.x, D30 = q6.x, D31 = q6.y, D32 = q7.x, D33 = q7.y;
             const bool real1 = 4 * kb + 1 < P, real2 = 4 * kb + 2 < P, real3 = 4 * kb + 3 < P;   // 4*kb < P always
             const double P0 = D00;
@@ -415,6 +376,9 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
             const double r3 = fast_rcp(D33);
             const int bad = (int)!(P0 > 0.0) | ((int)real1 & (int)!(P1 > 0.0)) | ((int)real2 & (int)!(P2 > 0.0)) | ((int)real3 & (int)!(P3 > 0.0));
             if (bad) s_fail = 1;
+#ifdef AVT_TIMING
+            { double keep = r3; asm volatile("" : "+v"(keep)); LPROBE(6); }
+#endif
             d2v* Wo = (d2v*)(s_W + (size_t)bi * 18);
             d2v* Lo = (d2v*)(Lblk + ((size_t)kb * NB + bi) * 18);
 #pragma unroll
@@ -426,6 +390,9 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
                 Wo[2 * r] = (d2v){w0, w1}; Wo[2 * r + 1] = (d2v){w2, w3};
                 Lo[2 * r] = (d2v){w0 * r0, w1 * r1}; Lo[2 * r + 1] = (d2v){w2 * r2, w3 * r3};
             }
+#ifdef AVT_TIMING
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); LPROBE(7);
+#endif
         }
         LPROBE(1);
         __syncthreads();                                    // B2: W and L of pivot block kb are visible
@@ -457,7 +424,7 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
         }
     }
 #ifdef AVT_TIMING
-    if (t == 251) for (int k = 0; k < 5; ++k) fb.trace[(size_t)f * 64 + 56 + k] = (double)lacc[k];
+    if (t == 251) { for (int k = 0; k < 5; ++k) fb.trace[(size_t)f * 64 + 56 + k] = (double)lacc[k]; for (int k = 5; k < 8; ++k) fb.trace[(size_t)f * 64 + 32 + k] = (double)lacc[k]; }
 #endif
     __syncthreads();
     TPROBE(3);
@@ -519,6 +486,10 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
     // ---- d. skeleton tables of the new trial point ----------------------------------------------------
     compute_prep(dm, xn, fb.prep + ((size_t)f * 2 + ntry) * d.prep_size, *ps);
     TPROBE(6);
+#ifdef AVT_TIMING
+    __syncthreads();
+    if (t == 0) { const double* pp = fb.prep + ((size_t)f * 2 + ntry) * d.prep_size; fb.trace[(size_t)f * 64 + 62] = pp[d.prep_size - 1]; fb.trace[(size_t)f * 64 + 63] = pp[d.prep_size - 2]; }
+#endif
 }
 
 static size_t solve_lds_bytes(const AvtDims& d) {
@@ -528,7 +499,7 @@ static size_t solve_lds_bytes(const AvtDims& d) {
 
 void launch_reduce(avt_ctx* c, int nframes) {
     const AvtDims& d = c->dm.d;
-    hipLaunchKernelGGL(k_reduce, dim3(d.NPAIR + std::max(0, d.ncomps), nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
+    hipLaunchKernelGGL(k_reduce, dim3(d.NPAIR, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
 }
 
 void launch_solve(avt_ctx* c, int nframes, int mode, const avt_options* o) {

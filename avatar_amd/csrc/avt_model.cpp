@@ -56,6 +56,8 @@ extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
     d.NPAIR = d.NT * (d.NT + 1) / 2;
     d.xsize = 3 + 4 * J + K;
     d.prep_size = prep_total(d);
+    d.rec_quad = 12 * d.K + 84;
+    d.nb_max = (d.V + AVT_EVAL_PTS - 1) / AVT_EVAL_PTS;
     d.num_parts = 0;
     m->parent.assign(desc->parent, desc->parent + J);
     m->jlevel.assign(J, 0);
