@@ -40,8 +40,17 @@ int dev_upload(avt_ctx* c, T** p, const std::vector<T>& v) {
     return 0;
 }
 
+// frame groups of one optimize(): measured on MI355X, two groups pay off from ~48 frames, more never do
+// (AVT_GROUPS overrides; tuning knob)
+int choose_groups(int nframes) {
+    int n = nframes >= 48 ? 2 : 1;
+    if (const char* e = getenv("AVT_GROUPS")) n = atoi(e);
+    if (getenv("AVT_ONE_GROUP")) n = 1;
+    return std::max(1, std::min(std::min(n, AVT_MAX_GROUPS), nframes));
+}
+
 int choose_G(int nframes) {
-    const int g = std::max(2, std::min(128, 512 / std::max(1, nframes)));
+    const int g = std::max(2, std::min(128, 768 / std::max(1, nframes)));   // 3 k_eval workgroups per CU when there are enough frames
     if (const char* e = getenv("AVT_G")) return std::max(1, std::min(g, atoi(e)));   // tuning knob, never above the allocation
     return g;
 }
@@ -111,18 +120,18 @@ int run_optimize(avt_ctx* c, const avt_options* o) {
     if (nf <= 0) { avt_set_error("avt_optimize: no frames resident"); return 1; }
     if (o->max_iters_per_icp < 0 || o->max_iters_per_icp > 62 || o->icp_iters < 0) { avt_set_error("avt_optimize: bad iteration counts"); return 1; }
     c->ran_max_iters = o->max_iters_per_icp;
-    // Large batches run as two frame groups on two streams: the latency-bound single-workgroup-per-frame kernels of
-    // one group (k_solve, k_finalize, k_reduce) overlap the throughput kernels (k_eval, k_nn) of the other.
-    const bool two_groups = c->use_graph && !c->profiling && nf >= 32 && !getenv("AVT_ONE_GROUP");
-    const int nfA = two_groups ? (nf + 1) / 2 : nf;
-    c->fb.G = choose_G(nfA);
+    // Large batches run as several frame groups on separate streams: the latency-bound single-workgroup-per-frame
+    // kernels of one group (k_solve, k_finalize, k_reduce) overlap the throughput kernels (k_eval, k_nn) of the others.
+    const int ngroups = (c->use_graph && !c->profiling) ? choose_groups(nf) : 1;
+    const int nfg = (nf + ngroups - 1) / ngroups;       // frames per group (the last group may be smaller)
+    c->fb.G = choose_G(nfg);
     if (!c->use_graph || c->profiling) {
         enqueue_optimize(c, o, 0, nf, c->stream);
         return check_launch("optimize launch sequence");
     }
     // The launch sequence depends only on (nframes, grid sizes, options): capture it once, replay it afterwards.
     char key[256];
-    snprintf(key, sizeof key, "%d|%d|%d|%d|%d|%d|%.17g|%.17g|%.17g|%.17g|%.17g|%.17g|%.17g", nf, (int)two_groups, c->launch_maxN, o->icp_iters,
+    snprintf(key, sizeof key, "%d|%d|%d|%d|%d|%d|%d|%.17g|%.17g|%.17g|%.17g|%.17g|%.17g|%.17g", nf, ngroups, c->fb.G, c->launch_maxN, o->icp_iters,
              o->max_iters_per_icp, o->enable_occlusion, o->beta_pose, o->beta_shape, o->lm_lambda0, o->lm_up, o->lm_down,
              o->lm_lambda_min, o->lm_lambda_max);
     auto it = c->graphs.find(key);
@@ -130,13 +139,17 @@ int run_optimize(avt_ctx* c, const avt_options* o) {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        if (two_groups) {
+        if (ngroups > 1) {
             HIP_OK(hipEventRecord(c->ev_fork, c->stream));
-            HIP_OK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-            enqueue_optimize(c, o, 0, nfA, c->stream);
-            enqueue_optimize(c, o, nfA, nf - nfA, c->stream2);
-            HIP_OK(hipEventRecord(c->ev_join, c->stream2));
-            HIP_OK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+            for (int gi = 1; gi < ngroups; ++gi) HIP_OK(hipStreamWaitEvent(c->side[gi - 1], c->ev_fork, 0));
+            for (int gi = 0; gi < ngroups; ++gi) {
+                const int f0 = gi * nfg, n = std::min(nfg, nf - f0);
+                if (n > 0) enqueue_optimize(c, o, f0, n, gi == 0 ? c->stream : c->side[gi - 1]);
+            }
+            for (int gi = 1; gi < ngroups; ++gi) {
+                HIP_OK(hipEventRecord(c->ev_join[gi - 1], c->side[gi - 1]));
+                HIP_OK(hipStreamWaitEvent(c->stream, c->ev_join[gi - 1], 0));
+            }
         } else {
             enqueue_optimize(c, o, 0, nf, c->stream);
         }
@@ -247,9 +260,11 @@ int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* par
     c->use_graph = getenv("AVT_NO_GRAPH") == nullptr;
     c->lbs_cleared = false;
     HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_OK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    HIP_OK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    for (int i = 0; i < AVT_MAX_GROUPS - 1; ++i) {
+        HIP_OK(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+    }
     c->cur_stream = c->stream;
     if (avt_solve_set_attributes() || avt_eval_set_attributes()) { avt_set_error("avt_ctx_create: hipFuncSetAttribute failed"); return 1; }
     DeviceModel& dm = c->dm;
@@ -286,12 +301,10 @@ int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* par
     fb.const_blocks = (max_points + 255) / 256;
     const size_t FN = (size_t)max_frames * max_points, FV = (size_t)max_frames * V;
     const AvtDims& d = dm.d;
-    // eval workgroups over all frames: nf*choose_G(nf) <= max(min(128*nf, 512), 2*nf)
+    // eval workgroups over all frames, for every way run_optimize may split them into groups
     size_t part_cap = 0;
-    for (int nf = 1; nf <= max_frames; ++nf) {
-        part_cap = std::max(part_cap, (size_t)nf * choose_G(nf));
-        if (nf >= 32) part_cap = std::max(part_cap, (size_t)nf * choose_G((nf + 1) / 2));
-    }
+    for (int nf = 1; nf <= max_frames; ++nf)
+        for (int k = 1; k <= std::min(AVT_MAX_GROUPS, nf); ++k) part_cap = std::max(part_cap, (size_t)nf * choose_G((nf + k - 1) / k));
     char* cntsum = nullptr;
     if (dev_alloc(c, &fb.data_raw, FN * 3) || dev_alloc(c, &fb.labels_raw, FN) || dev_alloc(c, &fb.dx, FN) || dev_alloc(c, &fb.dy, FN) ||
         dev_alloc(c, &fb.dz, FN) || dev_alloc(c, &fb.dorig, FN) || dev_alloc(c, &fb.part_off, (size_t)max_frames * (num_parts + 1)) || dev_alloc(c, &fb.part_cnt, (size_t)max_frames * 2 * (AVT_MAX_PARTS + 1)) ||
@@ -324,8 +337,7 @@ void avt_ctx_destroy(avt_ctx* c) {
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
     for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
     hipEventDestroy(c->ev_fork);
-    hipEventDestroy(c->ev_join);
-    hipStreamDestroy(c->stream2);
+    for (int i = 0; i < AVT_MAX_GROUPS - 1; ++i) { hipEventDestroy(c->ev_join[i]); hipStreamDestroy(c->side[i]); }
     hipStreamDestroy(c->stream);
     delete c;
 }

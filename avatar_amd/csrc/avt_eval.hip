@@ -51,7 +51,8 @@ __device__ __forceinline__ void wave_sync() {
 // Matched-point records.  Frame f, batch b (16 matched points), wave quad w (4 points) -> rec_quad doubles:
 //   double field F of point p4 at [F*4 + p4], F = 0..3K+2: shape plane k*3+c (k = K: base cloud);
 //   3K+3..3K+5: mean data point; 3K+6: sqrt(count); 3K+7..3K+10: assigned weights;
-//   then 20 int fields at int index [I*4 + p4]: I = 0..3 assigned joints, 4..19 ancestor words (0 = no ancestor).
+//   then 20 int fields at int index [I*4 + p4]: I = 0..3 assigned joints, 4..19 ancestor words
+//   joint | mask << 8 | (parent joint + 1) << 16 (mask bit a: assigned joint a lies under the joint; 0 = no ancestor).
 // Points past M in the last batch are written as zeros (sqrt(count) = 0 silences their rows).
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_records(DeviceModel dm, FrameBuffers fb) {
@@ -81,7 +82,10 @@ __global__ __launch_bounds__(256) void k_records(DeviceModel dm, FrameBuffers fb
         if (pos < M) {
             const int m = fb.matched[(size_t)f * V + pos];
             if (ifield < 4) v = dm.asg_j[(size_t)ifield * V + m];
-            else if (ifield - 4 < (int)dm.anc_n[m]) v = (int)dm.anc[(size_t)(ifield - 4) * V + m];
+            else if (ifield - 4 < (int)dm.anc_n[m]) {
+                v = (int)dm.anc[(size_t)(ifield - 4) * V + m];
+                v |= (dm.parent[v & 0xff] + 1) << 16;
+            }
         }
         RI[e] = v;
     }
@@ -100,13 +104,16 @@ __device__ constexpr int PAIR6_TJ[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 
 // operands are the same kind of fragment (lane l: column tile*16 + (l&15), row k0 + (l>>4)), so 6 LDS reads per
 // k-step feed all of them; straight-line code, no exec-mask branches between the matrix instructions.
 template <int W>
-__device__ __forceinline__ void mfma_batch6(const double* __restrict__ s_Jt, int ln, v4f64 (&acc)[6]) {
+__device__ __forceinline__ void mfma_batch6(const double* __restrict__ s_Jt, int ln, int NC, v4f64 (&acc)[6]) {
     const double* base = s_Jt + (size_t)(ln & 15) * AVT_EVAL_RS + (ln >> 4);
+    // last column tile: lanes past the real columns read the zero column
+    const double* base5 = s_Jt + (size_t)min(80 + (ln & 15), NC) * AVT_EVAL_RS + (ln >> 4);
 #pragma unroll
     for (int ks = 0; ks < AVT_EVAL_ROWS / 4; ++ks) {
         double fr[6];
 #pragma unroll
-        for (int ti = 0; ti < 6; ++ti) fr[ti] = base[(size_t)ti * 16 * AVT_EVAL_RS + 4 * ks];
+        for (int ti = 0; ti < 5; ++ti) fr[ti] = base[(size_t)ti * 16 * AVT_EVAL_RS + 4 * ks];
+        fr[5] = base5[4 * ks];
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int p = W + 4 * i;
@@ -133,7 +140,7 @@ __device__ __forceinline__ void mfma_batch6(const double* __restrict__ s_Jt, int
 // CJ/CK != 0: dimensions fixed at compile time (SMPL: 24 joints, 10 shape keys); 0: taken from the model.
 // =================================================================================================
 template <int CJ, int CK>
-__global__ __launch_bounds__(256, 2) void k_eval(DeviceModel dm, FrameBuffers fb, int nframes) {
+__global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm, FrameBuffers fb, int nframes) {
     constexpr bool FIXED = CJ != 0;
     const AvtDims d = dm.d;
     const int J = FIXED ? CJ : d.J, K = FIXED ? CK : d.K, P = 3 + 3 * J + K;
@@ -145,7 +152,8 @@ __global__ __launch_bounds__(256, 2) void k_eval(DeviceModel dm, FrameBuffers fb
     const int id = blockIdx.x;
     if (id >= nframes * G) {   // trailing workgroups: pose prior of the trial point, one (frame, GMM component) each
         const int id2 = id - nframes * G, fp = id2 / d.ncomps + fb.f0;
-        prior_component(dm, fb, fp, id2 % d.ncomps, 1 - fb.ctl[fp].cur_slot);
+        extern __shared__ __attribute__((aligned(16))) char smem_prior[];
+        prior_component(dm, fb, fp, id2 % d.ncomps, 1 - fb.ctl[fp].cur_slot, (double*)smem_prior);
         return;
     }
     const int f = id / G + fb.f0, g = id % G;
@@ -172,23 +180,29 @@ __global__ __launch_bounds__(256, 2) void k_eval(DeviceModel dm, FrameBuffers fb
     const int try_slot = 1 - ctl.cur_slot;
     const int nb = (M + AVT_EVAL_PTS - 1) / AVT_EVAL_PTS;
 
+    // LDS: the skeleton tables of the trial point (prep block without the quaternions), the transposed tile with one
+    // extra all-zero column that stands in for the padding columns P+1.. of the last column tile, the records of the
+    // 4 waves, per-point scratch.  53.2 KB for SMPL: three workgroups per CU.
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* s_prep = (double*)smem;                               // prep_size
-    double* s_Jt = s_prep + d.prep_size;                          // [NT*16][RS]
-    double* s_rec = s_Jt + (size_t)NT * 16 * RS;                  // [4 waves][RQ]
+    const int NC = P + 1;                                         // real columns; column NC is the zero column
+    const int npre = 15 * J + 3 * J * K, nprep = (npre + K + 3 + 1) & ~1;
+    double* s_prep = (double*)smem;                               // Rw o Jh G | w off
+    double* s_Jt = s_prep + nprep;                                // [NC + 1][RS]
+    double* s_rec = s_Jt + (size_t)(NC + 1) * RS;                 // [4 waves][RQ]
     double* s_xhat = s_rec + 4 * RQ;                              // [16][3]
     double* s_xk = s_xhat + 48;                                   // [16][4][3]
     double* s_T = s_xk + 192;                                     // [16][9]  blended rotation per point
-    int* s_par = (int*)(s_T + 144);                               // [J]
+    double* s_ident = s_T + 144;                                  // [9]  R(-1,parent of the root) = I
 
     const double* prep = fb.prep + ((size_t)f * 2 + try_slot) * d.prep_size;
-    for (int e = t; e < d.prep_size; e += 256) s_prep[e] = prep[e];
-    if (t < J) s_par[t] = dm.parent[t];
+    for (int e = t; e < npre + K + 3; e += 256) s_prep[e] = prep[e < npre ? e : e + 4 * J];
+    if (t < 9) s_ident[t] = (t == 0 || t == 4 || t == 8) ? 1.0 : 0.0;
+    if (t < RS) s_Jt[(size_t)NC * RS + t] = 0.0;
     const double* Rw = s_prep;                                    // prep_off_Rw = 0
     const double* oo = s_prep + 9 * J;
     const double* Jh = s_prep + 12 * J;
     const double* Gm = s_prep + 15 * J;
-    const double* ww = s_prep + 19 * J + 3 * J * K;
+    const double* ww = s_prep + npre;
     const double* off = ww + K;
 
     // generic shapes: static round-robin deal of whole tile pairs to the waves
@@ -229,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void k_eval(DeviceModel dm, FrameBuffers fb
             d2v* z = (d2v*)(s_Jt + (size_t)(ln / 6) * RS + wv * 12 + 2 * (ln % 6));
 #pragma unroll
             for (int pass = 0; pass < 2 * AVT_MAX_TILES; ++pass)
-                if (pass < 2 * NT) z[pass * 4 * RS] = (d2v){0.0, 0.0};
+                if (8 * pass + ln / 6 < NC) z[pass * 4 * RS] = (d2v){0.0, 0.0};
         }
         wave_sync();
         EPROBE(1);
@@ -265,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void k_eval(DeviceModel dm, FrameBuffers fb
         const int aword = RI[(4 + slot) * 4 + p4];
         if (aword != 0) {   // rotation block of ancestor j: -2 sqrt(c) [l_j]_x R(-1,parent j)
             const int j = aword & 0xff;
-            const unsigned mask = (unsigned)aword >> 8;
+            const unsigned mask = ((unsigned)aword >> 8) & 0xffu;
             double X0 = 0.0, X1 = 0.0, X2 = 0.0, cj = 0.0;
 #pragma unroll
             for (int a = 0; a < 4; ++a)
@@ -275,13 +289,8 @@ __global__ __launch_bounds__(256, 2) void k_eval(DeviceModel dm, FrameBuffers fb
                 }
             const double m2 = -2.0 * sc;
             const double L0 = m2 * (X0 - cj * oo[3 * j]), L1 = m2 * (X1 - cj * oo[3 * j + 1]), L2 = m2 * (X2 - cj * oo[3 * j + 2]);
-            double Rp[9];
-            if (j == 0) { Rp[0] = 1; Rp[1] = 0; Rp[2] = 0; Rp[3] = 0; Rp[4] = 1; Rp[5] = 0; Rp[6] = 0; Rp[7] = 0; Rp[8] = 1; }
-            else {
-                const double* src = Rw + 9 * s_par[j];
-#pragma unroll
-                for (int e = 0; e < 9; ++e) Rp[e] = src[e];
-            }
+            const int pj = (aword >> 16) & 0xff;
+            const double* Rp = pj ? Rw + 9 * (pj - 1) : s_ident;
             double* o0 = s_Jt + (size_t)(3 + 3 * j) * RS + pi * 3;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -317,10 +326,10 @@ __global__ __launch_bounds__(256, 2) void k_eval(DeviceModel dm, FrameBuffers fb
         // MFMA phase: 12 k-steps of 4 rows
         if constexpr (FIXED) {
             switch (wv) {
-                case 0: mfma_batch6<0>(s_Jt, ln, acc); break;
-                case 1: mfma_batch6<1>(s_Jt, ln, acc); break;
-                case 2: mfma_batch6<2>(s_Jt, ln, acc); break;
-                default: mfma_batch6<3>(s_Jt, ln, acc); break;
+                case 0: mfma_batch6<0>(s_Jt, ln, NC, acc); break;
+                case 1: mfma_batch6<1>(s_Jt, ln, NC, acc); break;
+                case 2: mfma_batch6<2>(s_Jt, ln, NC, acc); break;
+                default: mfma_batch6<3>(s_Jt, ln, NC, acc); break;
             }
         } else {
 #pragma unroll 1
@@ -329,8 +338,8 @@ __global__ __launch_bounds__(256, 2) void k_eval(DeviceModel dm, FrameBuffers fb
 #pragma unroll
                 for (int i = 0; i < MAXPW; ++i) {
                     if (pr_ti[i] >= 0) {
-                        const double a = s_Jt[(size_t)(pr_ti[i] * 16 + (ln & 15)) * RS + rowoff];
-                        const double bq = s_Jt[(size_t)(pr_tj[i] * 16 + (ln & 15)) * RS + rowoff];
+                        const double a = s_Jt[(size_t)min(pr_ti[i] * 16 + (ln & 15), NC) * RS + rowoff];
+                        const double bq = s_Jt[(size_t)min(pr_tj[i] * 16 + (ln & 15), NC) * RS + rowoff];
                         acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc[i], 0, 0, 0);
                     }
                 }
@@ -375,8 +384,8 @@ __global__ __launch_bounds__(256, 2) void k_eval(DeviceModel dm, FrameBuffers fb
 }
 
 static size_t eval_lds_bytes(const AvtDims& d) {
-    return sizeof(double) * ((size_t)d.prep_size + (size_t)d.NT * 16 * AVT_EVAL_RS + 4 * (size_t)d.rec_quad + 48 + 192 + 144) +
-           sizeof(int) * AVT_MAX_JOINTS;
+    const size_t nprep = ((size_t)15 * d.J + 3 * d.J * d.K + d.K + 3 + 1) & ~(size_t)1;
+    return sizeof(double) * (nprep + (size_t)(d.P + 2) * AVT_EVAL_RS + 4 * (size_t)d.rec_quad + 48 + 192 + 144 + 10);
 }
 
 static bool eval_fixed_shape(const AvtDims& d) { return d.J == 24 && d.K == 10; }

@@ -15,6 +15,7 @@
 #define AVT_EVAL_RS 50        // LDS row stride (doubles) of the transposed Jacobian tile: conflict-free b64 reads
 #define AVT_MAX_TILES 8       // ceil((P+1)/16) <= 8  (J<=32, K<=16)
 #define AVT_MAX_COMPS 16      // GMM components
+#define AVT_MAX_GROUPS 4      // frame groups of one optimize() running on separate streams
 #define AVT_PRIOR_STRIDE (2 + 3 * AVT_MAX_JOINTS)   // doubles per (frame, component) of prior scratch
 #define AVT_FIX_SCALE 1099511627776.0  // 2^40 fixed-point scale of the centred correspondence sums
 
@@ -161,8 +162,8 @@ struct avt_model {
 struct avt_ctx {
     int device;
     hipStream_t stream;
-    hipStream_t stream2;             // second branch of the two-group pipeline (large batches)
-    hipEvent_t ev_fork, ev_join;
+    hipStream_t side[AVT_MAX_GROUPS - 1];   // branches of the frame-group pipeline (large batches)
+    hipEvent_t ev_fork, ev_join[AVT_MAX_GROUPS - 1];
     hipStream_t cur_stream;          // stream the launch wrappers enqueue on
     const avt_model* model;
     DeviceModel dm;

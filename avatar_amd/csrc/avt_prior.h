@@ -5,12 +5,14 @@
 #pragma once
 #include "avt_device.h"
 
-__device__ __forceinline__ void prior_component(const DeviceModel& dm, const FrameBuffers& fb, int f, int c, int try_slot) {
+// scratch: 2*ndims doubles of LDS
+__device__ __forceinline__ void prior_component(const DeviceModel& dm, const FrameBuffers& fb, int f, int c, int try_slot, double* scratch) {
     const AvtDims d = dm.d;
     const int t = threadIdx.x;
     const int n = d.ndims, J = d.J;
     double* po = fb.prior + (((size_t)f * 2 + try_slot) * AVT_MAX_COMPS + c) * AVT_PRIOR_STRIDE;
-    __shared__ double s_x[AVT_MAX_JOINTS * 3], s_q[AVT_MAX_JOINTS * 3];
+    double* s_x = scratch;
+    double* s_q = scratch + AVT_MAX_JOINTS * 3;
     const double* x = fb.x + ((size_t)f * 2 + try_slot) * d.xsize;
     if (t < J - 1) {  // Eigen AngleAxis(Quaternion): angle in [0,pi], axis sign follows w
         const double* q = x + 3 + 4 * (t + 1);
