@@ -51,6 +51,35 @@ __host__ __device__ inline int prep_off_w(const AvtDims& d) { return 19 * d.J + 
 __host__ __device__ inline int prep_off_off(const AvtDims& d) { return 19 * d.J + 3 * d.J * d.K + d.K; }
 __host__ __device__ inline int prep_total(const AvtDims& d) { return ((19 * d.J + 3 * d.J * d.K + d.K + 3) + 7) & ~7; }
 
+// LDS scratch of k_solve's skeleton pass (avt_lm.hip): offsets in doubles; the host-built work items (DeviceModel::
+// fk_items) address it with 13-bit offsets
+struct PrepLayout {
+    int rot, Rw, o, jp, dv, H, Sp, S, jsr, jsrb, ident, zero, w, x0;
+    int ndoubles;   // even
+    int nitems;     // J*(12+3K)
+};
+__host__ __device__ inline PrepLayout prep_layout(int J, int K, int xsize) {
+    PrepLayout L;
+    int o = 0;
+    L.rot = o; o += 9 * J;
+    L.Rw = o; o += 9 * J;
+    L.o = o; o += 3 * J;
+    L.jp = o; o += 3 * J;
+    L.dv = o; o += 3 * J;
+    L.H = o; o += 3 * J * K;
+    L.Sp = o; o += 3 * J * K;
+    L.S = o; o += 3 * J * K;
+    L.jsr = o; o += 3 * J * K;
+    L.jsrb = o; o += 3 * J;
+    L.ident = o; o += 9;
+    L.zero = o; o += 3;
+    L.w = o; o += K;
+    L.x0 = o; o += 2 * xsize;
+    L.ndoubles = (o + 1) & ~1;
+    L.nitems = J * (12 + 3 * K);
+    return L;
+}
+
 // per-frame scalar control block
 struct AvtFrameCtl {
     double lambda;
@@ -88,7 +117,7 @@ struct DeviceModel {
     int* mesh;            // [3][F] SoA
     int* parent;          // [J]
     int* jlevel;          // [J] tree level of each joint (root = 0)
-    int* fk_items;        // [J*(12+3K)] per-level work items of compute_prep: (joint << 8) | entry, grouped by level
+    int* fk_items;        // [J*(12+3K)][2] per-level work items of k_solve's skeleton pass (see avt_lm.hip), grouped by level
     int* fk_level_off;    // [nlevels+1] offsets into fk_items
     double* jsr_base;     // [3J] initialJointPos
     double* jsr;          // [3J][K] row-major jointShapeReg

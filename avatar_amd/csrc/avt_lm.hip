@@ -19,95 +19,99 @@
 #endif
 
 // -------------------------------------------------------------------------------------------------
-// skeleton tables of a state x=(p,q,w) -> prep block in global memory.  Called by all 256 threads.
+// Skeleton pass: state x=(p,q,w) -> prep block (PrepareForEvaluation, AvatarOptimizer.cpp:283-325), LDS only.
+//   B      : double scratch laid out by prep_layout(J,K) (avt_internal.h);
+//   items  : host-built work items of the level-parallel pass, two 32-bit words each:
+//            word0 = rp | v << 13 | stride_code << 26,  word1 = add | out << 13   (offsets into B)
+//            B[out] = (B[rp] B[v] + B[rp+1] B[v+st] + B[rp+2] B[v+2st]) + B[add]
+//            which is a world-rotation entry (R(-1,pa) rot_j), a world-origin entry (o_pa + R(-1,pa)(J_j - J_pa)) or a
+//            shape-table entry (H_pa + R(-1,pa) Sp_j) depending on the offsets (:303-324); the root uses the identity.
+// prep_stage_constants() runs at kernel start (its global loads hide behind the LM decision and the factorisation),
+// prep_set_state() installs the state, prep_run() does the pass and writes the prep block.
 // -------------------------------------------------------------------------------------------------
-struct PrepScratch {
-    double rot[AVT_MAX_JOINTS * 9], Rw[AVT_MAX_JOINTS * 9], o[AVT_MAX_JOINTS * 3], jp[AVT_MAX_JOINTS * 3];
-    double H[AVT_MAX_JOINTS * 3 * AVT_MAX_SHAPE], Sp[AVT_MAX_JOINTS * 3 * AVT_MAX_SHAPE];
-    double w[AVT_MAX_SHAPE], p[3];
-    int parent[AVT_MAX_JOINTS], level[AVT_MAX_JOINTS + 2];
-    unsigned short items[AVT_MAX_JOINTS * (12 + 3 * AVT_MAX_SHAPE)];
-};
+__device__ __forceinline__ void prep_stage_constants(const DeviceModel& dm, const PrepLayout& L, double* __restrict__ B,
+                                                     int2* __restrict__ items, int* __restrict__ level,
+                                                     const double* __restrict__ xboth) {
+    const AvtDims& d = dm.d;
+    const int J = d.J, K = d.K, t = threadIdx.x;
+    for (int e = t; e < 3 * J * K; e += 256) {
+        B[L.Sp + e] = dm.Sp[e];
+        B[L.S + e] = dm.S[e];
+        B[L.jsr + e] = dm.jsr[e];
+    }
+    if (t < 3 * J) B[L.jsrb + t] = dm.jsr_base[t];
+    if (t < 9) B[L.ident + t] = (t == 0 || t == 4 || t == 8) ? 1.0 : 0.0;
+    if (t < 3) B[L.zero + t] = 0.0;
+    for (int e = t; e < 2 * d.xsize; e += 256) B[L.x0 + e] = xboth[e];
+    const int2* gi = (const int2*)dm.fk_items;
+    for (int e = t; e < L.nitems; e += 256) items[e] = gi[e];
+    if (t <= d.nlevels) level[t] = dm.fk_level_off[t];
+    if (t < J) level[AVT_MAX_JOINTS + 2 + t] = dm.parent[t];     // parents follow the level offsets
+}
 
-__device__ void compute_prep(const DeviceModel& dm, const double* __restrict__ x, double* __restrict__ prep, PrepScratch& s) {
+// local rotations, shape parameters and root position of the state into the scratch (q, w, p: LDS or registers' source)
+__device__ __forceinline__ void prep_set_state(const AvtDims& d, const PrepLayout& L, double* __restrict__ B, const double* q,
+                                               const double* w, const double* p) {
+    const int t = threadIdx.x;
+    if (t < d.J) quat_to_rot(q + 4 * t, B + L.rot + 9 * t);
+    if (t < d.K) B[L.w + t] = w[t];
+    if (t < 3) B[L.dv + t] = p[t];          // the root's "offset from its parent" is the global position
+}
+
+// callers: a barrier separates prep_set_state() from prep_run()
+__device__ void prep_run(const DeviceModel& dm, const PrepLayout& L, double* __restrict__ B, const int2* __restrict__ items,
+                         const int* __restrict__ level, const double* __restrict__ q, double* __restrict__ prep) {
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, t = threadIdx.x;
-    const double* q = x + 3;
-    const double* w = x + 3 + 4 * J;
-    // everything that comes from global memory is requested up front, in one round trip
-    if (t < J) { s.parent[t] = dm.parent[t]; quat_to_rot(q + 4 * t, s.rot + 9 * t); }
-    if (t < 3) s.p[t] = x[t];
-    if (t < K) s.w[t] = w[t];
-    if (t <= d.nlevels) s.level[t] = dm.fk_level_off[t];
-    for (int e = t; e < 3 * J * K; e += 256) s.Sp[e] = dm.Sp[e];
-    // CalcShape (AvatarOptimizer.cpp:249-281): jointPosInit = base + jointShapeReg*w
+    // CalcShape (AvatarOptimizer.cpp:249-281): jointPosInit = base + jointShapeReg*w, and each joint's offset from its
+    // parent (the parent's position is recomputed by the same lane: same operations, same bits, no barrier)
     if (t < 3 * J) {
+        const int j = t / 3, c = t - 3 * j;
         double a = 0.0;
-        for (int k = 0; k < K; ++k) a += dm.jsr[(size_t)t * K + k] * w[k];
-        s.jp[t] = dm.jsr_base[t] + a;
+        for (int k = 0; k < K; ++k) a += B[L.jsr + t * K + k] * B[L.w + k];
+        const double mine = B[L.jsrb + t] + a;
+        B[L.jp + t] = mine;
+        if (j > 0) {
+            const int tp = 3 * level[AVT_MAX_JOINTS + 2 + j] + c;
+            double ap = 0.0;
+            for (int k = 0; k < K; ++k) ap += B[L.jsr + tp * K + k] * B[L.w + k];
+            B[L.dv + t] = mine - (B[L.jsrb + tp] + ap);
+        }
     }
-    // per-level work items (joint, entry), at most one per lane and level for SMPL
-    const int per = 12 + 3 * K;
-    const int nitems = J * per;
-    for (int e = t; e < nitems; e += 256) s.items[e] = (unsigned short)dm.fk_items[e];
     __syncthreads();
 #ifdef AVT_TIMING
     if (threadIdx.x == 0) prep[d.prep_size - 1] = (double)clock64();
 #endif
-    // one tree level per barrier: world rotation/origin (:303-315) and H[j] = R(-1,parent j) Sp[j] + H[parent j]
-    // (:318-324) of every joint of the level in parallel
-    for (int L = 0; L < d.nlevels; ++L) {
-        const int lo = s.level[L], hi = s.level[L + 1];
+    // one tree level per barrier
+    for (int lv = 0; lv < d.nlevels; ++lv) {
+        const int lo = level[lv], hi = level[lv + 1];
         for (int idx = lo + t; idx < hi; idx += 256) {
-            const int item = s.items[idx];
-            const int j = item >> 8, e = item & 0xff;
-            const int pa = s.parent[j];
-            if (e < 12) {
-                if (j == 0) {
-                    if (e < 9) s.Rw[e] = s.rot[e];
-                    else s.o[e - 9] = s.p[e - 9];
-                } else {
-                    const double* Rp = s.Rw + 9 * pa;
-                    if (e < 9) {
-                        const int r = e / 3, c = e % 3;
-                        s.Rw[9 * j + e] = Rp[3 * r] * s.rot[9 * j + c] + Rp[3 * r + 1] * s.rot[9 * j + 3 + c] + Rp[3 * r + 2] * s.rot[9 * j + 6 + c];
-                    } else {
-                        const int r = e - 9;
-                        const double d0 = s.jp[3 * j] - s.jp[3 * pa], d1 = s.jp[3 * j + 1] - s.jp[3 * pa + 1], d2 = s.jp[3 * j + 2] - s.jp[3 * pa + 2];
-                        s.o[3 * j + r] = s.o[3 * pa + r] + (Rp[3 * r] * d0 + Rp[3 * r + 1] * d1 + Rp[3 * r + 2] * d2);
-                    }
-                }
-            } else {
-                const int e2 = e - 12, r = e2 / K, k = e2 - r * K;
-                double v = 0.0;
-                if (j > 0) {
-                    const double* Rp = s.Rw + 9 * pa;
-                    const double* Sp = s.Sp + j * 3 * K;
-                    v = (Rp[3 * r] * Sp[k] + Rp[3 * r + 1] * Sp[K + k] + Rp[3 * r + 2] * Sp[2 * K + k]) + s.H[pa * 3 * K + e2];
-                }
-                s.H[j * 3 * K + e2] = v;
-            }
+            const int2 it = items[idx];
+            const int rp = it.x & 0x1fff, v = (it.x >> 13) & 0x1fff, scode = (unsigned)it.x >> 26;
+            const int st = scode == 3 ? K : (scode == 2 ? 3 : scode);
+            const int add = it.y & 0x1fff, out = (unsigned)it.y >> 13;
+            B[out] = (B[rp] * B[v] + B[rp + 1] * B[v + st] + B[rp + 2] * B[v + 2 * st]) + B[add];
         }
         __syncthreads();
     }
 #ifdef AVT_TIMING
     if (threadIdx.x == 0) prep[d.prep_size - 2] = (double)clock64();
 #endif
-    const double off0 = s.jp[0], off1 = s.jp[1], off2 = s.jp[2];
-    for (int e = t; e < 9 * J; e += 256) prep[prep_off_Rw(d) + e] = s.Rw[e];
+    const double off0 = B[L.jp], off1 = B[L.jp + 1], off2 = B[L.jp + 2];
+    for (int e = t; e < 9 * J; e += 256) prep[prep_off_Rw(d) + e] = B[L.Rw + e];
     for (int e = t; e < 3 * J; e += 256) {
-        prep[prep_off_o(d) + e] = s.o[e];
+        prep[prep_off_o(d) + e] = B[L.o + e];
         const int c = e % 3;
-        prep[prep_off_Jh(d) + e] = s.jp[e] - (c == 0 ? off0 : (c == 1 ? off1 : off2));   // root at origin (:270-272)
+        prep[prep_off_Jh(d) + e] = B[L.jp + e] - (c == 0 ? off0 : (c == 1 ? off1 : off2));   // root at origin (:270-272)
     }
     for (int e = t; e < 3 * J * K; e += 256) {  // G[j] = H[j] - Rw[j]*S[j]  (shape block of :568-580)
         const int j = e / (3 * K), r = (e / K) % 3, k = e % K;
-        const double* Rj = s.Rw + 9 * j;
-        const double* S = dm.S + (size_t)j * 3 * K;
-        prep[prep_off_G(d) + e] = s.H[e] - (Rj[3 * r] * S[k] + Rj[3 * r + 1] * S[K + k] + Rj[3 * r + 2] * S[2 * K + k]);
+        const double* Rj = B + L.Rw + 9 * j;
+        const double* S = B + L.S + j * 3 * K;
+        prep[prep_off_G(d) + e] = B[L.H + e] - (Rj[3 * r] * S[k] + Rj[3 * r + 1] * S[K + k] + Rj[3 * r + 2] * S[2 * K + k]);
     }
     for (int e = t; e < 4 * J; e += 256) prep[prep_off_q(d) + e] = q[e];
-    if (t < K) prep[prep_off_w(d) + t] = s.w[t];
+    if (t < K) prep[prep_off_w(d) + t] = B[L.w + t];
     if (t < 3) prep[prep_off_off(d) + t] = (t == 0 ? off0 : (t == 1 ? off1 : off2));
 }
 
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) void k_reduce(DeviceModel dm, FrameBuffers fb)
     }
 }
 
-typedef double d2 __attribute__((ext_vector_type(2)));
+typedef double d2v __attribute__((ext_vector_type(2)));
 
 // reciprocal off the slow path: v_rcp_f64 (~2^-26 relative) + one cubic Newton step (error e^3)
 __device__ __forceinline__ double fast_rcp(double d) {
@@ -163,36 +167,65 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-// Back substitution L^T delta = w for a compile-time size, fully unrolled: lane indices of the v_readlane broadcasts
-// and all LDS offsets are immediates, so the factor rows are fetched far ahead of the 85-step dependency chain.
-template <int PP>
-__device__ __forceinline__ void backsub_unrolled(const double* __restrict__ Lblk, int NB, int t, double* __restrict__ s_delta) {
-    // element (i, l) of the unit-lower factor lives at Lblk[((l>>2)*NB + (i>>2))*18 + (i&3)*4 + (l&3)]: the lane-dependent
-    // part (column l = t or t+64) is a base pointer, the row-dependent part a compile-time offset
-    const double* col0 = Lblk + ((size_t)(t >> 2) * NB) * 18 + (t & 3);
-    const double* col1 = Lblk + ((size_t)((t + 64) >> 2) * NB) * 18 + (t & 3);
-    constexpr int PO = (PP >> 2) * 18 + (PP & 3) * 4;
-    const double w0 = (t < PP) ? col0[PO] : 0.0;
-    const double w1 = (t + 64 < PP) ? col1[PO] : 0.0;
-    double acc0 = 0.0, acc1 = 0.0, dl0 = 0.0, dl1 = 0.0;
+// Back substitution L^T delta = y by one wave, four unknowns per step.  The factorisation left W = L diag(d) and the
+// reciprocal pivots r; row P of W holds L^-1 rhs, so y_l = W(P,l) r_l and
+//   delta_i = r_i ( W(P,i) - sum_{k>i} W(k,i) delta_k ).
+// Lane l keeps W(P,l), W(P,l+64) and the running sums acc_l = sum_{k>i} W(k,l) delta_k in registers.  Per step the
+// four values W(P,.) - acc of the block cross the wave by v_readlane, the 4x4 triangular system is solved by every lane
+// alike, and each lane adds the block's contribution to its sums.
+template <int NBC>
+__device__ __forceinline__ void backsub_blocked(const double* __restrict__ Lblk, const double* __restrict__ s_R, int NBrt, int P, int t,
+                                                double* __restrict__ s_delta) {
+    const int NB = NBC > 0 ? NBC : NBrt;
+    auto Wat = [&](int i, int l) { return Lblk[((size_t)(l >> 2) * NB + (i >> 2)) * 18 + (i & 3) * 4 + (l & 3)]; };
+    const double wp0 = (t < P) ? Wat(P, t) : 0.0;
+    const double wp1 = (t + 64 < P) ? Wat(P, t + 64) : 0.0;
+    double acc0 = 0.0, acc1 = 0.0;
+    // column t (and t+64) of the rows of block kb: entries (k*4 + (t&3)) of block [t>>2][kb]
+    const double* col0 = Lblk + (size_t)(t >> 2) * NB * 18 + (t & 3);
+    const double* col1 = Lblk + (size_t)((t + 64) >> 2) * NB * 18 + (t & 3);
+    // The LDS reads of a step are issued DEPTH steps ahead into a register ring (one wave alone sees ~150 clocks of LDS
+    // latency, a step's dependency chain is shorter).  No selects: the factorisation stores the diagonal W blocks
+    // strictly lower triangular and the blocks above the diagonal were zeroed at kernel start, so W(k,l) reads as 0
+    // for every l >= k.  A lone wave issues one instruction every ~5 clocks: the step is kept to ~40 instructions.
+    constexpr int DEPTH = NBC > 0 ? 3 : 1;                            // runtime NB: no unrolling, no ring
+    double c0[DEPTH][4], c1[DEPTH][4], wd[DEPTH][6], rr[DEPTH][4];
+    auto fetch = [&](int kb, int sl) {
 #pragma unroll
-    for (int i = PP - 1; i >= 0; --i) {
-        const int io = (i >> 2) * 18 + (i & 3) * 4;
-        const double c0 = (t < i) ? col0[io] : 0.0;
-        double di;
-        if (i >= 64) {
-            const double c1 = (t + 64 < i) ? col1[io] : 0.0;
-            di = readlane_f64(w1, i - 64) - readlane_f64(acc1, i - 64);
-            if (t == i - 64) dl1 = di;
-            acc1 = fma(c1, di, acc1);
-        } else {
-            di = readlane_f64(w0, i) - readlane_f64(acc0, i);
-            if (t == i) dl0 = di;
+        for (int k = 0; k < 4; ++k) {
+            c0[sl][k] = col0[(size_t)kb * 18 + 4 * k];
+            c1[sl][k] = (4 * kb > 64) ? col1[(size_t)kb * 18 + 4 * k] : 0.0;
         }
-        acc0 = fma(c0, di, acc0);
+        // the diagonal block's strictly-lower entries W(base+k, base+i) at [k*4+i] and the reciprocal pivots (0 for the
+        // rows >= P of the last block, see the factorisation)
+        const d2v* Wd = (const d2v*)(Lblk + ((size_t)kb * NB + kb) * 18);
+        const d2v a = Wd[2], bq = Wd[4], c = Wd[6], e = Wd[7];
+        wd[sl][0] = a.x; wd[sl][1] = bq.x; wd[sl][2] = bq.y; wd[sl][3] = c.x; wd[sl][4] = c.y; wd[sl][5] = e.x;
+        const d2v* Rq = (const d2v*)(s_R + 4 * kb);
+        const d2v ra = Rq[0], rb = Rq[1];
+        rr[sl][0] = ra.x; rr[sl][1] = ra.y; rr[sl][2] = rb.x; rr[sl][3] = rb.y;
+    };
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i)
+        if (NB - 1 - i >= 0) fetch(NB - 1 - i, (NB - 1 - i) % DEPTH);
+#pragma unroll
+    for (int kb = NB - 1; kb >= 0; --kb) {
+        const int base = 4 * kb, sl = kb % DEPTH;
+        const double w10 = wd[sl][0], w20 = wd[sl][1], w21 = wd[sl][2], w30 = wd[sl][3], w31 = wd[sl][4], w32 = wd[sl][5];
+        const double r0 = rr[sl][0], r1 = rr[sl][1], r2 = rr[sl][2], r3 = rr[sl][3];
+        const double cc0[4] = {c0[sl][0], c0[sl][1], c0[sl][2], c0[sl][3]}, cc1[4] = {c1[sl][0], c1[sl][1], c1[sl][2], c1[sl][3]};
+        if (kb - DEPTH >= 0) fetch(kb - DEPTH, sl);
+        const double u = (base >= 64) ? wp1 - acc1 : wp0 - acc0;
+        const double u0 = readlane_f64(u, base & 63), u1 = readlane_f64(u, (base + 1) & 63);
+        const double u2 = readlane_f64(u, (base + 2) & 63), u3 = readlane_f64(u, (base + 3) & 63);
+        const double d3 = r3 * u3;
+        const double d2 = r2 * fma(-w32, d3, u2);
+        const double d1 = r1 * fma(-w21, d2, fma(-w31, d3, u1));
+        const double d0 = r0 * fma(-w10, d1, fma(-w20, d2, fma(-w30, d3, u0)));
+        acc0 += fma(cc0[0], d0, cc0[1] * d1) + fma(cc0[2], d2, cc0[3] * d3);
+        acc1 += fma(cc1[0], d0, cc1[1] * d1) + fma(cc1[2], d2, cc1[3] * d3);
+        if (t == 0) { d2v* o = (d2v*)(s_delta + base); o[0] = (d2v){d0, d1}; o[1] = (d2v){d2, d3}; }
     }
-    if (t < PP) s_delta[t] = dl0;
-    if (t + 64 < PP) s_delta[t + 64] = dl1;
 }
 
 // =================================================================================================
@@ -206,21 +239,32 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
     AvtFrameCtl& ctl = fb.ctl[f];
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NBk = HS >> 2;                                // 4-row blocks covering rows 0..P (22 for SMPL)
-    // unit-lower factor, block layout [pivot block kb][row block bi][18]: a 4x4 block is 16 doubles + 2 of padding
-    // (144 B), so lanes reading different blocks spread over the LDS banks; row P carries D^-1 L^-1 rhs
+    // W = L diag(d) of the factorisation H = L diag(d) L^T, block layout [pivot block kb][row block bi][18]: a 4x4
+    // block is 16 doubles + 2 of padding (144 B), so lanes reading different blocks spread over the LDS banks; row P
+    // carries L^-1 rhs
     double* Lblk = (double*)smem;
-    double* s_W = Lblk + (size_t)NBk * NBk * 18;            // [NB][18]  W = A_panel Ld^-T of the current pivot block
-    double* s_D = s_W + (size_t)NBk * 18;                   // [18]      updated diagonal block of the next pivot block
-    double* s_delta = s_D + 18;                             // [HS]
-    PrepScratch* ps = (PrepScratch*)(s_delta + HS + 2);
+    double* s_W = Lblk + (size_t)NBk * NBk * 18;            // [2][NB][18]  scratch: reciprocal pivots, later the new quaternions
+    double* s_D = s_W + 2 * (size_t)NBk * 18;               // [2][18]   diagonal block of the next panel column (double-buffered)
+    double* s_delta = s_D + 36;                             // [HS]
+    const PrepLayout L = prep_layout(J, K, d.xsize);
+    double* B = s_delta + HS + 2;                           // skeleton scratch (+ both state slots)
+    int2* s_items = (int2*)(B + L.ndoubles);
+    int* s_level = (int*)(s_items + L.nitems);
     __shared__ int s_fail;
     const int xs = d.xsize;
     double* x0 = fb.x + ((size_t)f * 2) * xs;
+    double* prep0 = fb.prep + ((size_t)f * 2) * d.prep_size;
+
+    // everything that does not depend on the LM decision is requested now: skeleton constants and both state slots
+    prep_stage_constants(dm, L, B, s_items, s_level, x0);
+    if (mode != SOLVE_INIT && mode != SOLVE_LAST) {   // the never-written blocks of the factor must read as zeros (back substitution)
+        d2v* z = (d2v*)Lblk;
+        for (int e = t; e < NBk * NBk * 9; e += 256) z[e] = (d2v){0.0, 0.0};
+    }
 
     if (mode == SOLVE_INIT) {
         // trial point := current point; sum the constant part of the data cost
         const int cur = ctl.cur_slot, tr = 1 - cur;
-        for (int e = t; e < xs; e += 256) x0[(size_t)tr * xs + e] = x0[(size_t)cur * xs + e];
         double a = 0.0;
         if (t < 64) {
             for (int e = t; e < fb.const_used; e += 64) a += fb.const_part[(size_t)f * fb.const_blocks + e];
@@ -228,27 +272,62 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
         }
         __syncthreads();
         if (t == 0) { ctl.cost_const = 0.5 * a; ctl.try_valid = 1; }
-        compute_prep(dm, x0 + (size_t)tr * xs, fb.prep + ((size_t)f * 2 + tr) * d.prep_size, *ps);
+        const double* xc = B + L.x0 + cur * xs;
+        for (int e = t; e < xs; e += 256) x0[(size_t)tr * xs + e] = xc[e];
+        prep_set_state(d, L, B, xc + 3, xc + 3 + 4 * J, xc);
+        __syncthreads();
+        prep_run(dm, L, B, s_items, s_level, xc + 3, prep0 + (size_t)tr * d.prep_size);
         return;
     }
     TPROBE(0);
-    // ---- a. objective of the trial point + LM decision (uniform work, done redundantly by every lane) -----
-    const int cur0 = ctl.cur_slot, try0 = 1 - cur0;
-    const int try_valid = ctl.try_valid, comp_cur0 = ctl.comp_cur;
+    // ---- a. one round trip for everything the LM decision and the system need: the control block, the objective
+    // terms of BOTH state slots and this thread's 4x4 block of BOTH data-term matrices (the slot is chosen below) ----
+    // Thread t owns the 4x4 block (bi >= bj) of the bordered (P+1)x(P+1) matrix [[H + lambda diag H, .],[-g^T, .]]
+    // (row P carries the rhs so D^-1 L^-1 (-g) falls out of the factorisation as row P of the unit-lower factor).
+    const int NB = HS >> 2;
+    int bi = -1, bj = -1;
+    if (t < NB * (NB + 1) / 2) {
+        int r0 = 0, rem = t;
+        while (rem > r0) { rem -= r0 + 1; ++r0; }
+        bi = r0; bj = rem;
+    }
+    const double* H0 = fb.Hraw + ((size_t)f * 2) * HS * HS;
+    d2v hraw[2][4][2];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const d2v* src = (const d2v*)(H0 + (size_t)sl * HS * HS + (size_t)(4 * max(bi, 0) + r) * HS + 4 * max(bj, 0));
+            hraw[sl][r][0] = src[0]; hraw[sl][r][1] = src[1];
+        }
+    const double hpp0 = H0[(size_t)P * HS + P], hpp1 = H0[(size_t)HS * HS + (size_t)P * HS + P];
+    const int cur0 = ctl.cur_slot, try_valid = ctl.try_valid, comp_cur0 = ctl.comp_cur;
     const double sbp = ctl.sbp, sbs = ctl.sbs, cost_cur0 = ctl.cost_cur, cost_const = ctl.cost_const;
     double lambda = ctl.lambda;
-    const double* Htry = fb.Hraw + ((size_t)f * 2 + try0) * HS * HS;
-    const double* xt = x0 + (size_t)try0 * xs;
-    double cost = 0.5 * Htry[(size_t)P * HS + P] + cost_const;
+    // prior score of every component at both slots: strict '<' in ascending component order (GaussianMixture.cpp:103)
+    double best[2] = {1.7976931348623157e308, 1.7976931348623157e308};
+    int bcomp[2] = {-1, -1};
+    if (d.ncomps > 0) {
+        double pr[2][AVT_MAX_COMPS];
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int c = 0; c < AVT_MAX_COMPS; ++c)
+                pr[sl][c] = (c < d.ncomps) ? fb.prior[(((size_t)f * 2 + sl) * AVT_MAX_COMPS + c) * AVT_PRIOR_STRIDE] : 0.0;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int c = 0; c < AVT_MAX_COMPS; ++c)
+                if (c < d.ncomps && pr[sl][c] < best[sl]) { best[sl] = pr[sl][c]; bcomp[sl] = c; }
+    }
+    __syncthreads();   // the staged state slots are visible; every lane has read the control block
+    const int try0 = 1 - cur0;
+    const double* xt = B + L.x0 + try0 * xs;
+    double cost = 0.5 * (try0 ? hpp1 : hpp0) + cost_const;
     int comp_try = -1;
     if (sbp > 0.0 && d.ncomps > 0) {
-        // best component: strict '<' in ascending component order (GaussianMixture.cpp:103)
-        double best = 1.7976931348623157e308;
-        for (int c = 0; c < d.ncomps; ++c) {
-            const double pr = fb.prior[(((size_t)f * 2 + try0) * AVT_MAX_COMPS + c) * AVT_PRIOR_STRIDE];
-            if (pr < best) { best = pr; comp_try = c; }
-        }
-        cost += 0.5 * sbp * sbp * best;
+        comp_try = try0 ? bcomp[1] : bcomp[0];
+        cost += 0.5 * sbp * sbp * (try0 ? best[1] : best[0]);
     }
     if (sbs > 0.0) {
         double a = 0.0;
@@ -266,7 +345,6 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
     }
     const double cost_cur = accepted ? cost : cost_cur0;
     const int comp = accepted ? comp_try : comp_cur0;
-    __syncthreads();   // every lane has read the control block before lane 0 rewrites it
     if (t == 0) {
         ctl.cur_slot = cur;
         ctl.cost_cur = cost_cur;
@@ -280,18 +358,9 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
     if (mode == SOLVE_LAST) return;
     TPROBE(1);
 
-    // ---- b. the damped system of the current point, straight into registers --------------------------------
-    // Thread t owns the 4x4 block (bi >= bj) of the bordered (P+1)x(P+1) matrix [[H + lambda diag H, .],[-g^T, .]]
-    // (row P carries the rhs so D^-1 L^-1 (-g) falls out of the factorisation as row P of the unit-lower factor).
-    const int NB = HS >> 2;
-    int bi = -1, bj = -1;
-    if (t < NB * (NB + 1) / 2) {
-        int r0 = 0, rem = t;
-        while (rem > r0) { rem -= r0 + 1; ++r0; }
-        bi = r0; bj = rem;
-    }
-    const double* Hc = fb.Hraw + ((size_t)f * 2 + cur) * HS * HS;
-    const double* xc = x0 + (size_t)cur * xs;
+    // ---- b. the damped system of the current point, straight into registers (second, short round trip: the
+    // precision block and gradient of the chosen GMM component, read-only data) ------------------------------
+    const double* xc = B + L.x0 + cur * xs;
     const double* pri = fb.prior + (((size_t)f * 2 + cur) * AVT_MAX_COMPS + (comp >= 0 ? comp : 0)) * AVT_PRIOR_STRIDE;
     const bool use_pose = sbp > 0.0 && d.ncomps > 0 && comp >= 0;
     const int n = d.ndims;
@@ -299,64 +368,65 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
     const double sc2 = sc * sc;
     const double gs = sc * sbp * 0.7071067811865476;    // J^T r = sc*sbp*sqrt(1/2) * Prec (x - mu)
     const double* Pr = dm.prior_prec + (size_t)(comp >= 0 ? comp : 0) * n * n;
+    // (all loads unconditional on clamped indices, the conditions applied as selects: 16 loads in flight, no branches)
     double a4[4][4];
+    double prv[4][4], gq[4], xq[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int col = 4 * max(bj, 0) + c, pc = min(max(col - 6, 0), max(n - 1, 0)), sk = min(max(col - (3 + 3 * J), 0), max(K - 1, 0));
+        gq[c] = use_pose ? pri[2 + pc] : 0.0;
+        xq[c] = xc[3 + 4 * J + sk];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int pr_ = min(max(4 * max(bi, 0) + r - 6, 0), max(n - 1, 0));
+            prv[r][c] = use_pose ? Pr[(size_t)pr_ * n + pc] : 0.0;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int row = 4 * bi + r, col = 4 * bj + c;
-            double v = (row == col) ? 1.0 : 0.0;
-            if (bi >= 0 && row <= P && col < P) {
-                v = Hc[(size_t)row * HS + col];
-                const int pc = col - 6, sk = col - (3 + 3 * J);
-                if (row < P) {
-                    const int pr_ = row - 6;
-                    if (use_pose && pr_ >= 0 && pr_ < n && pc >= 0 && pc < n) v += sc2 * Pr[(size_t)pr_ * n + pc];
-                    if (row == col) {
-                        if (sbs > 0.0 && sk >= 0) v += sbs * sbs;
-                        v += lambda * v;
-                    }
-                } else {  // rhs row: -(J^T r) including the priors
-                    if (use_pose && pc >= 0 && pc < n) v += gs * pri[2 + pc];
-                    if (sbs > 0.0 && sk >= 0) v += sbs * (xc[3 + 4 * J + sk] * sbs);
-                    v = -v;
-                }
-            }
-            a4[r][c] = v;
+            const d2v h = cur ? hraw[1][r][c >> 1] : hraw[0][r][c >> 1];
+            double v = (c & 1) ? h.y : h.x;
+            const int pc = col - 6, sk = col - (3 + 3 * J), pr_ = row - 6;
+            const bool in_pose_c = use_pose && pc >= 0 && pc < n;
+            const bool shape_c = sbs > 0.0 && sk >= 0 && col < P;
+            // rows < P: H + priors, diagonal damped
+            double vh = v;
+            vh += (in_pose_c && pr_ >= 0 && pr_ < n) ? sc2 * prv[r][c] : 0.0;
+            if (row == col) { vh += shape_c ? sbs * sbs : 0.0; vh += lambda * vh; }
+            // row P: -(J^T r) including the priors
+            double vg = v;
+            vg += in_pose_c ? gs * gq[c] : 0.0;
+            vg += shape_c ? sbs * (xq[c] * sbs) : 0.0;
+            const bool inside = bi >= 0 && row <= P && col < P;
+            a4[r][c] = inside ? (row < P ? vh : -vg) : ((row == col) ? 1.0 : 0.0);
         }
     TPROBE(2);
 
     // ---- c. register-blocked LDL^T, four pivots per round, two barriers per round -----------------------------------
     //  (1) the lanes owning the pivot block column (bj == kb) read the updated diagonal block, factor it
-    //      (D = Ld diag(d) Ld^T), solve their own 4x4 block W = A Ld^-T, L = W diag(d)^-1 and publish W and L;
-    //  (2) every trailing lane (bj > kb) reads W of its row block and L of its column block: A -= W L^T;
+    //      (D = Ld diag(d) Ld^T) and publish their own block of W = A Ld^-T; the diagonal lane also publishes 1/d;
+    //  (2) every trailing lane (bj > kb) reads W of its row block and of its column block: A -= W_i diag(1/d) W_j^T;
     //      the owner of the next diagonal block publishes it.
-    // Nothing is recomputed: per round a trailing lane issues 16 LDS reads and 64 FMAs.
-    typedef double d2v __attribute__((ext_vector_type(2)));
+    // Measured on MI355X (tools/ubench/ldlt.hip): the rounds are bound by LDS traffic and its latency, not by the
+    // FMAs; publishing W only (instead of W and L = W diag(1/d)) halves the panel's wide stores: 2520 -> 2215
+    // clocks per round.  A one-barrier look-ahead variant (panel column rebuilt redundantly) measured slower (2770).
+    double* s_R = s_W;                                      // [HS] reciprocal pivots
     if (t == 0) s_fail = 0;
     if (bi == 0 && bj == 0) {
+        d2v* Do = (d2v*)s_D;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) s_D[r * 4 + c] = a4[r][c];
+        for (int r = 0; r < 4; ++r) { Do[2 * r] = (d2v){a4[r][0], a4[r][1]}; Do[2 * r + 1] = (d2v){a4[r][2], a4[r][3]}; }
     }
-#ifdef AVT_TIMING
-    long long lacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long llast = clock64();
-#define LPROBE(k) do { const long long _n = clock64(); lacc[k] += _n - llast; llast = _n; } while (0)
-#else
-#define LPROBE(k) do {} while (0)
-#endif
     bool fail = false;
     for (int kb = 0; kb < NB; ++kb) {
         __syncthreads();                                    // B1: diagonal block kb is visible
-        LPROBE(0);
         if (bj == kb) {
             const d2v* Dq = (const d2v*)s_D;
             const d2v q0 = Dq[0], q2 = Dq[2], q4 = Dq[4], q5 = Dq[5], q6 = Dq[6], q7 = Dq[7];
             const double D00 = q0.x, D10 = q2.x;
-#ifdef AVT_TIMING
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); LPROBE(5);
-#endif
             double D11 = q2.y, D20 = q4.x, D21 = q4.y, D22 = q5.x, D30 = q6.x, D31 = q6.y, D32 = q7.x, D33 = q7.y;
             const bool real1 = 4 * kb + 1 < P, real2 = 4 * kb + 2 < P, real3 = 4 * kb + 3 < P;   // 4*kb < P always
             const double P0 = D00;
@@ -376,34 +446,35 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
             const double r3 = fast_rcp(D33);
             const int bad = (int)!(P0 > 0.0) | ((int)real1 & (int)!(P1 > 0.0)) | ((int)real2 & (int)!(P2 > 0.0)) | ((int)real3 & (int)!(P3 > 0.0));
             if (bad) s_fail = 1;
-#ifdef AVT_TIMING
-            { double keep = r3; asm volatile("" : "+v"(keep)); LPROBE(6); }
-#endif
-            d2v* Wo = (d2v*)(s_W + (size_t)bi * 18);
-            d2v* Lo = (d2v*)(Lblk + ((size_t)kb * NB + bi) * 18);
+            d2v* Wo = (d2v*)(Lblk + ((size_t)kb * NB + bi) * 18);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double w0 = a4[r][0];
                 const double w1 = fma(-w0, l10, a4[r][1]);
                 const double w2 = fma(-w1, l21, fma(-w0, l20, a4[r][2]));
                 const double w3 = fma(-w2, l32, fma(-w1, l31, fma(-w0, l30, a4[r][3])));
-                Wo[2 * r] = (d2v){w0, w1}; Wo[2 * r + 1] = (d2v){w2, w3};
-                Lo[2 * r] = (d2v){w0 * r0, w1 * r1}; Lo[2 * r + 1] = (d2v){w2 * r2, w3 * r3};
+                // (the diagonal block keeps its strictly lower part only: nobody but the back substitution reads it)
+                const bool dg = bi == kb;
+                Wo[2 * r] = (d2v){(dg && r < 1) ? 0.0 : w0, (dg && r < 2) ? 0.0 : w1};
+                Wo[2 * r + 1] = (d2v){(dg && r < 3) ? 0.0 : w2, dg ? 0.0 : w3};
             }
-#ifdef AVT_TIMING
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); LPROBE(7);
-#endif
+            if (bi == kb) {   // reciprocal pivots; 0 for the rhs / padding rows (only the back substitution reads those)
+                d2v* Ro = (d2v*)(s_R + 4 * kb);
+                Ro[0] = (d2v){r0, real1 ? r1 : 0.0}; Ro[1] = (d2v){real2 ? r2 : 0.0, real3 ? r3 : 0.0};
+            }
         }
-        LPROBE(1);
-        __syncthreads();                                    // B2: W and L of pivot block kb are visible
-        LPROBE(2);
+        __syncthreads();                                    // B2: W and 1/d of pivot block kb are visible
         if (s_fail) { fail = true; break; }
         if (bj > kb) {
-            const d2v* Wi = (const d2v*)(s_W + (size_t)bi * 18);
-            const d2v* Lj = (const d2v*)(Lblk + ((size_t)kb * NB + bj) * 18);
+            const d2v* Wi = (const d2v*)(Lblk + ((size_t)kb * NB + bi) * 18);
+            const d2v* Wj = (const d2v*)(Lblk + ((size_t)kb * NB + bj) * 18);
+            const d2v* Rq = (const d2v*)(s_R + 4 * kb);
             d2v wv[4][2], lv[4][2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { wv[r][0] = Wi[2 * r]; wv[r][1] = Wi[2 * r + 1]; lv[r][0] = Lj[2 * r]; lv[r][1] = Lj[2 * r + 1]; }
+            for (int r = 0; r < 4; ++r) { wv[r][0] = Wi[2 * r]; wv[r][1] = Wi[2 * r + 1]; lv[r][0] = Wj[2 * r]; lv[r][1] = Wj[2 * r + 1]; }
+            const d2v ra = Rq[0], rb = Rq[1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { lv[r][0].x *= ra.x; lv[r][0].y *= ra.y; lv[r][1].x *= rb.x; lv[r][1].y *= rb.y; }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -415,7 +486,6 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
                     v = fma(-wv[r][1].y, lv[cc][1].y, v);
                     a4[r][cc] = v;
                 }
-            LPROBE(3);
             if (bi == kb + 1 && bj == kb + 1) {             // publish the next diagonal block
                 d2v* Do = (d2v*)s_D;
 #pragma unroll
@@ -423,47 +493,29 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
             }
         }
     }
-#ifdef AVT_TIMING
-    if (t == 251) { for (int k = 0; k < 5; ++k) fb.trace[(size_t)f * 64 + 56 + k] = (double)lacc[k]; for (int k = 5; k < 8; ++k) fb.trace[(size_t)f * 64 + 32 + k] = (double)lacc[k]; }
-#endif
     __syncthreads();
     TPROBE(3);
     const bool ok = !fail;
     const int ntry = 1 - cur;
     double* xn = x0 + (size_t)ntry * xs;
+    double* s_qnew = s_W;                                   // [4J] quaternions of the new trial point (s_W is free again)
     if (ok) {
-        // ---- back substitution L^T delta = w (w = row P of Lf) by wave 0.  Lane l keeps w[l], w[l+64] and the
-        // running sums acc[l] = sum_{k>i} L[k][l] delta_k in registers; values cross lanes by v_readlane.
+        // ---- back substitution by wave 0 (the other waves wait at the barrier)
         if (t < 64) {
-            if (P == 85) backsub_unrolled<85>(Lblk, NB, t, s_delta);
-            else {
-                auto Lat = [&](int i, int l) { return Lblk[((size_t)(l >> 2) * NB + (i >> 2)) * 18 + (i & 3) * 4 + (l & 3)]; };
-                const double w0 = (t < P) ? Lat(P, t) : 0.0;
-                const double w1 = (t + 64 < P) ? Lat(P, t + 64) : 0.0;
-                double acc0 = 0.0, acc1 = 0.0, dl0 = 0.0, dl1 = 0.0;
-                for (int i = P - 1; i >= 0; --i) {
-                    const double c0 = (t < i) ? Lat(i, t) : 0.0;
-                    const double c1 = (t + 64 < i) ? Lat(i, t + 64) : 0.0;
-                    double di;
-                    if (i < 64) { di = readlane_f64(w0, i) - readlane_f64(acc0, i); if (t == i) dl0 = di; }
-                    else { di = readlane_f64(w1, i - 64) - readlane_f64(acc1, i - 64); if (t == i - 64) dl1 = di; }
-                    acc0 = fma(c0, di, acc0);
-                    acc1 = fma(c1, di, acc1);
-                }
-                if (t < P) s_delta[t] = dl0;
-                if (t + 64 < P) s_delta[t + 64] = dl1;
-            }
+            if (NB == 22) backsub_blocked<22>(Lblk, s_R, NB, P, t, s_delta);
+            else backsub_blocked<0>(Lblk, s_R, NB, P, t, s_delta);
         }
         __syncthreads();
         TPROBE(4);
-        // retraction (FakeQuaternionParameterization::Plus, :123-143)
-        if (t < 3) xn[t] = xc[t] + s_delta[t];
-        if (t < K) xn[3 + 4 * J + t] = xc[3 + 4 * J + t] + s_delta[3 + 3 * J + t];
+        // retraction (FakeQuaternionParameterization::Plus, :123-143): the new trial point goes to global memory for
+        // the kernels that follow and straight into the skeleton scratch
+        if (t < 3) { const double v = xc[t] + s_delta[t]; xn[t] = v; B[L.dv + t] = v; }
+        if (t < K) { const double v = xc[3 + 4 * J + t] + s_delta[3 + 3 * J + t]; xn[3 + 4 * J + t] = v; B[L.w + t] = v; }
         if (t < J) {
             const double* dl = s_delta + 3 + 3 * t;
             const double* q = xc + 3 + 4 * t;
             const double nd = sqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
-            double* qo = xn + 3 + 4 * t;
+            double qo[4];
             if (nd > 0.0) {
                 const double sdd = sin(nd) / nd;
                 const double a0 = sdd * dl[0], a1 = sdd * dl[1], a2 = sdd * dl[2], a3 = cos(nd);
@@ -474,27 +526,34 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
             } else {
                 qo[0] = q[0]; qo[1] = q[1]; qo[2] = q[2]; qo[3] = q[3];
             }
+            quat_to_rot(qo, B + L.rot + 9 * t);
+            double* qn = xn + 3 + 4 * t;
+            double* qs = s_qnew + 4 * t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { qn[e] = qo[e]; qs[e] = qo[e]; }
         }
     } else {
         for (int e = t; e < xs; e += 256) xn[e] = xc[e];
+        for (int e = t; e < 4 * J; e += 256) s_qnew[e] = xc[3 + e];
+        prep_set_state(d, L, B, xc + 3, xc + 3 + 4 * J, xc);
         lambda = fmin(lambda * lm_up, lm_max);
     }
     if (t == 0) { ctl.lambda = lambda; ctl.try_valid = ok ? 1 : 0; }
     __syncthreads();
-    __threadfence_block();
     TPROBE(5);
     // ---- d. skeleton tables of the new trial point ----------------------------------------------------
-    compute_prep(dm, xn, fb.prep + ((size_t)f * 2 + ntry) * d.prep_size, *ps);
+    prep_run(dm, L, B, s_items, s_level, s_qnew, prep0 + (size_t)ntry * d.prep_size);
     TPROBE(6);
 #ifdef AVT_TIMING
     __syncthreads();
-    if (t == 0) { const double* pp = fb.prep + ((size_t)f * 2 + ntry) * d.prep_size; fb.trace[(size_t)f * 64 + 62] = pp[d.prep_size - 1]; fb.trace[(size_t)f * 64 + 63] = pp[d.prep_size - 2]; }
+    if (t == 0) { const double* pp = prep0 + (size_t)ntry * d.prep_size; fb.trace[(size_t)f * 64 + 62] = pp[d.prep_size - 1]; fb.trace[(size_t)f * 64 + 63] = pp[d.prep_size - 2]; }
 #endif
 }
 
 static size_t solve_lds_bytes(const AvtDims& d) {
     const int HS = d.HS, NB = HS / 4;
-    return sizeof(double) * ((size_t)NB * NB * 18 + (size_t)NB * 18 + 18 + HS + 2) + sizeof(PrepScratch) + 64;
+    const PrepLayout L = prep_layout(d.J, d.K, d.xsize);
+    return sizeof(double) * ((size_t)NB * NB * 18 + 2 * (size_t)NB * 18 + 36 + HS + 2 + L.ndoubles) + sizeof(int) * (2 * (size_t)L.nitems + 2 * AVT_MAX_JOINTS + 4) + 64;
 }
 
 void launch_reduce(avt_ctx* c, int nframes) {

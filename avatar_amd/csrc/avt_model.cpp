@@ -64,14 +64,32 @@ extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
     d.nlevels = 1;
     for (int j = 1; j < J; ++j) { m->jlevel[j] = m->jlevel[desc->parent[j]] + 1; d.nlevels = std::max(d.nlevels, m->jlevel[j] + 1); }
     d.HS = 4 * ((d.P + 4) / 4);
-    // per-level work lists for the forward-kinematics / shape-table pass (entries 0..11: 3x3 rotation + origin,
-    // 12..12+3K-1: the joint's accumulated shape table)
-    m->fk_level_off.assign(d.nlevels + 1, 0);
-    for (int L = 0; L < d.nlevels; ++L) {
-        for (int j = 0; j < J; ++j)
-            if (m->jlevel[j] == L)
-                for (int e = 0; e < 12 + 3 * K; ++e) m->fk_items.push_back((j << 8) | e);
-        m->fk_level_off[L + 1] = (int)m->fk_items.size();
+    // per-level work lists for the forward-kinematics / shape-table pass of k_solve (avt_lm.hip): per joint 9 world-rotation
+    // entries, 3 world-origin entries and 3K shape-table entries, each one B[out] = B[rp..rp+2] . B[v, v+st, v+2st] + B[add]
+    {
+        const PrepLayout L = prep_layout(J, K, d.xsize);
+        if (L.ndoubles >= 8192) { delete m; avt_set_error("avt_model_create: skeleton scratch exceeds the 13-bit item offsets"); return 1; }
+        auto item = [&](int rp, int v, int scode, int add, int out) {
+            m->fk_items.push_back(rp | (v << 13) | (scode << 26));
+            m->fk_items.push_back(add | (out << 13));
+        };
+        m->fk_level_off.assign(d.nlevels + 1, 0);
+        for (int lv = 0; lv < d.nlevels; ++lv) {
+            for (int j = 0; j < J; ++j) {
+                if (m->jlevel[j] != lv) continue;
+                const int pa = desc->parent[j];
+                const int Rp = pa < 0 ? L.ident : L.Rw + 9 * pa;       // R(-1, parent): identity above the root
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c) item(Rp + 3 * r, L.rot + 9 * j + c, 2, L.zero, L.Rw + 9 * j + 3 * r + c);
+                for (int r = 0; r < 3; ++r) item(Rp + 3 * r, L.dv + 3 * j, 1, pa < 0 ? L.zero : L.o + 3 * pa + r, L.o + 3 * j + r);
+                for (int r = 0; r < 3; ++r)
+                    for (int k = 0; k < K; ++k) {
+                        if (pa < 0) item(L.ident + 3 * r, L.zero, 0, L.zero, L.H + r * K + k);               // H[root] = 0
+                        else item(Rp + 3 * r, L.Sp + j * 3 * K + k, 3, L.H + pa * 3 * K + r * K + k, L.H + j * 3 * K + r * K + k);
+                    }
+            }
+            m->fk_level_off[lv + 1] = (int)m->fk_items.size() / 2;
+        }
     }
 
     // shape planes
