@@ -66,6 +66,25 @@ def test_model_without_pose_prior(smpl):
     _check(ctx, ref, p, q, w, len(fr["labels"]))
 
 
+def test_model_with_six_shape_keys_runs_the_runtime_dimension_kernels(smpl):
+    """K = 6 (P = 81): k_eval<0,0>, the runtime-sized skeleton pass and LDL^T / back substitution (21 pivot blocks)."""
+    from avatar_amd import api
+    from oracle import oracle as orc
+    m2 = dict(smpl)
+    m2["shapedirs"] = np.ascontiguousarray(smpl["shapedirs"][:, :, :6])
+    gm, om = api.AvatarModel(m2), orc.OracleModel(m2)
+    fr = synth.make_frame(smpl, 17)
+    pm = synth.identity_part_map()
+    w0, p0, R0 = fr["start"]
+    w0 = np.ascontiguousarray(w0[:6]); q0 = api.rot_to_quat(R0)
+    opt = Options.demo()
+    ctx = api.Context(gm, 24, pm, len(fr["labels"]), 1)
+    p, q, w, st = ctx.optimize_batch([fr["data"]], [fr["labels"]], opt, p0[None], q0[None], w0[None])
+    ref = om.optimize(pm, 24, fr["data"], fr["labels"], opt, p0, q0, w0, aggregate=1)
+    _check(ctx, ref, p, q, w, len(fr["labels"]))
+    assert st[0].gn_iterations == ref["stats"].gn_iterations
+
+
 def test_ragged_batch_with_empty_frame_and_determinism(smpl, omodel, gmodel):
     from avatar_amd import api
     pm = synth.identity_part_map()
