@@ -15,7 +15,7 @@ from . import api
 
 class FrameTracker:
     def __init__(self, ava_opt: "api.AvatarOptimizer", interval=12, frame_icp_iters=3, reinit_icp_iters=6, reinit_cnz=1000,
-                 num_threads=4):
+                 num_threads=4, rtree=None, rtree_interval=2, dist_to_pre_weight=0.001):
         self.opt = ava_opt
         self.ava = ava_opt.ava
         self.interval = interval                      # demo.cpp:58  --data-interval
@@ -24,6 +24,10 @@ class FrameTracker:
         self.reinitCnz = reinit_cnz                   # demo.cpp:71  --min-points
         self.num_threads = num_threads
         self.reinit = True                            # demo.cpp:151
+        self.rtree = rtree                            # avatar_amd.rtree.RTree or None (labels supplied by the caller)
+        self.rtreeInterval = rtree_interval           # demo.cpp:198 (predictBest / postProcess interval)
+        self.distToPreWeight = dist_to_pre_weight     # live-demo.cpp:104-108
+        self.comPre = None                            # demo.cpp:148: previous centres of mass for the post-processor
 
     def subsample(self, xyz, part_mask, bbox=None):
         """Every `interval`-th pixel of the bounding box that carries a body-part label (demo.cpp:216-250);
@@ -59,3 +63,18 @@ class FrameTracker:
             icp_iters = self.reinitICPIters
         self.opt.optimize(data, labels, icp_iters, self.num_threads)
         return True
+
+    def label(self, xyz, bbox):
+        """Per-pixel body parts of a foreground XYZ map with the forest (demo.cpp:196-204): predictBest on the GPU at
+        `rtree_interval` inside the bounding box, then postProcess.  bbox = (top, left, bottom, right) inclusive."""
+        if self.rtree is None:
+            raise RuntimeError("FrameTracker.label: no RTree attached")
+        top, left, bottom, right = bbox
+        depth = np.ascontiguousarray(xyz[:, :, 2], np.float32)
+        mask = self.rtree.predictBest(depth, 0, self.rtreeInterval, (left, top), (right, bottom))
+        self.comPre = self.rtree.postProcess(mask, self.comPre, self.rtreeInterval, 1, (left, top), (right, bottom), self.distToPreWeight)
+        return mask
+
+    def process_depth(self, xyz, bbox):
+        """One tracked frame from depth alone: label() then process()."""
+        return self.process(xyz, self.label(xyz, bbox), bbox)

@@ -152,6 +152,55 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
     return res
 
 
+def label_stage(synth, smpl, with_cpu):
+    """SURVEY.md §8 row f4: RTree::predictBest on 1280x720 depth renders exactly as the tracker calls it (interval 2,
+    foreground bounding box, gaps filled; demo.cpp:196-199), 8 resident images per launch, plus the full-resolution walk."""
+    import numpy as np
+    from avatar_amd import rtree, synth_forest
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "forest_small.srtr")
+    tree = rtree.RTree(path)
+    depths, boxes = [], []
+    for s in range(8):
+        w, p, R = synth.sample_ground_truth(smpl, 300 + s)
+        xyz, mask, _ = synth.render_images(smpl, synth.pose_vertices(smpl, w, p, R), synth.identity_part_map())
+        depths.append(synth_forest.depth_of(xyz))
+        rr, cc = np.nonzero(mask != 255)
+        boxes.append(((int(cc.min()), int(rr.min())), (int(cc.max()), int(rr.max()))))
+    D = np.stack(depths)
+    tl = (min(b[0][0] for b in boxes), min(b[0][1] for b in boxes)); br = (max(b[1][0] for b in boxes), max(b[1][1] for b in boxes))
+    tree.upload_images(D)
+    res = {"workload": "8 synthetic 1280x720 depth renders (~30k foreground pixels each), toy tree tests/golden/forest_small.srtr "
+                       f"({len(tree.links)} nodes)", "unit": "images/s"}
+    for name, kw in (("tracker_call_interval2_bbox", dict(interval=2, top_left=tl, bot_right=br)), ("full_image_interval1", dict(interval=1))):
+        for _ in range(3):
+            tree.predict_resident(**kw)
+        tree.sync()
+        t0 = time.perf_counter()
+        reps = 50
+        for _ in range(reps):
+            tree.predict_resident(**kw)
+        tree.sync()
+        dt = time.perf_counter() - t0
+        walked = sum(int((d[kw.get("top_left", (0, 0))[1] + kw["interval"]::kw["interval"], ::kw["interval"]] != 0).sum()) for d in D) \
+            if "top_left" not in kw else sum(int((d[tl[1] + 2:br[1] + 1:2, tl[0]:br[0] + 1:2] != 0).sum()) for d in D)
+        res[name] = {"value": round(8 * reps / dt, 1), "ms_per_launch_of_8": round(dt / reps * 1e3, 4), "tree_walks_per_s": round(walked * reps / dt, 0)}
+    if with_cpu:
+        from oracle import rtree_oracle
+        ot = rtree_oracle.OracleRTree.load(path)
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 2.0:
+            ref = ot.predictBest(D[n % 8], interval=2, top_left=tl, bot_right=br)
+            n += 1
+        cpu = n / (time.perf_counter() - t0)
+        res["cpu_baseline"] = {"value": round(cpu, 1), "unit": "images/s", "cores": 1, "kind": "port",
+                               "sample": f"{n} x predictBest(interval 2, bbox) by the CPU restatement (oracle/rtree_oracle.cpp), 1 thread"}
+        tree.predict_resident(interval=2, top_left=tl, bot_right=br)
+        assert np.array_equal(tree.download_labels((n - 1) % 8), ref), "label stage: GPU labels differ from the oracle"
+        res["labels_bit_exact_vs_oracle"] = True
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,6 +211,7 @@ def main():
     ap.add_argument("--icp-iters", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-throughput-config", action="store_true", help="skip the secondary 64-frames-per-GPU measurement")
+    ap.add_argument("--no-label-stage", action="store_true", help="skip the body-part forest (RTree) stage measurement")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     args = ap.parse_args()
@@ -211,6 +261,10 @@ def main():
                 "workload": "BASELINE configs[2]: 64 independent ~30k-pt frames per GPU, same optimize()", "value": round(r2["value"], 2),
                 "unit": "GN iterations/s", "steps": r2["steps"], "ms_per_step": round(r2["elapsed"] / r2["steps"] * 1e3, 4),
                 "roofline": r2["roofline"], "eval_kernel": r2["eval_kernel"], "kernels": r2["kernels"]}
+        out["frames_per_s"] = round(F * world * args.steps / r["elapsed"], 2)
+        out["icp_iterations_per_s"] = round(F * world * opt.icp_iters * args.steps / r["elapsed"], 2)
+        if F == 1 and not args.dense and not args.no_label_stage:
+            out["label_stage"] = label_stage(synth, smpl, not args.no_cpu_baseline)
         if not args.no_cpu_baseline:
             from oracle import oracle as orc
             om = orc.OracleModel(smpl)
