@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
     double* B = s_delta + HS + 2;                           // skeleton scratch (+ both state slots)
     int2* s_items = (int2*)(B + L.ndoubles);
     int* s_level = (int*)(s_items + L.nitems);
-    __shared__ int s_fail;
+    __shared__ int s_failf[2];
     const int xs = d.xsize;
     double* x0 = fb.x + ((size_t)f * 2) * xs;
     double* prep0 = fb.prep + ((size_t)f * 2) * d.prep_size;
@@ -292,13 +292,15 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
         bi = r0; bj = rem;
     }
     const double* H0 = fb.Hraw + ((size_t)f * 2) * HS * HS;
-    d2v hraw[2][4][2];
+    d2v hraw[2][4][2], hdiag[2][4][2];       // my block, and the diagonal block of my block column
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const d2v* src = (const d2v*)(H0 + (size_t)sl * HS * HS + (size_t)(4 * max(bi, 0) + r) * HS + 4 * max(bj, 0));
             hraw[sl][r][0] = src[0]; hraw[sl][r][1] = src[1];
+            const d2v* srd = (const d2v*)(H0 + (size_t)sl * HS * HS + (size_t)(4 * max(bj, 0) + r) * HS + 4 * max(bj, 0));
+            hdiag[sl][r][0] = srd[0]; hdiag[sl][r][1] = srd[1];
         }
     const double hpp0 = H0[(size_t)P * HS + P], hpp1 = H0[(size_t)HS * HS + (size_t)P * HS + P];
     const int cur0 = ctl.cur_slot, try_valid = ctl.try_valid, comp_cur0 = ctl.comp_cur;
@@ -368,66 +370,72 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
     const double sc2 = sc * sc;
     const double gs = sc * sbp * 0.7071067811865476;    // J^T r = sc*sbp*sqrt(1/2) * Prec (x - mu)
     const double* Pr = dm.prior_prec + (size_t)(comp >= 0 ? comp : 0) * n * n;
-    // (all loads unconditional on clamped indices, the conditions applied as selects: 16 loads in flight, no branches)
-    double a4[4][4];
-    double prv[4][4], gq[4], xq[4];
+    // (all loads unconditional on clamped indices, the conditions applied as selects: loads in flight together, no branches)
+    // assemble(rb, h, out): block (rb, bj) of the bordered system from its raw data-term block h[slot][row][half]
+    double gq[4], xq[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int col = 4 * max(bj, 0) + c, pc = min(max(col - 6, 0), max(n - 1, 0)), sk = min(max(col - (3 + 3 * J), 0), max(K - 1, 0));
         gq[c] = use_pose ? pri[2 + pc] : 0.0;
         xq[c] = xc[3 + 4 * J + sk];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int pr_ = min(max(4 * max(bi, 0) + r - 6, 0), max(n - 1, 0));
-            prv[r][c] = use_pose ? Pr[(size_t)pr_ * n + pc] : 0.0;
-        }
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
+    auto assemble = [&](int rb, const d2v (&h)[2][4][2], double (&out)[4][4]) {
+        double prv[4][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int row = 4 * bi + r, col = 4 * bj + c;
-            const d2v h = cur ? hraw[1][r][c >> 1] : hraw[0][r][c >> 1];
-            double v = (c & 1) ? h.y : h.x;
-            const int pc = col - 6, sk = col - (3 + 3 * J), pr_ = row - 6;
-            const bool in_pose_c = use_pose && pc >= 0 && pc < n;
-            const bool shape_c = sbs > 0.0 && sk >= 0 && col < P;
-            // rows < P: H + priors, diagonal damped
-            double vh = v;
-            vh += (in_pose_c && pr_ >= 0 && pr_ < n) ? sc2 * prv[r][c] : 0.0;
-            if (row == col) { vh += shape_c ? sbs * sbs : 0.0; vh += lambda * vh; }
-            // row P: -(J^T r) including the priors
-            double vg = v;
-            vg += in_pose_c ? gs * gq[c] : 0.0;
-            vg += shape_c ? sbs * (xq[c] * sbs) : 0.0;
-            const bool inside = bi >= 0 && row <= P && col < P;
-            a4[r][c] = inside ? (row < P ? vh : -vg) : ((row == col) ? 1.0 : 0.0);
+            const int pc = min(max(4 * max(bj, 0) + c - 6, 0), max(n - 1, 0));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pr_ = min(max(4 * max(rb, 0) + r - 6, 0), max(n - 1, 0));
+                prv[r][c] = use_pose ? Pr[(size_t)pr_ * n + pc] : 0.0;
+            }
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int row = 4 * rb + r, col = 4 * bj + c;
+                const d2v hv = cur ? h[1][r][c >> 1] : h[0][r][c >> 1];
+                double v = (c & 1) ? hv.y : hv.x;
+                const int pc = col - 6, sk = col - (3 + 3 * J), pr_ = row - 6;
+                const bool in_pose_c = use_pose && pc >= 0 && pc < n;
+                const bool shape_c = sbs > 0.0 && sk >= 0 && col < P;
+                // rows < P: H + priors, diagonal damped
+                double vh = v;
+                vh += (in_pose_c && pr_ >= 0 && pr_ < n) ? sc2 * prv[r][c] : 0.0;
+                if (row == col) { vh += shape_c ? sbs * sbs : 0.0; vh += lambda * vh; }
+                // row P: -(J^T r) including the priors
+                double vg = v;
+                vg += in_pose_c ? gs * gq[c] : 0.0;
+                vg += shape_c ? sbs * (xq[c] * sbs) : 0.0;
+                const bool inside = rb >= 0 && row <= P && col < P;
+                out[r][c] = inside ? (row < P ? vh : -vg) : ((row == col) ? 1.0 : 0.0);
+            }
+    };
+    double a4[4][4], dg[4][4];
+    assemble(bi, hraw, a4);
+    assemble(bj, hdiag, dg);    // private copy of the diagonal block of my column (its lower triangle is what is used)
     TPROBE(2);
 
-    // ---- c. register-blocked LDL^T, four pivots per round, two barriers per round -----------------------------------
-    //  (1) the lanes owning the pivot block column (bj == kb) read the updated diagonal block, factor it
-    //      (D = Ld diag(d) Ld^T) and publish their own block of W = A Ld^-T; the diagonal lane also publishes 1/d;
-    //  (2) every trailing lane (bj > kb) reads W of its row block and of its column block: A -= W_i diag(1/d) W_j^T;
-    //      the owner of the next diagonal block publishes it.
-    // Measured on MI355X (tools/ubench/ldlt.hip): the rounds are bound by LDS traffic and its latency, not by the
-    // FMAs; publishing W only (instead of W and L = W diag(1/d)) halves the panel's wide stores: 2520 -> 2215
-    // clocks per round.  A one-barrier look-ahead variant (panel column rebuilt redundantly) measured slower (2770).
+    // ---- c. register-blocked LDL^T, four pivots and ONE barrier per round ---------------------------------------------
+    //  (1) the lanes owning the pivot block column (bj == kb) factor the diagonal block (D = Ld diag(d) Ld^T) from their
+    //      PRIVATE copy of it and publish their own block of W = A Ld^-T; the diagonal lane also publishes 1/d;
+    //  (2) after the barrier every trailing lane (bj > kb) reads W of its row block and of its column block and
+    //      applies the rank-4 update A -= W_i diag(1/d) W_j^T to its block and to its copy of its column's
+    //      diagonal block (same operands, +40 FMAs, no extra LDS traffic) - so nobody ever publishes or reads a
+    //      diagonal block, and the next round's panel can start without a second barrier.
+    // Measured on MI355X (tools/ubench/ldlt.hip), clocks per round: two barriers + published diagonal + W and L
+    // stored 2520; W only 2215; this scheme 2030.  The rounds are bound by LDS traffic and latency, not by the FMAs.
+    // (A look-ahead variant that rebuilt the diagonal block from a published copy measured slower, 2770.)
     double* s_R = s_W;                                      // [HS] reciprocal pivots
-    if (t == 0) s_fail = 0;
-    if (bi == 0 && bj == 0) {
-        d2v* Do = (d2v*)s_D;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { Do[2 * r] = (d2v){a4[r][0], a4[r][1]}; Do[2 * r + 1] = (d2v){a4[r][2], a4[r][3]}; }
-    }
+    if (t < 2) s_failf[t] = 0;
     bool fail = false;
+    __syncthreads();
     for (int kb = 0; kb < NB; ++kb) {
-        __syncthreads();                                    // B1: diagonal block kb is visible
+        if (kb > 0 && s_failf[(kb - 1) & 1]) { fail = true; break; }
         if (bj == kb) {
-            const d2v* Dq = (const d2v*)s_D;
-            const d2v q0 = Dq[0], q2 = Dq[2], q4 = Dq[4], q5 = Dq[5], q6 = Dq[6], q7 = Dq[7];
-            const double D00 = q0.x, D10 = q2.x;
-            double D11 = q2.y, D20 = q4.x, D21 = q4.y, D22 = q5.x, D30 = q6.x, D31 = q6.y, D32 = q7.x, D33 = q7.y;
+            const double D00 = dg[0][0], D10 = dg[1][0];
+            double D11 = dg[1][1], D20 = dg[2][0], D21 = dg[2][1], D22 = dg[2][2], D30 = dg[3][0], D31 = dg[3][1], D32 = dg[3][2], D33 = dg[3][3];
             const bool real1 = 4 * kb + 1 < P, real2 = 4 * kb + 2 < P, real3 = 4 * kb + 3 < P;   // 4*kb < P always
             const double P0 = D00;
             const double r0 = fast_rcp(D00);
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
             const double P3 = D33;
             const double r3 = fast_rcp(D33);
             const int bad = (int)!(P0 > 0.0) | ((int)real1 & (int)!(P1 > 0.0)) | ((int)real2 & (int)!(P2 > 0.0)) | ((int)real3 & (int)!(P3 > 0.0));
-            if (bad) s_fail = 1;
+            if (bad) s_failf[kb & 1] = 1;
             d2v* Wo = (d2v*)(Lblk + ((size_t)kb * NB + bi) * 18);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -454,27 +462,26 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
                 const double w2 = fma(-w1, l21, fma(-w0, l20, a4[r][2]));
                 const double w3 = fma(-w2, l32, fma(-w1, l31, fma(-w0, l30, a4[r][3])));
                 // (the diagonal block keeps its strictly lower part only: nobody but the back substitution reads it)
-                const bool dg = bi == kb;
-                Wo[2 * r] = (d2v){(dg && r < 1) ? 0.0 : w0, (dg && r < 2) ? 0.0 : w1};
-                Wo[2 * r + 1] = (d2v){(dg && r < 3) ? 0.0 : w2, dg ? 0.0 : w3};
+                const bool dgb = bi == kb;
+                Wo[2 * r] = (d2v){(dgb && r < 1) ? 0.0 : w0, (dgb && r < 2) ? 0.0 : w1};
+                Wo[2 * r + 1] = (d2v){(dgb && r < 3) ? 0.0 : w2, dgb ? 0.0 : w3};
             }
             if (bi == kb) {   // reciprocal pivots; 0 for the rhs / padding rows (only the back substitution reads those)
                 d2v* Ro = (d2v*)(s_R + 4 * kb);
                 Ro[0] = (d2v){r0, real1 ? r1 : 0.0}; Ro[1] = (d2v){real2 ? r2 : 0.0, real3 ? r3 : 0.0};
             }
         }
-        __syncthreads();                                    // B2: W and 1/d of pivot block kb are visible
-        if (s_fail) { fail = true; break; }
+        __syncthreads();                                    // W and 1/d of pivot block kb are visible
         if (bj > kb) {
             const d2v* Wi = (const d2v*)(Lblk + ((size_t)kb * NB + bi) * 18);
             const d2v* Wj = (const d2v*)(Lblk + ((size_t)kb * NB + bj) * 18);
             const d2v* Rq = (const d2v*)(s_R + 4 * kb);
-            d2v wv[4][2], lv[4][2];
+            d2v wv[4][2], wj[4][2], lv[4][2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { wv[r][0] = Wi[2 * r]; wv[r][1] = Wi[2 * r + 1]; lv[r][0] = Wj[2 * r]; lv[r][1] = Wj[2 * r + 1]; }
+            for (int r = 0; r < 4; ++r) { wv[r][0] = Wi[2 * r]; wv[r][1] = Wi[2 * r + 1]; wj[r][0] = Wj[2 * r]; wj[r][1] = Wj[2 * r + 1]; }
             const d2v ra = Rq[0], rb = Rq[1];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { lv[r][0].x *= ra.x; lv[r][0].y *= ra.y; lv[r][1].x *= rb.x; lv[r][1].y *= rb.y; }
+            for (int r = 0; r < 4; ++r) { lv[r][0].x = wj[r][0].x * ra.x; lv[r][0].y = wj[r][0].y * ra.y; lv[r][1].x = wj[r][1].x * rb.x; lv[r][1].y = wj[r][1].y * rb.y; }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -486,13 +493,20 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
                     v = fma(-wv[r][1].y, lv[cc][1].y, v);
                     a4[r][cc] = v;
                 }
-            if (bi == kb + 1 && bj == kb + 1) {             // publish the next diagonal block
-                d2v* Do = (d2v*)s_D;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { Do[2 * r] = (d2v){a4[r][0], a4[r][1]}; Do[2 * r + 1] = (d2v){a4[r][2], a4[r][3]}; }
-            }
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int cc = 0; cc <= r; ++cc) {
+                    double v = dg[r][cc];
+                    v = fma(-wj[r][0].x, lv[cc][0].x, v);
+                    v = fma(-wj[r][0].y, lv[cc][0].y, v);
+                    v = fma(-wj[r][1].x, lv[cc][1].x, v);
+                    v = fma(-wj[r][1].y, lv[cc][1].y, v);
+                    dg[r][cc] = v;
+                }
         }
     }
+    if (!fail && s_failf[(NB - 1) & 1]) fail = true;
     __syncthreads();
     TPROBE(3);
     const bool ok = !fail;
