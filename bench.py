@@ -36,8 +36,7 @@ def algorithmic_bytes_per_gn_iter(N, V, K, P):
 
 
 PMC_FILES = {1: "profiles/r01_pmc_single_frame.json", 64: "profiles/r01_pmc_64_frames.json"}
-KERNEL_SYMBOL = {"eval": "_Z6k_evalILi6EEv11DeviceModel12FrameBuffers.kd", "solve": "_Z7k_solve11DeviceModel12FrameBuffersidddd.kd",
-                 "reduce": "_Z8k_reduce11DeviceModel12FrameBuffers.kd", "nn": "_Z4k_nn11DeviceModel12FrameBuffers.kd"}
+KERNEL_SYMBOL = {"eval": "k_evalILi24ELi10", "solve": "k_solve", "reduce": "k_reduce", "nn": "k_nnILi"}   # mangled-name fragments
 
 
 def pmc_traffic(frames, kernel_class):
@@ -46,7 +45,8 @@ def pmc_traffic(frames, kernel_class):
     path = os.path.join(ROOT, PMC_FILES.get(frames, ""))
     try:
         d = json.load(open(path))
-        return int(d["kernels"][KERNEL_SYMBOL[kernel_class]]["hbm_bytes"])
+        hit = [v for k, v in d["kernels"].items() if KERNEL_SYMBOL[kernel_class] in k]
+        return int(hit[0]["hbm_bytes"])
     except Exception:
         return None
 
