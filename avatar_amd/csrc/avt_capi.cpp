@@ -197,8 +197,7 @@ int upload_state(avt_ctx* c, int nframes, const double* p, const double* q, cons
         std::copy(w + (size_t)d.K * f, w + (size_t)d.K * (f + 1), x + 3 + 4 * d.J);
         std::memset(&ctl[f], 0, sizeof(AvtFrameCtl));
         ctl[f].N = c->frame_N[f];
-        ctl[f].data_off = c->frame_off[f];
-        ctl[f].comp_cur = ctl[f].comp_try = -1;
+        ctl[f].comp_cur = -1;
     }
     HIP_OK(hipMemcpyAsync(c->fb.x, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipMemcpyAsync(c->fb.ctl, ctl.data(), ctl.size() * sizeof(AvtFrameCtl), hipMemcpyHostToDevice, c->stream));
@@ -287,10 +286,10 @@ int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* par
     }
     if (dev_upload(c, &dm.shape_planes, m->shape_planes) || dev_upload(c, &dm.lbs_w, m->lbs_w) || dev_upload(c, &dm.lbs_j, m->lbs_j) ||
         dev_upload(c, &dm.asg_w, m->asg_w) || dev_upload(c, &dm.asg_j, m->asg_j) || dev_upload(c, &dm.anc_n, m->anc_n) ||
-        dev_upload(c, &dm.anc, m->anc) || dev_upload(c, &dm.mesh, m->mesh_soa) || dev_upload(c, &dm.parent, m->parent) || dev_upload(c, &dm.jlevel, m->jlevel) || dev_upload(c, &dm.fk_items, m->fk_items) || dev_upload(c, &dm.fk_level_off, m->fk_level_off) ||
+        dev_upload(c, &dm.anc, m->anc) || dev_upload(c, &dm.mesh, m->mesh_soa) || dev_upload(c, &dm.parent, m->parent) || dev_upload(c, &dm.fk_items, m->fk_items) || dev_upload(c, &dm.fk_level_off, m->fk_level_off) ||
         dev_upload(c, &dm.jsr_base, m->jsr_base) || dev_upload(c, &dm.jsr, m->jsr) || dev_upload(c, &dm.S, m->S) ||
         dev_upload(c, &dm.Sp, m->Sp) || dev_upload(c, &dm.prior_mean, m->prior_mean) || dev_upload(c, &dm.prior_prec, m->prior_prec) ||
-        dev_upload(c, &dm.prior_L, m->prior_L) || dev_upload(c, &dm.prior_clog, m->prior_clog) || dev_upload(c, &dm.part_of_vertex, pov) ||
+        dev_upload(c, &dm.prior_clog, m->prior_clog) || dev_upload(c, &dm.part_of_vertex, pov) ||
         dev_upload(c, &dm.part_start, pstart) || dev_upload(c, &dm.part_vertices, pverts) || dev_upload(c, &dm.part_pos, ppos))
         return 1;
     FrameBuffers& fb = c->fb;

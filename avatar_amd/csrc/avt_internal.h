@@ -84,7 +84,6 @@ __host__ __device__ inline PrepLayout prep_layout(int J, int K, int xsize) {
 struct AvtFrameCtl {
     double lambda;
     double cost_cur;          // objective of the current state (data part uses centred form + cost_const)
-    double cost_try;
     double cost_const;        // 0.5 * sum_i |d_i - dbar_m(i)|^2 for the current correspondences
     double cost_initial;
     double sbp, sbs;          // scaledBetaPose / scaledBetaShape (AvatarOptimizer.cpp:1457-1458)
@@ -95,9 +94,8 @@ struct AvtFrameCtl {
     int T;                    // total correspondences
     int gn_iterations;
     int accepted;
-    int comp_cur, comp_try;   // GMM component chosen at cur / try
+    int comp_cur;             // GMM component chosen at the current point
     int N;                    // data points of this frame
-    int data_off;             // offset of this frame's points in the packed data arrays
     int pad[2];
 };
 
@@ -116,7 +114,6 @@ struct DeviceModel {
     unsigned short* anc;  // [AVT_ANC_MAX][V]
     int* mesh;            // [3][F] SoA
     int* parent;          // [J]
-    int* jlevel;          // [J] tree level of each joint (root = 0)
     int* fk_items;        // [J*(12+3K)][2] per-level work items of k_solve's skeleton pass (see avt_lm.hip), grouped by level
     int* fk_level_off;    // [nlevels+1] offsets into fk_items
     double* jsr_base;     // [3J] initialJointPos
@@ -126,7 +123,6 @@ struct DeviceModel {
     // GMM
     double* prior_mean;   // [C][n]
     double* prior_prec;   // [C][n][n] precision = L L^T
-    double* prior_L;      // [C][n][n] lower Cholesky of the precision
     double* prior_clog;   // [C]
     // part structure (context-level, depends on part_map)
     int* part_of_vertex;  // [V]
