@@ -116,32 +116,47 @@ __device__ void prep_run(const DeviceModel& dm, const PrepLayout& L, double* __r
 }
 
 // =================================================================================================
-// k_reduce.  grid (NPAIR, nframes), block 256.
-//   Hraw[f][try][r][c] = sum_g partial[f][g][pair][e], g ascending (deterministic); the tile is written to both
-//   triangles of the dense (HS x HS) symmetric block; row/column P carry J^T r and sum c|r|^2.
-//   (The GMM pose prior of the trial point is evaluated by extra workgroups of k_eval, avt_prior.h.)
+// k_reduce<Q>.  grid (NPAIR, nframes), block Q x 256 tile elements; Q = 4 quarters when a frame has >= 64 partial
+// tiles per pair (few frames), Q = 1 for frame batches (few partials each, many workgroups).
+//   Hraw[f][try][r][c] = sum_g partial[f][g][pair][e] in a fixed order (deterministic): quarter q sums its
+//   contiguous range of workgroups g in ascending order with up to 32 loads in flight (the kernel is a chain of
+//   L2 round trips, so what counts is how few rounds it takes), the four quarter sums are added in order 0..3.
+//   The tile is written to both triangles of the dense (HS x HS) symmetric block; row/column P carry J^T r and
+//   sum c|r|^2.  (The GMM pose prior of the trial point is evaluated by extra workgroups of k_eval, avt_prior.h.)
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_reduce(DeviceModel dm, FrameBuffers fb) {
+template <int Q>
+__global__ __launch_bounds__(256 * Q) void k_reduce(DeviceModel dm, FrameBuffers fb) {
     const AvtDims d = dm.d;
-    const int f = blockIdx.y + fb.f0, t = threadIdx.x, NPAIR = d.NPAIR, NT = d.NT, P = d.P, HS = d.HS;
+    const int f = blockIdx.y + fb.f0, t = threadIdx.x & 255, q = threadIdx.x >> 8, NPAIR = d.NPAIR, NT = d.NT, P = d.P, HS = d.HS;
+    const int G = fb.G, glo = (G * q) / Q, ghi = (G * (q + 1)) / Q;
+    const double* part = fb.partial + ((size_t)f * G * NPAIR + blockIdx.x) * 256 + t;
+    const size_t st = (size_t)NPAIR * 256;
+    // the partial tiles do not depend on the control block: request them first
+    double a = 0.0;
+    int g = glo;
+#define AVT_REDUCE_ROUND(NLD)                                                                        \
+    for (; g + NLD <= ghi; g += NLD) {                                                                \
+        double v[NLD];                                                                               \
+        _Pragma("unroll") for (int u = 0; u < NLD; ++u) v[u] = __builtin_nontemporal_load(part + (size_t)(g + u) * st); \
+        _Pragma("unroll") for (int u = 0; u < NLD; ++u) a += v[u];                                    \
+    }
+    if constexpr (Q > 1) { AVT_REDUCE_ROUND(32) }      // (the batch variant stays at 16 loads in flight: fewer registers, it co-runs with k_eval)
+    AVT_REDUCE_ROUND(16) AVT_REDUCE_ROUND(8) AVT_REDUCE_ROUND(4) AVT_REDUCE_ROUND(1)
+#undef AVT_REDUCE_ROUND
     const int try_slot = 1 - fb.ctl[f].cur_slot;
-    {
+    __shared__ double s_q[Q > 1 ? Q - 1 : 1][256];
+    if constexpr (Q > 1) {
+        if (q > 0) s_q[q - 1][t] = a;
+        __syncthreads();
+    }
+    if (q == 0) {
+        if constexpr (Q > 1) {
+#pragma unroll
+            for (int i = 0; i < Q - 1; ++i) a += s_q[i][t];
+        }
         int p = blockIdx.x, ti = 0;
         while (p >= NT - ti) { p -= NT - ti; ++ti; }
         const int tj = ti + p;
-        const double* part = fb.partial + ((size_t)f * fb.G * NPAIR + blockIdx.x) * 256 + t;
-        // 16 independent loads in flight per lane, summed in ascending g (same order as a plain loop)
-        const size_t st = (size_t)NPAIR * 256;
-        double a = 0.0;
-        int g = 0;
-        for (; g + 16 <= fb.G; g += 16) {
-            double v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = __builtin_nontemporal_load(part + (size_t)(g + u) * st);
-#pragma unroll
-            for (int u = 0; u < 16; ++u) a += v[u];
-        }
-        for (; g < fb.G; ++g) a += part[(size_t)g * st];
         const int r = ti * 16 + ((t >> 4) & 3) + 4 * (t >> 6), c = tj * 16 + (t & 15);
         if (r <= P && c <= P) {
             double* H = fb.Hraw + ((size_t)f * 2 + try_slot) * HS * HS;
@@ -572,7 +587,8 @@ static size_t solve_lds_bytes(const AvtDims& d) {
 
 void launch_reduce(avt_ctx* c, int nframes) {
     const AvtDims& d = c->dm.d;
-    hipLaunchKernelGGL(k_reduce, dim3(d.NPAIR, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
+    if (c->fb.G >= 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<4>), dim3(d.NPAIR, nframes), dim3(1024), 0, c->cur_stream, c->dm, c->fb);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<1>), dim3(d.NPAIR, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
 }
 
 void launch_solve(avt_ctx* c, int nframes, int mode, const avt_options* o) {
