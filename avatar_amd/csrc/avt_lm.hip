@@ -7,9 +7,10 @@
 //              (PrepareForEvaluation, :283-325).  The whole inner loop runs without host synchronisation.
 //
 // Everything in k_solve is latency-bound (an 85-long pivot chain), so it is organised around the dependency
-// chain: no divide / sqrt on the chain (v_rcp_f64 + cubic Newton), one barrier per 4 pivots, the diagonal 4x4
-// block factored redundantly by every lane instead of being published, back-substitution by cross-lane
-// v_readlane instead of LDS round trips, and no global load inside any sequential loop.
+// chain: one global round trip for all inputs, no divide / sqrt on the chain (v_rcp_f64 + cubic Newton), one barrier
+// per 4 pivots, every lane keeps its own copy of its column's diagonal block instead of reading a published one,
+// back-substitution four unknowns at a time with cross-lane v_readlane, the skeleton pass from LDS only, and no global
+// load inside any sequential loop.  -DAVT_TIMING adds s_memtime probes (tools/kernel_timing_probe.py).
 #include "avt_device.h"
 
 #ifdef AVT_TIMING

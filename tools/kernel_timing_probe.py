@@ -16,12 +16,9 @@ lib=capi.load_library(); buf=np.zeros(64)
 lib.avt_debug_trace(ctx.h,0,buf.ctypes.data_as(C.POINTER(C.c_double)))
 names=['barrier(top)','rec->LDS+zero','xhat+xk+T','jac+shape','barrier(mid)','mfma(last batch)+tail']
 t=buf[48:54]; print('F',F,'eval block0 cycles per phase:'); [print('  %-14s %10.0f  %5.1f%%'%(n,v,100*v/t.sum())) for n,v in zip(names,t)]; print('  total',t.sum(), 'cycles; wall (100 MHz counter) %.2f us -> shader clock %.2f GHz' % (buf[54]/100.0, t.sum()/(buf[54]*10.0)))
-s=buf[40:47]; print('solve probes deltas', np.diff(s))
+s=np.diff(buf[41:47]); print('k_solve cycles: system assembly %.0f | LDL^T %.0f | back substitution %.0f | retraction %.0f | skeleton pass %.0f' % tuple(s))
 
-l=buf[56:61]; print('LDLT wave3 cycles: barrier %.0f | rank-4 update %.0f | panel column %.0f | (sum %.0f over 22 rounds)'%(l[0],l[1],l[2],l[:3].sum()))
 
-r=buf[8:30]; print('per-round cycles (thread 251):', np.diff(r).astype(int))
 
 # compute_prep internal probes live in the last two doubles of the prep block of the try slot (AVT_TIMING builds)
 print('compute_prep: loads+barrier %.0f | level loop %.0f | outputs %.0f cycles' % (buf[62]-buf[45], buf[63]-buf[62], buf[46]-buf[63]))
-print('panel column, diagonal owner, summed over the rounds: reads + diagonal update %.0f | 4x4 factor %.0f | W/L + LDS writes %.0f' % (buf[37], buf[38], buf[39]))
