@@ -263,6 +263,13 @@ class Context:
         _check(self._lib.avt_get_cloud(self.h, C.c_int(frame), dptr(out)))
         return out
 
+    def posed(self, frame=0):
+        """(cloud (V,3), jointPos (J,3), jointTrans (J,12)) left by the update() that ends optimize()."""
+        m = self.model
+        cloud = np.empty((m.numPoints(), 3)); jp = np.empty((m.numJoints(), 3)); jt = np.empty((m.numJoints(), 12))
+        _check(self._lib.avt_get_posed(self.h, C.c_int(frame), dptr(cloud), dptr(jp), dptr(jt)))
+        return cloud, jp, jt
+
     def normal_equations(self, frame=0):
         P = self.model.arrays.P
         H = np.empty((P, P)); g = np.empty(P); cost = C.c_double()
@@ -330,5 +337,5 @@ class AvatarOptimizer:
                                               ava.p[None], self.r[None], ava.w[None])
         ava.p, self.r, ava.w = p[0], q[0], w[0]
         ava.r = quat_to_rot(self.r)                                              # :1494-1496
-        ava.update()                                                             # :1497
+        ava.cloud, ava.jointPos, ava.jointTrans = self.ctx.posed(0)              # :1497 (the update() the launch sequence ended with)
         self.last_stats = st[0]

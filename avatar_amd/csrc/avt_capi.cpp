@@ -525,6 +525,17 @@ int avt_get_cloud(avt_ctx* c, int frame, double* cloud) {
     return 0;
 }
 
+int avt_get_posed(avt_ctx* c, int frame, double* cloud, double* joint_pos, double* joint_trans) {
+    if (!c || frame < 0 || frame >= c->fb.max_frames) { avt_set_error("avt_get_posed: bad argument"); return 1; }
+    const AvtDims& d = c->dm.d;
+    HIP_OK(hipSetDevice(c->device));
+    if (cloud) HIP_OK(hipMemcpyAsync(cloud, c->fb.cloud + (size_t)frame * 3 * d.V, (size_t)3 * d.V * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (joint_pos) HIP_OK(hipMemcpyAsync(joint_pos, c->fb.jointpos + (size_t)frame * 3 * d.J, (size_t)3 * d.J * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (joint_trans) HIP_OK(hipMemcpyAsync(joint_trans, c->fb.jointtrans + (size_t)frame * 12 * d.J, (size_t)12 * d.J * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int avt_get_normal_equations(avt_ctx* c, int frame, double* H, double* g, double* cost) {
     if (!c || frame < 0 || frame >= c->nframes) { avt_set_error("avt_get_normal_equations: bad argument"); return 1; }
     const AvtDims& d = c->dm.d;

@@ -39,7 +39,11 @@ class AvatarOptimizer {
             for (int c = 0; c < 4; ++c) r[i].c[c] = q[4 * i + c];
             ava.r[i] = quaternionToRotation(r[i]);                               // :1494-1496
         }
-        ava.update();                                                            // :1497
+        // :1497 ava.update(): the launch sequence ended with exactly that update; fetch its outputs
+        ava.cloud.resize(3, ava.model.numPoints());
+        ava.jointPos.resize(3, J);
+        ava.jointTrans.resize(12, J);
+        ARK_AVT_CHECK(avt_get_posed(ctx, 0, ava.cloud.data(), ava.jointPos.data(), ava.jointTrans.data()));
     }
 
     /** Rotation representation size */

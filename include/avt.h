@@ -162,6 +162,10 @@ int avt_frames_download(avt_ctx* c, int frame, double* data_3xN, int* labels);
 /* ---- introspection of the last optimize call (tests / diagnostics) */
 int avt_get_correspondences(avt_ctx* c, int frame, int* model_idx_out /* N of that frame */);
 int avt_get_cloud(avt_ctx* c, int frame, double* cloud_3xV);       /* ava.cloud after the final update() */
+/* ava.cloud, ava.jointPos (3 x J) and ava.jointTrans (12 x J) as the update() that ends optimize() left them
+ * (AvatarOptimizer.cpp:1494-1497, Avatar.cpp:22-75): a caller refreshes its Avatar from these instead of running
+ * update() a second time.  Any pointer may be NULL. */
+int avt_get_posed(avt_ctx* c, int frame, double* cloud_3xV, double* joint_pos_3xJ, double* joint_trans_12xJ);
 /* data-term Gauss-Newton normal equations J^T J (P x P) and J^T r (P) at the current point + its objective */
 int avt_get_normal_equations(avt_ctx* c, int frame, double* H /* P x P */, double* g /* P */, double* cost);
 
