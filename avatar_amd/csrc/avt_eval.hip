@@ -95,6 +95,118 @@ void launch_records(avt_ctx* c, int nframes) {
     hipLaunchKernelGGL(k_records, dim3(c->dm.d.nb_max, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
 }
 
+// What a wave needs to turn the records of its 4 points into rows of the tile: the skeleton tables staged in LDS
+struct EvalTables {
+    const double *Rw, *oo, *Jh, *Gm, *ww, *off, *ident;
+};
+
+// One wave, 4 points x 16 slots (after stage_records put the wave's records in LDS): my 12 rows of the tile zeroed, shaped rest position,
+// the <= 4 carried points x_k, then one lane per (point, ancestor) writes the rotation block; shape block, residual
+// column and translation block follow.  Everything is wave-local (LDS operations of one wave execute in order), so the
+// caller needs no workgroup barrier around it.  qw = the wave's point quad (rows 12*qw..12*qw+11 of the tile), R = the
+// wave's record region, s_xhat / s_xk / s_T = scratch of the 16 points this wave's workgroup (or producer group) builds.
+template <int NPF>
+__device__ __forceinline__ void stage_records(double* __restrict__ Rrec, int RQ2, int ln, const d2v (&pf)[NPF]) {
+    d2v* R2 = (d2v*)Rrec;
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+        const int idx = ln + 64 * i;
+        if (idx < RQ2) R2[idx] = pf[i];
+    }
+}
+
+template <int CJ, int CK>
+__device__ __forceinline__ void build_rows(const AvtDims& d, const EvalTables& T, double* __restrict__ s_Jt, const double* __restrict__ Rrec,
+                                           double* __restrict__ s_xhat, double* __restrict__ s_xk, double* __restrict__ s_T, int qw, int ln) {
+    constexpr bool FIXED = CJ != 0;
+    constexpr int RS = AVT_EVAL_RS;
+    const int J = FIXED ? CJ : d.J, K = FIXED ? CK : d.K, P = 3 + 3 * J + K, NC = P + 1;
+    const int ND = 3 * K + 11;
+    const int p4 = ln >> 4, slot = ln & 15, pi = qw * 4 + p4;
+    const double *Rw = T.Rw, *oo = T.oo, *Jh = T.Jh, *Gm = T.Gm, *ww = T.ww, *off = T.off;
+    if (ln < 48) {   // zero my wave's 12 rows of every column: 8 columns x 6 double2 per pass
+        d2v* z = (d2v*)(s_Jt + (size_t)(ln / 6) * RS + qw * 12 + 2 * (ln % 6));
+#pragma unroll
+        for (int pass = 0; pass < 2 * AVT_MAX_TILES; ++pass)
+            if (8 * pass + ln / 6 < NC) z[pass * 4 * RS] = (d2v){0.0, 0.0};
+    }
+    wave_sync();
+    const double* R = Rrec;
+    const int* RI = (const int*)(R + ND * 4);
+    if (slot < 3) {   // shaped rest position, root-subtracted (CalcShape, :249-272)
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < (FIXED ? CK : AVT_MAX_SHAPE); ++k)
+            if (k < K) a += R[(3 * k + slot) * 4 + p4] * ww[k];
+        s_xhat[pi * 3 + slot] = (a + R[(3 * K + slot) * 4 + p4]) - off[slot];
+    }
+    wave_sync();
+    const double sc = R[(3 * K + 6) * 4 + p4];
+    double aw[4];
+    int aj[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { aw[a] = R[(3 * K + 7 + a) * 4 + p4]; aj[a] = RI[a * 4 + p4]; }
+    // x_k = R(-1,k)(x^ - J^_k) + t(-1,k) for the <=4 assigned joints (:508-514); blended rotation T = sum a_k Rw_k
+    if (slot < 4) {
+        const int k = aj[slot];
+        const double* Rk = Rw + 9 * k;
+        const double e0 = s_xhat[pi * 3] - Jh[3 * k], e1 = s_xhat[pi * 3 + 1] - Jh[3 * k + 1], e2 = s_xhat[pi * 3 + 2] - Jh[3 * k + 2];
+        double* xk = s_xk + (pi * 4 + slot) * 3;
+        xk[0] = (Rk[0] * e0 + Rk[1] * e1 + Rk[2] * e2) + oo[3 * k];
+        xk[1] = (Rk[3] * e0 + Rk[4] * e1 + Rk[5] * e2) + oo[3 * k + 1];
+        xk[2] = (Rk[6] * e0 + Rk[7] * e1 + Rk[8] * e2) + oo[3 * k + 2];
+    } else if (slot < 13) {
+        const int e9 = slot - 4;
+        s_T[pi * 9 + e9] = ((aw[0] * Rw[9 * aj[0] + e9] + aw[1] * Rw[9 * aj[1] + e9]) + aw[2] * Rw[9 * aj[2] + e9]) + aw[3] * Rw[9 * aj[3] + e9];
+    }
+    wave_sync();
+    const double* xk = s_xk + pi * 12;
+    const int aword = RI[(4 + slot) * 4 + p4];
+    if (aword != 0) {   // rotation block of ancestor j: -2 sqrt(c) [l_j]_x R(-1,parent j)
+        const int j = aword & 0xff;
+        const unsigned mask = ((unsigned)aword >> 8) & 0xffu;
+        double X0 = 0.0, X1 = 0.0, X2 = 0.0, cj = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            if (mask & (1u << a)) {
+                X0 += aw[a] * xk[3 * a]; X1 += aw[a] * xk[3 * a + 1]; X2 += aw[a] * xk[3 * a + 2];
+                cj += aw[a];
+            }
+        const double m2 = -2.0 * sc;
+        const double L0 = m2 * (X0 - cj * oo[3 * j]), L1 = m2 * (X1 - cj * oo[3 * j + 1]), L2 = m2 * (X2 - cj * oo[3 * j + 2]);
+        const int pj = (aword >> 16) & 0xff;
+        const double* Rp = pj ? Rw + 9 * (pj - 1) : T.ident;
+        double* o0 = s_Jt + (size_t)(3 + 3 * j) * RS + pi * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            o0[c * RS] = L1 * Rp[6 + c] - L2 * Rp[3 + c];
+            o0[c * RS + 1] = L2 * Rp[c] - L0 * Rp[6 + c];
+            o0[c * RS + 2] = L0 * Rp[3 + c] - L1 * Rp[c];
+        }
+    }
+    // shape block (:568-580): (sum a_k Rw_k) D_k + sum a_k G_k
+#pragma unroll
+    for (int it = 0; it < (3 * (FIXED ? CK : AVT_MAX_SHAPE) + 15) / 16; ++it) {
+        const int e = slot + 16 * it;
+        if (e < 3 * K) {
+            const int r = e / K, k = e - r * K;
+            const double* Tr = s_T + pi * 9 + 3 * r;
+            const double gs = ((aw[0] * Gm[aj[0] * 3 * K + e] + aw[1] * Gm[aj[1] * 3 * K + e]) + aw[2] * Gm[aj[2] * 3 * K + e]) + aw[3] * Gm[aj[3] * 3 * K + e];
+            const double a = (Tr[0] * R[(3 * k) * 4 + p4] + Tr[1] * R[(3 * k + 1) * 4 + p4] + Tr[2] * R[(3 * k + 2) * 4 + p4]) + gs;
+            s_Jt[(size_t)(3 + 3 * J + k) * RS + pi * 3 + r] = sc * a;
+        }
+    }
+    if (slot < 3) {          // residual column: sqrt(c) (x_m - dbar_m)
+        double xm = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) xm += aw[a] * xk[3 * a + slot];
+        s_Jt[(size_t)P * RS + pi * 3 + slot] = sc * (xm - R[(3 * K + 3 + slot) * 4 + p4]);
+    } else if (slot < 6) {   // identity root-translation block (:476-481)
+        const int r = slot - 3;
+        s_Jt[(size_t)r * RS + pi * 3 + r] = sc;
+    }
+}
+
 // upper-triangular tile pairs of the 6x6 tile grid, in the order k_reduce / k_solve decode them
 __device__ constexpr int PAIR6_TI[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
 __device__ constexpr int PAIR6_TJ[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
@@ -204,6 +316,7 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm,
     const double* Gm = s_prep + 15 * J;
     const double* ww = s_prep + npre;
     const double* off = ww + K;
+    const EvalTables tabs{Rw, oo, Jh, Gm, ww, off, s_ident};
 
     // generic shapes: static round-robin deal of whole tile pairs to the waves
     int pr_ti[MAXPW], pr_tj[MAXPW];
@@ -224,102 +337,13 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm,
 #ifdef AVT_TIMING
     long long tacc[6] = {0, 0, 0, 0, 0, 0}; long long tlast = clock64(); const long long wall0 = wall_clock64();
 #endif
-    const double* R = s_rec + (size_t)wv * RQ;
-    const int* RI = (const int*)(R + ND * 4);
     for (int b = g; b < nb; b += G) {
         __syncthreads();  // previous batch's MFMA reads are done (also covers the prep staging on the first pass)
         EPROBE(0);
         // ---- wave-local from here to the next barrier ------------------------------------------------------
-        {
-            d2v* R2 = (d2v*)(s_rec + (size_t)wv * RQ);
-#pragma unroll
-            for (int i = 0; i < NPF; ++i) {
-                const int idx = ln + 64 * i;
-                if (idx < RQ2) R2[idx] = pf[i];
-            }
-        }
+        stage_records<NPF>(s_rec + (size_t)wv * RQ, RQ2, ln, pf);
         if (b + G < nb) prefetch(b + G);
-        if (ln < 48) {   // zero my wave's 12 rows of every column: 8 columns x 6 double2 per pass
-            d2v* z = (d2v*)(s_Jt + (size_t)(ln / 6) * RS + wv * 12 + 2 * (ln % 6));
-#pragma unroll
-            for (int pass = 0; pass < 2 * AVT_MAX_TILES; ++pass)
-                if (8 * pass + ln / 6 < NC) z[pass * 4 * RS] = (d2v){0.0, 0.0};
-        }
-        wave_sync();
-        EPROBE(1);
-        if (slot < 3) {   // shaped rest position, root-subtracted (CalcShape, :249-272)
-            double a = 0.0;
-#pragma unroll
-            for (int k = 0; k < (FIXED ? CK : AVT_MAX_SHAPE); ++k)
-                if (k < K) a += R[(3 * k + slot) * 4 + p4] * ww[k];
-            s_xhat[pi * 3 + slot] = (a + R[(3 * K + slot) * 4 + p4]) - off[slot];
-        }
-        wave_sync();
-        const double sc = R[(3 * K + 6) * 4 + p4];
-        double aw[4];
-        int aj[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) { aw[a] = R[(3 * K + 7 + a) * 4 + p4]; aj[a] = RI[a * 4 + p4]; }
-        // x_k = R(-1,k)(x^ - J^_k) + t(-1,k) for the <=4 assigned joints (:508-514); blended rotation T = sum a_k Rw_k
-        if (slot < 4) {
-            const int k = aj[slot];
-            const double* Rk = Rw + 9 * k;
-            const double e0 = s_xhat[pi * 3] - Jh[3 * k], e1 = s_xhat[pi * 3 + 1] - Jh[3 * k + 1], e2 = s_xhat[pi * 3 + 2] - Jh[3 * k + 2];
-            double* xk = s_xk + (pi * 4 + slot) * 3;
-            xk[0] = (Rk[0] * e0 + Rk[1] * e1 + Rk[2] * e2) + oo[3 * k];
-            xk[1] = (Rk[3] * e0 + Rk[4] * e1 + Rk[5] * e2) + oo[3 * k + 1];
-            xk[2] = (Rk[6] * e0 + Rk[7] * e1 + Rk[8] * e2) + oo[3 * k + 2];
-        } else if (slot < 13) {
-            const int e9 = slot - 4;
-            s_T[pi * 9 + e9] = ((aw[0] * Rw[9 * aj[0] + e9] + aw[1] * Rw[9 * aj[1] + e9]) + aw[2] * Rw[9 * aj[2] + e9]) + aw[3] * Rw[9 * aj[3] + e9];
-        }
-        wave_sync();
-        EPROBE(2);
-        const double* xk = s_xk + pi * 12;
-        const int aword = RI[(4 + slot) * 4 + p4];
-        if (aword != 0) {   // rotation block of ancestor j: -2 sqrt(c) [l_j]_x R(-1,parent j)
-            const int j = aword & 0xff;
-            const unsigned mask = ((unsigned)aword >> 8) & 0xffu;
-            double X0 = 0.0, X1 = 0.0, X2 = 0.0, cj = 0.0;
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-                if (mask & (1u << a)) {
-                    X0 += aw[a] * xk[3 * a]; X1 += aw[a] * xk[3 * a + 1]; X2 += aw[a] * xk[3 * a + 2];
-                    cj += aw[a];
-                }
-            const double m2 = -2.0 * sc;
-            const double L0 = m2 * (X0 - cj * oo[3 * j]), L1 = m2 * (X1 - cj * oo[3 * j + 1]), L2 = m2 * (X2 - cj * oo[3 * j + 2]);
-            const int pj = (aword >> 16) & 0xff;
-            const double* Rp = pj ? Rw + 9 * (pj - 1) : s_ident;
-            double* o0 = s_Jt + (size_t)(3 + 3 * j) * RS + pi * 3;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                o0[c * RS] = L1 * Rp[6 + c] - L2 * Rp[3 + c];
-                o0[c * RS + 1] = L2 * Rp[c] - L0 * Rp[6 + c];
-                o0[c * RS + 2] = L0 * Rp[3 + c] - L1 * Rp[c];
-            }
-        }
-        // shape block (:568-580): (sum a_k Rw_k) D_k + sum a_k G_k
-#pragma unroll
-        for (int it = 0; it < (3 * (FIXED ? CK : AVT_MAX_SHAPE) + 15) / 16; ++it) {
-            const int e = slot + 16 * it;
-            if (e < 3 * K) {
-                const int r = e / K, k = e - r * K;
-                const double* Tr = s_T + pi * 9 + 3 * r;
-                const double gs = ((aw[0] * Gm[aj[0] * 3 * K + e] + aw[1] * Gm[aj[1] * 3 * K + e]) + aw[2] * Gm[aj[2] * 3 * K + e]) + aw[3] * Gm[aj[3] * 3 * K + e];
-                const double a = (Tr[0] * R[(3 * k) * 4 + p4] + Tr[1] * R[(3 * k + 1) * 4 + p4] + Tr[2] * R[(3 * k + 2) * 4 + p4]) + gs;
-                s_Jt[(size_t)(3 + 3 * J + k) * RS + pi * 3 + r] = sc * a;
-            }
-        }
-        if (slot < 3) {          // residual column: sqrt(c) (x_m - dbar_m)
-            double xm = 0.0;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) xm += aw[a] * xk[3 * a + slot];
-            s_Jt[(size_t)P * RS + pi * 3 + slot] = sc * (xm - R[(3 * K + 3 + slot) * 4 + p4]);
-        } else if (slot < 6) {   // identity root-translation block (:476-481)
-            const int r = slot - 3;
-            s_Jt[(size_t)r * RS + pi * 3 + r] = sc;
-        }
+        build_rows<CJ, CK>(d, tabs, s_Jt, s_rec + (size_t)wv * RQ, s_xhat, s_xk, s_T, wv, ln);
         EPROBE(3);
         __syncthreads();
         EPROBE(4);
