@@ -124,11 +124,11 @@ __device__ __forceinline__ void build_rows(const AvtDims& d, const EvalTables& T
     const int ND = 3 * K + 11;
     const int p4 = ln >> 4, slot = ln & 15, pi = qw * 4 + p4;
     const double *Rw = T.Rw, *oo = T.oo, *Jh = T.Jh, *Gm = T.Gm, *ww = T.ww, *off = T.off;
-    if (ln < 48) {   // zero my wave's 12 rows of every column: 8 columns x 6 double2 per pass
-        d2v* z = (d2v*)(s_Jt + (size_t)(ln / 6) * RS + qw * 12 + 2 * (ln % 6));
+    if (ln < 60) {   // zero my wave's 12 rows of every column: 5 columns x 12 rows per pass (the stride is odd: 8-byte stores)
+        double* z = s_Jt + (size_t)(ln / 12) * RS + qw * 12 + (ln % 12);
 #pragma unroll
-        for (int pass = 0; pass < 2 * AVT_MAX_TILES; ++pass)
-            if (8 * pass + ln / 6 < NC) z[pass * 4 * RS] = (d2v){0.0, 0.0};
+        for (int pass = 0; pass < (16 * AVT_MAX_TILES + 4) / 5; ++pass)
+            if (5 * pass + ln / 12 < NC) z[pass * 5 * RS] = 0.0;
     }
     wave_sync();
     const double* R = Rrec;
@@ -245,8 +245,8 @@ __device__ __forceinline__ void mfma_batch6(const double* __restrict__ s_Jt, int
 //   Per batch, wave-local (no workgroup barrier): records registers -> LDS, next batch's records requested,
 //     own 12 rows of the tile zeroed, shaped rest position, the <= 4 carried points x_k, then one lane per
 //     (point, ancestor) writes B_j scaled by sqrt(c_m); shape block, residual column, translation block.
-//   The tile is stored transposed [column][row] with row stride 50 doubles (MFMA operand fetch = 16 columns x 4
-//     rows per ds_read_b64, conflict-free per half-wave).
+//   The tile is stored transposed [column][row] with an odd row stride of 49 doubles (MFMA operand fetch = 16
+//     columns x 4 rows per ds_read_b64 / two k-steps per ds_read2_b64, conflict-free either way).
 //   MFMA phase between two workgroup barriers: the upper-triangular 16x16 output tiles accumulate in registers
 //     over all batches of the workgroup and leave as NPAIR partial tiles (reduced in fixed order by k_reduce).
 // CJ/CK != 0: dimensions fixed at compile time (SMPL: 24 joints, 10 shape keys); 0: taken from the model.
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm,
     const int npre = 15 * J + 3 * J * K, nprep = (npre + K + 3 + 1) & ~1;
     double* s_prep = (double*)smem;                               // Rw o Jh G | w off
     double* s_Jt = s_prep + nprep;                                // [NC + 1][RS]
-    double* s_rec = s_Jt + (size_t)(NC + 1) * RS;                 // [4 waves][RQ]
+    double* s_rec = s_Jt + AVT_EVAL_TILE(NC + 1);                 // [4 waves][RQ]
     double* s_xhat = s_rec + 4 * RQ;                              // [16][3]
     double* s_xk = s_xhat + 48;                                   // [16][4][3]
     double* s_T = s_xk + 192;                                     // [16][9]  blended rotation per point
@@ -407,12 +407,12 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm,
     }
 }
 
+static bool eval_fixed_shape(const AvtDims& d) { return d.J == 24 && d.K == 10; }
+
 static size_t eval_lds_bytes(const AvtDims& d) {
     const size_t nprep = ((size_t)15 * d.J + 3 * d.J * d.K + d.K + 3 + 1) & ~(size_t)1;
-    return sizeof(double) * (nprep + (size_t)(d.P + 2) * AVT_EVAL_RS + 4 * (size_t)d.rec_quad + 48 + 192 + 144 + 10);
+    return sizeof(double) * (nprep + (size_t)AVT_EVAL_TILE(d.P + 2) + 4 * (size_t)d.rec_quad + 48 + 192 + 144 + 10);
 }
-
-static bool eval_fixed_shape(const AvtDims& d) { return d.J == 24 && d.K == 10; }
 
 void launch_eval(avt_ctx* c, int nframes) {
     const AvtDims& d = c->dm.d;

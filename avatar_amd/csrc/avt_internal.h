@@ -12,7 +12,10 @@
 #define AVT_TILE 16           // MFMA f64 16x16x4 tile edge
 #define AVT_EVAL_PTS 16       // model points per eval batch (48 Jacobian rows)
 #define AVT_EVAL_ROWS (3 * AVT_EVAL_PTS)
-#define AVT_EVAL_RS 50        // LDS row stride (doubles) of the transposed Jacobian tile: conflict-free b64 reads
+#define AVT_EVAL_RS 49        // LDS row stride (doubles) of the transposed Jacobian tile.  ODD on purpose: the compiler pairs the MFMA
+                              // operand fetches of two k-steps into ds_read2_b64, which is banked modulo 32 in 16-lane groups - an even
+                              // stride makes columns c and c+8 collide (2-way), an odd one is conflict-free (plain ds_read_b64 too)
+#define AVT_EVAL_TILE(ncols) ((((ncols) * AVT_EVAL_RS) + 1) & ~1)   // doubles of a tile of ncols columns, kept even (16-byte alignment of what follows)
 #define AVT_MAX_TILES 8       // ceil((P+1)/16) <= 8  (J<=32, K<=16)
 #define AVT_MAX_COMPS 16      // GMM components
 #define AVT_MAX_GROUPS 4      // frame groups of one optimize() running on separate streams
