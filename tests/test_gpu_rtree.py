@@ -125,3 +125,43 @@ def test_cpp_facade_labels_like_the_oracle(smpl, trees, tmp_path):
     ref = o.predictBest(depth, interval=2, top_left=tl, bot_right=br)
     com_ref = o.postProcess(ref, None, interval=2, top_left=tl, bot_right=br)
     assert np.array_equal(got, ref) and np.array_equal(com, com_ref)
+
+
+def _random_tree(rng, depth, num_parts):
+    """Random full-ish binary tree in parent-before-children order with random probe offsets and thresholds."""
+    feature, links, leaves = [], [], []
+    todo = [(0, -1, 0)]
+    while todo:
+        dep, parent, side = todo.pop(0)
+        me = len(feature)
+        if parent >= 0:
+            links[parent][side] = me
+        if dep < depth and (dep < 2 or rng.random() < 0.8):
+            u, v = rng.uniform(-60, 60, 2), rng.uniform(-60, 60, 2)
+            feature.append([u[0], u[1], v[0], v[1], rng.normal(0, 0.4)]); links.append([-1, -1, -1])
+            todo.append((dep + 1, me, 0)); todo.append((dep + 1, me, 1))
+        else:
+            feature.append([0, 0, 0, 0, 0]); links.append([-1, -1, len(leaves)])
+            d = rng.random(num_parts) * (rng.random(num_parts) < 0.4)
+            if d.sum() == 0:
+                d[rng.integers(num_parts)] = 1.0
+            leaves.append(d / d.sum())
+    return np.asarray(feature, np.float32), np.asarray(links, np.int32), np.asarray(leaves, np.float32), num_parts
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_trees_and_images_bit_exact(seed):
+    rng = np.random.default_rng(seed)
+    f, l, d, npp = _random_tree(rng, depth=int(rng.integers(3, 12)), num_parts=int(rng.integers(2, 40)))
+    g, o = rtree.RTree.from_arrays(f, l, d, npp), ro.OracleRTree.from_arrays(f, l, d, npp)
+    assert np.array_equal(g.leafBestMatch, o.leafBestMatch)
+    for _ in range(6):
+        H, W = int(rng.integers(1, 90)), int(rng.integers(1, 120))
+        depth = rng.choice([0.0, 0.6, 1.5, 2.5, 7.0], (H, W), p=[0.3, 0.1, 0.3, 0.2, 0.1]).astype(np.float32)
+        depth *= (1 + 0.05 * rng.standard_normal((H, W))).astype(np.float32)
+        interval = int(rng.integers(1, 6))
+        x0, y0 = int(rng.integers(0, W)), int(rng.integers(0, H))
+        x1, y1 = int(rng.integers(x0, W)), int(rng.integers(y0, H))
+        for kw in (dict(interval=interval), dict(interval=interval, fill_in_gaps=False),
+                   dict(interval=interval, top_left=(x0, y0), bot_right=(x1, y1))):
+            assert np.array_equal(g.predictBest(depth, **kw), o.predictBest(depth, **kw)), (H, W, kw)
