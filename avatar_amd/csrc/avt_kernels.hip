@@ -1,6 +1,6 @@
 // avt_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the fitting path, part 1:
 // linear-blend skinning, back-face visibility, data bucketing by body part, correspondence finalisation.
-// (nearest neighbour: avt_nn.hip; residual/Jacobian/J^T J/solve: avt_solve.hip)
+// (nearest neighbour: avt_nn.hip; residual/Jacobian/J^T J: avt_eval.hip; reduce + LM solve: avt_lm.hip)
 #include "avt_device.h"
 
 // =================================================================================================

@@ -1,4 +1,4 @@
-"""In-kernel phase timing (s_memtime) of k_eval / k_solve.  Needs a -DAVT_TIMING build: make -C avatar_amd/csrc EXTRA=-DAVT_TIMING (after touching avt_solve.hip avt_lm.hip).  Usage: python tools/kernel_timing_probe.py [frames]"""
+"""In-kernel phase timing (s_memtime) of k_eval / k_solve.  Needs a -DAVT_TIMING build: `touch avt_lm.hip && make -C avatar_amd/csrc EXTRA=-DAVT_TIMING` for k_solve, and avt_eval.o compiled by hand with -DAVT_TIMING for k_eval (the Makefile's EXTRA only reaches avt_lm.o).  Usage: python tools/kernel_timing_probe.py [frames]"""
 import sys, numpy as np, ctypes as C
 sys.path.insert(0,'/root/repo')
 from avatar_amd import api, synth, capi
@@ -20,5 +20,5 @@ s=np.diff(buf[41:47]); print('k_solve cycles: system assembly %.0f | LDL^T %.0f 
 
 
 
-# compute_prep internal probes live in the last two doubles of the prep block of the try slot (AVT_TIMING builds)
-print('compute_prep: loads+barrier %.0f | level loop %.0f | outputs %.0f cycles' % (buf[62]-buf[45], buf[63]-buf[62], buf[46]-buf[63]))
+# skeleton-pass internal probes live in the last two doubles of the prep block of the try slot (AVT_TIMING builds)
+print('skeleton pass: joint positions + barrier %.0f | level loop %.0f | outputs %.0f cycles' % (buf[62]-buf[45], buf[63]-buf[62], buf[46]-buf[63]))
