@@ -54,12 +54,14 @@ int upload_tree(avt_rtree* rt) {
     for (int i = 0; i < n; ++i) {
         const float* f = &rt->feature[5 * (size_t)i];
         const int leaf = rt->links[3 * i + 2];
-        dev[i] = RtNodeDev{f[0], f[1], f[2], f[3], f[4], leaf < 0 ? rt->links[3 * i] : (int)rt->leaf_best[leaf], leaf < 0 ? rt->links[3 * i + 1] : 0,
+        dev[i] = RtNodeDev{f[0], f[1], f[2], f[3], f[4], leaf < 0 ? rt->links[3 * i] : (int)rt->leaf_best[leaf], leaf < 0 ? rt->links[3 * i + 1] : leaf,
                            leaf < 0 ? 0 : 1};
     }
     RT_HIP(hipStreamCreateWithFlags(&rt->stream, hipStreamNonBlocking));
     RT_HIP(hipMalloc((void**)&rt->d_nodes, sizeof(RtNodeDev) * n));
     RT_HIP(hipMemcpy(rt->d_nodes, dev.data(), sizeof(RtNodeDev) * n, hipMemcpyHostToDevice));
+    RT_HIP(hipMalloc((void**)&rt->d_leaf, sizeof(float) * std::max<size_t>(1, rt->leaf_data.size())));
+    RT_HIP(hipMemcpy(rt->d_leaf, rt->leaf_data.data(), sizeof(float) * rt->leaf_data.size(), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -282,6 +284,7 @@ int avt_rtree_export(const avt_rtree* rt, const char* path) {
 void avt_rtree_destroy(avt_rtree* rt) {
     if (!rt) return;
     if (rt->d_nodes) (void)hipFree(rt->d_nodes);
+    if (rt->d_leaf) (void)hipFree(rt->d_leaf);
     if (rt->d_depth) (void)hipFree(rt->d_depth);
     if (rt->d_labels) (void)hipFree(rt->d_labels);
     if (rt->stream) (void)hipStreamDestroy(rt->stream);
@@ -347,6 +350,20 @@ int avt_rtree_predict_best(avt_rtree* rt, const float* depth, int rows, int cols
     if (avt_rtree_images_upload(rt, 1, rows, cols, depth)) return 1;
     if (avt_rtree_launch_predict(rt, 1, rows, cols, interval, tlx, tly, brx, bry, fill)) { avt_set_error("rtree: kernel launch failed"); return 1; }
     return avt_rtree_labels_download(rt, 0, labels_out);
+}
+
+int avt_rtree_predict(avt_rtree* rt, const float* depth, int rows, int cols, float* dist_out) {
+    if (!rt || !depth || !dist_out || rows <= 0 || cols <= 0) { avt_set_error("avt_rtree_predict: bad arguments"); return 1; }
+    if (avt_rtree_images_upload(rt, 1, rows, cols, depth)) return 1;
+    const size_t n = (size_t)rt->num_parts * rows * cols;
+    float* d_out = nullptr;
+    RT_HIP(hipMalloc((void**)&d_out, n * sizeof(float)));
+    int rc = avt_rtree_launch_predict_dist(rt, rows, cols, d_out);
+    if (rc) avt_set_error("rtree: kernel launch failed");
+    if (!rc && hipMemcpyAsync(dist_out, d_out, n * sizeof(float), hipMemcpyDeviceToHost, rt->stream) != hipSuccess) { avt_set_error("rtree: download failed"); rc = 1; }
+    if (hipStreamSynchronize(rt->stream) != hipSuccess && !rc) { avt_set_error("rtree: stream failed"); rc = 1; }
+    (void)hipFree(d_out);
+    return rc;
 }
 
 int avt_rtree_post_process(const avt_rtree* rt, unsigned char* image, int rows, int cols, double* com_pre, int com_pre_valid, int interval, int tlx,

@@ -12,7 +12,7 @@ struct RtNodeDev {
     float ux, uy, vx, vy;
     float thresh;
     int lnode;      // internal: left child; leaf: best-match label
-    int rnode;      // internal: right child
+    int rnode;      // internal: right child; leaf: leaf id (row of the distribution table)
     int leaf;       // 1: leaf
 };
 
@@ -28,10 +28,12 @@ struct avt_rtree {
     // device
     hipStream_t stream = nullptr;
     RtNodeDev* d_nodes = nullptr;
+    float* d_leaf = nullptr;         // [n_leafs][num_parts] distributions
     float* d_depth = nullptr;
     unsigned char* d_labels = nullptr;
     size_t cap_pixels = 0;           // capacity of d_depth / d_labels in pixels
     int n_images = 0, rows = 0, cols = 0;
 };
 
+int avt_rtree_launch_predict_dist(avt_rtree* rt, int rows, int cols, float* d_out);
 int avt_rtree_launch_predict(avt_rtree* rt, int n_images, int rows, int cols, int interval, int tlx, int tly, int brx, int bry, int fill);

@@ -46,6 +46,40 @@ __global__ __launch_bounds__(256) void k_rtree_predict(const RtNodeDev* __restri
     }
 }
 
+// RTree::predict(depth) (RTree.cpp:3156-3182): every pixel, probes bounded by the image, the whole leaf distribution out
+__global__ __launch_bounds__(256) void k_rtree_predict_dist(const RtNodeDev* __restrict__ nodes, const float* __restrict__ leaf_data,
+                                                            const float* __restrict__ depth, float* __restrict__ out, int rows, int cols, int num_parts) {
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), r = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (c >= cols || r >= rows) return;
+    const float sample = depth[(size_t)r * cols + c];
+    const size_t plane = (size_t)rows * cols, o = (size_t)r * cols + c;
+    if (!(sample > 0.f)) {
+        for (int i = 0; i < num_parts; ++i) out[(size_t)i * plane + o] = 0.f;
+        return;
+    }
+    int nodeid = 0;
+    const float4* nv = (const float4*)nodes;
+    int leaf;
+    for (;;) {
+        const float4 a = nv[2 * nodeid], b = nv[2 * nodeid + 1];
+        if (__float_as_int(b.w)) { leaf = __float_as_int(b.z); break; }
+        const int ux = (int)roundf(__fdiv_rn(a.x, sample)) + c, uy = (int)roundf(__fdiv_rn(a.y, sample)) + r;
+        const int vx = (int)roundf(__fdiv_rn(a.z, sample)) + c, vy = (int)roundf(__fdiv_rn(a.w, sample)) + r;
+        float zu = RT_BACKGROUND_DEPTH, zv = RT_BACKGROUND_DEPTH;
+        if (!(ux < 0 || uy < 0 || ux >= cols || uy >= rows)) { zu = depth[(size_t)uy * cols + ux]; if (zu == 0.0f) zu = RT_BACKGROUND_DEPTH; }
+        if (!(vx < 0 || vy < 0 || vx >= cols || vy >= rows)) { zv = depth[(size_t)vy * cols + vx]; if (zv == 0.0f) zv = RT_BACKGROUND_DEPTH; }
+        nodeid = (zu - zv < b.x) ? __float_as_int(b.y) : __float_as_int(b.z);
+    }
+    const float* d = leaf_data + (size_t)leaf * num_parts;
+    for (int i = 0; i < num_parts; ++i) out[(size_t)i * plane + o] = d[i];
+}
+
+int avt_rtree_launch_predict_dist(avt_rtree* rt, int rows, int cols, float* d_out) {
+    dim3 grid((cols + 15) / 16, (rows + 15) / 16);
+    hipLaunchKernelGGL(k_rtree_predict_dist, grid, dim3(256), 0, rt->stream, rt->d_nodes, rt->d_leaf, rt->d_depth, d_out, rows, cols, rt->num_parts);
+    return hipGetLastError() != hipSuccess;
+}
+
 int avt_rtree_launch_predict(avt_rtree* rt, int n_images, int rows, int cols, int interval, int tlx, int tly, int brx, int bry, int fill) {
     const size_t npix = (size_t)n_images * rows * cols;
     if (hipMemsetAsync(rt->d_labels, 255, npix, rt->stream) != hipSuccess) return 1;

@@ -13,7 +13,7 @@ from . import capi
 
 RTREE_SYMBOLS = [
     "avt_rtree_create", "avt_rtree_load", "avt_rtree_export", "avt_rtree_destroy", "avt_rtree_info", "avt_rtree_get",
-    "avt_rtree_predict_best", "avt_rtree_images_upload", "avt_rtree_predict_best_resident", "avt_rtree_labels_download",
+    "avt_rtree_predict_best", "avt_rtree_predict", "avt_rtree_images_upload", "avt_rtree_predict_best_resident", "avt_rtree_labels_download",
     "avt_rtree_sync", "avt_rtree_post_process",
 ]
 
@@ -102,6 +102,13 @@ class RTree:
         _check(self._lib, self._lib.avt_rtree_predict_best(self._h, _fp(d), C.c_int(d.shape[0]), C.c_int(d.shape[1]), C.c_int(interval),
                                                            C.c_int(top_left[0]), C.c_int(top_left[1]), C.c_int(bot_right[0]),
                                                            C.c_int(bot_right[1]), C.c_int(1 if fill_in_gaps else 0), _up(out)))
+        return out
+
+    def predict(self, depth):
+        """std::vector<cv::Mat> RTree::predict(depth): (numParts, H, W) float32 leaf distributions (0 where depth <= 0)."""
+        d = np.ascontiguousarray(depth, np.float32)
+        out = np.empty((self.numParts,) + d.shape, np.float32)
+        _check(self._lib, self._lib.avt_rtree_predict(self._h, _fp(d), C.c_int(d.shape[0]), C.c_int(d.shape[1]), _fp(out)))
         return out
 
     def postProcess(self, image, com_pre=None, interval=1, num_threads=1, top_left=(0, 0), bot_right=(-1, -1), dist_to_pre_weight=0.001):

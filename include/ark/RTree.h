@@ -80,6 +80,15 @@ public:
         return result;
     }
 
+    /** Predict distribution for all of image: numParts planes of CV_32F (RTree.h:59-61) */
+    std::vector<ImageF> predict(const ImageF& depth) {
+        std::vector<float> all((size_t)numParts * depth.rows * depth.cols);
+        if (!ensure() || avt_rtree_predict(h_, depth.data(), depth.rows, depth.cols, all.data()) != 0) die("predict");
+        std::vector<ImageF> result(numParts, ImageF(depth.rows, depth.cols));
+        for (int i = 0; i < numParts; ++i) result[i].a.assign(all.begin() + (size_t)i * depth.rows * depth.cols, all.begin() + (size_t)(i + 1) * depth.rows * depth.cols);
+        return result;
+    }
+
     /** RTree.h:150-166 */
     void postProcess(Image8& image, MatrixNX<2>& com_pre, int interval = 1, int /*num_threads*/ = 1, Point top_left = Point(0, 0),
                      Point bot_right = Point(-1, -1), double dist_to_pre_weight = 0.001) {

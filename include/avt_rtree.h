@@ -47,6 +47,10 @@ int avt_rtree_get(const avt_rtree* rt, float* feature, int* links, float* leaf_d
 int avt_rtree_predict_best(avt_rtree* rt, const float* depth, int rows, int cols, int interval, int tl_x, int tl_y, int br_x, int br_y,
                            int fill_in_gaps, unsigned char* labels_out);
 
+/* std::vector<cv::Mat> RTree::predict(depth) (RTree.cpp:3156-3182): the leaf distribution of every pixel with depth > 0,
+ * probes bounded by the image; out = num_parts planes of rows x cols float32 (0 where depth <= 0). */
+int avt_rtree_predict(avt_rtree* rt, const float* depth, int rows, int cols, float* dist_out);
+
 /* Batch form for resident images (throughput use, bench.py): upload n images once, label them all with one launch
  * sequence on the tree's stream, download what is needed.  avt_rtree_sync waits for the stream. */
 int avt_rtree_images_upload(avt_rtree* rt, int n_images, int rows, int cols, const float* depth);

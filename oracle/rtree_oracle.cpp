@@ -6,6 +6,7 @@
 //   best-match table    RTree::updateBestMatchTable             RTree.cpp:3451-3463
 //   per-pixel feature   scoreByFeature / getDepth               RTree.cpp:39-68
 //   image inference     RTree::predictBest(depth, ...)          RTree.cpp:3184-3262 (+ upscaleGrid :70-99)
+//                       RTree::predict(depth) distributions     RTree.cpp:3122-3132, :3156-3182
 //   post-processing     RTree::postProcess                      RTree.cpp:3422-3449
 //                       suppressPartNonMax / removeSmallPieces  RTree.cpp:125-323
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
@@ -223,6 +224,32 @@ void predict_best(const Tree& t, const float* depth, int rows, int cols, int int
     }
 }
 
+// RTree.cpp:3156-3182 with predictRecursive (:3122-3132) and scoreByFeature / getDepth (:39-68): every pixel with
+// depth > 0, probes bounded by the IMAGE, out[part][r][c] = leaf distribution (0 elsewhere)
+void predict_dist(const Tree& t, const float* depth, int rows, int cols, float* out) {
+    std::memset(out, 0, sizeof(float) * (size_t)t.num_parts * rows * cols);
+    auto get = [&](int x, int y) {
+        if (y < 0 || x < 0 || y >= rows || x >= cols) return BACKGROUND_DEPTH;
+        const float z = depth[(size_t)y * cols + x];
+        return z == 0.0f ? BACKGROUND_DEPTH : z;
+    };
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) {
+            const float sample = depth[(size_t)r * cols + c];
+            if (sample <= 0.f) continue;
+            int nodeid = 0;
+            while (t.nodes[nodeid].leafid == -1) {
+                const Node& nd = t.nodes[nodeid];
+                const float utx = nd.ux / sample, uty = nd.uy / sample, vtx = nd.vx / sample, vty = nd.vy / sample;
+                const int ux = (int32_t)std::round(utx) + c, uy = (int32_t)std::round(uty) + r;
+                const int vx = (int32_t)std::round(vtx) + c, vy = (int32_t)std::round(vty) + r;
+                nodeid = (get(ux, uy) - get(vx, vy) < nd.thresh) ? nd.lnode : nd.rnode;
+            }
+            const std::vector<float>& d = t.leaf[t.nodes[nodeid].leafid];
+            for (int i = 0; i < t.num_parts; ++i) out[((size_t)i * rows + r) * cols + c] = d[i];
+        }
+}
+
 void upscale(uint8_t* image, int rows, int cols, int interval, int tlx, int tly, int brx, int bry) {
     for (int rr = tly + interval; rr <= bry; rr += interval) {
         const uint8_t* ref = image + (size_t)rr * cols;
@@ -367,6 +394,8 @@ void orc_rtree_predict_best(const void* h, const float* depth, int rows, int col
                             int fill_in_gaps, unsigned char* out) {
     predict_best(*(const Tree*)h, depth, rows, cols, interval, tlx, tly, brx, bry, fill_in_gaps, out);
 }
+
+void orc_rtree_predict(const void* h, const float* depth, int rows, int cols, float* out) { predict_dist(*(const Tree*)h, depth, rows, cols, out); }
 
 // com_pre: 2 x num_parts column-major; com_pre_valid == 0 reproduces the resize branch of RTree.cpp:3431-3435
 void orc_rtree_post_process(const void* h, unsigned char* image, int rows, int cols, double* com_pre, int com_pre_valid, int interval,

@@ -66,6 +66,13 @@ class OracleRTree:
                                      C.c_int(top_left[1]), C.c_int(bot_right[0]), C.c_int(bot_right[1]), C.c_int(1 if fill_in_gaps else 0), _up(out))
         return out
 
+    def predict(self, depth):
+        """(numParts, H, W) float32 distributions (RTree::predict(depth))."""
+        d = np.ascontiguousarray(depth, np.float32)
+        out = np.empty((self.numParts,) + d.shape, np.float32)
+        lib().orc_rtree_predict(self._h, _fp(d), C.c_int(d.shape[0]), C.c_int(d.shape[1]), _fp(out))
+        return out
+
     def postProcess(self, image, com_pre=None, interval=1, top_left=(0, 0), bot_right=(-1, -1), dist_to_pre_weight=0.001):
         valid = com_pre is not None and com_pre.shape == (2, self.numParts)
         cp = np.ascontiguousarray(com_pre.T, np.float64) if valid else np.zeros((self.numParts, 2))

@@ -165,3 +165,14 @@ def test_random_trees_and_images_bit_exact(seed):
         for kw in (dict(interval=interval), dict(interval=interval, fill_in_gaps=False),
                    dict(interval=interval, top_left=(x0, y0), bot_right=(x1, y1))):
             assert np.array_equal(g.predictBest(depth, **kw), o.predictBest(depth, **kw)), (H, W, kw)
+
+
+def test_predict_distributions_bit_exact(smpl, trees):
+    """RTree::predict(depth): leaf distributions per pixel, probes bounded by the image, every row."""
+    g, o = trees
+    _, mask, depth, _ = _render(smpl, 28)
+    tile = np.ascontiguousarray(depth[200:520:2, 400:900:2])
+    a, b = g.predict(tile), o.predict(tile)
+    assert a.shape == (24,) + tile.shape and np.array_equal(a, b)
+    fg = tile > 0
+    assert np.allclose(a.sum(0)[fg], 1.0, atol=1e-5) and (a[:, ~fg] == 0).all()
