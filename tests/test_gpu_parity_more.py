@@ -121,3 +121,20 @@ def test_translation_equivariance_and_monotone_cost(smpl, gmodel):
     pt, qt, wt, stt = ctx.optimize_batch([fr["data"] + t], [fr["labels"]], opt, (p0 + t)[None], q0[None], w0[None])
     assert np.abs(pt[0] - t - p[0]).max() < 1e-7 and np.abs(wt[0] - w[0]).max() < 1e-6
     assert np.abs(qt[0] - q[0]).max() < 1e-7
+
+
+def test_large_batch_two_frame_groups_matches_oracle(smpl, omodel, gmodel):
+    """70 frames: the two-stream frame-group pipeline (uneven 35/35 split boundary checked), spot-checked against the oracle."""
+    from avatar_amd import api
+    F = 70
+    frs = [synth.make_frame(smpl, 100 + s) for s in range(F)]
+    pm = synth.identity_part_map()
+    ctx = api.Context(gmodel, 24, pm, 60000, F)
+    p0 = np.array([f["start"][1] for f in frs]); q0 = np.array([api.rot_to_quat(f["start"][2]) for f in frs]); w0 = np.array([f["start"][0] for f in frs])
+    opt = Options.demo()
+    p, q, w, st = ctx.optimize_batch([f["data"] for f in frs], [f["labels"] for f in frs], opt, p0, q0, w0)
+    for i in (0, 34, 35, 69):
+        ref = omodel.optimize(pm, 24, frs[i]["data"], frs[i]["labels"], opt, p0[i], q0[i], w0[i], aggregate=1)
+        assert np.array_equal(ctx.correspondences(i, len(frs[i]["labels"])), ref["corr"])
+        assert np.abs(ctx.cloud(i) - ref["cloud"]).max() < 1e-6
+        assert st[i].gn_iterations == ref["stats"].gn_iterations and st[i].accepted_steps == ref["stats"].accepted_steps
