@@ -434,40 +434,40 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
     TPROBE(2);
 
     // ---- c. register-blocked LDL^T, four pivots and ONE barrier per round ---------------------------------------------
-    //  (1) the lanes owning the pivot block column (bj == kb) factor the diagonal block (D = Ld diag(d) Ld^T) from their
-    //      PRIVATE copy of it and publish their own block of W = A Ld^-T; the diagonal lane also publishes 1/d;
+    //  (1) the lanes owning the pivot block column (bj == kb) take the factorisation D = Ld diag(d) Ld^T of their PRIVATE
+    //      copy of the diagonal block and publish their own block of W = A Ld^-T; the diagonal lane also publishes 1/d;
     //  (2) after the barrier every trailing lane (bj > kb) reads W of its row block and of its column block and
     //      applies the rank-4 update A -= W_i diag(1/d) W_j^T to its block and to its copy of its column's
     //      diagonal block (same operands, +40 FMAs, no extra LDS traffic) - so nobody ever publishes or reads a
     //      diagonal block, and the next round's panel can start without a second barrier.
     // Measured on MI355X (tools/ubench/ldlt.hip), clocks per round: two barriers + published diagonal + W and L
-    // stored 2520; W only 2215; this scheme 2030.  The rounds are bound by LDS traffic and latency, not by the FMAs.
+    // stored 2520; W only 2215; private diagonal copies 2030; with the factorisation hoisted (below) 1900.  The rounds are
+    // bound by LDS traffic and latency, not by the FMAs.
     // (A look-ahead variant that rebuilt the diagonal block from a published copy measured slower, 2770.)
     double* s_R = s_W;                                      // [HS] reciprocal pivots
+    // D = Ld diag(d) Ld^T of my diagonal-block copy.  Every lane factors its copy right after updating it - wasted work
+    // unless its column is the next panel, but it keeps the rcp chain in the same straight-line block as the 64
+    // independent FMAs of the lane's own block update, where its latency hides (2030 -> 1900 clocks per round).
+    double l10, l20, l30, l21, l31, l32, r0, r1, r2, r3, P0, P1, P2, P3;
+#define AVT_FACTOR_DG() do {                                                                                       \
+        const double D00 = dg[0][0], D10 = dg[1][0];                                                                \
+        double D11 = dg[1][1], D20 = dg[2][0], D21 = dg[2][1], D22 = dg[2][2], D30 = dg[3][0], D31 = dg[3][1], D32 = dg[3][2], D33 = dg[3][3]; \
+        P0 = D00; r0 = fast_rcp(D00); l10 = D10 * r0; l20 = D20 * r0; l30 = D30 * r0;                              \
+        D11 = fma(-l10, D10, D11); D21 = fma(-l20, D10, D21); D31 = fma(-l30, D10, D31);                            \
+        D22 = fma(-l20, D20, D22); D32 = fma(-l30, D20, D32); D33 = fma(-l30, D30, D33);                            \
+        P1 = D11; r1 = fast_rcp(D11); l21 = D21 * r1; l31 = D31 * r1;                                               \
+        D22 = fma(-l21, D21, D22); D32 = fma(-l31, D21, D32); D33 = fma(-l31, D31, D33);                            \
+        P2 = D22; r2 = fast_rcp(D22); l32 = D32 * r2; D33 = fma(-l32, D32, D33);                                    \
+        P3 = D33; r3 = fast_rcp(D33);                                                                               \
+    } while (0)
+    AVT_FACTOR_DG();
     if (t < 2) s_failf[t] = 0;
     bool fail = false;
     __syncthreads();
     for (int kb = 0; kb < NB; ++kb) {
         if (kb > 0 && s_failf[(kb - 1) & 1]) { fail = true; break; }
         if (bj == kb) {
-            const double D00 = dg[0][0], D10 = dg[1][0];
-            double D11 = dg[1][1], D20 = dg[2][0], D21 = dg[2][1], D22 = dg[2][2], D30 = dg[3][0], D31 = dg[3][1], D32 = dg[3][2], D33 = dg[3][3];
             const bool real1 = 4 * kb + 1 < P, real2 = 4 * kb + 2 < P, real3 = 4 * kb + 3 < P;   // 4*kb < P always
-            const double P0 = D00;
-            const double r0 = fast_rcp(D00);
-            const double l10 = D10 * r0, l20 = D20 * r0, l30 = D30 * r0;
-            D11 = fma(-l10, D10, D11); D21 = fma(-l20, D10, D21); D31 = fma(-l30, D10, D31);
-            D22 = fma(-l20, D20, D22); D32 = fma(-l30, D20, D32); D33 = fma(-l30, D30, D33);
-            const double P1 = D11;
-            const double r1 = fast_rcp(D11);
-            const double l21 = D21 * r1, l31 = D31 * r1;
-            D22 = fma(-l21, D21, D22); D32 = fma(-l31, D21, D32); D33 = fma(-l31, D31, D33);
-            const double P2 = D22;
-            const double r2 = fast_rcp(D22);
-            const double l32 = D32 * r2;
-            D33 = fma(-l32, D32, D33);
-            const double P3 = D33;
-            const double r3 = fast_rcp(D33);
             const int bad = (int)!(P0 > 0.0) | ((int)real1 & (int)!(P1 > 0.0)) | ((int)real2 & (int)!(P2 > 0.0)) | ((int)real3 & (int)!(P3 > 0.0));
             if (bad) s_failf[kb & 1] = 1;
             d2v* Wo = (d2v*)(Lblk + ((size_t)kb * NB + bi) * 18);
@@ -493,22 +493,14 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
             const d2v* Wj = (const d2v*)(Lblk + ((size_t)kb * NB + bj) * 18);
             const d2v* Rq = (const d2v*)(s_R + 4 * kb);
             d2v wv[4][2], wj[4][2], lv[4][2];
+            // column-block operands first: the diagonal copy and its factorisation are the critical chain
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { wv[r][0] = Wi[2 * r]; wv[r][1] = Wi[2 * r + 1]; wj[r][0] = Wj[2 * r]; wj[r][1] = Wj[2 * r + 1]; }
+            for (int r = 0; r < 4; ++r) { wj[r][0] = Wj[2 * r]; wj[r][1] = Wj[2 * r + 1]; }
             const d2v ra = Rq[0], rb = Rq[1];
 #pragma unroll
+            for (int r = 0; r < 4; ++r) { wv[r][0] = Wi[2 * r]; wv[r][1] = Wi[2 * r + 1]; }
+#pragma unroll
             for (int r = 0; r < 4; ++r) { lv[r][0].x = wj[r][0].x * ra.x; lv[r][0].y = wj[r][0].y * ra.y; lv[r][1].x = wj[r][1].x * rb.x; lv[r][1].y = wj[r][1].y * rb.y; }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    double v = a4[r][cc];
-                    v = fma(-wv[r][0].x, lv[cc][0].x, v);
-                    v = fma(-wv[r][0].y, lv[cc][0].y, v);
-                    v = fma(-wv[r][1].x, lv[cc][1].x, v);
-                    v = fma(-wv[r][1].y, lv[cc][1].y, v);
-                    a4[r][cc] = v;
-                }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -520,8 +512,21 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
                     v = fma(-wj[r][1].y, lv[cc][1].y, v);
                     dg[r][cc] = v;
                 }
+            AVT_FACTOR_DG();
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    double v = a4[r][cc];
+                    v = fma(-wv[r][0].x, lv[cc][0].x, v);
+                    v = fma(-wv[r][0].y, lv[cc][0].y, v);
+                    v = fma(-wv[r][1].x, lv[cc][1].x, v);
+                    v = fma(-wv[r][1].y, lv[cc][1].y, v);
+                    a4[r][cc] = v;
+                }
         }
     }
+#undef AVT_FACTOR_DG
     if (!fail && s_failf[(NB - 1) & 1]) fail = true;
     __syncthreads();
     TPROBE(3);
