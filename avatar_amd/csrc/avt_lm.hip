@@ -105,12 +105,16 @@ __device__ void prep_run(const DeviceModel& dm, const PrepLayout& L, double* __r
         const int c = e % 3;
         prep[prep_off_Jh(d) + e] = B[L.jp + e] - (c == 0 ? off0 : (c == 1 ? off1 : off2));   // root at origin (:270-272)
     }
-    for (int e = t; e < 3 * J * K; e += 256) {  // G[j] = H[j] - Rw[j]*S[j]  (shape block of :568-580)
-        const int j = e / (3 * K), r = (e / K) % 3, k = e % K;
-        const double* Rj = B + L.Rw + 9 * j;
-        const double* S = B + L.S + j * 3 * K;
-        prep[prep_off_G(d) + e] = B[L.H + e] - (Rj[3 * r] * S[k] + Rj[3 * r + 1] * S[K + k] + Rj[3 * r + 2] * S[2 * K + k]);
-    }
+    // G[j] = H[j] - Rw[j]*S[j]  (shape block of :568-580); the index split divides by K: constant for SMPL
+    auto g_table = [&](const int KK) {
+        for (int e = t; e < 3 * J * KK; e += 256) {
+            const int j = e / (3 * KK), r = (e / KK) % 3, k = e % KK;
+            const double* Rj = B + L.Rw + 9 * j;
+            const double* S = B + L.S + j * 3 * KK;
+            prep[prep_off_G(d) + e] = B[L.H + e] - (Rj[3 * r] * S[k] + Rj[3 * r + 1] * S[KK + k] + Rj[3 * r + 2] * S[2 * KK + k]);
+        }
+    };
+    if (K == 10) g_table(10); else g_table(K);
     for (int e = t; e < 4 * J; e += 256) prep[prep_off_q(d) + e] = q[e];
     if (t < K) prep[prep_off_w(d) + t] = B[L.w + t];
     if (t < 3) prep[prep_off_off(d) + t] = (t == 0 ? off0 : (t == 1 ? off1 : off2));
