@@ -243,6 +243,10 @@ class Context:
     def optimize_resident(self, opt: Options):
         _check(self._lib.avt_optimize_resident(self.h, C.byref(opt)))
 
+    def state_reset(self):
+        """Asynchronous device-side reinstall of the last uploaded start state (no host transfer, no synchronisation)."""
+        _check(self._lib.avt_state_reset(self.h))
+
     def sync(self):
         _check(self._lib.avt_sync(self.h))
 

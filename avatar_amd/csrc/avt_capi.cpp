@@ -201,6 +201,8 @@ int upload_state(avt_ctx* c, int nframes, const double* p, const double* q, cons
     }
     HIP_OK(hipMemcpyAsync(c->fb.x, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipMemcpyAsync(c->fb.ctl, ctl.data(), ctl.size() * sizeof(AvtFrameCtl), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(c->fb.x_start, c->fb.x, xs.size() * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(c->fb.ctl_start, c->fb.ctl, ctl.size() * sizeof(AvtFrameCtl), hipMemcpyDeviceToDevice, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));  // host vectors go out of scope
     return 0;
 }
@@ -312,7 +314,8 @@ int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* par
         dev_alloc(c, &fb.vcz, FV) || dev_alloc(c, &fb.vcid, FV) || dev_alloc(c, &fb.vcount, (size_t)max_frames * num_parts) ||
         dev_alloc(c, &cntsum, FV * (sizeof(int) + 3 * sizeof(long long)) + 64) || dev_alloc(c, &fb.matched, FV) || dev_alloc(c, &fb.mcnt, FV) ||
         dev_alloc(c, &fb.mdbar, FV * 3) || dev_alloc(c, &fb.const_part, (size_t)max_frames * fb.const_blocks) ||
-        dev_alloc(c, &fb.x, (size_t)max_frames * 2 * d.xsize) || dev_alloc(c, &fb.prep, (size_t)max_frames * 2 * d.prep_size) ||
+        dev_alloc(c, &fb.x, (size_t)max_frames * 2 * d.xsize) || dev_alloc(c, &fb.x_start, (size_t)max_frames * 2 * d.xsize) ||
+        dev_alloc(c, &fb.ctl_start, (size_t)max_frames) || dev_alloc(c, &fb.prep, (size_t)max_frames * 2 * d.prep_size) ||
         dev_alloc(c, &fb.rec, (size_t)max_frames * d.nb_max * 4 * d.rec_quad) || dev_alloc(c, &fb.partial, part_cap * d.NPAIR * 256) || dev_alloc(c, &fb.Hraw, (size_t)max_frames * 2 * d.HS * d.HS) ||
         dev_alloc(c, &fb.prior, (size_t)max_frames * 2 * AVT_MAX_COMPS * AVT_PRIOR_STRIDE) || dev_alloc(c, &fb.ctl, (size_t)max_frames) ||
         dev_alloc(c, &fb.jointpos, (size_t)max_frames * 3 * J) || dev_alloc(c, &fb.jointtrans, (size_t)max_frames * 12 * J) ||
@@ -485,6 +488,15 @@ int avt_optimize_resident(avt_ctx* c, const avt_options* opt) {
     if (!c || !opt) { avt_set_error("avt_optimize_resident: null argument"); return 1; }
     HIP_OK(hipSetDevice(c->device));
     return run_optimize(c, opt);
+}
+
+int avt_state_reset(avt_ctx* c) {
+    if (!c || c->nframes <= 0) { avt_set_error("avt_state_reset: no state resident"); return 1; }
+    HIP_OK(hipSetDevice(c->device));
+    const AvtDims& d = c->dm.d;
+    HIP_OK(hipMemcpyAsync(c->fb.x, c->fb.x_start, (size_t)c->nframes * 2 * d.xsize * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(c->fb.ctl, c->fb.ctl_start, (size_t)c->nframes * sizeof(AvtFrameCtl), hipMemcpyDeviceToDevice, c->stream));
+    return 0;
 }
 
 int avt_state_download(avt_ctx* c, double* p, double* q, double* w, avt_stats* stats) {

@@ -166,6 +166,8 @@ struct FrameBuffers {
     int const_used;       // blocks written by the last k_cost_const launch
     // optimiser state
     double* x;            // [max_frames][2][xsize]
+    double* x_start;      // copy of x as avt_state_upload installed it (avt_state_reset)
+    AvtFrameCtl* ctl_start;
     double* prep;         // [max_frames][2][prep_size]
     double* rec;          // [max_frames][nb_max][4][rec_quad] matched-point records (k_records)
     double* partial;      // [max_frames][G][NPAIR][256]

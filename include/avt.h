@@ -148,6 +148,10 @@ int avt_optimize_batch(avt_ctx* c, int nframes, const double* data, const int* l
 int avt_frames_upload(avt_ctx* c, int nframes, const double* data, const int* labels, const int* frame_offsets);
 int avt_state_upload(avt_ctx* c, int nframes, const double* p, const double* q, const double* w);
 int avt_optimize_resident(avt_ctx* c, const avt_options* opt);
+/* Re-installs, on the device and asynchronously, the start state of the last avt_state_upload (a device-side copy is kept):
+ * a caller that fits the same resident frames repeatedly from the same start (benchmarks, multi-hypothesis restarts)
+ * enqueues avt_state_reset + avt_optimize_resident without any host-to-device transfer or host synchronisation. */
+int avt_state_reset(avt_ctx* c);
 int avt_state_download(avt_ctx* c, double* p, double* q, double* w, avt_stats* stats);
 
 /* ---- synthetic-frame generator on the GPU: AvatarRenderer::renderDepth / renderPartMask
