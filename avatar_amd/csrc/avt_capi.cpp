@@ -91,7 +91,7 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
     c->ran_icp_iters = 0;
     const int vis_init = o->enable_occlusion ? 0 : 1;
     c->lbs_cleared = true;
-    { ProfScope ps(c, AVT_K_BUCKET); launch_bucket(c, nf); }
+    { ProfScope ps(c, AVT_K_BUCKET); launch_bucket(c, nf, o->icp_iters <= 0); }   // k_finalize restores the cursors
     { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 1, vis_init); }   // ava.update() precondition (:1356)
     for (int icp = 0; icp < o->icp_iters; ++icp) {
         { ProfScope ps(c, AVT_K_VISIBILITY); launch_visibility(c, nf, o->enable_occlusion); }
@@ -326,6 +326,7 @@ int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* par
     HIP_OK(hipMemset(fb.trace, 0, (size_t)max_frames * 64 * sizeof(double)));
     HIP_OK(hipMemset(fb.ctl, 0, (size_t)max_frames * sizeof(AvtFrameCtl)));
     HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemset(fb.part_cnt, 0, (size_t)max_frames * 2 * (AVT_MAX_PARTS + 1) * sizeof(int)));   // invariant of launch_bucket
     if (getenv("AVT_DEBUG")) avt_eval_report_occupancy(dm.d);
     *out = c;
     return 0;
@@ -405,7 +406,7 @@ int avt_nn(avt_ctx* c, const double* model_cloud, const unsigned char* visible, 
     std::memset(&ctl, 0, sizeof(ctl));
     ctl.N = N;
     HIP_OK(hipMemcpyAsync(c->fb.ctl, &ctl, sizeof(ctl), hipMemcpyHostToDevice, c->stream));
-    { ProfScope ps(c, AVT_K_BUCKET); launch_bucket(c, 1); }
+    { ProfScope ps(c, AVT_K_BUCKET); launch_bucket(c, 1, true); }
     { ProfScope ps(c, AVT_K_NN); launch_nn(c, 1); }
     if (check_launch("k_nn")) return 1;
     HIP_OK(hipMemcpyAsync(out, c->fb.corr, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -493,10 +494,8 @@ int avt_optimize_resident(avt_ctx* c, const avt_options* opt) {
 int avt_state_reset(avt_ctx* c) {
     if (!c || c->nframes <= 0) { avt_set_error("avt_state_reset: no state resident"); return 1; }
     HIP_OK(hipSetDevice(c->device));
-    const AvtDims& d = c->dm.d;
-    HIP_OK(hipMemcpyAsync(c->fb.x, c->fb.x_start, (size_t)c->nframes * 2 * d.xsize * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    HIP_OK(hipMemcpyAsync(c->fb.ctl, c->fb.ctl_start, (size_t)c->nframes * sizeof(AvtFrameCtl), hipMemcpyDeviceToDevice, c->stream));
-    return 0;
+    launch_state_reset(c, c->nframes);
+    return check_launch("k_state_reset");
 }
 
 int avt_state_download(avt_ctx* c, double* p, double* q, double* w, avt_stats* stats) {

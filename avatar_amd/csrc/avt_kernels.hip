@@ -228,12 +228,29 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(DeviceModel dm, FrameBuf
     }
 }
 
-void launch_bucket(avt_ctx* c, int nframes) {
+// Invariant: the label histogram / scatter cursors (part_cnt) are all zero between API calls.  optimize() restores it in
+// k_finalize (one memset node less per call); the stand-alone avt_nn path clears after itself (clear_after).
+// avt_state_reset: start state -> working state, both buffers in one launch
+__global__ __launch_bounds__(256) void k_state_reset(FrameBuffers fb, int nx, int nctl) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nx) fb.x[i] = fb.x_start[i];
+    const int* src = (const int*)fb.ctl_start;
+    int* dst = (int*)fb.ctl;
+    if (i < nctl) dst[i] = src[i];
+}
+
+void launch_state_reset(avt_ctx* c, int nframes) {
+    const int nx = nframes * 2 * c->dm.d.xsize, nctl = nframes * (int)(sizeof(AvtFrameCtl) / sizeof(int));
+    hipLaunchKernelGGL(k_state_reset, dim3((std::max(nx, nctl) + 255) / 256), dim3(256), 0, c->stream, c->fb, nx, nctl);
+}
+
+void launch_bucket(avt_ctx* c, int nframes, bool clear_after) {
     const int maxN = c->launch_maxN;
     const int nb = std::max(1, (maxN + BUCKET_TILE - 1) / BUCKET_TILE);
-    (void)hipMemsetAsync(c->fb.part_cnt + (size_t)c->fb.f0 * 2 * (AVT_MAX_PARTS + 1), 0, (size_t)nframes * 2 * (AVT_MAX_PARTS + 1) * sizeof(int), c->cur_stream);
     hipLaunchKernelGGL(k_bucket_count, dim3(nb, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
     hipLaunchKernelGGL(k_bucket_scatter, dim3(nb, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
+    if (clear_after)
+        (void)hipMemsetAsync(c->fb.part_cnt + (size_t)c->fb.f0 * 2 * (AVT_MAX_PARTS + 1), 0, (size_t)nframes * 2 * (AVT_MAX_PARTS + 1) * sizeof(int), c->cur_stream);
 }
 
 // =================================================================================================
@@ -246,6 +263,7 @@ __global__ __launch_bounds__(1024) void k_finalize(DeviceModel dm, FrameBuffers 
                                                    double lambda0, int first_icp) {
     const int f = blockIdx.x + fb.f0, t = threadIdx.x, V = dm.d.V;
     AvtFrameCtl& ctl = fb.ctl[f];
+    if (t < 2 * (AVT_MAX_PARTS + 1)) fb.part_cnt[(size_t)f * 2 * (AVT_MAX_PARTS + 1) + t] = 0;   // bucketing is over: restore the invariant
     __shared__ int s_wave_m[16], s_wave_t[16];
     const int chunk = (V + 1023) / 1024;
     const int lo = min(V, t * chunk), hi = min(V, lo + chunk);
