@@ -73,3 +73,34 @@ __device__ __forceinline__ void fk_chain(int J, const int* __restrict__ parent, 
         __syncthreads();
     }
 }
+
+// 0.5*sum_i |d_i - dbar_m(i)|^2: the part of the data cost that does not depend on the parameters once the
+// correspondences are fixed.  Deterministic two-level reduction in original data order (block partials,
+// summed in a fixed order by the solve kernel).
+__device__ __forceinline__ void cost_const_block(const DeviceModel& dm, const FrameBuffers& fb, int f, int blk) {
+    const int t = threadIdx.x, V = dm.d.V;
+    const AvtFrameCtl& ctl = fb.ctl[f];
+    const int N = ctl.N;
+    const size_t base = (size_t)f * fb.max_points;
+    const int i = blk * 256 + t;             // ORIGINAL data index: the reduction order is fixed
+    double acc = 0.0;
+    if (i < N) {
+        const int m = fb.corr[base + i];
+        if (m >= 0) {
+            const int c = fb.cnt[(size_t)f * V + m];
+            const long long* fs = fb.fsum + (size_t)f * 3 * V;
+            const double mx = ctl.centre[0] + ((double)fs[m] / AVT_FIX_SCALE) / (double)c;
+            const double my = ctl.centre[1] + ((double)fs[(size_t)V + m] / AVT_FIX_SCALE) / (double)c;
+            const double mz = ctl.centre[2] + ((double)fs[2 * (size_t)V + m] / AVT_FIX_SCALE) / (double)c;
+            const double* dp = fb.data_raw + 3 * (base + i);
+            const double ex = dp[0] - mx, ey = dp[1] - my, ez = dp[2] - mz;
+            acc = ex * ex + ey * ey + ez * ez;
+        }
+    }
+    __shared__ double s_part[4];
+    acc = wave_sum(acc);
+    if (lane_id() == 0) s_part[wave_id()] = acc;
+    __syncthreads();
+    if (t == 0) fb.const_part[(size_t)f * fb.const_blocks + blk] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);   // every block of the grid writes
+}
+

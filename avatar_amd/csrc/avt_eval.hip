@@ -58,6 +58,10 @@ __device__ __forceinline__ void wave_sync() {
 __global__ __launch_bounds__(256) void k_records(DeviceModel dm, FrameBuffers fb) {
     const AvtDims d = dm.d;
     const int f = blockIdx.y + fb.f0, b = blockIdx.x, t = threadIdx.x, V = d.V, K = d.K;
+    if (b >= d.nb_max) {   // trailing workgroups of the grid: the constant part of the data cost (one launch less)
+        cost_const_block(dm, fb, f, b - d.nb_max);
+        return;
+    }
     const int M = fb.ctl[f].M;
     if (b * AVT_EVAL_PTS >= M) return;
     const int wv = t >> 6, ln = t & 63;
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(256) void k_records(DeviceModel dm, FrameBuffers fb
 }
 
 void launch_records(avt_ctx* c, int nframes) {
-    hipLaunchKernelGGL(k_records, dim3(c->dm.d.nb_max, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
+    hipLaunchKernelGGL(k_records, dim3(c->dm.d.nb_max + c->fb.const_used, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
 }
 
 // What a wave needs to turn the records of its 4 points into rows of the tile: the skeleton tables staged in LDS
