@@ -73,8 +73,10 @@ __global__ __launch_bounds__(256) void k_records(DeviceModel dm, FrameBuffers fb
         if (pos < M) {
             const int m = fb.matched[(size_t)f * V + pos];
             if (field < 3 * (K + 1)) v = dm.shape_planes[(size_t)field * V + m];
-            else if (field < 3 * K + 6) v = fb.mdbar[((size_t)f * 3 + (field - 3 * (K + 1))) * V + pos];
-            else if (field == 3 * K + 6) v = fb.mcnt[(size_t)f * V + pos];
+            else if (field < 3 * K + 6) {       // mean data point of the vertex (AvatarOptimizer.cpp:1419-1431), from the NN kernel's fixed-point sums
+                const int k = field - 3 * (K + 1);
+                v = fb.ctl[f].centre[k] + ((double)fb.fsum[((size_t)f * 3 + k) * V + m] / AVT_FIX_SCALE) / (double)fb.cnt[(size_t)f * V + m];
+            } else if (field == 3 * K + 6) v = sqrt((double)fb.cnt[(size_t)f * V + m]);
             else v = dm.asg_w[(size_t)(field - (3 * K + 7)) * V + m];
         }
         R[e] = v;

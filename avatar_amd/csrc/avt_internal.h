@@ -159,8 +159,6 @@ struct FrameBuffers {
     int* cnt;             // [max_frames][V]
     long long* fsum;      // [max_frames][3][V] fixed-point centred sums
     int* matched;         // [max_frames][V] compacted matched vertex ids
-    double* mcnt;         // [max_frames][V] sqrt(c) per compacted entry
-    double* mdbar;        // [max_frames][3][V] mean data point per compacted entry
     double* const_part;   // [max_frames][const_blocks]
     int const_blocks;
     int const_used;       // blocks written by the last k_cost_const launch

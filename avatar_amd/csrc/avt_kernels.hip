@@ -255,8 +255,9 @@ void launch_bucket(avt_ctx* c, int nframes, bool clear_after) {
 
 // =================================================================================================
 // Correspondence finalisation: turns the per-vertex (count, fixed-point sum) accumulated by the NN kernel
-// into the compacted list of matched model points (the `caches` of AvatarOptimizer.cpp:1419-1431) with
-// sqrt(count) and the mean data point, and the prior weight rescale (AvatarOptimizer.cpp:1457-1458).
+// into the compacted list of matched model points (the `caches` of AvatarOptimizer.cpp:1419-1431; sqrt(count) and
+// the mean data point are formed where the records are gathered, k_records) and the prior weight rescale
+// (AvatarOptimizer.cpp:1457-1458).
 // One workgroup of 1024 threads per frame; the compaction keeps ascending vertex order.
 // =================================================================================================
 __global__ __launch_bounds__(1024) void k_finalize(DeviceModel dm, FrameBuffers fb, double beta_pose, double beta_shape,
@@ -284,19 +285,8 @@ __global__ __launch_bounds__(1024) void k_finalize(DeviceModel dm, FrameBuffers 
         total_t += s_wave_t[w];
     }
     int pos = mbase + im - m;
-    const long long* fs = fb.fsum + (size_t)f * 3 * V;
-    for (int v = lo; v < hi; ++v) {
-        const int c = cnt[v];
-        if (c > 0) {
-            fb.matched[(size_t)f * V + pos] = v;
-            fb.mcnt[(size_t)f * V + pos] = sqrt((double)c);
-            for (int k = 0; k < 3; ++k) {
-                const double mean = ctl.centre[k] + ((double)fs[(size_t)k * V + v] / AVT_FIX_SCALE) / (double)c;
-                fb.mdbar[((size_t)f * 3 + k) * V + pos] = mean;
-            }
-            ++pos;
-        }
-    }
+    for (int v = lo; v < hi; ++v)
+        if (cnt[v] > 0) fb.matched[(size_t)f * V + pos++] = v;
     if (t == 0) {
         ctl.M = total_m;
         ctl.T = total_t;
