@@ -288,7 +288,8 @@ int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* par
     }
     if (dev_upload(c, &dm.shape_planes, m->shape_planes) || dev_upload(c, &dm.lbs_w, m->lbs_w) || dev_upload(c, &dm.lbs_j, m->lbs_j) ||
         dev_upload(c, &dm.asg_w, m->asg_w) || dev_upload(c, &dm.asg_j, m->asg_j) || dev_upload(c, &dm.anc_n, m->anc_n) ||
-        dev_upload(c, &dm.anc, m->anc) || dev_upload(c, &dm.mesh, m->mesh_soa) || dev_upload(c, &dm.parent, m->parent) || dev_upload(c, &dm.fk_items, m->fk_items) || dev_upload(c, &dm.fk_level_off, m->fk_level_off) ||
+        dev_upload(c, &dm.anc, m->anc) || dev_upload(c, &dm.mesh, m->mesh_soa) || dev_upload(c, &dm.parent, m->parent) || dev_upload(c, &dm.fk_items, m->fk_items) || dev_upload(c, &dm.tile_col, m->tile_col) || dev_upload(c, &dm.tile_param, m->tile_param) ||
+        dev_upload(c, &dm.joint_col, m->joint_col) || dev_upload(c, &dm.vorder, m->vorder) || dev_upload(c, &dm.vmask, m->vmask) || dev_upload(c, &dm.fk_level_off, m->fk_level_off) ||
         dev_upload(c, &dm.jsr_base, m->jsr_base) || dev_upload(c, &dm.jsr, m->jsr) || dev_upload(c, &dm.S, m->S) ||
         dev_upload(c, &dm.Sp, m->Sp) || dev_upload(c, &dm.prior_mean, m->prior_mean) || dev_upload(c, &dm.prior_prec, m->prior_prec) ||
         dev_upload(c, &dm.prior_clog, m->prior_clog) || dev_upload(c, &dm.part_of_vertex, pov) ||
@@ -316,7 +317,7 @@ int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* par
         dev_alloc(c, &fb.const_part, (size_t)max_frames * fb.const_blocks) ||
         dev_alloc(c, &fb.x, (size_t)max_frames * 2 * d.xsize) || dev_alloc(c, &fb.x_start, (size_t)max_frames * 2 * d.xsize) ||
         dev_alloc(c, &fb.ctl_start, (size_t)max_frames) || dev_alloc(c, &fb.prep, (size_t)max_frames * 2 * d.prep_size) ||
-        dev_alloc(c, &fb.rec, (size_t)max_frames * d.nb_max * 4 * d.rec_quad) || dev_alloc(c, &fb.partial, part_cap * d.NPAIR * 256) || dev_alloc(c, &fb.Hraw, (size_t)max_frames * 2 * d.HS * d.HS) ||
+        dev_alloc(c, &fb.rec, (size_t)max_frames * d.nb_max * 4 * d.rec_quad) || dev_alloc(c, &fb.partial, part_cap * d.NPAIR * 256) || dev_alloc(c, &fb.bmask, (size_t)max_frames * d.nb_max) || dev_alloc(c, &fb.Hraw, (size_t)max_frames * 2 * d.HS * d.HS) ||
         dev_alloc(c, &fb.prior, (size_t)max_frames * 2 * AVT_MAX_COMPS * AVT_PRIOR_STRIDE) || dev_alloc(c, &fb.ctl, (size_t)max_frames) ||
         dev_alloc(c, &fb.jointpos, (size_t)max_frames * 3 * J) || dev_alloc(c, &fb.jointtrans, (size_t)max_frames * 12 * J) ||
         dev_alloc(c, &fb.trace, (size_t)max_frames * 64))

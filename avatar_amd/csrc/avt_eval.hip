@@ -52,7 +52,8 @@ __device__ __forceinline__ void wave_sync() {
 //   double field F of point p4 at [F*4 + p4], F = 0..3K+2: shape plane k*3+c (k = K: base cloud);
 //   3K+3..3K+5: mean data point; 3K+6: sqrt(count); 3K+7..3K+10: assigned weights;
 //   then 20 int fields at int index [I*4 + p4]: I = 0..3 assigned joints, 4..19 ancestor words
-//   joint | mask << 8 | (parent joint + 1) << 16 (mask bit a: assigned joint a lies under the joint; 0 = no ancestor).
+//   joint | mask << 8 | (parent joint + 1) << 16 | storage column of the joint << 24 (mask bit a: assigned joint a lies
+//   under the joint; 0 = no ancestor).
 // Points past M in the last batch are written as zeros (sqrt(count) = 0 silences their rows).
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_records(DeviceModel dm, FrameBuffers fb) {
@@ -90,10 +91,22 @@ __global__ __launch_bounds__(256) void k_records(DeviceModel dm, FrameBuffers fb
             if (ifield < 4) v = dm.asg_j[(size_t)ifield * V + m];
             else if (ifield - 4 < (int)dm.anc_n[m]) {
                 v = (int)dm.anc[(size_t)(ifield - 4) * V + m];
-                v |= (dm.parent[v & 0xff] + 1) << 16;
+                v |= ((dm.parent[v & 0xff] + 1) << 16) | (dm.joint_col[v & 0xff] << 24);
             }
         }
         RI[e] = v;
+    }
+    if (t < 32) {   // tiles this batch's rows touch: J^T J skips the other tile pairs (k_eval)
+        const int pos = b * AVT_EVAL_PTS + t;
+        int bm = (t < 16 && pos < M) ? (int)dm.vmask[fb.matched[(size_t)f * V + pos]] : 0;
+#pragma unroll
+        for (int s = 16; s >= 1; s >>= 1) bm |= __shfl_xor(bm, s, 64);
+        // word: bits 24..31 live tiles; bits 0..23 live tile pairs in upper-triangle order (lane p = pair p; used when NT <= 6)
+        int p = t, ti = 0;
+        while (ti < d.NT && p >= d.NT - ti) { p -= d.NT - ti; ++ti; }
+        const bool live = t < 24 && ti < d.NT && ((bm >> ti) & (bm >> (ti + p)) & 1);
+        const unsigned long long bal = __ballot(live);
+        if (t == 0) fb.bmask[(size_t)f * d.nb_max + b] = (int)(bal & 0xffffffu) | (bm << 24);
     }
 }
 
@@ -123,18 +136,20 @@ __device__ __forceinline__ void stage_records(double* __restrict__ Rrec, int RQ2
 
 template <int CJ, int CK>
 __device__ __forceinline__ void build_rows(const AvtDims& d, const EvalTables& T, double* __restrict__ s_Jt, const double* __restrict__ Rrec,
-                                           double* __restrict__ s_xhat, double* __restrict__ s_xk, double* __restrict__ s_T, int qw, int ln) {
+                                           double* __restrict__ s_xhat, double* __restrict__ s_xk, double* __restrict__ s_T, int qw, int ln, int zmask) {
     constexpr bool FIXED = CJ != 0;
     constexpr int RS = AVT_EVAL_RS;
     const int J = FIXED ? CJ : d.J, K = FIXED ? CK : d.K, P = 3 + 3 * J + K, NC = P + 1;
     const int ND = 3 * K + 11;
     const int p4 = ln >> 4, slot = ln & 15, pi = qw * 4 + p4;
     const double *Rw = T.Rw, *oo = T.oo, *Jh = T.Jh, *Gm = T.Gm, *ww = T.ww, *off = T.off;
-    if (ln < 60) {   // zero my wave's 12 rows of every column: 5 columns x 12 rows per pass (the stride is odd: 8-byte stores)
+    if (ln < 60) {   // zero my wave's 12 rows of every column of the batch's live tiles: 5 columns x 12 rows per pass (the stride is odd: 8-byte stores)
         double* z = s_Jt + (size_t)(ln / 12) * RS + qw * 12 + (ln % 12);
 #pragma unroll
         for (int pass = 0; pass < (16 * AVT_MAX_TILES + 4) / 5; ++pass)
-            if (5 * pass + ln / 12 < NC) z[pass * 5 * RS] = 0.0;
+            if ((zmask >> pass) & 1) {          // wave-uniform: some column of this pass lies in a live tile
+                if (5 * pass + ln / 12 < NC) z[pass * 5 * RS] = 0.0;
+            }
     }
     wave_sync();
     const double* R = Rrec;
@@ -182,7 +197,7 @@ __device__ __forceinline__ void build_rows(const AvtDims& d, const EvalTables& T
         const double L0 = m2 * (X0 - cj * oo[3 * j]), L1 = m2 * (X1 - cj * oo[3 * j + 1]), L2 = m2 * (X2 - cj * oo[3 * j + 2]);
         const int pj = (aword >> 16) & 0xff;
         const double* Rp = pj ? Rw + 9 * (pj - 1) : T.ident;
-        double* o0 = s_Jt + (size_t)(3 + 3 * j) * RS + pi * 3;
+        double* o0 = s_Jt + (size_t)((unsigned)aword >> 24) * RS + pi * 3;      // the joint's three storage columns
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             o0[c * RS] = L1 * Rp[6 + c] - L2 * Rp[3 + c];
@@ -199,17 +214,17 @@ __device__ __forceinline__ void build_rows(const AvtDims& d, const EvalTables& T
             const double* Tr = s_T + pi * 9 + 3 * r;
             const double gs = ((aw[0] * Gm[aj[0] * 3 * K + e] + aw[1] * Gm[aj[1] * 3 * K + e]) + aw[2] * Gm[aj[2] * 3 * K + e]) + aw[3] * Gm[aj[3] * 3 * K + e];
             const double a = (Tr[0] * R[(3 * k) * 4 + p4] + Tr[1] * R[(3 * k + 1) * 4 + p4] + Tr[2] * R[(3 * k + 2) * 4 + p4]) + gs;
-            s_Jt[(size_t)(3 + 3 * J + k) * RS + pi * 3 + r] = sc * a;
+            s_Jt[(size_t)(d.col_shape + k) * RS + pi * 3 + r] = sc * a;
         }
     }
     if (slot < 3) {          // residual column: sqrt(c) (x_m - dbar_m)
         double xm = 0.0;
 #pragma unroll
         for (int a = 0; a < 4; ++a) xm += aw[a] * xk[3 * a + slot];
-        s_Jt[(size_t)P * RS + pi * 3 + slot] = sc * (xm - R[(3 * K + 3 + slot) * 4 + p4]);
+        s_Jt[(size_t)d.col_res * RS + pi * 3 + slot] = sc * (xm - R[(3 * K + 3 + slot) * 4 + p4]);
     } else if (slot < 6) {   // identity root-translation block (:476-481)
         const int r = slot - 3;
-        s_Jt[(size_t)r * RS + pi * 3 + r] = sc;
+        s_Jt[(size_t)(d.col_tr + r) * RS + pi * 3 + r] = sc;
     }
 }
 
@@ -217,27 +232,35 @@ __device__ __forceinline__ void build_rows(const AvtDims& d, const EvalTables& T
 __device__ constexpr int PAIR6_TI[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
 __device__ constexpr int PAIR6_TJ[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
 
-// SMPL shape (6 column tiles, 21 tile pairs, 12 k-steps per batch = 252 matrix instructions): wave W owns pairs
-// W, W+4, .., W+16 and k-steps 3W..3W+2 of the last pair (5,5), 63 instructions per wave and batch.  A and B
-// operands are the same kind of fragment (lane l: column tile*16 + (l&15), row k0 + (l>>4)), so 6 LDS reads per
-// k-step feed all of them; straight-line code, no exec-mask branches between the matrix instructions.
+// SMPL shape (6 column tiles, 21 tile pairs, 12 k-steps per batch = 252 matrix instructions when every tile is live):
+// wave W owns pairs W, W+4, .., W+16 and k-steps 3W..3W+2 of the last pair (5,5), 63 instructions per wave and batch.
+// A and B operands are the same kind of fragment (lane l: tile column (l&15) -> its storage column, row k0 + (l>>4)), so
+// a pair costs 24 LDS reads (12 on the diagonal).  pm = the batch's live tile pairs (bit p): one wave-uniform scalar
+// branch per pair (matrix instructions ignore EXEC), the 12 k-steps of a live pair are straight-line code.
 template <int W>
-__device__ __forceinline__ void mfma_batch6(const double* __restrict__ s_Jt, int ln, int NC, v4f64 (&acc)[6]) {
-    const double* base = s_Jt + (size_t)(ln & 15) * AVT_EVAL_RS + (ln >> 4);
-    // last column tile: lanes past the real columns read the zero column
-    const double* base5 = s_Jt + (size_t)min(80 + (ln & 15), NC) * AVT_EVAL_RS + (ln >> 4);
+__device__ __forceinline__ void mfma_batch6(const double* const (&base)[6], int pm, v4f64 (&acc)[6]) {
 #pragma unroll
-    for (int ks = 0; ks < AVT_EVAL_ROWS / 4; ++ks) {
-        double fr[6];
+    for (int i = 0; i < 5; ++i) {
+        const int p = W + 4 * i;
+        if ((pm >> p) & 1) {                 // one scalar branch per live pair, straight-line code inside
+            constexpr int NK = AVT_EVAL_ROWS / 4;
+            const int ti = PAIR6_TI[p], tj = PAIR6_TJ[p];
+            double fa[NK], fbv[NK];
 #pragma unroll
-        for (int ti = 0; ti < 5; ++ti) fr[ti] = base[(size_t)ti * 16 * AVT_EVAL_RS + 4 * ks];
-        fr[5] = base5[4 * ks];
+            for (int ks = 0; ks < NK; ++ks) {
+                fa[ks] = base[ti][4 * ks];
+                fbv[ks] = (ti != tj) ? base[tj][4 * ks] : fa[ks];
+            }
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int p = W + 4 * i;
-            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[PAIR6_TI[p]], fr[PAIR6_TJ[p]], acc[i], 0, 0, 0);
+            for (int ks = 0; ks < NK; ++ks) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks], fbv[ks], acc[i], 0, 0, 0);
         }
-        if (ks / 3 == W) acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[5], fr[5], acc[5], 0, 0, 0);
+    }
+    if ((pm >> 20) & 1) {
+#pragma unroll
+        for (int ks = 3 * W; ks < 3 * W + 3; ++ks) {
+            const double f = base[5][4 * ks];
+            acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(f, f, acc[5], 0, 0, 0);
+        }
     }
 }
 
@@ -285,7 +308,9 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm,
     d2v pf[NPF];
 #pragma unroll
     for (int i = 0; i < NPF; ++i) pf[i] = (d2v){0.0, 0.0};
+    int bm_next = 0;                                               // live tiles / pairs word of the batch being prefetched
     auto prefetch = [&](int b) {
+        bm_next = fb.bmask[(size_t)f * d.nb_max + b];
         const d2v* src = recf + ((size_t)b * 4 + wv) * RQ2;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
@@ -316,6 +341,12 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm,
     for (int e = t; e < npre + K + 3; e += 256) s_prep[e] = prep[e < npre ? e : e + 4 * J];
     if (t < 9) s_ident[t] = (t == 0 || t == 4 || t == 8) ? 1.0 : 0.0;
     if (t < RS) s_Jt[(size_t)NC * RS + t] = 0.0;
+    // MFMA operand fragments: lane l reads storage column tile_col[tile*16 + (l&15)] (padding -> the zero column), rows k0 + (l>>4)
+    const double* fbase[6];
+    if constexpr (FIXED) {
+#pragma unroll
+        for (int ti = 0; ti < 6; ++ti) fbase[ti] = s_Jt + (size_t)dm.tile_col[ti * 16 + (ln & 15)] * RS + (ln >> 4);
+    }
     const double* Rw = s_prep;                                    // prep_off_Rw = 0
     const double* oo = s_prep + 9 * J;
     const double* Jh = s_prep + 12 * J;
@@ -326,13 +357,17 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm,
 
     // generic shapes: static round-robin deal of whole tile pairs to the waves
     int pr_ti[MAXPW], pr_tj[MAXPW];
+    const double *pr_a[MAXPW], *pr_b[MAXPW];
     if constexpr (!FIXED) {
 #pragma unroll
         for (int i = 0; i < MAXPW; ++i) {
             int p = wv + 4 * i, ti = 0;
+            pr_a[i] = s_Jt; pr_b[i] = s_Jt;
             if (p < NPAIR) {
                 while (p >= NT - ti) { p -= NT - ti; ++ti; }
                 pr_ti[i] = ti; pr_tj[i] = ti + p;
+                pr_a[i] = s_Jt + (size_t)dm.tile_col[pr_ti[i] * 16 + (ln & 15)] * RS + (ln >> 4);
+                pr_b[i] = s_Jt + (size_t)dm.tile_col[pr_tj[i] * 16 + (ln & 15)] * RS + (ln >> 4);
             } else { pr_ti[i] = -1; pr_tj[i] = -1; }
         }
     }
@@ -348,29 +383,33 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm,
         EPROBE(0);
         // ---- wave-local from here to the next barrier ------------------------------------------------------
         stage_records<NPF>(s_rec + (size_t)wv * RQ, RQ2, ln, pf);
+        const int bw = __builtin_amdgcn_readfirstlane(bm_next);   // live tiles / tile pairs of this batch (k_records)
+        const int tm = (unsigned)bw >> 24, pm = bw & 0xffffff;
         if (b + G < nb) prefetch(b + G);
-        build_rows<CJ, CK>(d, tabs, s_Jt, s_rec + (size_t)wv * RQ, s_xhat, s_xk, s_T, wv, ln);
+        // zeroing passes (5 consecutive storage columns each) that touch a live tile (AvtDims::tile_zpass, avt_model.cpp)
+        int zmask = 0;
+#pragma unroll
+        for (int ti = 0; ti < AVT_MAX_TILES; ++ti)
+            if (ti < NT && ((tm >> ti) & 1)) zmask |= d.tile_zpass[ti];
+        build_rows<CJ, CK>(d, tabs, s_Jt, s_rec + (size_t)wv * RQ, s_xhat, s_xk, s_T, wv, ln, zmask);
         EPROBE(3);
         __syncthreads();
         EPROBE(4);
         // MFMA phase: 12 k-steps of 4 rows
         if constexpr (FIXED) {
             switch (wv) {
-                case 0: mfma_batch6<0>(s_Jt, ln, NC, acc); break;
-                case 1: mfma_batch6<1>(s_Jt, ln, NC, acc); break;
-                case 2: mfma_batch6<2>(s_Jt, ln, NC, acc); break;
-                default: mfma_batch6<3>(s_Jt, ln, NC, acc); break;
+                case 0: mfma_batch6<0>(fbase, pm, acc); break;
+                case 1: mfma_batch6<1>(fbase, pm, acc); break;
+                case 2: mfma_batch6<2>(fbase, pm, acc); break;
+                default: mfma_batch6<3>(fbase, pm, acc); break;
             }
         } else {
 #pragma unroll 1
             for (int k0 = 0; k0 < AVT_EVAL_ROWS; k0 += 4) {
-                const int rowoff = k0 + (ln >> 4);
 #pragma unroll
                 for (int i = 0; i < MAXPW; ++i) {
-                    if (pr_ti[i] >= 0) {
-                        const double a = s_Jt[(size_t)min(pr_ti[i] * 16 + (ln & 15), NC) * RS + rowoff];
-                        const double bq = s_Jt[(size_t)min(pr_tj[i] * 16 + (ln & 15), NC) * RS + rowoff];
-                        acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc[i], 0, 0, 0);
+                    if (pr_ti[i] >= 0 && ((tm >> pr_ti[i]) & (tm >> pr_tj[i]) & 1)) {
+                        acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(pr_a[i][k0], pr_b[i][k0], acc[i], 0, 0, 0);
                     }
                 }
             }

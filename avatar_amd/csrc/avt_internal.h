@@ -37,6 +37,8 @@ struct AvtDims {
     int HS;                  // row stride of the dense normal-equation block: 4*ceil((P+1)/4)
     int rec_quad;            // doubles per 4-point matched-point record (avt_eval.hip): 12K + 84
     int nb_max;              // eval batches a frame can have: ceil(V/16)
+    int col_tr, col_shape, col_res;   // storage columns of the evaluation tile: root translation, first shape key, residual (avt_model.cpp)
+    int tile_zpass[AVT_MAX_TILES];    // per tile: the 5-column zeroing passes of build_rows that overlap its storage columns (bit = pass)
 };
 
 // prep block layout (doubles), one per frame per slot: what an evaluation needs about the skeleton state
@@ -117,6 +119,12 @@ struct DeviceModel {
     unsigned short* anc;  // [AVT_ANC_MAX][V]
     int* mesh;            // [3][F] SoA
     int* parent;          // [J]
+    // column layout of the evaluation tile (build_tile_layout, avt_model.cpp)
+    int* tile_col;        // [16*NT] tile column -> storage column (P+1 = the all-zero column for padding)
+    int* tile_param;      // [16*NT] tile column -> parameter index (P = residual), -1 = padding
+    int* joint_col;       // [J] storage column of the joint's first rotation parameter
+    int* vorder;          // [V] vertices ordered by the set of tiles their rows touch, then by id
+    unsigned char* vmask; // [V] that set (bit = tile)
     int* fk_items;        // [J*(12+3K)][2] per-level work items of k_solve's skeleton pass (see avt_lm.hip), grouped by level
     int* fk_level_off;    // [nlevels+1] offsets into fk_items
     double* jsr_base;     // [3J] initialJointPos
@@ -168,6 +176,7 @@ struct FrameBuffers {
     AvtFrameCtl* ctl_start;
     double* prep;         // [max_frames][2][prep_size]
     double* rec;          // [max_frames][nb_max][4][rec_quad] matched-point records (k_records)
+    int* bmask;           // [max_frames][nb_max] tiles touched by each batch of 16 matched points
     double* partial;      // [max_frames][G][NPAIR][256]
     double* Hraw;         // [max_frames][2][HS*HS] reduced data-term [J|r]^T W [J|r] (full symmetric) per state slot
     double* prior;        // [max_frames][2][AVT_MAX_COMPS][AVT_PRIOR_STRIDE] GMM scores / Prec*(x-mu) per state slot
@@ -182,7 +191,8 @@ struct avt_model {
     // host copies (used by avt_ctx_create to build the device model and by accessors)
     std::vector<double> shape_planes, lbs_w, asg_w, jsr_base, jsr, S, Sp;
     std::vector<int> lbs_j, asg_j, mesh_soa, parent, main_joint, jlevel, fk_items, fk_level_off;
-    std::vector<unsigned char> anc_n;
+    std::vector<int> tile_col, tile_param, joint_col, vorder;
+    std::vector<unsigned char> anc_n, vmask;
     std::vector<unsigned short> anc;
     std::vector<double> prior_mean, prior_prec, prior_L, prior_clog;
 };

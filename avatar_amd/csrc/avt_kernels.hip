@@ -258,7 +258,8 @@ void launch_bucket(avt_ctx* c, int nframes, bool clear_after) {
 // into the compacted list of matched model points (the `caches` of AvatarOptimizer.cpp:1419-1431; sqrt(count) and
 // the mean data point are formed where the records are gathered, k_records) and the prior weight rescale
 // (AvatarOptimizer.cpp:1457-1458).
-// One workgroup of 1024 threads per frame; the compaction keeps ascending vertex order.
+// One workgroup of 1024 threads per frame; the compaction keeps the model's vertex order (vorder: by the set of
+// tiles a vertex's rows touch, then ascending id), so that batches of 16 matched points share their live tiles.
 // =================================================================================================
 __global__ __launch_bounds__(1024) void k_finalize(DeviceModel dm, FrameBuffers fb, double beta_pose, double beta_shape,
                                                    double lambda0, int first_icp) {
@@ -269,11 +270,26 @@ __global__ __launch_bounds__(1024) void k_finalize(DeviceModel dm, FrameBuffers 
     const int chunk = (V + 1023) / 1024;
     const int lo = min(V, t * chunk), hi = min(V, lo + chunk);
     const int* cnt = fb.cnt + (size_t)f * V;
-    int m = 0, tt = 0;
-    for (int v = lo; v < hi; ++v) {
-        const int c = cnt[v];
-        m += (c > 0);
-        tt += c;
+    // positions in the model's tile-set order (DeviceModel::vorder); up to 8 per thread are kept in registers so that the
+    // gathers of both passes are in flight together
+    constexpr int CH = 8;
+    int m = 0, tt = 0, vs[CH], cs[CH];
+    const bool small = chunk <= CH;
+    if (small) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) vs[u] = dm.vorder[min(lo + u, V - 1)];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            cs[u] = (lo + u < hi) ? cnt[vs[u]] : 0;
+            m += (cs[u] > 0);
+            tt += cs[u];
+        }
+    } else {
+        for (int i = lo; i < hi; ++i) {
+            const int c = cnt[dm.vorder[i]];
+            m += (c > 0);
+            tt += c;
+        }
     }
     const int im = wave_incl_scan(m), it = wave_incl_scan(tt);
     if (lane_id() == 63) { s_wave_m[wave_id()] = im; s_wave_t[wave_id()] = it; }
@@ -285,8 +301,16 @@ __global__ __launch_bounds__(1024) void k_finalize(DeviceModel dm, FrameBuffers 
         total_t += s_wave_t[w];
     }
     int pos = mbase + im - m;
-    for (int v = lo; v < hi; ++v)
-        if (cnt[v] > 0) fb.matched[(size_t)f * V + pos++] = v;
+    if (small) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+            if (cs[u] > 0) fb.matched[(size_t)f * V + pos++] = vs[u];
+    } else {
+        for (int i = lo; i < hi; ++i) {
+            const int v = dm.vorder[i];
+            if (cnt[v] > 0) fb.matched[(size_t)f * V + pos++] = v;
+        }
+    }
     if (t == 0) {
         ctl.M = total_m;
         ctl.T = total_t;

@@ -162,8 +162,9 @@ __global__ __launch_bounds__(256 * Q) void k_reduce(DeviceModel dm, FrameBuffers
         int p = blockIdx.x, ti = 0;
         while (p >= NT - ti) { p -= NT - ti; ++ti; }
         const int tj = ti + p;
-        const int r = ti * 16 + ((t >> 4) & 3) + 4 * (t >> 6), c = tj * 16 + (t & 15);
-        if (r <= P && c <= P) {
+        // tile coordinates -> parameter indices (the evaluation tile has its own column order, avt_model.cpp)
+        const int r = dm.tile_param[ti * 16 + ((t >> 4) & 3) + 4 * (t >> 6)], c = dm.tile_param[tj * 16 + (t & 15)];
+        if (r >= 0 && c >= 0) {
             double* H = fb.Hraw + ((size_t)f * 2 + try_slot) * HS * HS;
             H[(size_t)r * HS + c] = a;
             if (ti != tj) H[(size_t)c * HS + r] = a;

@@ -10,7 +10,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <limits>
+#include <numeric>
 
 #include "avt_internal.h"
 
@@ -33,6 +35,94 @@ static bool chol_lower(const double* A, int n, double* L) {
         }
     }
     return true;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Column layout of the evaluation tile [J | r] (avt_eval.hip).  A model point's rows are non-zero only in the columns
+// of its ancestors' rotations, the root translation, the shape keys and the residual, so the columns are grouped
+// into the 16-wide MFMA tiles by branch of the kinematic tree and J^T J skips the tile pairs a batch of points does
+// not touch:
+//   tile 0: root translation, shape keys, root rotation (every point);
+//   one tile per group of <= 5 joints, packed bottom-up along the tree (SMPL: spine+head, each arm, each leg);
+//   the residual column rides in tile 0 if it has room, else in the group tile most vertices touch.
+// Vertices are then ordered by the set of tiles they touch, so that batches of 16 matched points are (mostly)
+// uniform.  Skeletons that do not pack into the tile grid keep the plain order (storage column = parameter index,
+// every tile live).  k_reduce maps tile coordinates back to parameter indices: nothing outside k_eval sees the order.
+// -------------------------------------------------------------------------------------------------
+static void build_tile_layout(avt_model* m, const int* parent) {
+    AvtDims& d = m->d;
+    const int V = d.V, J = d.J, K = d.K, P = d.P, NT = d.NT, NC = P + 1;
+    auto plain = [&]() {
+        m->tile_col.assign((size_t)16 * NT, NC); m->tile_param.assign((size_t)16 * NT, -1);
+        for (int tc = 0; tc < NC; ++tc) { m->tile_col[tc] = tc; m->tile_param[tc] = tc; }
+        m->joint_col.resize(J);
+        for (int j = 0; j < J; ++j) m->joint_col[j] = 3 + 3 * j;
+        d.col_tr = 0; d.col_shape = 3 + 3 * J; d.col_res = P;
+        m->vorder.resize(V); std::iota(m->vorder.begin(), m->vorder.end(), 0);
+        m->vmask.assign(V, (unsigned char)((1u << NT) - 1));
+    };
+    if (6 + K > 16 || NT > 8) { plain(); return; }
+    std::vector<std::vector<int>> children(J), groups;
+    for (int j = 1; j < J; ++j) children[parent[j]].push_back(j);
+    const size_t cap = 5;
+    std::function<std::vector<int>(int)> pack = [&](int j) {
+        std::vector<std::vector<int>> open;
+        size_t total = 1;
+        for (int c : children[j]) { open.push_back(pack(c)); total += open.back().size(); }
+        std::stable_sort(open.begin(), open.end(), [](const std::vector<int>& a, const std::vector<int>& b) { return a.size() > b.size(); });
+        size_t first = 0;
+        while (total > cap && first < open.size()) { groups.push_back(open[first]); total -= open[first].size(); ++first; }
+        std::vector<int> res{j};
+        for (size_t i = first; i < open.size(); ++i) res.insert(res.end(), open[i].begin(), open[i].end());
+        return res;
+    };
+    for (int c : children[0]) { std::vector<int> g = pack(c); if (!g.empty()) groups.push_back(g); }
+    while ((int)groups.size() > NT - 1) {       // too many branches: merge the two smallest while they fit one tile
+        std::stable_sort(groups.begin(), groups.end(), [](const std::vector<int>& a, const std::vector<int>& b) { return a.size() < b.size(); });
+        if (groups[0].size() + groups[1].size() > cap) { plain(); return; }
+        groups[1].insert(groups[1].end(), groups[0].begin(), groups[0].end());
+        groups.erase(groups.begin());
+    }
+    for (auto& g : groups) std::sort(g.begin(), g.end());
+    std::sort(groups.begin(), groups.end());            // by smallest joint id: a fixed, model-only order
+    std::vector<int> tile_of(J, 0);
+    for (size_t gi = 0; gi < groups.size(); ++gi)
+        for (int j : groups[gi]) tile_of[j] = (int)gi + 1;
+    // tiles a vertex touches (without the residual's tile), from its ancestor list
+    std::vector<unsigned char> vm(V, 1);
+    std::vector<int> touched(NT, 0);
+    for (int v = 0; v < V; ++v) {
+        for (int a = 0; a < m->anc_n[v]; ++a) vm[v] |= (unsigned char)(1u << tile_of[m->anc[(size_t)a * V + v] & 0xff]);
+        for (int ti = 0; ti < NT; ++ti) touched[ti] += (vm[v] >> ti) & 1;
+    }
+    int res_tile = 0;
+    if (6 + K >= 16) {
+        res_tile = -1;
+        for (size_t gi = 0; gi < groups.size(); ++gi)
+            if (3 * groups[gi].size() < 16 && (res_tile < 0 || touched[gi + 1] > touched[res_tile])) res_tile = (int)gi + 1;
+        if (res_tile < 0) { plain(); return; }
+    }
+    // storage order = tile order with the padding squeezed out
+    m->tile_col.assign((size_t)16 * NT, NC); m->tile_param.assign((size_t)16 * NT, -1);
+    m->joint_col.assign(J, 0);
+    int store = 0;
+    auto put = [&](int tile, int& fill, int param) { m->tile_col[16 * tile + fill] = store; m->tile_param[16 * tile + fill] = param; ++fill; return store++; };
+    {
+        int fill = 0;
+        d.col_tr = store; for (int c = 0; c < 3; ++c) put(0, fill, c);
+        d.col_shape = store; for (int k = 0; k < K; ++k) put(0, fill, 3 + 3 * J + k);
+        m->joint_col[0] = store; for (int c = 0; c < 3; ++c) put(0, fill, 3 + c);
+        if (res_tile == 0) d.col_res = put(0, fill, P);
+    }
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        int fill = 0;
+        for (int j : groups[gi]) { m->joint_col[j] = store; for (int c = 0; c < 3; ++c) put((int)gi + 1, fill, 3 + 3 * j + c); }
+        if (res_tile == (int)gi + 1) d.col_res = put((int)gi + 1, fill, P);
+    }
+    m->vmask.resize(V);
+    for (int v = 0; v < V; ++v) m->vmask[v] = (unsigned char)(vm[v] | (1u << res_tile));
+    m->vorder.resize(V); std::iota(m->vorder.begin(), m->vorder.end(), 0);
+    std::stable_sort(m->vorder.begin(), m->vorder.end(), [&](int a, int b) { return m->vmask[a] < m->vmask[b]; });
 }
 
 extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
@@ -170,6 +260,13 @@ extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
         anc_max = std::max(anc_max, n);
     }
     d.anc_max = anc_max;
+    build_tile_layout(m, desc->parent);
+    for (int ti = 0; ti < AVT_MAX_TILES; ++ti) {
+        int lo = d.P + 1, hi = -1;
+        if (ti < d.NT)
+            for (int i = 0; i < 16; ++i) { const int c = m->tile_col[ti * 16 + i]; if (c <= d.P) { lo = std::min(lo, c); hi = std::max(hi, c); } }
+        d.tile_zpass[ti] = hi >= lo ? (int)(((2u << (hi / 5)) - 1u) & ~((1u << (lo / 5)) - 1u)) : 0;
+    }
 
     // mesh SoA
     m->mesh_soa.assign((size_t)3 * F, 0);
