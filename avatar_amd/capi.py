@@ -161,6 +161,7 @@ def load_library():
         "avt_model_dims": [vp, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p],
         "avt_model_main_joint": [vp, c_int_p],
         "avt_model_joint_regression": [vp, c_double_p, c_double_p],
+        "avt_model_tile_layout": [vp, c_int_p, c_int_p, C.POINTER(C.c_ubyte), c_int_p],
         "avt_ctx_create": [C.c_int, vp, C.c_int, c_int_p, C.c_int, C.c_int, C.POINTER(vp)],
         "avt_ctx_destroy": [vp],
         "avt_sync": [vp],
@@ -200,7 +201,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "avt_last_error", "avt_kernel_name", "avt_options_default", "avt_model_create", "avt_model_destroy",
-    "avt_model_dims", "avt_model_main_joint", "avt_model_joint_regression", "avt_ctx_create", "avt_ctx_destroy",
+    "avt_model_dims", "avt_model_main_joint", "avt_model_joint_regression", "avt_model_tile_layout", "avt_ctx_create", "avt_ctx_destroy",
     "avt_sync", "avt_lbs_update", "avt_visibility", "avt_nn", "avt_optimize", "avt_optimize_batch",
     "avt_frames_upload", "avt_synth_render_frames", "avt_frames_download", "avt_state_upload", "avt_optimize_resident", "avt_state_reset", "avt_state_download",
     "avt_get_correspondences", "avt_get_cloud", "avt_get_posed", "avt_get_normal_equations", "avt_debug_trace", "avt_profile_begin", "avt_profile_select", "avt_profile_end",

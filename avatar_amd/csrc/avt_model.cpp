@@ -377,3 +377,12 @@ extern "C" const char* avt_kernel_name(int k) {
     static const char* names[AVT_K_COUNT] = {"lbs", "visibility", "bucket", "nn", "aggregate", "prepare", "eval", "reduce", "solve"};
     return (k >= 0 && k < AVT_K_COUNT) ? names[k] : "?";
 }
+
+extern "C" int avt_model_tile_layout(const avt_model* m, int* ntiles, int* tile_param, unsigned char* vertex_tiles, int* vertex_order) {
+    if (!m) { avt_set_error("avt_model_tile_layout: null model"); return 1; }
+    if (ntiles) *ntiles = m->d.NT;
+    if (tile_param) std::copy(m->tile_param.begin(), m->tile_param.end(), tile_param);
+    if (vertex_tiles) std::copy(m->vmask.begin(), m->vmask.end(), vertex_tiles);
+    if (vertex_order) std::copy(m->vorder.begin(), m->vorder.end(), vertex_order);
+    return 0;
+}

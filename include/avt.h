@@ -109,6 +109,11 @@ int avt_model_dims(const avt_model* m, int* V, int* J, int* K, int* F, int* P);
 int avt_model_main_joint(const avt_model* m, int* main_joint_V);
 /* initialJointPos (3xJ) and jointShapeReg (3J x K col-major) (AvatarModel.cpp:112-127) */
 int avt_model_joint_regression(const avt_model* m, double* initial_joint_pos_3xJ, double* joint_shape_reg_3JxK);
+/* Column layout of the evaluation kernel's [J | r] tile (no reference counterpart; the parameter blocks are those of
+ * AvatarOptimizer.cpp:620-629): `tile_param[16*ntiles]` = parameter index of every tile column (P = residual, -1 = padding),
+ * `vertex_tiles[V]` = bit mask of the 16-column tiles a vertex's residual rows touch, `vertex_order[V]` = the order in which
+ * matched vertices are batched (by tile set, then id).  Any pointer may be NULL; *ntiles = ceil((P+1)/16). */
+int avt_model_tile_layout(const avt_model* m, int* ntiles, int* tile_param, unsigned char* vertex_tiles, int* vertex_order);
 
 /* ---- context: one HIP device + stream + persistent buffers.  `part_map` (>= J entries) and `num_parts`
  * are the AvatarOptimizer ctor arguments (AvatarOptimizer.h:14, AvatarOptimizer.cpp:1213-1244). */

@@ -272,6 +272,53 @@ def test_model_create_host_side(smpl, omodel):
     assert b"parent[0]" in lib.avt_last_error()
 
 
+def test_tile_layout_of_the_evaluation_kernel(smpl):
+    """Host-side column layout behind the block-sparse J^T J (avt_model.cpp::build_tile_layout): a permutation of the
+    parameters into 16-column tiles, every vertex's tile set covers the parameter blocks its residual depends on
+    (AvatarOptimizer.cpp:620-629: root translation, ancestors' rotations, shape keys), vertices ordered by tile set."""
+    lib = capi.load_library()
+    arr = capi.ModelArrays(smpl)
+    desc = arr.desc()
+    h = ctypes.c_void_p()
+    assert lib.avt_model_create(ctypes.byref(desc), ctypes.byref(h)) == 0
+    V, J, K = arr.V, 24, 10
+    P = 3 + 3 * J + K
+    nt = ctypes.c_int()
+    tp = np.full(16 * 8, -7, np.int32); vt = np.zeros(V, np.uint8); vo = np.zeros(V, np.int32)
+    assert lib.avt_model_tile_layout(h, ctypes.byref(nt), capi.iptr(tp), vt.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), capi.iptr(vo)) == 0
+    NT = nt.value
+    assert NT == (P + 1 + 15) // 16 == 6
+    tp = tp[:16 * NT]
+    real = tp[tp >= 0]
+    assert sorted(real.tolist()) == list(range(P + 1)), "every parameter and the residual column exactly once"
+    tile_of_param = np.empty(P + 1, int); tile_of_param[tp[tp >= 0]] = np.nonzero(tp >= 0)[0] // 16
+    # the three parameters of a joint, the translation and the shape keys each stay inside one tile
+    for j in range(J):
+        assert len(set(tile_of_param[3 + 3 * j: 6 + 3 * j])) == 1
+    assert len(set(tile_of_param[0:3])) == 1 and len(set(tile_of_param[3 + 3 * J: P])) == 1
+    parent = np.asarray(arr.parent)
+    W = np.asarray(smpl["weights"])
+    pairs = 0
+    for v in range(V):
+        need = {tile_of_param[0], tile_of_param[3 + 3 * J], tile_of_param[P]}
+        asg = np.nonzero(W[v] > 1e-12)[0]
+        asg = asg[np.argsort(-W[v, asg], kind="stable")][:4]
+        for k in asg:
+            j = int(k)
+            while j >= 0:
+                need.add(tile_of_param[3 + 3 * j]); j = int(parent[j])
+        got = {t for t in range(NT) if (vt[v] >> t) & 1}
+        assert need <= got, (v, need, got)
+        pairs += len(got) * (len(got) + 1) // 2
+    assert pairs / V < 8.0, "the synthetic SMPL-shaped skeleton packs: few of the 21 tile pairs per vertex"
+    assert sorted(vo.tolist()) == list(range(V))
+    m = vt[vo]
+    assert np.all(np.diff(m.astype(int)) >= 0), "vertices ordered by tile set"
+    same = np.diff(m.astype(int)) == 0
+    assert np.all(np.diff(vo)[same] > 0), "ascending vertex id inside a tile set"
+    lib.avt_model_destroy(h)
+
+
 def test_no_gpu_means_loud_failure(smpl):
     """Without a HIP device the product path must fail loudly, not fall back."""
     import torch
