@@ -85,6 +85,33 @@ def test_model_with_six_shape_keys_runs_the_runtime_dimension_kernels(smpl):
     assert st[0].gn_iterations == ref["stats"].gn_iterations
 
 
+def test_model_with_twelve_shape_keys_keeps_the_plain_column_order(smpl):
+    """K = 12 (P = 87, the largest system this build accepts): translation + shape keys + root no longer fit one 16-column
+    tile, so build_tile_layout falls back to storage column = parameter index with every tile live; k_eval<0,0>."""
+    import ctypes
+    from avatar_amd import api, capi
+    from oracle import oracle as orc
+    rng = np.random.default_rng(5)
+    m2 = dict(smpl)
+    extra = 0.01 * rng.standard_normal(smpl["shapedirs"].shape[:2] + (2,))
+    m2["shapedirs"] = np.ascontiguousarray(np.concatenate([smpl["shapedirs"], extra], axis=2))
+    gm, om = api.AvatarModel(m2), orc.OracleModel(m2)
+    lib = capi.load_library()
+    nt = ctypes.c_int(); tp = np.zeros(16 * 8, np.int32)
+    assert lib.avt_model_tile_layout(gm.h, ctypes.byref(nt), capi.iptr(tp), None, None) == 0
+    assert nt.value == 6 and np.array_equal(tp[:88], np.arange(88)) and np.all(tp[88:96] == -1)
+    fr = synth.make_frame(smpl, 18)
+    pm = synth.identity_part_map()
+    w0, p0, R0 = fr["start"]
+    w0 = np.ascontiguousarray(np.concatenate([w0, [0.3, -0.2]])); q0 = api.rot_to_quat(R0)
+    opt = Options.demo()
+    ctx = api.Context(gm, 24, pm, len(fr["labels"]), 1)
+    p, q, w, st = ctx.optimize_batch([fr["data"]], [fr["labels"]], opt, p0[None], q0[None], w0[None])
+    ref = om.optimize(pm, 24, fr["data"], fr["labels"], opt, p0, q0, w0, aggregate=1)
+    _check(ctx, ref, p, q, w, len(fr["labels"]))
+    assert st[0].gn_iterations == ref["stats"].gn_iterations
+
+
 def test_ragged_batch_with_empty_frame_and_determinism(smpl, omodel, gmodel):
     from avatar_amd import api
     pm = synth.identity_part_map()
