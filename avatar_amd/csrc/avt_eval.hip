@@ -1,18 +1,21 @@
 // avt_eval.hip — data term of one Gauss-Newton / LM evaluation (gfx950, wave64):
 //   k_records : once per ICP iteration, gathers everything an evaluation needs about each matched model point
 //               (shape planes, mean data point, sqrt(count), assigned joints/weights, ancestor words) into
-//               contiguous per-wave records, so that k_eval streams them with two 16-byte loads per lane;
+//               contiguous per-wave records, so that k_eval streams them with two 16-byte loads per lane, plus one
+//               word per batch of 16 points with the 16-column tiles (and tile pairs) its rows touch;
 //   k_eval    : residual + analytic Jacobian rows per matched model point (AvatarCostFunctorCache::updateData,
 //               AvatarOptimizer.cpp:505-582) staged in LDS and contracted on the fp64 matrix cores
-//               (v_mfma_f64_16x16x4_f64) into per-workgroup partial tiles of [J | r]^T W [J | r]; extra
-//               workgroups of the same grid evaluate the GMM pose prior (avt_prior.h), one component each.
+//               (v_mfma_f64_16x16x4_f64) into per-workgroup partial tiles of [J | r]^T W [J | r] - block-sparse: the
+//               columns are grouped into tiles by branch of the kinematic tree (build_tile_layout, avt_model.cpp) and
+//               only the tile pairs a batch touches are multiplied; extra workgroups of the same grid evaluate the GMM
+//               pose prior (avt_prior.h), one component each.
 //   (k_reduce / k_solve: avt_lm.hip.)
 //
 // Algebra used (exact, only the summation order differs from the reference's per-residual-block form):
 // all residual blocks matched to model point m share one Jacobian block J_m (AvatarOptimizer.cpp:1445-1449),
 // so with c_m = #matches and dbar_m their mean data point,
 //   J^T J = sum_m c_m J_m^T J_m,  J^T r = sum_m c_m J_m^T (x_m - dbar_m),
-//   sum_i |x_m - d_i|^2 = c_m |x_m - dbar_m|^2 + sum_i |d_i - dbar_m|^2   (2nd term: k_cost_const).
+//   sum_i |x_m - d_i|^2 = c_m |x_m - dbar_m|^2 + sum_i |d_i - dbar_m|^2   (2nd term: cost_const_block, avt_device.h).
 // Each matched point therefore contributes 3 rows sqrt(c_m) [J_m | x_m - dbar_m] to an augmented matrix
 // A (3M x (P+1)); A^T A holds H, g and the data cost at once.
 //
@@ -277,7 +280,8 @@ __device__ __forceinline__ void mfma_batch6(const double* const (&base)[6], int 
 //   The tile is stored transposed [column][row] with an odd row stride of 49 doubles (MFMA operand fetch = 16
 //     columns x 4 rows per ds_read_b64 / two k-steps per ds_read2_b64, conflict-free either way).
 //   MFMA phase between two workgroup barriers: the upper-triangular 16x16 output tiles accumulate in registers
-//     over all batches of the workgroup and leave as NPAIR partial tiles (reduced in fixed order by k_reduce).
+//     over all batches of the workgroup and leave as NPAIR partial tiles (reduced in fixed order by k_reduce, which
+//     also maps tile coordinates back to parameter indices); tile pairs the batch does not touch are skipped.
 // CJ/CK != 0: dimensions fixed at compile time (SMPL: 24 joints, 10 shape keys); 0: taken from the model.
 // =================================================================================================
 template <int CJ, int CK>
