@@ -322,7 +322,10 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm,
             pf[i] = (idx < RQ2) ? __builtin_nontemporal_load(src + idx) : (d2v){0.0, 0.0};
         }
     };
-    if (g < d.nb_max) prefetch(g);
+    // a workgroup takes chunks of S consecutive batches (consecutive matched points share their live tiles), chunk g, g+G, ...
+    const int S = AVT_EVAL_CHUNK(G);
+    auto next_batch = [&](int b) { const int b1 = b + 1; return (b1 % S) ? b1 : b1 - S + G * S; };
+    if (g * S < d.nb_max) prefetch(g * S);
     const int M = ctl.M;
     const int try_slot = 1 - ctl.cur_slot;
     const int nb = (M + AVT_EVAL_PTS - 1) / AVT_EVAL_PTS;
@@ -382,14 +385,17 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm,
 #ifdef AVT_TIMING
     long long tacc[6] = {0, 0, 0, 0, 0, 0}; long long tlast = clock64(); const long long wall0 = wall_clock64();
 #endif
-    for (int b = g; b < nb; b += G) {
+    // tile pairs this workgroup accumulated into; with few frames (S == 1) k_reduce<4> reads every tile without asking
+    // (it is latency-bound: the extra round trip costs more than the loads it saves), so every tile is written
+    unsigned long long wm = (FIXED && S > 1) ? 0ull : ~0ull;
+    for (int b = g * S; b < nb; b = next_batch(b)) {
         __syncthreads();  // previous batch's MFMA reads are done (also covers the prep staging on the first pass)
         EPROBE(0);
         // ---- wave-local from here to the next barrier ------------------------------------------------------
         stage_records<NPF>(s_rec + (size_t)wv * RQ, RQ2, ln, pf);
         const int bw = __builtin_amdgcn_readfirstlane(bm_next);   // live tiles / tile pairs of this batch (k_records)
         const int tm = (unsigned)bw >> 24, pm = bw & 0xffffff;
-        if (b + G < nb) prefetch(b + G);
+        if (next_batch(b) < nb) prefetch(next_batch(b));
         // zeroing passes (5 consecutive storage columns each) that touch a live tile (AvtDims::tile_zpass, avt_model.cpp)
         int zmask = 0;
 #pragma unroll
@@ -400,6 +406,7 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm,
         __syncthreads();
         EPROBE(4);
         // MFMA phase: 12 k-steps of 4 rows
+        wm |= (unsigned long long)pm;
         if constexpr (FIXED) {
             switch (wv) {
                 case 0: mfma_batch6<0>(fbase, pm, acc); break;
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm,
         tr[0] = (double)wall0; tr[1] = (double)wall_clock64(); tr[2] = (double)((xcc & 0xf) * 65536 + (hw & 0xffff));
     }
 #endif
-    if constexpr (FIXED) {   // the four waves' shares of pair (5,5) are summed in wave order by wave 0
+    if (FIXED && ((wm >> 20) & 1)) {   // the four waves' shares of pair (5,5) are summed in wave order by wave 0 (wm is workgroup-uniform)
         __syncthreads();
         if (wv > 0) {
 #pragma unroll
@@ -449,11 +456,12 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm,
 #pragma unroll
     for (int i = 0; i < MAXPW; ++i) {
         const int p = wv + 4 * i;
-        if (p < NPAIR) {
+        if (p < NPAIR && ((wm >> p) & 1)) {          // untouched pairs stay unwritten: k_reduce reads the mask
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[(size_t)p * 256 + r * 64 + ln] = acc[i][r];
         }
     }
+    if (t == 0) fb.wmask[(size_t)f * G + g] = wm;
 }
 
 static bool eval_fixed_shape(const AvtDims& d) { return d.J == 24 && d.K == 10; }

@@ -12,6 +12,7 @@
 #define AVT_TILE 16           // MFMA f64 16x16x4 tile edge
 #define AVT_EVAL_PTS 16       // model points per eval batch (48 Jacobian rows)
 #define AVT_EVAL_ROWS (3 * AVT_EVAL_PTS)
+#define AVT_EVAL_CHUNK(G) ((G) >= 64 ? 1 : 4)   // consecutive batches a workgroup takes before striding by G chunks (few live tile pairs per workgroup)
 #define AVT_EVAL_RS 49        // LDS row stride (doubles) of the transposed Jacobian tile.  ODD on purpose: the compiler pairs the MFMA
                               // operand fetches of two k-steps into ds_read2_b64, which is banked modulo 32 in 16-lane groups - an even
                               // stride makes columns c and c+8 collide (2-way), an odd one is conflict-free (plain ds_read_b64 too)
@@ -178,6 +179,7 @@ struct FrameBuffers {
     double* rec;          // [max_frames][nb_max][4][rec_quad] matched-point records (k_records)
     int* bmask;           // [max_frames][nb_max] tiles touched by each batch of 16 matched points
     double* partial;      // [max_frames][G][NPAIR][256]
+    unsigned long long* wmask;   // [max_frames][G] tile pairs workgroup g of the frame wrote to `partial` (bit = pair); k_reduce skips the rest
     double* Hraw;         // [max_frames][2][HS*HS] reduced data-term [J|r]^T W [J|r] (full symmetric) per state slot
     double* prior;        // [max_frames][2][AVT_MAX_COMPS][AVT_PRIOR_STRIDE] GMM scores / Prec*(x-mu) per state slot
     AvtFrameCtl* ctl;     // [max_frames]

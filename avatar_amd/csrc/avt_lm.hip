@@ -136,13 +136,21 @@ __global__ __launch_bounds__(256 * Q) void k_reduce(DeviceModel dm, FrameBuffers
     const int G = fb.G, glo = (G * q) / Q, ghi = (G * (q + 1)) / Q;
     const double* part = fb.partial + ((size_t)f * G * NPAIR + blockIdx.x) * 256 + t;
     const size_t st = (size_t)NPAIR * 256;
-    // the partial tiles do not depend on the control block: request them first
+    // which of my workgroups g wrote this pair (k_eval skips the tile pairs its batches never touch): lane l asks for
+    // g = glo + l, the ballot makes the answer wave-uniform (ghi - glo <= 64 in both launch shapes)
+    // (only the batch shape Q = 1 asks: with few frames the extra round trip costs more than the loads it saves)
+    unsigned long long live = ~0ull;
+    if constexpr (Q == 1) {
+        const int lane = threadIdx.x & 63;
+        const unsigned long long wmine = (glo + lane < ghi) ? fb.wmask[(size_t)f * G + glo + lane] : 0ull;
+        live = __ballot((int)((wmine >> blockIdx.x) & 1ull));
+    }
     double a = 0.0;
     int g = glo;
 #define AVT_REDUCE_ROUND(NLD)                                                                        \
     for (; g + NLD <= ghi; g += NLD) {                                                                \
         double v[NLD];                                                                               \
-        _Pragma("unroll") for (int u = 0; u < NLD; ++u) v[u] = __builtin_nontemporal_load(part + (size_t)(g + u) * st); \
+        _Pragma("unroll") for (int u = 0; u < NLD; ++u) v[u] = ((live >> (g + u - glo)) & 1ull) ? __builtin_nontemporal_load(part + (size_t)(g + u) * st) : 0.0; \
         _Pragma("unroll") for (int u = 0; u < NLD; ++u) a += v[u];                                    \
     }
     if constexpr (Q > 1) { AVT_REDUCE_ROUND(32) }      // (the batch variant stays at 16 loads in flight: fewer registers, it co-runs with k_eval)
