@@ -12,7 +12,10 @@
 #define AVT_TILE 16           // MFMA f64 16x16x4 tile edge
 #define AVT_EVAL_PTS 16       // model points per eval batch (48 Jacobian rows)
 #define AVT_EVAL_ROWS (3 * AVT_EVAL_PTS)
-#define AVT_EVAL_CHUNK(G) ((G) >= 64 ? 1 : 4)   // consecutive batches a workgroup takes before striding by G chunks (few live tile pairs per workgroup)
+#ifndef AVT_EVAL_CHUNK_BATCH
+#define AVT_EVAL_CHUNK_BATCH 2
+#endif
+#define AVT_EVAL_CHUNK(G) ((G) >= 64 ? 1 : AVT_EVAL_CHUNK_BATCH)   // consecutive batches a workgroup takes before striding by G chunks (few live tile pairs per workgroup)
 #define AVT_EVAL_RS 49        // LDS row stride (doubles) of the transposed Jacobian tile.  ODD on purpose: the compiler pairs the MFMA
                               // operand fetches of two k-steps into ds_read2_b64, which is banked modulo 32 in 16-lane groups - an even
                               // stride makes columns c and c+8 collide (2-way), an odd one is conflict-free (plain ds_read_b64 too)
