@@ -112,6 +112,33 @@ def test_model_with_twelve_shape_keys_keeps_the_plain_column_order(smpl):
     assert st[0].gn_iterations == ref["stats"].gn_iterations
 
 
+def test_normal_equations_in_parameter_order(smpl, omodel, gmodel):
+    """avt_get_normal_equations after a fit: the data term J^T J, J^T r the block-sparse contraction leaves (tile order inside
+    k_eval, parameter order on the ABI) against the oracle's dense per-block accumulation at the same point and
+    correspondences (AvatarOptimizer.cpp:473-503, :609-644)."""
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    fr = synth.make_frame(smpl, 19)
+    p0, q0, w0 = _start(fr)
+    opt = Options.demo(max_iters_per_icp=5)
+    n = len(fr["labels"])
+    for frames in (1, 16):       # one frame: every tile written (k_reduce<4>); a batch: chunked batches, masked partial tiles (k_reduce<1>)
+        ctx = api.Context(gmodel, 24, pm, n, frames)
+        p, q, w, st = ctx.optimize_batch([fr["data"]] * frames, [fr["labels"]] * frames, opt, np.repeat(p0[None], frames, 0),
+                                         np.repeat(q0[None], frames, 0), np.repeat(w0[None], frames, 0))
+        f = frames - 1
+        H, g, cost = ctx.normal_equations(f)
+        corr = ctx.correspondences(f, n)
+        oc, og, oH, _ = omodel.evaluate(p[f], q[f], w[f], corr, fr["data"], 0.0, 0.0, aggregate=0)
+        scale = np.abs(oH).max()
+        assert np.abs(H - oH).max() < 1e-9 * scale, np.abs(H - oH).max() / scale
+        assert np.abs(H - H.T).max() == 0.0
+        assert np.abs(g - og).max() < 1e-9 * max(1.0, np.abs(og).max())
+        # structural zeros the tile grouping relies on: a left-leg joint and a right-arm joint never share a model point
+        blk = H[3 + 3 * 4: 6 + 3 * 4, 3 + 3 * 19: 6 + 3 * 19]
+        assert np.all(blk == 0.0) and np.all(oH[3 + 3 * 4: 6 + 3 * 4, 3 + 3 * 19: 6 + 3 * 19] == 0.0)
+
+
 def test_ragged_batch_with_empty_frame_and_determinism(smpl, omodel, gmodel):
     from avatar_amd import api
     pm = synth.identity_part_map()
