@@ -385,9 +385,8 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm,
 #ifdef AVT_TIMING
     long long tacc[6] = {0, 0, 0, 0, 0, 0}; long long tlast = clock64(); const long long wall0 = wall_clock64();
 #endif
-    // tile pairs this workgroup accumulated into; with few frames (S == 1) k_reduce<4> reads every tile without asking
-    // (it is latency-bound: the extra round trip costs more than the loads it saves), so every tile is written
-    unsigned long long wm = (FIXED && S > 1) ? 0ull : ~0ull;
+    // tile pairs this workgroup accumulated into: only those partial tiles are written, k_reduce reads the mask
+    unsigned long long wm = FIXED ? 0ull : ~0ull;
     for (int b = g * S; b < nb; b = next_batch(b)) {
         __syncthreads();  // previous batch's MFMA reads are done (also covers the prep staging on the first pass)
         EPROBE(0);

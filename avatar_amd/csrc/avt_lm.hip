@@ -137,14 +137,13 @@ __global__ __launch_bounds__(256 * Q) void k_reduce(DeviceModel dm, FrameBuffers
     const double* part = fb.partial + ((size_t)f * G * NPAIR + blockIdx.x) * 256 + t;
     const size_t st = (size_t)NPAIR * 256;
     // which of my workgroups g wrote this pair (k_eval skips the tile pairs its batches never touch): lane l asks for
-    // g = glo + l, the ballot makes the answer wave-uniform (ghi - glo <= 64 in both launch shapes)
-    // (only the batch shape Q = 1 asks: with few frames the extra round trip costs more than the loads it saves)
+    // g = glo + l, the ballot makes the answer wave-uniform (ghi - glo <= 64 in both launch shapes).  Q = 1 (frame batches)
+    // asks first and skips the loads; Q = 4 (few frames, one L2 round trip long) requests mask and tiles together and
+    // discards what was never written - there the point is the producer's shorter store tail, not the loads.
+    const int lane = threadIdx.x & 63;
+    const unsigned long long wmine = (glo + lane < ghi) ? fb.wmask[(size_t)f * G + glo + lane] : 0ull;
     unsigned long long live = ~0ull;
-    if constexpr (Q == 1) {
-        const int lane = threadIdx.x & 63;
-        const unsigned long long wmine = (glo + lane < ghi) ? fb.wmask[(size_t)f * G + glo + lane] : 0ull;
-        live = __ballot((int)((wmine >> blockIdx.x) & 1ull));
-    }
+    if constexpr (Q == 1) live = __ballot((int)((wmine >> blockIdx.x) & 1ull));
     double a = 0.0;
     int g = glo;
 #define AVT_REDUCE_ROUND(NLD)                                                                        \
@@ -153,7 +152,16 @@ __global__ __launch_bounds__(256 * Q) void k_reduce(DeviceModel dm, FrameBuffers
         _Pragma("unroll") for (int u = 0; u < NLD; ++u) v[u] = ((live >> (g + u - glo)) & 1ull) ? __builtin_nontemporal_load(part + (size_t)(g + u) * st) : 0.0; \
         _Pragma("unroll") for (int u = 0; u < NLD; ++u) a += v[u];                                    \
     }
-    if constexpr (Q > 1) { AVT_REDUCE_ROUND(32) }      // (the batch variant stays at 16 loads in flight: fewer registers, it co-runs with k_eval)
+    if constexpr (Q > 1) {      // G/4 <= 32 tiles per quarter: all in flight together with the mask, selected afterwards
+        double v[32];
+        const int ng = ghi - glo;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = (u < ng) ? __builtin_nontemporal_load(part + (size_t)(glo + u) * st) : 0.0;
+        const unsigned long long wrote = __ballot((int)((wmine >> blockIdx.x) & 1ull));
+#pragma unroll
+        for (int u = 0; u < 32; ++u) a += ((wrote >> u) & 1ull) ? v[u] : 0.0;
+        g = ghi;
+    }
     AVT_REDUCE_ROUND(16) AVT_REDUCE_ROUND(8) AVT_REDUCE_ROUND(4) AVT_REDUCE_ROUND(1)
 #undef AVT_REDUCE_ROUND
     const int try_slot = 1 - fb.ctl[f].cur_slot;
