@@ -154,6 +154,37 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
     return res
 
 
+def render_stage(api, synth, smpl, gm, with_cpu, local_rank):
+    """the synthetic-frame generator (depth + part render of a posed avatar, back-projection, labels)
+    on the GPU, 8 frames per call into the resident frame buffers, against the host generator the parity tests use."""
+    import numpy as np
+    F = 8
+    pm = synth.identity_part_map()
+    gts = [synth.sample_ground_truth(smpl, 500 + f) for f in range(F)]
+    W, Pp, R = (np.array([g[i] for g in gts]) for i in range(3))
+    ctx = api.Context(gm, 24, pm, 65536, F, device=local_rank)
+    for _ in range(3):
+        npts = ctx.render_frames(W, Pp, R)
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.render_frames(W, Pp, R)            # synchronous: returns the point count of every frame
+    dt = time.perf_counter() - t0
+    res = {"workload": f"{F} posed avatars at 1280x720 (K4A intrinsics) per call, {int(np.mean(npts))} foreground points per frame",
+           "value": round(F * reps / dt, 1), "unit": "frames/s", "ms_per_call_of_8": round(dt / reps * 1e3, 3)}
+    if with_cpu:
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 2.0:
+            w, p, Rg = gts[n % F]
+            synth.render_images(smpl, synth.pose_vertices(smpl, w, p, Rg), pm)
+            n += 1
+        res["cpu_baseline"] = {"value": round(n / (time.perf_counter() - t0), 1), "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": f"{n} frames by the host generator (avatar_amd/csrc/synth_render.cpp + numpy LBS), 1 thread; "
+                                         "tests/test_gpu_render.py checks the GPU frames against it bit for bit"}
+    return res
+
+
 def label_stage(synth, smpl, with_cpu):
     """SURVEY.md §8 row f4: RTree::predictBest on 1280x720 depth renders exactly as the tracker calls it (interval 2,
     foreground bounding box, gaps filled; demo.cpp:196-199), 8 resident images per launch, plus the full-resolution walk."""
@@ -214,6 +245,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-throughput-config", action="store_true", help="skip the secondary 64-frames-per-GPU measurement")
     ap.add_argument("--no-label-stage", action="store_true", help="skip the body-part forest (RTree) stage measurement")
+    ap.add_argument("--no-render-stage", action="store_true", help="skip the synthetic-frame generator (row f1) measurement")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     args = ap.parse_args()
@@ -265,6 +297,8 @@ def main():
                 "roofline": r2["roofline"], "eval_kernel": r2["eval_kernel"], "kernels": r2["kernels"]}
         out["frames_per_s"] = round(F * world * args.steps / r["elapsed"], 2)
         out["icp_iterations_per_s"] = round(F * world * opt.icp_iters * args.steps / r["elapsed"], 2)
+        if F == 1 and not args.dense and not args.no_render_stage:
+            out["render_stage"] = render_stage(api, synth, smpl, gm, not args.no_cpu_baseline, local_rank)
         if F == 1 and not args.dense and not args.no_label_stage:
             out["label_stage"] = label_stage(synth, smpl, not args.no_cpu_baseline)
         if not args.no_cpu_baseline:
