@@ -66,19 +66,22 @@ __device__ void prep_run(const DeviceModel& dm, const PrepLayout& L, double* __r
     const int J = d.J, K = d.K, t = threadIdx.x;
     // CalcShape (AvatarOptimizer.cpp:249-281): jointPosInit = base + jointShapeReg*w, and each joint's offset from its
     // parent (the parent's position is recomputed by the same lane: same operations, same bits, no barrier)
-    if (t < 3 * J) {
-        const int j = t / 3, c = t - 3 * j;
-        double a = 0.0;
-        for (int k = 0; k < K; ++k) a += B[L.jsr + t * K + k] * B[L.w + k];
-        const double mine = B[L.jsrb + t] + a;
-        B[L.jp + t] = mine;
-        if (j > 0) {
-            const int tp = 3 * level[AVT_MAX_JOINTS + 2 + j] + c;
-            double ap = 0.0;
-            for (int k = 0; k < K; ++k) ap += B[L.jsr + tp * K + k] * B[L.w + k];
-            B[L.dv + t] = mine - (B[L.jsrb + tp] + ap);
+    auto joint_positions = [&](const int KK) {    // KK: constant for SMPL, so both dot products unroll and their LDS reads are in flight together
+        if (t < 3 * J) {
+            const int j = t / 3, c = t - 3 * j;
+            const int tp = j > 0 ? 3 * level[AVT_MAX_JOINTS + 2 + j] + c : t;
+            double a = 0.0, ap = 0.0;
+            for (int k = 0; k < KK; ++k) {
+                const double wk = B[L.w + k];
+                a += B[L.jsr + t * KK + k] * wk;
+                ap += B[L.jsr + tp * KK + k] * wk;
+            }
+            const double mine = B[L.jsrb + t] + a;
+            B[L.jp + t] = mine;
+            if (j > 0) B[L.dv + t] = mine - (B[L.jsrb + tp] + ap);
         }
-    }
+    };
+    if (K == 10) joint_positions(10); else joint_positions(K);
     __syncthreads();
 #ifdef AVT_TIMING
     if (threadIdx.x == 0) prep[d.prep_size - 1] = (double)clock64();
