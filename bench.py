@@ -311,7 +311,7 @@ def main():
     r = measure(api, synth, Options, torch, dist, smpl, gm, args, F, args.steps, args.warmup, rank, world, local_rank, args.dense)
     r2 = None
     if F == 1 and not args.dense and not args.no_throughput_config:
-        r2 = measure(api, synth, Options, torch, dist, smpl, gm, args, 64, max(5, args.steps // 5), 2, rank, world, local_rank, False)
+        r2 = measure(api, synth, Options, torch, dist, smpl, gm, args, 64, max(10, args.steps // 2), 3, rank, world, local_rank, False)
     if rank == 0:
         opt = r["opt"]
         out = {
