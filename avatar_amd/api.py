@@ -78,7 +78,7 @@ class AvatarModel:
     """`struct AvatarModel` (Avatar.h:64-151).  Built from SMPL-npz-style arrays (dict) or from a directory
     holding `model.npz` (+ optional `pose_prior.txt`), the reference's model_dir convention (AvatarModel.cpp:18-23)."""
 
-    def __init__(self, model=None, limit_one_joint_per_point=False):
+    def __init__(self, model=None, limit_one_joint_per_point=False, handle=None):
         if limit_one_joint_per_point:
             raise NotImplementedError("limit_one_joint_per_point is a legacy-format option (AvatarModel.cpp:128-288)")
         if isinstance(model, (str, os.PathLike)):
@@ -89,8 +89,16 @@ class AvatarModel:
         self.arrays = ModelArrays(model)
         self._desc = self.arrays.desc()
         self._lib = capi.load_library()
-        self.h = C.c_void_p()
-        _check(self._lib.avt_model_create(C.byref(self._desc), C.byref(self.h)))
+        if handle is not None:      # an avt_model* built elsewhere (avt_model_unpack / avt_shard_broadcast_model): adopt it
+            self.h = handle
+            V, J, K, F, P = (C.c_int() for _ in range(5))
+            _check(self._lib.avt_model_dims(self.h, C.byref(V), C.byref(J), C.byref(K), C.byref(F), C.byref(P)))
+            a = self.arrays
+            if (V.value, J.value, K.value, F.value, P.value) != (a.V, a.J, a.K, a.F, a.P):
+                raise AvtError("AvatarModel: adopted handle and host arrays disagree on the model dimensions")
+        else:
+            self.h = C.c_void_p()
+            _check(self._lib.avt_model_create(C.byref(self._desc), C.byref(self.h)))
         self.parent = self.arrays.parent
         self.mesh = self.arrays.mesh
         ijp = np.empty(3 * self.numJoints()); jsr = np.empty(3 * self.numJoints() * self.numShapeKeys())
@@ -279,6 +287,12 @@ class Context:
         H = np.empty((P, P)); g = np.empty(P); cost = C.c_double()
         _check(self._lib.avt_get_normal_equations(self.h, C.c_int(frame), dptr(H), dptr(g), C.byref(cost)))
         return H, g, cost.value
+
+    def launch_shape(self):
+        """(groups, frames per group, k_eval workgroups per frame) of optimize() over the resident frames."""
+        g, n, G = C.c_int(), C.c_int(), C.c_int()
+        _check(self._lib.avt_launch_shape(self.h, C.byref(g), C.byref(n), C.byref(G)))
+        return g.value, n.value, G.value
 
     def profile_begin(self, classes=None):
         mask = 0xffffffff if classes is None else sum(1 << capi.AVT_K_NAMES.index(c) for c in classes)

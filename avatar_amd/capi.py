@@ -184,14 +184,37 @@ def load_library():
         "avt_get_posed": [vp, C.c_int, c_double_p, c_double_p, c_double_p],
         "avt_get_normal_equations": [vp, C.c_int, c_double_p, c_double_p, c_double_p],
         "avt_debug_trace": [vp, C.c_int, c_double_p],
+        "avt_launch_shape": [vp, c_int_p, c_int_p, c_int_p],
         "avt_profile_begin": [vp],
         "avt_profile_select": [vp, C.c_uint],
         "avt_profile_end": [vp, C.POINTER(Profile)],
+        # include/avt_shard.h
+        "avt_shard_owner": [C.c_int, C.c_int],
+        "avt_shard_local_count": [C.c_int, C.c_int, C.c_int],
+        "avt_shard_local_index": [C.c_int, C.c_int],
+        "avt_shard_global_frame": [C.c_int, C.c_int, C.c_int],
+        "avt_model_pack_size": [C.POINTER(ModelDesc), C.POINTER(C.c_size_t)],
+        "avt_model_pack": [C.POINTER(ModelDesc), vp, C.c_size_t],
+        "avt_model_unpack": [vp, C.c_size_t, C.POINTER(vp)],
+        "avt_shard_unique_id": [C.c_char_p],
+        "avt_shard_create": [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)],
+        "avt_shard_destroy": [vp],
+        "avt_shard_rank": [vp],
+        "avt_shard_world": [vp],
+        "avt_shard_backend": [vp],
+        "avt_shard_broadcast_model": [vp, C.c_int, C.POINTER(ModelDesc), C.POINTER(vp)],
+        "avt_shard_scatter_frames": [vp, vp, C.c_int, C.c_int, c_double_p, c_int_p, c_int_p, c_double_p, c_double_p, c_double_p],
+        "avt_shard_gather_enqueue": [vp, vp, C.c_int],
+        "avt_shard_gather_download": [vp, vp, C.c_int, c_double_p, c_double_p, c_double_p, C.POINTER(Stats)],
+        "avt_shard_gather_results": [vp, vp, C.c_int, c_double_p, c_double_p, c_double_p, C.POINTER(Stats)],
+        "avt_shard_barrier": [vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.argtypes = args
-        if name not in ("avt_model_destroy", "avt_ctx_destroy", "avt_options_default"):
+        if name == "avt_shard_backend":
+            fn.restype = C.c_char_p
+        elif name not in ("avt_model_destroy", "avt_ctx_destroy", "avt_options_default", "avt_shard_destroy"):
             fn.restype = C.c_int
         else:
             fn.restype = None
@@ -204,5 +227,10 @@ EXPORTED_SYMBOLS = [
     "avt_model_dims", "avt_model_main_joint", "avt_model_joint_regression", "avt_model_tile_layout", "avt_ctx_create", "avt_ctx_destroy",
     "avt_sync", "avt_lbs_update", "avt_visibility", "avt_nn", "avt_optimize", "avt_optimize_batch",
     "avt_frames_upload", "avt_synth_render_frames", "avt_frames_download", "avt_state_upload", "avt_optimize_resident", "avt_state_reset", "avt_state_download",
-    "avt_get_correspondences", "avt_get_cloud", "avt_get_posed", "avt_get_normal_equations", "avt_debug_trace", "avt_profile_begin", "avt_profile_select", "avt_profile_end",
+    "avt_get_correspondences", "avt_get_cloud", "avt_get_posed", "avt_get_normal_equations", "avt_debug_trace", "avt_launch_shape", "avt_profile_begin", "avt_profile_select", "avt_profile_end",
+    # include/avt_shard.h
+    "avt_shard_owner", "avt_shard_local_count", "avt_shard_local_index", "avt_shard_global_frame", "avt_model_pack_size", "avt_model_pack",
+    "avt_model_unpack", "avt_shard_unique_id", "avt_shard_create", "avt_shard_destroy", "avt_shard_rank", "avt_shard_world", "avt_shard_backend",
+    "avt_shard_broadcast_model", "avt_shard_scatter_frames", "avt_shard_gather_enqueue", "avt_shard_gather_download",
+    "avt_shard_gather_results", "avt_shard_barrier",
 ]

@@ -6,7 +6,15 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <exception>
+
 #include "avt_internal.h"
+
+// No C++ exception may cross the C ABI: every entry point that allocates runs inside this guard.
+#define AVT_API_GUARD_BEGIN try {
+#define AVT_API_GUARD_END(fn)                                                                      \
+    } catch (const std::exception& e) { avt_set_error(std::string(fn) + ": " + e.what()); return 1; } \
+    catch (...) { avt_set_error(std::string(fn) + ": unknown exception"); return 1; }
 
 int avt_solve_set_attributes();
 int avt_eval_set_attributes();
@@ -96,17 +104,17 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
     for (int icp = 0; icp < o->icp_iters; ++icp) {
         { ProfScope ps(c, AVT_K_VISIBILITY); launch_visibility(c, nf, o->enable_occlusion); }
         { ProfScope ps(c, AVT_K_NN); launch_nn(c, nf); }
-        { ProfScope ps(c, AVT_K_AGGREGATE); launch_finalize(c, nf, o); launch_records(c, nf); }
-        { ProfScope ps(c, AVT_K_PREPARE); launch_solve(c, nf, SOLVE_INIT, o); }
+        { ProfScope ps(c, AVT_K_AGGREGATE); launch_finalize(c, nf); launch_records(c, nf); }
+        { ProfScope ps(c, AVT_K_PREPARE); launch_solve(c, nf, SOLVE_INIT); }
         { ProfScope ps(c, AVT_K_EVAL); launch_eval(c, nf); }
         { ProfScope ps(c, AVT_K_REDUCE); launch_reduce(c, nf); }
         for (int it = 1; it <= std::max(1, o->max_iters_per_icp); ++it) {
-            { ProfScope ps(c, AVT_K_SOLVE); launch_solve(c, nf, it == 1 ? SOLVE_FIRST : SOLVE_NORMAL, o); }
+            { ProfScope ps(c, AVT_K_SOLVE); launch_solve(c, nf, it == 1 ? SOLVE_FIRST : SOLVE_NORMAL); }
             if (o->max_iters_per_icp == 0) break;
             { ProfScope ps(c, AVT_K_EVAL); launch_eval(c, nf); }
             { ProfScope ps(c, AVT_K_REDUCE); launch_reduce(c, nf); }
         }
-        if (o->max_iters_per_icp > 0) { ProfScope ps(c, AVT_K_SOLVE); launch_solve(c, nf, SOLVE_LAST, o); }
+        if (o->max_iters_per_icp > 0) { ProfScope ps(c, AVT_K_SOLVE); launch_solve(c, nf, SOLVE_LAST); }
         { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 1, vis_init); }   // :1494-1497
         c->ran_icp_iters++;
     }
@@ -115,79 +123,141 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
     c->cur_stream = c->stream;
 }
 
+// the option scalars the kernels read live in device memory (AvtRunParams): uploaded only when they change
+int sync_params(avt_ctx* c, const avt_options* o) {
+    AvtRunParams pr;
+    std::memset(&pr, 0, sizeof pr);
+    pr.beta_pose = o->beta_pose; pr.beta_shape = o->beta_shape; pr.lambda0 = o->lm_lambda0;
+    pr.lm_up = o->lm_up; pr.lm_down = o->lm_down; pr.lm_min = o->lm_lambda_min; pr.lm_max = o->lm_lambda_max;
+    if (c->params_valid && std::memcmp(&pr, &c->params_host, sizeof pr) == 0) return 0;
+    c->params_host = pr;
+    HIP_OK(hipMemcpyAsync((void*)c->fb.params, &c->params_host, sizeof pr, hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));     // params_host may be rewritten by the next call
+    c->params_valid = true;
+    return 0;
+}
+
+constexpr size_t GRAPH_CACHE_ENTRIES = 8;
+
 int run_optimize(avt_ctx* c, const avt_options* o) {
     const int nf = c->nframes;
-    if (nf <= 0) { avt_set_error("avt_optimize: no frames resident"); return 1; }
+    if (nf <= 0 || !c->frames_valid) { avt_set_error("avt_optimize: no frames resident (upload frames first; the stand-alone entry points avt_nn / avt_visibility / avt_lbs_update invalidate them)"); return 1; }
+    if (!c->state_valid) { avt_set_error("avt_optimize: no start state resident for these frames (avt_state_upload)"); return 1; }
     if (o->max_iters_per_icp < 0 || o->max_iters_per_icp > 62 || o->icp_iters < 0) { avt_set_error("avt_optimize: bad iteration counts"); return 1; }
+    if (sync_params(c, o)) return 1;
     c->ran_max_iters = o->max_iters_per_icp;
-    // Large batches run as several frame groups on separate streams: the latency-bound single-workgroup-per-frame
-    // kernels of one group (k_solve, k_finalize, k_reduce) overlap the throughput kernels (k_eval, k_nn) of the others.
-    const int ngroups = (c->use_graph && !c->profiling) ? choose_groups(nf) : 1;
+    // Large batches run as several frame groups: the latency-bound single-workgroup-per-frame kernels of one group
+    // (k_solve, k_finalize, k_reduce) overlap the throughput kernels (k_eval, k_nn) of the others on separate streams.
+    // The instrumented (profiling) path keeps the SAME groups and launch shapes and runs them one after the other on
+    // the main stream, so that per-launch timings describe the launches the graph replays.
+    const int ngroups = choose_groups(nf);
     const int nfg = (nf + ngroups - 1) / ngroups;       // frames per group (the last group may be smaller)
     c->fb.G = choose_G(nfg);
     if (!c->use_graph || c->profiling) {
-        enqueue_optimize(c, o, 0, nf, c->stream);
+        for (int gi = 0; gi < ngroups; ++gi) {
+            const int f0 = gi * nfg, n = std::min(nfg, nf - f0);
+            if (n > 0) enqueue_optimize(c, o, f0, n, c->stream);
+        }
+        c->ran_icp_iters = o->icp_iters;
         return check_launch("optimize launch sequence");
     }
-    // The launch sequence depends only on (nframes, grid sizes, options): capture it once, replay it afterwards.
-    char key[256];
-    snprintf(key, sizeof key, "%d|%d|%d|%d|%d|%d|%d|%.17g|%.17g|%.17g|%.17g|%.17g|%.17g|%.17g", nf, ngroups, c->fb.G, c->launch_maxN, o->icp_iters,
-             o->max_iters_per_icp, o->enable_occlusion, o->beta_pose, o->beta_shape, o->lm_lambda0, o->lm_up, o->lm_down,
-             o->lm_lambda_min, o->lm_lambda_max);
-    auto it = c->graphs.find(key);
-    if (it == c->graphs.end()) {
+    // The launch sequence depends only on the launch shape: capture it once, replay it afterwards.
+    char key[160];
+    snprintf(key, sizeof key, "%d|%d|%d|%d|%d|%d|%d", nf, ngroups, c->fb.G, c->launch_maxN, o->icp_iters, o->max_iters_per_icp, o->enable_occlusion);
+    avt_ctx::GraphEntry* hit = nullptr;
+    for (auto& e : c->graphs) if (e.key == key) { hit = &e; break; }
+    if (!hit) {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        bool bad = false;
+        auto cap = [&](hipError_t e) { if (e != hipSuccess && !bad) { bad = true; avt_set_error(std::string("optimize graph capture: ") + hipGetErrorString(e)); } };
         if (ngroups > 1) {
-            HIP_OK(hipEventRecord(c->ev_fork, c->stream));
-            for (int gi = 1; gi < ngroups; ++gi) HIP_OK(hipStreamWaitEvent(c->side[gi - 1], c->ev_fork, 0));
+            cap(hipEventRecord(c->ev_fork, c->stream));
+            for (int gi = 1; gi < ngroups; ++gi) cap(hipStreamWaitEvent(c->side[gi - 1], c->ev_fork, 0));
             for (int gi = 0; gi < ngroups; ++gi) {
                 const int f0 = gi * nfg, n = std::min(nfg, nf - f0);
                 if (n > 0) enqueue_optimize(c, o, f0, n, gi == 0 ? c->stream : c->side[gi - 1]);
             }
             for (int gi = 1; gi < ngroups; ++gi) {
-                HIP_OK(hipEventRecord(c->ev_join[gi - 1], c->side[gi - 1]));
-                HIP_OK(hipStreamWaitEvent(c->stream, c->ev_join[gi - 1], 0));
+                cap(hipEventRecord(c->ev_join[gi - 1], c->side[gi - 1]));
+                cap(hipStreamWaitEvent(c->stream, c->ev_join[gi - 1], 0));
             }
         } else {
             enqueue_optimize(c, o, 0, nf, c->stream);
         }
-        HIP_OK(hipStreamEndCapture(c->stream, &graph));
-        HIP_OK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-        HIP_OK(hipGraphDestroy(graph));
-        it = c->graphs.emplace(key, exec).first;
+        cap(hipGetLastError());
+        // the capture is ALWAYS ended, so that a failure does not leave the stream stuck in capture mode
+        const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
+        if (bad || ee != hipSuccess) {
+            if (!bad) avt_set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ee));
+            if (graph) (void)hipGraphDestroy(graph);
+            return 1;
+        }
+        const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ei != hipSuccess) { avt_set_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); return 1; }
+        if (c->graphs.size() >= GRAPH_CACHE_ENTRIES) {      // evict the least recently used launch shape
+            size_t lru = 0;
+            for (size_t i = 1; i < c->graphs.size(); ++i) if (c->graphs[i].last_used < c->graphs[lru].last_used) lru = i;
+            HIP_OK(hipStreamSynchronize(c->stream));
+            (void)hipGraphExecDestroy(c->graphs[lru].exec);
+            c->graphs.erase(c->graphs.begin() + lru);
+        }
+        c->graphs.push_back({key, exec, 0});
+        hit = &c->graphs.back();
     }
-    HIP_OK(hipGraphLaunch(it->second, c->stream));
+    hit->last_used = ++c->graph_clock;
+    HIP_OK(hipGraphLaunch(hit->exec, c->stream));
     c->ran_icp_iters = o->icp_iters;
+    return 0;
+}
+
+// Installs `nframes` frames with `counts[f]` points each; data / labels are packed back to back (frame f starts at the sum
+// of the previous counts) in host memory or, with device_src, in device memory (the batch split's receive buffer).
+// Everything is validated before any host or device state changes.  The per-frame point count is also written into the
+// device control blocks (working copy and start copy), so that swapping frames under a resident state - the warm-start
+// pattern avt_frames_upload + avt_optimize_resident - runs with the new counts.
+int install_frames(avt_ctx* c, int nframes, const int* counts, const double* data, const int* labels, bool device_src) {
+    if (nframes <= 0 || nframes > c->fb.max_frames) { avt_set_error("frames: nframes out of range for this context"); return 1; }
+    int mx = 0;
+    for (int f = 0; f < nframes; ++f) {
+        if (counts[f] < 0) { avt_set_error("frames: negative point count (frame_offsets must be non-decreasing)"); return 1; }
+        if (counts[f] > c->fb.max_points) { avt_set_error("frames: a frame has more points than max_points_per_frame"); return 1; }
+        mx = std::max(mx, counts[f]);
+    }
+    const bool same_shape = c->frames_valid && nframes == c->nframes;
+    c->frames_valid = false;
+    c->nframes = nframes;
+    c->frame_N.assign(counts, counts + nframes);
+    c->frame_off.assign(nframes + 1, 0);
+    for (int f = 0; f < nframes; ++f) c->frame_off[f + 1] = c->frame_off[f] + counts[f];
+    c->launch_maxN = std::max(mx, std::min(c->fb.max_points, ((mx + 2047) / 2048) * 2048));
+    const hipMemcpyKind kind = device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    for (int f = 0; f < nframes; ++f) {
+        const size_t N = (size_t)counts[f], o = (size_t)c->frame_off[f];
+        if (N == 0) continue;
+        HIP_OK(hipMemcpyAsync(c->fb.data_raw + (size_t)f * c->fb.max_points * 3, data + o * 3, N * 3 * sizeof(double), kind, c->stream));
+        HIP_OK(hipMemcpyAsync(c->fb.labels_raw + (size_t)f * c->fb.max_points, labels + o, N * sizeof(int), kind, c->stream));
+    }
+    for (AvtFrameCtl* dst : {c->fb.ctl, c->fb.ctl_start})
+        HIP_OK(hipMemcpy2DAsync(&dst->N, sizeof(AvtFrameCtl), c->frame_N.data(), sizeof(int), sizeof(int), (size_t)nframes, hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    c->frames_valid = true;
+    if (!same_shape) c->state_valid = false;     // a different number of frames needs a new start state
     return 0;
 }
 
 int upload_frames(avt_ctx* c, int nframes, const double* data, const int* labels, const int* offs) {
     if (nframes <= 0 || nframes > c->fb.max_frames) { avt_set_error("frames: nframes out of range for this context"); return 1; }
-    c->nframes = nframes;
-    c->frame_N.assign(nframes, 0);
-    c->frame_off.assign(offs, offs + nframes + 1);
-    int mx = 0;
-    for (int f = 0; f < nframes; ++f) mx = std::max(mx, offs[f + 1] - offs[f]);
-    c->launch_maxN = std::min(c->fb.max_points, ((mx + 2047) / 2048) * 2048);
-    if (c->launch_maxN < mx) c->launch_maxN = mx;
-    for (int f = 0; f < nframes; ++f) {
-        const int N = offs[f + 1] - offs[f];
-        if (N < 0 || N > c->fb.max_points) { avt_set_error("frames: a frame has more points than max_points_per_frame"); return 1; }
-        c->frame_N[f] = N;
-        if (N == 0) continue;
-        HIP_OK(hipMemcpyAsync(c->fb.data_raw + (size_t)f * c->fb.max_points * 3, data + (size_t)offs[f] * 3, (size_t)N * 3 * sizeof(double),
-                              hipMemcpyHostToDevice, c->stream));
-        HIP_OK(hipMemcpyAsync(c->fb.labels_raw + (size_t)f * c->fb.max_points, labels + offs[f], (size_t)N * sizeof(int), hipMemcpyHostToDevice,
-                              c->stream));
-    }
-    return 0;
+    std::vector<int> counts(nframes);
+    for (int f = 0; f < nframes; ++f) counts[f] = offs[f + 1] - offs[f];
+    return install_frames(c, nframes, counts.data(), data + (size_t)offs[0] * 3, labels + offs[0], false);
 }
 
 int upload_state(avt_ctx* c, int nframes, const double* p, const double* q, const double* w) {
     const AvtDims& d = c->dm.d;
-    if (nframes != c->nframes) { avt_set_error("state: nframes differs from the resident frames"); return 1; }
+    if (!c->frames_valid || nframes != c->nframes) { avt_set_error("state: nframes differs from the resident frames"); return 1; }
     std::vector<double> xs((size_t)nframes * 2 * d.xsize, 0.0);
     std::vector<AvtFrameCtl> ctl(nframes);
     for (int f = 0; f < nframes; ++f) {
@@ -204,6 +274,7 @@ int upload_state(avt_ctx* c, int nframes, const double* p, const double* q, cons
     HIP_OK(hipMemcpyAsync(c->fb.x_start, c->fb.x, xs.size() * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     HIP_OK(hipMemcpyAsync(c->fb.ctl_start, c->fb.ctl, ctl.size() * sizeof(AvtFrameCtl), hipMemcpyDeviceToDevice, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));  // host vectors go out of scope
+    c->state_valid = true;
     return 0;
 }
 
@@ -235,9 +306,14 @@ int download_state(avt_ctx* c, double* p, double* q, double* w, avt_stats* st) {
 
 }  // namespace
 
+// batch split (avt_shard.cpp): frames received into a device buffer become this context's resident frames
+int avt_internal_install_frames(avt_ctx* c, int nframes, const int* counts, const double* data, const int* labels, int device_src) {
+    return install_frames(c, nframes, counts, data, labels, device_src != 0);
+}
+
 extern "C" {
 
-int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* part_map, int max_points, int max_frames, avt_ctx** out) {
+static int ctx_create_impl(int device, const avt_model* m, int num_parts, const int* part_map, int max_points, int max_frames, avt_ctx** out) {
     if (!m || !part_map || !out) { avt_set_error("avt_ctx_create: null argument"); return 1; }
     if (num_parts <= 0 || num_parts > AVT_MAX_PARTS) { avt_set_error("avt_ctx_create: num_parts out of range (1..64)"); return 1; }
     if (max_points <= 0 || max_frames <= 0) { avt_set_error("avt_ctx_create: max_points/max_frames must be positive"); return 1; }
@@ -248,7 +324,8 @@ int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* par
     }
     if (device < 0 || device >= ndev) { avt_set_error("avt_ctx_create: device index out of range"); return 1; }
     HIP_OK(hipSetDevice(device));
-    avt_ctx* c = new avt_ctx();
+    avt_ctx* c = new avt_ctx();     // value-initialised: every handle starts null, avt_ctx_destroy copes with a partial context
+    *out = c;
     c->device = device;
     c->model = m;
     c->profiling = false;
@@ -260,6 +337,10 @@ int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* par
     c->launch_maxN = 0;
     c->use_graph = getenv("AVT_NO_GRAPH") == nullptr;
     c->lbs_cleared = false;
+    c->graph_clock = 0;
+    c->params_valid = false;
+    c->frames_valid = c->state_valid = false;
+    c->render_zkey = nullptr; c->render_label = nullptr; c->render_block = nullptr; c->render_cap_pix = c->render_cap_blk = 0;
     HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < AVT_MAX_GROUPS - 1; ++i) {
@@ -322,6 +403,11 @@ int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* par
         dev_alloc(c, &fb.jointpos, (size_t)max_frames * 3 * J) || dev_alloc(c, &fb.jointtrans, (size_t)max_frames * 12 * J) ||
         dev_alloc(c, &fb.trace, (size_t)max_frames * 64))
         return 1;
+    {
+        AvtRunParams* pr = nullptr;
+        if (dev_alloc(c, &pr, 1)) return 1;
+        fb.params = pr;
+    }
     fb.fsum = (long long*)cntsum;                                   // 8-byte aligned first
     fb.cnt = (int*)(cntsum + FV * 3 * sizeof(long long));
     HIP_OK(hipMemset(fb.trace, 0, (size_t)max_frames * 64 * sizeof(double)));
@@ -329,20 +415,41 @@ int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* par
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemset(fb.part_cnt, 0, (size_t)max_frames * 2 * (AVT_MAX_PARTS + 1) * sizeof(int)));   // invariant of launch_bucket
     if (getenv("AVT_DEBUG")) avt_eval_report_occupancy(dm.d);
-    *out = c;
     return 0;
+}
+
+
+int avt_ctx_create(int device, const avt_model* m, int num_parts, const int* part_map, int max_points, int max_frames, avt_ctx** out) {
+    if (out) *out = nullptr;
+    int rc = 1;
+    try {
+        rc = ctx_create_impl(device, m, num_parts, part_map, max_points, max_frames, out);
+    } catch (const std::exception& e) { avt_set_error(std::string("avt_ctx_create: ") + e.what()); rc = 1; }
+    if (rc != 0 && out && *out) {     // streams, events and every allocation made so far are released
+        const std::string keep = avt_last_error();
+        avt_ctx_destroy(*out);
+        *out = nullptr;
+        avt_set_error(keep);
+    }
+    return rc;
 }
 
 void avt_ctx_destroy(avt_ctx* c) {
     if (!c) return;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
-    for (void* p : c->allocs) hipFree(p);
-    for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
-    for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
-    hipEventDestroy(c->ev_fork);
-    for (int i = 0; i < AVT_MAX_GROUPS - 1; ++i) { hipEventDestroy(c->ev_join[i]); hipStreamDestroy(c->side[i]); }
-    hipStreamDestroy(c->stream);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (void* p : c->allocs) (void)hipFree(p);
+    if (c->render_zkey) (void)hipFree(c->render_zkey);
+    if (c->render_label) (void)hipFree(c->render_label);
+    if (c->render_block) (void)hipFree(c->render_block);
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (int i = 0; i < AVT_MAX_GROUPS - 1; ++i) {
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+        if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -353,10 +460,12 @@ int avt_sync(avt_ctx* c) {
 
 int avt_lbs_update(avt_ctx* c, int nframes, const double* w, const double* p, const double* R, double* cloud, double* joint_pos,
                    double* joint_trans) {
+    AVT_API_GUARD_BEGIN
     if (!c || !w || !p || !R) { avt_set_error("avt_lbs_update: null argument"); return 1; }
     const AvtDims& d = c->dm.d;
     if (nframes <= 0 || nframes > c->fb.max_frames) { avt_set_error("avt_lbs_update: nframes out of range"); return 1; }
     HIP_OK(hipSetDevice(c->device));
+    c->frames_valid = c->state_valid = false;    // frame slots' posed clouds / skeleton scratch are overwritten
     // stage the parameters in the (otherwise unused here) prep buffer: w | p | R
     double* dw = c->fb.prep;
     double* dp = dw + (size_t)nframes * d.K;
@@ -372,12 +481,14 @@ int avt_lbs_update(avt_ctx* c, int nframes, const double* w, const double* p, co
     if (joint_trans) HIP_OK(hipMemcpyAsync(joint_trans, c->fb.jointtrans, (size_t)nframes * 12 * d.J * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
     return 0;
+    AVT_API_GUARD_END("avt_lbs_update")
 }
 
 int avt_visibility(avt_ctx* c, const double* cloud, int enable, unsigned char* visible) {
     if (!c || !cloud || !visible) { avt_set_error("avt_visibility: null argument"); return 1; }
     const AvtDims& d = c->dm.d;
     HIP_OK(hipSetDevice(c->device));
+    c->frames_valid = c->state_valid = false;
     HIP_OK(hipMemcpyAsync(c->fb.cloud, cloud, (size_t)3 * d.V * sizeof(double), hipMemcpyHostToDevice, c->stream));
     { ProfScope ps(c, AVT_K_VISIBILITY); launch_visibility(c, 1, enable); }
     if (check_launch("k_visibility")) return 1;
@@ -387,6 +498,7 @@ int avt_visibility(avt_ctx* c, const double* cloud, int enable, unsigned char* v
 }
 
 int avt_nn(avt_ctx* c, const double* model_cloud, const unsigned char* visible, const double* data, const int* labels, int N, int* out) {
+    AVT_API_GUARD_BEGIN
     if (!c || !model_cloud || !visible || !data || !labels || !out) { avt_set_error("avt_nn: null argument"); return 1; }
     const AvtDims& d = c->dm.d;
     const int V = d.V;
@@ -394,6 +506,7 @@ int avt_nn(avt_ctx* c, const double* model_cloud, const unsigned char* visible, 
     if (N == 0) return 0;
     const int offs[2] = {0, N};
     if (upload_frames(c, 1, data, labels, offs)) return 1;
+    c->frames_valid = c->state_valid = false;    // frame slot 0 is scratch for this call
     // part-sorted SoA copy of the model cloud
     std::vector<int> ppos(V);
     HIP_OK(hipMemcpy(ppos.data(), c->dm.part_pos, (size_t)V * sizeof(int), hipMemcpyDeviceToHost));
@@ -413,10 +526,12 @@ int avt_nn(avt_ctx* c, const double* model_cloud, const unsigned char* visible, 
     HIP_OK(hipMemcpyAsync(out, c->fb.corr, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
     return 0;
+    AVT_API_GUARD_END("avt_nn")
 }
 
 int avt_synth_render_frames(avt_ctx* c, int nframes, const double* w, const double* p, const double* R, double fx, double fy, double cx,
                             double cy, int width, int height, int* points_per_frame) {
+    AVT_API_GUARD_BEGIN
     if (!c || !w || !p || !R || width <= 0 || height <= 0) { avt_set_error("avt_synth_render_frames: bad argument"); return 1; }
     const AvtDims& d = c->dm.d;
     if (nframes <= 0 || nframes > c->fb.max_frames) { avt_set_error("avt_synth_render_frames: nframes out of range"); return 1; }
@@ -433,21 +548,29 @@ int avt_synth_render_frames(avt_ctx* c, int nframes, const double* w, const doub
     const size_t npix = (size_t)width * height;
     const int chunk = std::max(1, std::min(nframes, (int)((256ull << 20) / (npix * 9 + 64))));
     const int nb = (int)((npix + 255) / 256);
-    unsigned long long* zkey = nullptr; unsigned char* label = nullptr; int* block = nullptr;
-    HIP_OK(hipMalloc((void**)&zkey, npix * chunk * sizeof(unsigned long long)));
-    HIP_OK(hipMalloc((void**)&label, npix * chunk));
-    HIP_OK(hipMalloc((void**)&block, (size_t)nb * chunk * sizeof(int)));
+    // z-buffer keys, labels and block counts live in the context and only grow (no hipMalloc / hipFree per call)
+    if (c->render_cap_pix < npix * chunk || c->render_cap_blk < (size_t)nb * chunk) {
+        HIP_OK(hipStreamSynchronize(c->stream));
+        if (c->render_zkey) (void)hipFree(c->render_zkey);
+        if (c->render_label) (void)hipFree(c->render_label);
+        if (c->render_block) (void)hipFree(c->render_block);
+        c->render_zkey = nullptr; c->render_label = nullptr; c->render_block = nullptr; c->render_cap_pix = c->render_cap_blk = 0;
+        HIP_OK(hipMalloc((void**)&c->render_zkey, npix * chunk * sizeof(unsigned long long)));
+        HIP_OK(hipMalloc((void**)&c->render_label, npix * chunk));
+        HIP_OK(hipMalloc((void**)&c->render_block, (size_t)nb * chunk * sizeof(int)));
+        c->render_cap_pix = npix * chunk; c->render_cap_blk = (size_t)nb * chunk;
+    }
     int rc = 0;
     for (int f0 = 0; f0 < nframes && !rc; f0 += chunk) {
         c->fb.f0 = f0;
-        rc = avt_render_enqueue(c, std::min(chunk, nframes - f0), c->dm.part_of_vertex, zkey, label, block, fx, fy, cx, cy, width, height);
+        rc = avt_render_enqueue(c, std::min(chunk, nframes - f0), c->dm.part_of_vertex, c->render_zkey, c->render_label, c->render_block, fx, fy, cx, cy, width, height);
     }
     c->fb.f0 = 0;
-    hipError_t e = hipStreamSynchronize(c->stream);
-    hipFree(zkey); hipFree(label); hipFree(block);
-    if (rc || e != hipSuccess) { avt_set_error("avt_synth_render_frames: render launch failed"); return 1; }
+    if (rc) { avt_set_error("avt_synth_render_frames: render launch failed"); return 1; }
     std::vector<AvtFrameCtl> ctl(nframes);
-    HIP_OK(hipMemcpy(ctl.data(), c->fb.ctl, ctl.size() * sizeof(AvtFrameCtl), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpyAsync(ctl.data(), c->fb.ctl, ctl.size() * sizeof(AvtFrameCtl), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    c->frames_valid = c->state_valid = false;
     c->nframes = nframes;
     c->frame_N.assign(nframes, 0);
     c->frame_off.assign(nframes + 1, 0);
@@ -459,12 +582,17 @@ int avt_synth_render_frames(avt_ctx* c, int nframes, const double* w, const doub
         mx = std::max(mx, ctl[f].N);
         if (points_per_frame) points_per_frame[f] = ctl[f].N;
     }
-    c->launch_maxN = std::min(c->fb.max_points, ((mx + 2047) / 2048) * 2048);
+    c->launch_maxN = std::max(mx, std::min(c->fb.max_points, ((mx + 2047) / 2048) * 2048));
+    // the render kernels wrote N into the working control blocks; the start copies follow (avt_state_reset)
+    HIP_OK(hipMemcpy2DAsync(&c->fb.ctl_start->N, sizeof(AvtFrameCtl), c->frame_N.data(), sizeof(int), sizeof(int), (size_t)nframes, hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    c->frames_valid = true;
     return 0;
+    AVT_API_GUARD_END("avt_synth_render_frames")
 }
 
 int avt_frames_download(avt_ctx* c, int frame, double* data_3xN, int* labels) {
-    if (!c || frame < 0 || frame >= c->nframes) { avt_set_error("avt_frames_download: bad argument"); return 1; }
+    if (!c || !c->frames_valid || frame < 0 || frame >= c->nframes) { avt_set_error("avt_frames_download: bad argument"); return 1; }
     HIP_OK(hipSetDevice(c->device));
     const size_t N = c->frame_N[frame];
     if (data_3xN) HIP_OK(hipMemcpy(data_3xN, c->fb.data_raw + (size_t)frame * c->fb.max_points * 3, N * 3 * sizeof(double), hipMemcpyDeviceToHost));
@@ -473,46 +601,56 @@ int avt_frames_download(avt_ctx* c, int frame, double* data_3xN, int* labels) {
 }
 
 int avt_frames_upload(avt_ctx* c, int nframes, const double* data, const int* labels, const int* frame_offsets) {
+    AVT_API_GUARD_BEGIN
     if (!c || !data || !labels || !frame_offsets) { avt_set_error("avt_frames_upload: null argument"); return 1; }
     HIP_OK(hipSetDevice(c->device));
     if (upload_frames(c, nframes, data, labels, frame_offsets)) return 1;
     HIP_OK(hipStreamSynchronize(c->stream));
     return 0;
+    AVT_API_GUARD_END("avt_frames_upload")
 }
 
 int avt_state_upload(avt_ctx* c, int nframes, const double* p, const double* q, const double* w) {
+    AVT_API_GUARD_BEGIN
     if (!c || !p || !q || !w) { avt_set_error("avt_state_upload: null argument"); return 1; }
     HIP_OK(hipSetDevice(c->device));
     return upload_state(c, nframes, p, q, w);
+    AVT_API_GUARD_END("avt_state_upload")
 }
 
 int avt_optimize_resident(avt_ctx* c, const avt_options* opt) {
+    AVT_API_GUARD_BEGIN
     if (!c || !opt) { avt_set_error("avt_optimize_resident: null argument"); return 1; }
     HIP_OK(hipSetDevice(c->device));
     return run_optimize(c, opt);
+    AVT_API_GUARD_END("avt_optimize_resident")
 }
 
 int avt_state_reset(avt_ctx* c) {
-    if (!c || c->nframes <= 0) { avt_set_error("avt_state_reset: no state resident"); return 1; }
+    if (!c || c->nframes <= 0 || !c->state_valid) { avt_set_error("avt_state_reset: no state resident"); return 1; }
     HIP_OK(hipSetDevice(c->device));
     launch_state_reset(c, c->nframes);
     return check_launch("k_state_reset");
 }
 
 int avt_state_download(avt_ctx* c, double* p, double* q, double* w, avt_stats* stats) {
+    AVT_API_GUARD_BEGIN
     if (!c) { avt_set_error("avt_state_download: null context"); return 1; }
     HIP_OK(hipSetDevice(c->device));
     return download_state(c, p, q, w, stats);
+    AVT_API_GUARD_END("avt_state_download")
 }
 
 int avt_optimize_batch(avt_ctx* c, int nframes, const double* data, const int* labels, const int* frame_offsets, const avt_options* opt,
                        double* p, double* q, double* w, avt_stats* stats) {
+    AVT_API_GUARD_BEGIN
     if (!c || !data || !labels || !frame_offsets || !opt || !p || !q || !w) { avt_set_error("avt_optimize_batch: null argument"); return 1; }
     HIP_OK(hipSetDevice(c->device));
     if (upload_frames(c, nframes, data, labels, frame_offsets)) return 1;
     if (upload_state(c, nframes, p, q, w)) return 1;
     if (run_optimize(c, opt)) return 1;
     return download_state(c, p, q, w, stats);
+    AVT_API_GUARD_END("avt_optimize_batch")
 }
 
 int avt_optimize(avt_ctx* c, const double* data, const int* labels, int N, const avt_options* opt, double* p, double* q, double* w,
@@ -549,6 +687,7 @@ int avt_get_posed(avt_ctx* c, int frame, double* cloud, double* joint_pos, doubl
 }
 
 int avt_get_normal_equations(avt_ctx* c, int frame, double* H, double* g, double* cost) {
+    AVT_API_GUARD_BEGIN
     if (!c || frame < 0 || frame >= c->nframes) { avt_set_error("avt_get_normal_equations: bad argument"); return 1; }
     const AvtDims& d = c->dm.d;
     HIP_OK(hipSetDevice(c->device));
@@ -563,6 +702,7 @@ int avt_get_normal_equations(avt_ctx* c, int frame, double* H, double* g, double
     }
     if (cost) *cost = ctl.cost_cur;
     return 0;
+    AVT_API_GUARD_END("avt_get_normal_equations")
 }
 
 int avt_debug_trace(avt_ctx* c, int frame, double* out64) {
@@ -570,6 +710,15 @@ int avt_debug_trace(avt_ctx* c, int frame, double* out64) {
     HIP_OK(hipSetDevice(c->device));
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipMemcpy(out64, c->fb.trace + (size_t)frame * 64, 64 * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int avt_launch_shape(avt_ctx* c, int* groups, int* frames_per_group, int* eval_workgroups_per_frame) {
+    if (!c || c->nframes <= 0) { avt_set_error("avt_launch_shape: no frames resident"); return 1; }
+    const int ng = choose_groups(c->nframes), nfg = (c->nframes + ng - 1) / ng;
+    if (groups) *groups = ng;
+    if (frames_per_group) *frames_per_group = nfg;
+    if (eval_workgroups_per_frame) *eval_workgroups_per_frame = choose_G(nfg);
     return 0;
 }
 

@@ -108,6 +108,12 @@ struct AvtFrameCtl {
     int pad[2];
 };
 
+// the knobs of optimize() the kernels read (avt_options), kept in device memory so that they are not baked into the
+// captured launch sequence: a tracker that varies betaPose / the LM scalars replays the same hipGraph
+struct AvtRunParams {
+    double beta_pose, beta_shape, lambda0, lm_up, lm_down, lm_min, lm_max, pad;
+};
+
 struct DeviceModel {
     AvtDims d;
     // shape planes [(K+1)*3][V]: plane k*3+c = keyClouds component c of key k; planes K*3+c = baseCloud
@@ -189,6 +195,7 @@ struct FrameBuffers {
     double* jointpos;     // [max_frames][3J]
     double* jointtrans;   // [max_frames][12J]
     double* trace;        // [max_frames][64] cost trace (debug)
+    const AvtRunParams* params;   // one block per context
 };
 
 struct avt_model {
@@ -224,7 +231,14 @@ struct avt_ctx {
     int launch_maxN;                 // max points per frame of the resident batch, rounded up to 2048 (grid sizing)
     bool lbs_cleared;                // the preceding k_lbs reset visibility / correspondence bookkeeping
     bool use_graph;                  // replay the optimize() launch sequence as a hipGraph (AVT_NO_GRAPH=1 disables)
-    std::map<std::string, hipGraphExec_t> graphs;
+    struct GraphEntry { std::string key; hipGraphExec_t exec; unsigned long long last_used; };
+    std::vector<GraphEntry> graphs;  // small LRU cache keyed on the launch SHAPE only (frames, groups, grids, iteration counts)
+    unsigned long long graph_clock;
+    AvtRunParams params_host;        // what fb.params currently holds
+    bool params_valid;
+    bool frames_valid, state_valid;  // resident frames / start state usable by avt_optimize_resident
+    // persistent scratch of avt_synth_render_frames (z-buffer keys, labels, block counts), grown on demand
+    unsigned long long* render_zkey; unsigned char* render_label; int* render_block; size_t render_cap_pix; size_t render_cap_blk;
 };
 
 void avt_set_error(const std::string& s);
@@ -237,8 +251,9 @@ void launch_visibility(avt_ctx* c, int nframes, int enable);
 void launch_bucket(avt_ctx* c, int nframes, bool clear_after);
 void launch_state_reset(avt_ctx* c, int nframes);
 void launch_nn(avt_ctx* c, int nframes);
-void launch_finalize(avt_ctx* c, int nframes, const avt_options* o);
+void launch_finalize(avt_ctx* c, int nframes);
 void launch_eval(avt_ctx* c, int nframes);
 void launch_records(avt_ctx* c, int nframes);
 void launch_reduce(avt_ctx* c, int nframes);
-void launch_solve(avt_ctx* c, int nframes, int mode, const avt_options* o);
+void launch_solve(avt_ctx* c, int nframes, int mode);
+void launch_pack_results(avt_ctx* c, int nframes, double* out, int stride);

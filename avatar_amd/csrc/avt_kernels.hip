@@ -261,8 +261,8 @@ void launch_bucket(avt_ctx* c, int nframes, bool clear_after) {
 // One workgroup of 1024 threads per frame; the compaction keeps the model's vertex order (vorder: by the set of
 // tiles a vertex's rows touch, then ascending id), so that batches of 16 matched points share their live tiles.
 // =================================================================================================
-__global__ __launch_bounds__(1024) void k_finalize(DeviceModel dm, FrameBuffers fb, double beta_pose, double beta_shape,
-                                                   double lambda0, int first_icp) {
+__global__ __launch_bounds__(1024) void k_finalize(DeviceModel dm, FrameBuffers fb, int first_icp) {
+    const double beta_pose = fb.params->beta_pose, beta_shape = fb.params->beta_shape, lambda0 = fb.params->lambda0;
     const int f = blockIdx.x + fb.f0, t = threadIdx.x, V = dm.d.V;
     AvtFrameCtl& ctl = fb.ctl[f];
     if (t < 2 * (AVT_MAX_PARTS + 1)) fb.part_cnt[(size_t)f * 2 * (AVT_MAX_PARTS + 1) + t] = 0;   // bucketing is over: restore the invariant
@@ -324,8 +324,28 @@ __global__ __launch_bounds__(1024) void k_finalize(DeviceModel dm, FrameBuffers 
     }
 }
 
-void launch_finalize(avt_ctx* c, int nframes, const avt_options* o) {
-    hipLaunchKernelGGL(k_finalize, dim3(nframes), dim3(1024), 0, c->cur_stream, c->dm, c->fb, o->beta_pose, o->beta_shape,
-                       o->lm_lambda0, c->ran_icp_iters == 0 ? 1 : 0);
+void launch_finalize(avt_ctx* c, int nframes) {
+    hipLaunchKernelGGL(k_finalize, dim3(nframes), dim3(1024), 0, c->cur_stream, c->dm, c->fb, c->ran_icp_iters == 0 ? 1 : 0);
     c->fb.const_used = (c->launch_maxN + 255) / 256;      // cost-constant workgroups ride in k_records' grid (avt_eval.hip)
+}
+
+// =================================================================================================
+// Result record of every resident frame for the batch split's all-gather (include/avt_shard.h): the current state
+// x = (p, q, w) followed by AVT_SHARD_STAT_DOUBLES statistics, `stride` doubles per frame.  grid (nframes), block 128.
+// =================================================================================================
+__global__ __launch_bounds__(128) void k_pack_results(FrameBuffers fb, double* __restrict__ out, int xsize, int stride) {
+    const int f = blockIdx.x, t = threadIdx.x;
+    const AvtFrameCtl& ctl = fb.ctl[f];
+    const double* x = fb.x + ((size_t)f * 2 + ctl.cur_slot) * xsize;
+    double* o = out + (size_t)f * stride;
+    for (int e = t; e < xsize; e += 128) o[e] = x[e];
+    if (t == 0) {
+        double* s = o + xsize;
+        s[0] = ctl.cost_initial; s[1] = ctl.cost_cur; s[2] = ctl.lambda; s[3] = (double)ctl.T; s[4] = (double)ctl.M;
+        s[5] = (double)ctl.gn_iterations; s[6] = (double)ctl.accepted; s[7] = (double)ctl.N;
+    }
+}
+
+void launch_pack_results(avt_ctx* c, int nframes, double* out, int stride) {
+    hipLaunchKernelGGL(k_pack_results, dim3(nframes), dim3(128), 0, c->stream, c->fb, out, c->dm.d.xsize, stride);
 }

@@ -271,8 +271,7 @@ __device__ __forceinline__ void backsub_blocked(const double* __restrict__ Lblk,
 // =================================================================================================
 // k_solve.  grid (nframes), block 256.
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, int mode, double lm_up, double lm_down,
-                                               double lm_min, double lm_max) {
+__global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, int mode) {
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, P = d.P, HS = d.HS;
     const int f = blockIdx.x + fb.f0, t = threadIdx.x;
@@ -343,6 +342,7 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
             hdiag[sl][r][0] = srd[0]; hdiag[sl][r][1] = srd[1];
         }
     const double hpp0 = H0[(size_t)P * HS + P], hpp1 = H0[(size_t)HS * HS + (size_t)P * HS + P];
+    const double lm_up = fb.params->lm_up, lm_down = fb.params->lm_down, lm_min = fb.params->lm_min, lm_max = fb.params->lm_max;   // same round trip
     const int cur0 = ctl.cur_slot, try_valid = ctl.try_valid, comp_cur0 = ctl.comp_cur;
     const double sbp = ctl.sbp, sbs = ctl.sbs, cost_cur0 = ctl.cost_cur, cost_const = ctl.cost_const;
     double lambda = ctl.lambda;
@@ -621,10 +621,9 @@ void launch_reduce(avt_ctx* c, int nframes) {
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<1>), dim3(d.NPAIR, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
 }
 
-void launch_solve(avt_ctx* c, int nframes, int mode, const avt_options* o) {
+void launch_solve(avt_ctx* c, int nframes, int mode) {
     const AvtDims& d = c->dm.d;
-    hipLaunchKernelGGL(k_solve, dim3(nframes), dim3(256), solve_lds_bytes(d), c->cur_stream, c->dm, c->fb, mode, o->lm_up, o->lm_down,
-                       o->lm_lambda_min, o->lm_lambda_max);
+    hipLaunchKernelGGL(k_solve, dim3(nframes), dim3(256), solve_lds_bytes(d), c->cur_stream, c->dm, c->fb, mode);
 }
 
 int avt_solve_set_attributes() {

@@ -1,0 +1,504 @@
+// avt_shard.cpp — batch split of independent frames over the GPUs of one node behind the C ABI of include/avt_shard.h
+// (SURVEY.md §8e): frame f -> rank f mod W, model constants replicated, RCCL over xGMI for exactly three exchanges
+// (model broadcast, cloud scatter, result all-gather), all on device buffers.  The reference has no counterpart: it is
+// a single process whose parallelism are per-call std::thread pools (AvatarOptimizer.cpp:337-343, :883-889).
+// Compiled with hipcc (host only).  librccl is opened with dlopen at the first use, see rccl_api().
+#include <dlfcn.h>
+#include <link.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/avt_shard.h"
+#include "avt_internal.h"
+
+int avt_internal_install_frames(avt_ctx* c, int nframes, const int* counts, const double* data, const int* labels, int device_src);
+void launch_pack_results(avt_ctx* c, int nframes, double* out, int stride);
+
+#define HIP_OK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            avt_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// partition
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int avt_shard_owner(int frame, int world) { return world > 0 ? frame % world : 0; }
+extern "C" int avt_shard_local_count(int num_frames, int rank, int world) {
+    if (world <= 0 || rank < 0 || rank >= world || num_frames <= rank) return 0;
+    return (num_frames - rank + world - 1) / world;
+}
+extern "C" int avt_shard_local_index(int frame, int world) { return world > 0 ? frame / world : frame; }
+extern "C" int avt_shard_global_frame(int local_index, int rank, int world) { return rank + world * local_index; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// packed model: header + the arrays of avt_model_desc, each 8-byte aligned, in declaration order
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct PackHeader {
+    char magic[8];                 // "AVTMODEL"
+    std::int32_t version, V, J, K, F, nnz_w, nnz_r, ncomps, ndims, pad;
+    std::uint64_t bytes;           // of the whole block
+};
+
+struct PackLayout {
+    size_t off[13], len[13];       // byte offset / byte length of every array
+    size_t total;
+};
+
+size_t align8(size_t x) { return (x + 7) & ~(size_t)7; }
+
+bool pack_layout(const PackHeader& h, PackLayout& L) {
+    if (h.V <= 0 || h.J <= 0 || h.K < 0 || h.F < 0 || h.nnz_w < 0 || h.nnz_r < 0 || h.ncomps < 0 || h.ndims < 0) return false;
+    if (h.J > AVT_MAX_JOINTS || h.K > AVT_MAX_SHAPE || h.V > (1 << 24) || h.F > (1 << 25) || h.ncomps > 4096 || h.ndims > 4096) return false;
+    const size_t V = h.V, J = h.J, K = h.K, F = h.F, C = h.ncomps, n = h.ndims;
+    const size_t lens[13] = {3 * V * 8, 3 * V * K * 8, J * 4, 3 * F * 4, (V + 1) * 4, (size_t)h.nnz_w * 4, (size_t)h.nnz_w * 8,
+                             (J + 1) * 4, (size_t)h.nnz_r * 4, (size_t)h.nnz_r * 8, C * 8, C * n * 8, C * n * n * 8};
+    size_t o = align8(sizeof(PackHeader));
+    for (int i = 0; i < 13; ++i) { L.off[i] = o; L.len[i] = lens[i]; o = align8(o + lens[i]); }
+    L.total = o;
+    return true;
+}
+
+bool header_of(const avt_model_desc* d, PackHeader& h) {
+    if (!d || d->num_points <= 0 || d->num_joints <= 0 || !d->weights_colptr || !d->jreg_colptr) return false;
+    std::memset(&h, 0, sizeof h);
+    std::memcpy(h.magic, "AVTMODEL", 8);
+    h.version = 1;
+    h.V = d->num_points; h.J = d->num_joints; h.K = d->num_shape_keys; h.F = d->num_faces;
+    h.nnz_w = d->weights_colptr[d->num_points];
+    h.nnz_r = d->jreg_colptr[d->num_joints];
+    h.ncomps = d->prior_ncomps > 0 ? d->prior_ncomps : 0;
+    h.ndims = h.ncomps ? d->prior_ndims : 0;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int avt_model_pack_size(const avt_model_desc* desc, size_t* bytes) {
+    PackHeader h; PackLayout L;
+    if (!bytes || !header_of(desc, h) || !pack_layout(h, L)) { avt_set_error("avt_model_pack_size: bad model description"); return 1; }
+    *bytes = L.total;
+    return 0;
+}
+
+extern "C" int avt_model_pack(const avt_model_desc* d, void* buf, size_t bytes) {
+    PackHeader h; PackLayout L;
+    if (!buf || !header_of(d, h) || !pack_layout(h, L)) { avt_set_error("avt_model_pack: bad model description"); return 1; }
+    if (bytes < L.total) { avt_set_error("avt_model_pack: buffer too small"); return 1; }
+    h.bytes = L.total;
+    char* b = (char*)buf;
+    std::memset(b, 0, L.total);
+    std::memcpy(b, &h, sizeof h);
+    const void* src[13] = {d->base_cloud, d->key_clouds, d->parent, d->mesh, d->weights_colptr, d->weights_row, d->weights_val,
+                           d->jreg_colptr, d->jreg_row, d->jreg_val, d->prior_weight, d->prior_mean, d->prior_cov};
+    for (int i = 0; i < 13; ++i) {
+        if (L.len[i] == 0) continue;
+        if (!src[i]) { avt_set_error("avt_model_pack: a required array of the model description is NULL"); return 1; }
+        std::memcpy(b + L.off[i], src[i], L.len[i]);
+    }
+    return 0;
+}
+
+extern "C" int avt_model_unpack(const void* buf, size_t bytes, avt_model** out) {
+    if (!buf || !out || bytes < sizeof(PackHeader)) { avt_set_error("avt_model_unpack: block too small"); return 1; }
+    PackHeader h;
+    std::memcpy(&h, buf, sizeof h);
+    PackLayout L;
+    if (std::memcmp(h.magic, "AVTMODEL", 8) != 0 || h.version != 1 || !pack_layout(h, L) || h.bytes != L.total || bytes < L.total) {
+        avt_set_error("avt_model_unpack: not a packed model (magic / version / size mismatch)");
+        return 1;
+    }
+    const char* b = (const char*)buf;
+    avt_model_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.num_points = h.V; d.num_joints = h.J; d.num_shape_keys = h.K; d.num_faces = h.F;
+    d.base_cloud = (const double*)(b + L.off[0]); d.key_clouds = (const double*)(b + L.off[1]);
+    d.parent = (const int*)(b + L.off[2]); d.mesh = (const int*)(b + L.off[3]);
+    d.weights_colptr = (const int*)(b + L.off[4]); d.weights_row = (const int*)(b + L.off[5]); d.weights_val = (const double*)(b + L.off[6]);
+    d.jreg_colptr = (const int*)(b + L.off[7]); d.jreg_row = (const int*)(b + L.off[8]); d.jreg_val = (const double*)(b + L.off[9]);
+    d.prior_ncomps = h.ncomps; d.prior_ndims = h.ndims;
+    if (h.ncomps) { d.prior_weight = (const double*)(b + L.off[10]); d.prior_mean = (const double*)(b + L.off[11]); d.prior_cov = (const double*)(b + L.off[12]); }
+    // the column pointers index the arrays that follow them: check before avt_model_create walks them
+    if (d.weights_colptr[0] != 0 || d.weights_colptr[h.V] != h.nnz_w || d.jreg_colptr[0] != 0 || d.jreg_colptr[h.J] != h.nnz_r) {
+        avt_set_error("avt_model_unpack: sparse column pointers do not match the block");
+        return 1;
+    }
+    for (int v = 0; v < h.V; ++v)
+        if (d.weights_colptr[v + 1] < d.weights_colptr[v]) { avt_set_error("avt_model_unpack: weight column pointers not monotone"); return 1; }
+    for (int j = 0; j < h.J; ++j) {
+        if (d.jreg_colptr[j + 1] < d.jreg_colptr[j]) { avt_set_error("avt_model_unpack: regressor column pointers not monotone"); return 1; }
+        for (int e = d.jreg_colptr[j]; e < d.jreg_colptr[j + 1]; ++e)
+            if (d.jreg_row[e] < 0 || d.jreg_row[e] >= h.V) { avt_set_error("avt_model_unpack: regressor row out of range"); return 1; }
+    }
+    return avt_model_create(&d, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RCCL, opened at run time
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    std::string path, error;
+    int version = 0;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+};
+
+int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* data) {
+    if (info->dlpi_name && std::strstr(info->dlpi_name, "librccl")) { *(std::string*)data = info->dlpi_name; return 1; }
+    return 0;
+}
+
+RcclApi* rccl_api() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.handle ? &api : nullptr;
+    tried = true;
+    // one RCCL per process: if the host program (PyTorch) already mapped a librccl, use that very copy
+    std::string loaded;
+    dl_iterate_phdr(find_loaded_rccl, &loaded);
+    std::vector<std::string> cand;
+    if (const char* e = getenv("AVT_RCCL_LIB")) cand.push_back(e);
+    if (!loaded.empty()) cand.push_back(loaded);
+    cand.push_back("librccl.so.1"); cand.push_back("librccl.so"); cand.push_back("/opt/rocm/lib/librccl.so.1");
+    for (const std::string& p : cand) {
+        api.handle = dlopen(p.c_str(), RTLD_NOW | RTLD_GLOBAL);
+        if (api.handle) { api.path = p; break; }
+        api.error = dlerror() ? dlerror() : "dlopen failed";
+    }
+    if (!api.handle) { avt_set_error("avt_shard: cannot open librccl (" + api.error + "); set AVT_RCCL_LIB"); return nullptr; }
+    bool ok = true;
+    auto sym = [&](const char* n) { void* s = dlsym(api.handle, n); if (!s) { ok = false; api.error = std::string("missing symbol ") + n; } return s; };
+    api.GetVersion = (decltype(api.GetVersion))sym("ncclGetVersion");
+    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    api.Broadcast = (decltype(api.Broadcast))sym("ncclBroadcast");
+    api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+    api.Send = (decltype(api.Send))sym("ncclSend");
+    api.Recv = (decltype(api.Recv))sym("ncclRecv");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    if (!ok) { avt_set_error("avt_shard: " + api.path + ": " + api.error); dlclose(api.handle); api.handle = nullptr; return nullptr; }
+    Dl_info di;
+    if (dladdr((void*)api.GetUniqueId, &di) && di.dli_fname) api.path = di.dli_fname;
+    api.GetVersion(&api.version);
+    return &api;
+}
+
+}  // namespace
+
+struct avt_shard {
+    RcclApi* api = nullptr;
+    ncclComm_t comm = nullptr;
+    int device = 0, rank = 0, world = 1;
+    hipStream_t stream = nullptr;          // exchanges that happen before a context exists (model broadcast)
+    std::string backend;
+    // result gather: per-rank send block and the gathered block, device
+    double* d_send = nullptr; double* d_recv = nullptr; size_t gather_cap = 0;   // doubles per rank block
+    void* d_stage = nullptr; size_t stage_cap = 0;                              // scatter / broadcast staging, bytes
+    void* d_stage2 = nullptr; size_t stage2_cap = 0;
+};
+
+#define NCCL_OK(s, expr)                                                                                       \
+    do {                                                                                                       \
+        ncclResult_t _r = (expr);                                                                              \
+        if (_r != ncclSuccess) {                                                                               \
+            avt_set_error(std::string(#expr) + ": " + ((s)->api->GetErrorString ? (s)->api->GetErrorString(_r) : "rccl error")); \
+            return 1;                                                                                          \
+        }                                                                                                      \
+    } while (0)
+
+namespace {
+
+int grow(void** p, size_t* cap, size_t bytes) {
+    if (*cap >= bytes && *p) return 0;
+    if (*p) HIP_OK(hipFree(*p));
+    *p = nullptr; *cap = 0;
+    HIP_OK(hipMalloc(p, std::max<size_t>(bytes, 256)));
+    *cap = std::max<size_t>(bytes, 256);
+    return 0;
+}
+
+int gather_stride(const avt_ctx* c) { return c->dm.d.xsize + AVT_SHARD_STAT_DOUBLES; }
+
+}  // namespace
+
+extern "C" int avt_shard_unique_id(char id[AVT_SHARD_ID_BYTES]) {
+    RcclApi* a = rccl_api();
+    if (!a) return 1;
+    if (!id) { avt_set_error("avt_shard_unique_id: null argument"); return 1; }
+    static_assert(AVT_SHARD_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId u;
+    const ncclResult_t r = a->GetUniqueId(&u);
+    if (r != ncclSuccess) { avt_set_error(std::string("ncclGetUniqueId: ") + a->GetErrorString(r)); return 1; }
+    std::memcpy(id, u.internal, AVT_SHARD_ID_BYTES);
+    return 0;
+}
+
+extern "C" int avt_shard_create(int device, int rank, int world, const char id[AVT_SHARD_ID_BYTES], avt_shard** out) {
+    if (!id || !out || world <= 0 || rank < 0 || rank >= world) { avt_set_error("avt_shard_create: bad argument"); return 1; }
+    RcclApi* a = rccl_api();
+    if (!a) return 1;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { avt_set_error("avt_shard_create: device index out of range"); return 2; }
+    HIP_OK(hipSetDevice(device));
+    avt_shard* s = new avt_shard();
+    s->api = a; s->device = device; s->rank = rank; s->world = world;
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, AVT_SHARD_ID_BYTES);
+    const ncclResult_t r = a->CommInitRank(&s->comm, world, u, rank);
+    if (r != ncclSuccess) {
+        avt_set_error(std::string("ncclCommInitRank: ") + a->GetErrorString(r));
+        delete s;
+        return 1;
+    }
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+        avt_set_error("avt_shard_create: hipStreamCreate failed");
+        a->CommDestroy(s->comm);
+        delete s;
+        return 1;
+    }
+    char buf[512];
+    snprintf(buf, sizeof buf, "rccl %d.%d.%d, %s", a->version / 10000, (a->version / 100) % 100, a->version % 100, a->path.c_str());
+    s->backend = buf;
+    *out = s;
+    return 0;
+}
+
+extern "C" void avt_shard_destroy(avt_shard* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->comm) s->api->CommDestroy(s->comm);
+    for (void* p : {(void*)s->d_send, (void*)s->d_recv, s->d_stage, s->d_stage2})
+        if (p) (void)hipFree(p);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+extern "C" int avt_shard_rank(const avt_shard* s) { return s ? s->rank : -1; }
+extern "C" int avt_shard_world(const avt_shard* s) { return s ? s->world : 0; }
+extern "C" const char* avt_shard_backend(const avt_shard* s) { return s ? s->backend.c_str() : ""; }
+
+extern "C" int avt_shard_broadcast_model(avt_shard* s, int root, const avt_model_desc* desc, avt_model** out) try {
+    if (!s || !out || root < 0 || root >= s->world) { avt_set_error("avt_shard_broadcast_model: bad argument"); return 1; }
+    HIP_OK(hipSetDevice(s->device));
+    // 1. size of the packed block (8 bytes), 2. the block itself; both as device-buffer broadcasts
+    unsigned long long nbytes = 0;
+    std::vector<char> host;
+    if (s->rank == root) {
+        size_t n = 0;
+        if (avt_model_pack_size(desc, &n)) return 1;
+        host.resize(n);
+        if (avt_model_pack(desc, host.data(), n)) return 1;
+        nbytes = n;
+    }
+    if (grow(&s->d_stage2, &s->stage2_cap, 64)) return 1;
+    HIP_OK(hipMemcpyAsync(s->d_stage2, &nbytes, 8, hipMemcpyHostToDevice, s->stream));
+    NCCL_OK(s, s->api->Broadcast(s->d_stage2, s->d_stage2, 8, ncclChar, root, s->comm, s->stream));
+    HIP_OK(hipMemcpyAsync(&nbytes, s->d_stage2, 8, hipMemcpyDeviceToHost, s->stream));
+    HIP_OK(hipStreamSynchronize(s->stream));
+    if (nbytes < sizeof(PackHeader) || nbytes > (1ull << 32)) { avt_set_error("avt_shard_broadcast_model: implausible model size received"); return 1; }
+    if (grow(&s->d_stage, &s->stage_cap, nbytes)) return 1;
+    if (s->rank == root) HIP_OK(hipMemcpyAsync(s->d_stage, host.data(), nbytes, hipMemcpyHostToDevice, s->stream));
+    NCCL_OK(s, s->api->Broadcast(s->d_stage, s->d_stage, nbytes, ncclChar, root, s->comm, s->stream));
+    host.resize(nbytes);
+    HIP_OK(hipMemcpyAsync(host.data(), s->d_stage, nbytes, hipMemcpyDeviceToHost, s->stream));
+    HIP_OK(hipStreamSynchronize(s->stream));
+    return avt_model_unpack(host.data(), host.size(), out);
+} catch (const std::exception& e) { avt_set_error(std::string("avt_shard_broadcast_model: ") + e.what()); return 1; }
+
+extern "C" int avt_shard_scatter_frames(avt_shard* s, avt_ctx* c, int root, int B, const double* data, const int* labels,
+                                        const int* offs, const double* p, const double* q, const double* w) try {
+    if (!s || !c || root < 0 || root >= s->world || B <= 0) { avt_set_error("avt_shard_scatter_frames: bad argument"); return 1; }
+    const bool is_root = s->rank == root;
+    if (is_root && (!data || !labels || !offs || !p || !q || !w)) { avt_set_error("avt_shard_scatter_frames: root needs all host arrays"); return 1; }
+    const AvtDims& d = c->dm.d;
+    const int W = s->world, xs = d.xsize, J = d.J, K = d.K;
+    const int nloc = avt_shard_local_count(B, s->rank, W);
+    if (nloc > c->fb.max_frames) { avt_set_error("avt_shard_scatter_frames: this rank's share exceeds the context's max_frames"); return 1; }
+    HIP_OK(hipSetDevice(s->device));
+    hipStream_t st = c->stream;
+    // ---- 1. frame table and start states: one small broadcast.  block = [B point counts as doubles | B x xsize states]
+    const size_t tab_n = (size_t)B * (1 + xs);
+    std::vector<double> tab(tab_n, 0.0);
+    if (is_root) {
+        for (int f = 0; f < B; ++f) {
+            const int n = offs[f + 1] - offs[f];
+            if (n < 0) { avt_set_error("avt_shard_scatter_frames: frame_offsets not monotone"); return 1; }
+            tab[f] = (double)n;
+            double* x = &tab[(size_t)B + (size_t)f * xs];
+            std::copy(p + 3 * (size_t)f, p + 3 * (size_t)f + 3, x);
+            std::copy(q + (size_t)4 * J * f, q + (size_t)4 * J * (f + 1), x + 3);
+            std::copy(w + (size_t)K * f, w + (size_t)K * (f + 1), x + 3 + 4 * J);
+        }
+    }
+    if (grow(&s->d_stage2, &s->stage2_cap, tab_n * 8)) return 1;
+    if (is_root) HIP_OK(hipMemcpyAsync(s->d_stage2, tab.data(), tab_n * 8, hipMemcpyHostToDevice, st));
+    NCCL_OK(s, s->api->Broadcast(s->d_stage2, s->d_stage2, tab_n, ncclDouble, root, s->comm, st));
+    HIP_OK(hipMemcpyAsync(tab.data(), s->d_stage2, tab_n * 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    std::vector<int> cnt(B);
+    std::vector<long long> rank_pts(W, 0);
+    for (int f = 0; f < B; ++f) {
+        cnt[f] = (int)tab[f];
+        if (cnt[f] < 0 || cnt[f] > c->fb.max_points) { avt_set_error("avt_shard_scatter_frames: a frame has more points than max_points_per_frame"); return 1; }
+        rank_pts[f % W] += cnt[f];
+    }
+    // ---- 2. clouds: the root permutes the batch so that every rank's frames are contiguous (rank-major, then local
+    // order), uploads it once and sends each rank its block: [3 n doubles | n ints] -> two sends per peer, one group
+    std::vector<long long> rank_off(W + 1, 0);
+    for (int r = 0; r < W; ++r) rank_off[r + 1] = rank_off[r] + rank_pts[r];
+    const long long total = rank_off[W], mine = rank_pts[s->rank];
+    double* d_data = nullptr; int* d_lab = nullptr;
+    if (is_root) {
+        std::vector<double> hd((size_t)total * 3);
+        std::vector<int> hl((size_t)total);
+        std::vector<long long> cur(rank_off.begin(), rank_off.end() - 1);
+        for (int f = 0; f < B; ++f) {
+            const int r = f % W, n = cnt[f];
+            std::memcpy(&hd[(size_t)cur[r] * 3], data + (size_t)offs[f] * 3, (size_t)n * 24);
+            std::memcpy(&hl[(size_t)cur[r]], labels + offs[f], (size_t)n * 4);
+            cur[r] += n;
+        }
+        if (grow(&s->d_stage, &s->stage_cap, (size_t)total * 28 + 64)) return 1;
+        d_data = (double*)s->d_stage; d_lab = (int*)((char*)s->d_stage + (size_t)total * 24);
+        if (total) {
+            HIP_OK(hipMemcpyAsync(d_data, hd.data(), (size_t)total * 24, hipMemcpyHostToDevice, st));
+            HIP_OK(hipMemcpyAsync(d_lab, hl.data(), (size_t)total * 4, hipMemcpyHostToDevice, st));
+        }
+        HIP_OK(hipStreamSynchronize(st));   // the host vectors go out of scope below
+    } else {
+        if (grow(&s->d_stage, &s->stage_cap, (size_t)mine * 28 + 64)) return 1;
+        d_data = (double*)s->d_stage; d_lab = (int*)((char*)s->d_stage + (size_t)mine * 24);
+    }
+    const bool self_loop = getenv("AVT_SHARD_SELF_SENDRECV") != nullptr;   // dry runs: push the root's own block through RCCL too
+    double* my_data = d_data; int* my_lab = d_lab;
+    if (is_root) { my_data = d_data + rank_off[s->rank] * 3; my_lab = d_lab + rank_off[s->rank]; }
+    double* loop_data = nullptr; int* loop_lab = nullptr;
+    if (is_root && self_loop && mine) {
+        if (grow(&s->d_stage2, &s->stage2_cap, std::max<size_t>((size_t)mine * 28 + 64, tab_n * 8))) return 1;
+        loop_data = (double*)s->d_stage2; loop_lab = (int*)((char*)s->d_stage2 + (size_t)mine * 24);
+    }
+    NCCL_OK(s, s->api->GroupStart());
+    if (is_root) {
+        for (int r = 0; r < W; ++r) {
+            if (rank_pts[r] == 0 || (r == s->rank && !self_loop)) continue;
+            NCCL_OK(s, s->api->Send(d_data + rank_off[r] * 3, (size_t)rank_pts[r] * 3, ncclDouble, r, s->comm, st));
+            NCCL_OK(s, s->api->Send(d_lab + rank_off[r], (size_t)rank_pts[r], ncclInt32, r, s->comm, st));
+        }
+        if (self_loop && mine) {
+            NCCL_OK(s, s->api->Recv(loop_data, (size_t)mine * 3, ncclDouble, root, s->comm, st));
+            NCCL_OK(s, s->api->Recv(loop_lab, (size_t)mine, ncclInt32, root, s->comm, st));
+            my_data = loop_data; my_lab = loop_lab;
+        }
+    } else if (mine) {
+        NCCL_OK(s, s->api->Recv(d_data, (size_t)mine * 3, ncclDouble, root, s->comm, st));
+        NCCL_OK(s, s->api->Recv(d_lab, (size_t)mine, ncclInt32, root, s->comm, st));
+    }
+    NCCL_OK(s, s->api->GroupEnd());
+    // ---- 3. install this rank's frames in the context's resident buffers (device-to-device) and its start states
+    std::vector<int> lcnt(nloc);
+    std::vector<double> lp((size_t)nloc * 3), lq((size_t)nloc * 4 * J), lw((size_t)nloc * K);
+    for (int i = 0; i < nloc; ++i) {
+        const int f = avt_shard_global_frame(i, s->rank, W);
+        lcnt[i] = cnt[f];
+        const double* x = &tab[(size_t)B + (size_t)f * xs];
+        std::copy(x, x + 3, &lp[(size_t)i * 3]);
+        std::copy(x + 3, x + 3 + 4 * J, &lq[(size_t)i * 4 * J]);
+        std::copy(x + 3 + 4 * J, x + xs, &lw[(size_t)i * K]);
+    }
+    if (nloc == 0) return 0;
+    if (avt_internal_install_frames(c, nloc, lcnt.data(), my_data, my_lab, 1)) return 1;
+    if (avt_state_upload(c, nloc, lp.data(), lq.data(), lw.data())) return 1;
+    HIP_OK(hipStreamSynchronize(st));
+    return 0;
+} catch (const std::exception& e) { avt_set_error(std::string("avt_shard_scatter_frames: ") + e.what()); return 1; }
+
+extern "C" int avt_shard_gather_enqueue(avt_shard* s, avt_ctx* c, int B) {
+    if (!s || !c || B <= 0) { avt_set_error("avt_shard_gather_enqueue: bad argument"); return 1; }
+    const int W = s->world, per = (B + W - 1) / W, stride = gather_stride(c);
+    const int nloc = avt_shard_local_count(B, s->rank, W);
+    if (nloc != c->nframes) { avt_set_error("avt_shard_gather_enqueue: resident frames differ from this rank's share of the batch"); return 1; }
+    HIP_OK(hipSetDevice(s->device));
+    const size_t blk = (size_t)per * stride;
+    if (s->gather_cap < blk) {
+        HIP_OK(hipStreamSynchronize(c->stream));
+        if (s->d_send) HIP_OK(hipFree(s->d_send));
+        if (s->d_recv) HIP_OK(hipFree(s->d_recv));
+        s->d_send = s->d_recv = nullptr; s->gather_cap = 0;
+        HIP_OK(hipMalloc((void**)&s->d_send, blk * 8));
+        HIP_OK(hipMalloc((void**)&s->d_recv, blk * 8 * W));
+        HIP_OK(hipMemset(s->d_send, 0, blk * 8));
+        s->gather_cap = blk;
+    }
+    if (nloc) launch_pack_results(c, nloc, s->d_send, stride);
+    NCCL_OK(s, s->api->AllGather(s->d_send, s->d_recv, blk, ncclDouble, s->comm, c->stream));
+    return 0;
+}
+
+extern "C" int avt_shard_gather_download(avt_shard* s, avt_ctx* c, int B, double* p, double* q, double* w, avt_stats* stats) try {
+    if (!s || !c || B <= 0) { avt_set_error("avt_shard_gather_download: bad argument"); return 1; }
+    const AvtDims& d = c->dm.d;
+    const int W = s->world, per = (B + W - 1) / W, stride = gather_stride(c), xs = d.xsize, J = d.J, K = d.K;
+    const size_t blk = (size_t)per * stride;
+    if (s->gather_cap < blk || !s->d_recv) { avt_set_error("avt_shard_gather_download: nothing was gathered"); return 1; }
+    HIP_OK(hipSetDevice(s->device));
+    std::vector<double> host(blk * W);
+    HIP_OK(hipMemcpyAsync(host.data(), s->d_recv, host.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    for (int f = 0; f < B; ++f) {
+        const double* x = &host[(size_t)(f % W) * blk + (size_t)(f / W) * stride];
+        if (p) std::copy(x, x + 3, p + 3 * (size_t)f);
+        if (q) std::copy(x + 3, x + 3 + 4 * J, q + (size_t)4 * J * f);
+        if (w) std::copy(x + 3 + 4 * J, x + xs, w + (size_t)K * f);
+        if (stats) {
+            const double* t = x + xs;
+            stats[f].initial_cost = t[0]; stats[f].final_cost = t[1]; stats[f].lambda = t[2];
+            stats[f].num_correspondences = (int)t[3]; stats[f].matched_model_points = (int)t[4];
+            stats[f].gn_iterations = (int)t[5]; stats[f].accepted_steps = (int)t[6];
+        }
+    }
+    return 0;
+} catch (const std::exception& e) { avt_set_error(std::string("avt_shard_gather_download: ") + e.what()); return 1; }
+
+extern "C" int avt_shard_gather_results(avt_shard* s, avt_ctx* c, int B, double* p, double* q, double* w, avt_stats* stats) {
+    if (avt_shard_gather_enqueue(s, c, B)) return 1;
+    return avt_shard_gather_download(s, c, B, p, q, w, stats);
+}
+
+extern "C" int avt_shard_barrier(avt_shard* s, avt_ctx* c) {
+    if (!s) { avt_set_error("avt_shard_barrier: null argument"); return 1; }
+    HIP_OK(hipSetDevice(s->device));
+    hipStream_t st = c ? c->stream : s->stream;
+    if (grow(&s->d_stage2, &s->stage2_cap, (size_t)(s->world + 1) * 8)) return 1;
+    double* b = (double*)s->d_stage2;
+    NCCL_OK(s, s->api->AllGather(b + s->world, b, 1, ncclDouble, s->comm, st));
+    HIP_OK(hipStreamSynchronize(st));
+    return 0;
+}

@@ -14,6 +14,11 @@
  *   - every function returns 0 on success, non-zero on error; avt_last_error() describes the last failure
  *     on the calling thread.  (The reference's `void` + std::exit(1) asserts live in the C++ facade.)
  *   - a context is NOT thread-safe: one context per host thread / HIP stream   (Avatar.h:191 lifetimes)
+ *   - resident state: avt_frames_upload / avt_synth_render_frames make frames resident, avt_state_upload the start
+ *     states of exactly those frames; avt_optimize_resident needs both.  Uploading the same NUMBER of frames again keeps
+ *     the resident states (temporal warm start); a different number invalidates them.  The stand-alone entry points
+ *     avt_lbs_update / avt_visibility / avt_nn use the frame slots as scratch and invalidate frames and states: upload
+ *     again before the next avt_optimize_resident (it fails with a message otherwise).
  */
 #ifndef AVT_H_
 #define AVT_H_
@@ -181,6 +186,11 @@ int avt_get_normal_equations(avt_ctx* c, int frame, double* H /* P x P */, doubl
 /* diagnostics: 64 doubles per frame (objective after every GN iteration; with -DAVT_TIMING builds also in-kernel
  * s_memtime probes, see tools/kernel_timing_probe.py) */
 int avt_debug_trace(avt_ctx* c, int frame, double* out64);
+
+/* How optimize() will launch over the resident frames: the batch runs as `groups` frame groups of `frames_per_group` frames
+ * (each kernel of the sequence is launched once per group, on the group's own stream when replayed as a hipGraph), the
+ * evaluation kernel with `eval_workgroups_per_frame` workgroups per frame.  Lets a profiler label launches by shape. */
+int avt_launch_shape(avt_ctx* c, int* groups, int* frames_per_group, int* eval_workgroups_per_frame);
 
 int avt_profile_begin(avt_ctx* c);
 /* restrict event insertion to the kernel classes in `mask` (bit k = class k); default: all classes */

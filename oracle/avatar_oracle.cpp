@@ -29,13 +29,76 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <limits>
+#include <mutex>
 #include <thread>
 #include <vector>
 
 #include "../include/avt.h"  // data-layout structs only (avt_model_desc, avt_options, avt_stats)
 
 namespace {
+
+// ---- threading of the TIMED BASELINE (bench.py cpu_baseline).  Two styles:
+//   spawn/join per evaluation, exactly like the reference's per-call std::thread pool (AvatarOptimizer.cpp:327-343,
+//   :883-889) - the "reference structure" number; and a persistent pool (g_persistent_pool), which is what a CPU
+//   implementation tuned for speed would do - the "fastest CPU" number the GPU speed-up is quoted against.
+// Results do not depend on the style: work is split by index range and partial sums are added in thread order.
+struct Pool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::function<void(int)> job;
+    int active = 0, gen = 0, pending = 0;
+    bool stop = false;
+    explicit Pool(int n) {
+        for (int i = 0; i < n; ++i) th.emplace_back([this, i] { loop(i); });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> l(mu); stop = true; ++gen; }
+        cv_go.notify_all();
+        for (auto& t : th) t.join();
+    }
+    void loop(int id) {
+        int seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> l(mu);
+            cv_go.wait(l, [&] { return gen != seen; });
+            seen = gen;
+            if (stop) return;
+            if (id >= active) continue;
+            l.unlock();
+            job(id);
+            l.lock();
+            if (--pending == 0) cv_done.notify_one();
+        }
+    }
+    void run(int n, const std::function<void(int)>& f) {   // f(0..n-1), n <= th.size()
+        std::unique_lock<std::mutex> l(mu);
+        job = f; active = n; pending = n; ++gen;
+        cv_go.notify_all();
+        cv_done.wait(l, [&] { return pending == 0; });
+    }
+};
+Pool* g_pool = nullptr;
+int g_persistent_pool = 0;   // 0: spawn/join per call (reference style); 1: persistent pool
+int g_parallel_nn = 0;       // 1: nearest-neighbour queries split over the threads too (the reference runs them serially, :896-904)
+typedef int (*nn_override_fn)(int, int, const int*, const double*, const unsigned char*, const double*, const int*, int, int*, double*, int);
+nn_override_fn g_nn_override = nullptr;   // e.g. oracle/_ref's nanoflann KD-tree search (the reference's own NN)
+
+void parallel_for(int nthreads, const std::function<void(int)>& f) {
+    if (nthreads <= 1) { f(0); return; }
+    if (g_persistent_pool) {
+        if (!g_pool || (int)g_pool->th.size() < nthreads) { delete g_pool; g_pool = new Pool(std::max(nthreads, (int)std::thread::hardware_concurrency())); }
+        g_pool->run(nthreads, f);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; ++t) pool.emplace_back(f, t);
+    for (auto& th : pool) th.join();
+}
 
 struct M3 {
     double a[3][3];
@@ -397,8 +460,17 @@ void model_part_indices(const orc_model& m, const int* part_map, int num_parts, 
 // scan using nanoflann's metric arithmetic ((d0*d0)+d1*d1)+d2*d2 and strict '<' (nanoflann.hpp:432-440,
 // :175-199).  Equal to the KD-tree result whenever no two candidates are at exactly equal distance.
 void find_nn(const orc_model& m, const std::vector<std::vector<int>>& partIdx, const double* modelCloud,
-             const unsigned char* vis, const double* data, const int* labels, int N, int* out) {
+             const unsigned char* vis, const double* data, const int* labels, int N, int* out, int nthreads = 1) {
     const int numParts = (int)partIdx.size();
+    bool labels_ok = true;
+    for (int i = 0; i < N && labels_ok; ++i) labels_ok = labels[i] >= 0 && labels[i] < numParts;
+    if (g_nn_override && labels_ok) {   // the reference's own KD-tree search (bit-identical results: tests/test_oracle_cpu.py)
+        std::vector<int> modelPart(m.V, 0);
+        for (int q = 0; q < numParts; ++q) for (int k : partIdx[q]) modelPart[k] = q;
+        std::vector<int> lab(labels, labels + N);
+        g_nn_override(m.V, numParts, modelPart.data(), modelCloud, vis, data, lab.data(), N, out, nullptr, g_parallel_nn ? nthreads : 1);
+        return;
+    }
     std::vector<std::vector<int>> newIdx(numParts);
     std::vector<std::vector<double>> partCloud(numParts);
     for (int q = 0; q < numParts; ++q) {
@@ -410,7 +482,10 @@ void find_nn(const orc_model& m, const std::vector<std::vector<int>>& partIdx, c
             partCloud[q].push_back(modelCloud[3 * k + 2]);
         }
     }
-    for (int i = 0; i < N; ++i) {
+    const int nt = (g_parallel_nn && nthreads > 1) ? std::min(nthreads, std::max(1, N / 256)) : 1;
+    parallel_for(nt, [&](int tid) {
+    const int lo = (int)((long long)N * tid / nt), hi = (int)((long long)N * (tid + 1) / nt);
+    for (int i = lo; i < hi; ++i) {
         const int q = labels[i];
         if (q < 0 || q >= numParts || newIdx[q].empty()) { out[i] = -1; continue; }
         const double* a = data + 3 * i;
@@ -427,6 +502,7 @@ void find_nn(const orc_model& m, const std::vector<std::vector<int>>& partIdx, c
         }
         out[i] = newIdx[q][bi];
     }
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -649,7 +725,11 @@ void evaluate(const orc_model& m, Common& cm, const double* p, const double* q, 
               const double* data, double betaPose, double betaShape, bool wantJac, int aggregate, int nthreads,
               EvalOut& out) {
     const int J = m.J, K = m.K, P = m.P;
+    static const bool timing = getenv("ORC_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_a = now();
     cm.Prepare(p, q, w);
+    const double t_b = now();
     out.g.assign(P, 0.0);
     out.H.assign((size_t)P * P, 0.0);
     const size_t M = corr.matched.size();
@@ -657,6 +737,7 @@ void evaluate(const orc_model& m, Common& cm, const double* p, const double* q, 
     std::vector<double> costs(nthreads, 0.0);
     std::vector<std::vector<double>> gs(nthreads), Hs(nthreads);
     auto worker = [&](int tid) {
+        const double t_w0 = now();
         std::vector<double>& g = gs[tid];
         std::vector<double>& H = Hs[tid];
         g.assign(P, 0.0);
@@ -726,14 +807,10 @@ void evaluate(const orc_model& m, Common& cm, const double* p, const double* q, 
             }
         }
         costs[tid] = cost;
+        if (timing && nthreads > 1) fprintf(stderr, "[orc]     worker %d: points %zu..%zu started +%.3f done +%.3f ms\n", tid, lo, hi, t_w0 - t_b, now() - t_b);
     };
-    if (nthreads == 1) {
-        worker(0);
-    } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker, t);
-        for (auto& th : pool) th.join();
-    }
+    parallel_for(nthreads, worker);
+    if (timing) fprintf(stderr, "[orc]   evaluate: Prepare %.3f ms, %d workers %.3f ms\n", t_b - t_a, nthreads, now() - t_b);
     double cost = 0.0;
     for (int t = 0; t < nthreads; ++t) {
         cost += costs[t];
@@ -972,14 +1049,21 @@ int orc_optimize(const orc_model* m, int num_parts, const int* part_map, const d
     double lambda = o->lm_lambda0;
     avt_stats s{};
     for (int icp = 0; icp < o->icp_iters; ++icp) {
+        static const bool timing = getenv("ORC_TIMING") != nullptr;   // phase timing of the baseline (stderr)
+        auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t_a = now();
         visibility(*m, cloud.data(), o->enable_occlusion, vis.data());
-        find_nn(*m, partIdx, cloud.data(), vis.data(), data, labels, N, idx.data());
+        find_nn(*m, partIdx, cloud.data(), vis.data(), data, labels, N, idx.data(), nthreads);
+        const double t_b = now();
         Corr corr;
         build_corr(*m, idx.data(), N, corr);
+        if (timing) fprintf(stderr, "[orc] visibility+nn %.3f ms, build_corr %.3f ms\n", t_b - t_a, now() - t_b);
         s.num_correspondences = (int)corr.total;
         s.matched_model_points = (int)corr.matched.size();
         EvalOut cur, tr;
+        const double t_c = now();
         evaluate(*m, cm, p, q, w, corr, data, o->beta_pose, o->beta_shape, true, aggregate, nthreads, cur);
+        if (timing) fprintf(stderr, "[orc] first evaluate %.3f ms\n", now() - t_c);
         s.initial_cost = cur.cost;
         if (trace_cost) trace_cost[(size_t)icp * (o->max_iters_per_icp + 1)] = cur.cost;
         for (int it = 0; it < o->max_iters_per_icp; ++it) {
@@ -1014,6 +1098,33 @@ int orc_optimize(const orc_model* m, int num_parts, const int* part_map, const d
     if (st) *st = s;
     if (corr_out) std::copy(idx.begin(), idx.end(), corr_out);
     if (cloud_out) std::copy(cloud.begin(), cloud.end(), cloud_out);
+    return 0;
+}
+
+// ---- knobs of the timed baseline (bench.py): threading style and the nearest-neighbour implementation
+void orc_set_threading(int persistent_pool, int parallel_nn) { g_persistent_pool = persistent_pool; g_parallel_nn = parallel_nn; }
+void orc_set_nn_override(void* fn) { g_nn_override = (nn_override_fn)fn; }
+int orc_hardware_concurrency() { return (int)std::thread::hardware_concurrency(); }
+
+// Independent frames on independent cores (one single-threaded optimize() per worker, frames dealt round-robin): the
+// CPU counterpart of the GPU's frame batches; states are updated in place (frame-major p, q, w).
+int orc_optimize_batch(const orc_model* m, int num_parts, const int* part_map, int nframes, const double* data, const int* labels,
+                       const int* frame_offsets, const avt_options* o, int aggregate, int nworkers, double* p, double* q, double* w,
+                       avt_stats* st) {
+    nworkers = std::max(1, std::min(nworkers, nframes));
+    const int saved = g_persistent_pool;
+    std::vector<std::thread> pool;
+    std::atomic<int> next(0);
+    auto work = [&]() {
+        for (int f = next.fetch_add(1); f < nframes; f = next.fetch_add(1)) {
+            const int N = frame_offsets[f + 1] - frame_offsets[f];
+            orc_optimize(m, num_parts, part_map, data + 3 * (size_t)frame_offsets[f], labels + frame_offsets[f], N, o, aggregate, 1,
+                         p + 3 * (size_t)f, q + (size_t)4 * m->J * f, w + (size_t)m->K * f, st ? st + f : nullptr, nullptr, nullptr, nullptr, nullptr);
+        }
+    };
+    for (int t = 0; t < nworkers; ++t) pool.emplace_back(work);
+    for (auto& th : pool) th.join();
+    g_persistent_pool = saved;
     return 0;
 }
 

@@ -10,6 +10,7 @@
 #include <nanoflann.hpp>
 
 #include <cstddef>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -23,9 +24,9 @@ struct PartCloud {
 typedef nanoflann::KDTreeSingleIndexAdaptor<nanoflann::L2_Simple_Adaptor<double, PartCloud>, PartCloud, 3, int> Tree;
 }  // namespace
 
-extern "C" int ref_find_nn_inverted(int V, int num_parts, const int* model_part /*V: part of each model point*/,
-                                    const double* model_cloud, const unsigned char* visible, const double* data,
-                                    const int* labels, int N, int* model_idx_out, double* dist_out) {
+extern "C" int ref_find_nn_inverted_mt(int V, int num_parts, const int* model_part /*V: part of each model point*/,
+                                       const double* model_cloud, const unsigned char* visible, const double* data,
+                                       const int* labels, int N, int* model_idx_out, double* dist_out, int nthreads) {
     std::vector<PartCloud> clouds(num_parts);
     std::vector<std::vector<int>> newIdx(num_parts);
     std::vector<Tree*> trees(num_parts, nullptr);
@@ -42,7 +43,8 @@ extern "C" int ref_find_nn_inverted(int V, int num_parts, const int* model_part 
         trees[q] = new Tree(3, clouds[q], nanoflann::KDTreeSingleIndexAdaptorParams(10));
         trees[q]->buildIndex();
     }
-    for (int i = 0; i < N; ++i) {
+    auto query = [&](int lo, int hi) {
+    for (int i = lo; i < hi; ++i) {
         const int q = labels[i];
         if (trees[q] == nullptr) {
             model_idx_out[i] = -1;
@@ -57,6 +59,20 @@ extern "C" int ref_find_nn_inverted(int V, int num_parts, const int* model_part 
         model_idx_out[i] = newIdx[q][index];
         if (dist_out) dist_out[i] = dist;
     }
+    };
+    // the reference queries serially (AvatarOptimizer.cpp:896-904); nthreads > 1 is the bench's "fastest CPU" mode: the
+    // built trees are read-only, every query writes its own output slot
+    if (nthreads <= 1) query(0, N);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t) pool.emplace_back(query, (int)((long long)N * t / nthreads), (int)((long long)N * (t + 1) / nthreads));
+        for (auto& th : pool) th.join();
+    }
     for (auto* t : trees) delete t;
     return 0;
+}
+
+extern "C" int ref_find_nn_inverted(int V, int num_parts, const int* model_part, const double* model_cloud, const unsigned char* visible,
+                                    const double* data, const int* labels, int N, int* model_idx_out, double* dist_out) {
+    return ref_find_nn_inverted_mt(V, num_parts, model_part, model_cloud, visible, data, labels, N, model_idx_out, dist_out, 1);
 }

@@ -174,6 +174,44 @@ class OracleModel:
         return dict(p=p, q=q.reshape(self.J, 4), w=w, stats=st, trace_cost=tc, trace_acc=ta, corr=corr,
                     cloud=cloud.reshape(self.V, 3))
 
+    def optimize_batch(self, part_map, num_parts, datas, labels, opt: Options, p, q, w, aggregate=1, nworkers=1):
+        """Independent frames on independent cores (one single-threaded optimize() per worker)."""
+        F = len(datas)
+        pm = np.ascontiguousarray(part_map, np.int32)
+        offs = np.zeros(F + 1, np.int32)
+        for f in range(F):
+            offs[f + 1] = offs[f] + len(labels[f])
+        data = np.ascontiguousarray(np.concatenate([np.asarray(d, np.float64).reshape(-1, 3) for d in datas], 0))
+        lab = np.ascontiguousarray(np.concatenate([np.asarray(l, np.int32) for l in labels]))
+        p = np.array(p, np.float64).reshape(F, 3).copy(); q = np.array(q, np.float64).reshape(F, -1).copy()
+        w = np.array(w, np.float64).reshape(F, -1).copy()
+        st = (Stats * F)()
+        lib().orc_optimize_batch(self.h, C.c_int(num_parts), iptr(pm), C.c_int(F), dptr(data), iptr(lab), iptr(offs), C.byref(opt),
+                                 C.c_int(aggregate), C.c_int(nworkers), dptr(p), dptr(q), dptr(w), st)
+        return p, q.reshape(F, self.J, 4), w, list(st)
+
+
+def set_threading(persistent_pool=False, parallel_nn=False):
+    """Threading style of the timed CPU baseline: spawn/join per evaluation like the reference (AvatarOptimizer.cpp:
+    327-343) or a persistent pool; nearest-neighbour queries serial like the reference (:896-904) or split over threads."""
+    lib().orc_set_threading(C.c_int(int(persistent_pool)), C.c_int(int(parallel_nn)))
+
+
+def set_nn_implementation(kind="bruteforce"):
+    """"bruteforce": the oracle's ordered exhaustive scan; "nanoflann": the reference's own KD-tree search from
+    oracle/_ref (prebuilt in the build container; bit-identical results).  Returns the kind actually in effect."""
+    if kind == "nanoflann" and have_reference_nn():
+        ref = C.CDLL(_REF_SO)
+        lib().orc_set_nn_override(C.cast(ref.ref_find_nn_inverted_mt, C.c_void_p))
+        set_nn_implementation._keep = ref
+        return "nanoflann"
+    lib().orc_set_nn_override(C.c_void_p(0))
+    return "bruteforce"
+
+
+def hardware_concurrency():
+    return int(lib().orc_hardware_concurrency())
+
 
 def rot_to_quat(R):
     """(J,3,3) -> (J,4) xyzw, as optimize() converts ava.r (AvatarOptimizer.cpp:1250-1254)."""

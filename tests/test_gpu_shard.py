@@ -1,0 +1,119 @@
+"""The batch split of include/avt_shard.h on hardware: a ONE-rank RCCL communicator on this GPU (the only size a 1-GPU
+box can build: RCCL refuses two ranks on one device) pushes the model broadcast, the cloud scatter (grouped
+ncclSend/ncclRecv, the root's own block looped through RCCL by AVT_SHARD_SELF_SENDRECV) and the result all-gather
+through the real library on device buffers, and everything must come out bit-identical to the plain single-context path."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from avatar_amd import synth
+from avatar_amd.capi import Options
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def one_rank_shard():
+    from avatar_amd import capi, shard
+    lib = capi.load_library()
+    buf = ctypes.create_string_buffer(shard.ID_BYTES)
+    assert lib.avt_shard_unique_id(buf) == 0, lib.avt_last_error()
+    s = shard.Shard(0, 0, 1, buf.raw)
+    yield s
+    s.close()
+
+
+def test_backend_is_rccl(one_rank_shard):
+    assert one_rank_shard.backend.startswith("rccl ") and "librccl" in one_rank_shard.backend
+
+
+def test_broadcast_model_builds_the_same_model(smpl, gmodel, one_rank_shard):
+    from avatar_amd import api
+    h = one_rank_shard.broadcast_model(gmodel.arrays, root=0)
+    m2 = api.AvatarModel(smpl, handle=h)
+    assert np.array_equal(m2.mainJoint, gmodel.mainJoint) and np.array_equal(m2.jointShapeReg, gmodel.jointShapeReg)
+    w, p, R = synth.sample_ground_truth(smpl, 3)
+    c1 = gmodel.default_ctx().lbs_update(w[None], p[None], R[None])[0]
+    c2 = m2.default_ctx().lbs_update(w[None], p[None], R[None])[0]
+    assert np.array_equal(c1, c2)
+
+
+def test_scatter_optimize_gather_equals_plain_path(smpl, gmodel, one_rank_shard):
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    B = 3
+    frames = [synth.make_frame(smpl, 40 + f) for f in range(B)]
+    datas = [fr["data"][::5 + f] for f, fr in enumerate(frames)]            # ragged point counts
+    labels = [fr["labels"][::5 + f] for f, fr in enumerate(frames)]
+    p0 = np.array([fr["start"][1] for fr in frames]); w0 = np.array([fr["start"][0] for fr in frames])
+    q0 = np.array([api.rot_to_quat(fr["start"][2]) for fr in frames])
+    opt = Options.demo(max_iters_per_icp=4)
+    # plain path
+    ctx_a = api.Context(gmodel, 24, pm, 16384, B, device=0)
+    pa, qa, wa, sta = ctx_a.optimize_batch(datas, labels, opt, p0, q0, w0)
+    # split path (one rank owns every frame), the root's block going through ncclSend/ncclRecv
+    os.environ["AVT_SHARD_SELF_SENDRECV"] = "1"
+    try:
+        ctx_b = api.Context(gmodel, 24, pm, 16384, B, device=0)
+        one_rank_shard.scatter_frames(ctx_b, B, datas, labels, p0, q0, w0, root=0)
+    finally:
+        del os.environ["AVT_SHARD_SELF_SENDRECV"]
+    ctx_b._N = np.array([len(l) for l in labels], np.int32)
+    for f in range(B):
+        d, l = ctx_b.frame_download(f)
+        assert np.array_equal(d, datas[f]) and np.array_equal(l, labels[f])
+    ctx_b.optimize_resident(opt)
+    pg, qg, wg, stg = one_rank_shard.gather_results(ctx_b, B)
+    pl, ql, wl, stl = ctx_b.state_download()
+    assert np.array_equal(pg, pl) and np.array_equal(qg, ql) and np.array_equal(wg, wl)
+    assert np.array_equal(pg, pa) and np.array_equal(qg, qa) and np.array_equal(wg, wa)       # bit-reproducible pipeline
+    for f in range(B):
+        assert stg[f].final_cost == sta[f].final_cost and stg[f].num_correspondences == sta[f].num_correspondences
+        assert stg[f].gn_iterations == 4 and stg[f].matched_model_points == sta[f].matched_model_points
+    one_rank_shard.barrier(ctx_b)
+
+
+def test_frames_swap_under_resident_state(smpl, gmodel):
+    """avt_frames_upload followed by avt_optimize_resident must run with the NEW frames' point counts."""
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    fa, fb = synth.make_frame(smpl, 50), synth.make_frame(smpl, 51)
+    da, la = fa["data"][::6], fa["labels"][::6]
+    db, lb = fb["data"][::9], fb["labels"][::9]           # a different, smaller point count
+    opt = Options.demo(max_iters_per_icp=3)
+    w0, p0, R0 = fa["start"]
+    q0 = api.rot_to_quat(R0)
+    ctx = api.Context(gmodel, 24, pm, 16384, 1, device=0)
+    ctx.frames_upload([da], [la]); ctx.state_upload(p0[None], q0[None], w0[None])
+    ctx.optimize_resident(opt)
+    p1, q1, w1, _ = ctx.state_download()
+    ctx.frames_upload([db], [lb])                          # warm start: keep the state, swap the frame
+    ctx.optimize_resident(opt)
+    p2, q2, w2, st2 = ctx.state_download()
+    ref = api.Context(gmodel, 24, pm, 16384, 1, device=0)
+    pr, qr, wr, str_ = ref.optimize_batch([db], [lb], opt, p1, q1, w1)
+    assert np.array_equal(p2, pr) and np.array_equal(q2, qr) and np.array_equal(w2, wr)
+    assert st2[0].num_correspondences == str_[0].num_correspondences == int((ctx.correspondences(0, len(lb)) >= 0).sum())
+
+
+def test_stand_alone_calls_invalidate_resident_state(smpl, gmodel, frame0):
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    d, l = frame0["data"][::8], frame0["labels"][::8]
+    w0, p0, R0 = frame0["start"]
+    ctx = api.Context(gmodel, 24, pm, 16384, 1, device=0)
+    ctx.frames_upload([d], [l]); ctx.state_upload(p0[None], api.rot_to_quat(R0)[None], w0[None])
+    ctx.lbs_update(w0[None], p0[None], R0[None])           # uses the frame slots as scratch
+    with pytest.raises(api.AvtError, match="no frames resident"):
+        ctx.optimize_resident(Options.demo())
+
+
+def test_failed_context_creation_releases_everything(gmodel):
+    """avt_ctx_create error paths clean up: many failing creations must not exhaust streams or memory."""
+    from avatar_amd import api
+    bad_map = np.full(24, 99, np.int32)                    # part ids outside [0, num_parts)
+    for _ in range(200):
+        with pytest.raises(api.AvtError):
+            api.Context(gmodel, 24, bad_map, 1 << 20, 64, device=0)

@@ -234,7 +234,7 @@ def test_lm_not_worse_than_scipy_bfgs(smpl, omodel, frame0):
 
 # ------------------------------------------------------------------------------------------------ C ABI
 def test_abi_library_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, "include", "avt.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "avt.h")).read() + open(os.path.join(ROOT, "include", "avt_shard.h")).read()
     declared = set(re.findall(r"\b(avt_[a-z_]+)\s*\(", hdr))
     assert declared == set(capi.EXPORTED_SYMBOLS), declared ^ set(capi.EXPORTED_SYMBOLS)
     assert os.path.exists(capi.LIB_PATH), "run __graft_entry__.build() first"

@@ -1,0 +1,67 @@
+"""Host side of the batch split (include/avt_shard.h): the frame partition, the packed model the broadcast ships.
+No GPU, no RCCL (the world-size-2 gloo run of the N>1 path is tests/test_oracle_cpu.py::test_frame_sharding_world_size_2_gloo)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from avatar_amd import capi, shard
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_partition_is_a_bijection():
+    lib = capi.load_library()
+    for B in (1, 5, 64, 512, 513):
+        for W in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(W):
+                n = lib.avt_shard_local_count(B, r, W)
+                assert n == len(shard.frames_of_rank(B, r, W))
+                for i in range(n):
+                    f = lib.avt_shard_global_frame(i, r, W)
+                    assert f == shard.frames_of_rank(B, r, W)[i]
+                    assert lib.avt_shard_owner(f, W) == r and lib.avt_shard_local_index(f, W) == i
+                    seen.append(f)
+            assert sorted(seen) == list(range(B))
+    assert lib.avt_shard_local_count(3, 5, 8) == 0            # more ranks than frames: the surplus ranks hold nothing
+
+
+def test_packed_model_round_trip(smpl, omodel):
+    """avt_model_pack -> bytes -> avt_model_unpack yields the same derived model data as avt_model_create."""
+    lib = capi.load_library()
+    arr = capi.ModelArrays(smpl)
+    block = shard.pack_model(arr)
+    assert block[:8] == b"AVTMODEL" and len(block) % 8 == 0
+    h = shard.unpack_model(block)
+    V, J, K, F, P = (ctypes.c_int() for _ in range(5))
+    assert lib.avt_model_dims(h, ctypes.byref(V), ctypes.byref(J), ctypes.byref(K), ctypes.byref(F), ctypes.byref(P)) == 0
+    assert (V.value, J.value, K.value, F.value, P.value) == (arr.V, arr.J, arr.K, arr.F, arr.P)
+    mj = np.empty(arr.V, np.int32)
+    assert lib.avt_model_main_joint(h, capi.iptr(mj)) == 0
+    assert np.array_equal(mj, omodel.main_joint())
+    ijp = np.empty(3 * arr.J); jsr = np.empty(3 * arr.J * arr.K)
+    assert lib.avt_model_joint_regression(h, capi.dptr(ijp), capi.dptr(jsr)) == 0
+    o_ijp, o_jsr = omodel.joint_regression()
+    assert np.array_equal(ijp.reshape(-1, 3), o_ijp) and np.array_equal(jsr.reshape(arr.K, -1).T, o_jsr)
+    lib.avt_model_destroy(h)
+    # the block is position independent: a copy at another address unpacks too
+    h2 = shard.unpack_model(bytes(bytearray(block)))
+    lib.avt_model_destroy(h2)
+
+
+def test_packed_model_rejects_damage(smpl):
+    from avatar_amd.api import AvtError
+    block = shard.pack_model(capi.ModelArrays(smpl))
+    for bad in (block[:100], block[:-8], b"XXXXXXXX" + block[8:], block[:8] + b"\x07" + block[9:]):
+        with pytest.raises(AvtError):
+            shard.unpack_model(bad)
+    # a corrupted sparse column pointer must be caught before avt_model_create walks it
+    hdr = np.frombuffer(block[:56], np.int32)
+    V = int(hdr[3])
+    off_colptr = 56 + 8 * 3 * V + 8 * 3 * V * int(hdr[5]) + ((4 * int(hdr[4]) + 7) & ~7) + ((4 * 3 * int(hdr[6]) + 7) & ~7)
+    b = bytearray(block)
+    b[off_colptr + 4 * V:off_colptr + 4 * V + 4] = np.int32(7).tobytes()          # weights_colptr[V] != nnz
+    with pytest.raises(AvtError):
+        shard.unpack_model(bytes(b))
