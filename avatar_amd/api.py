@@ -9,6 +9,7 @@ no CPU path here.
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 
 import numpy as np
@@ -30,47 +31,64 @@ def _check(rc):
 # Matrix3 -> Quaternion -> AngleAxis -> Quaternion on the way in, Quaternion::toRotationMatrix on the way out
 # (Eigen 3.3 closed forms).
 def rot_to_quat(R):
-    R = np.asarray(R, np.float64).reshape(-1, 3, 3)
-    out = np.empty((R.shape[0], 4))
-    for n, m in enumerate(R):
-        q = np.empty(4)
-        t = m[0, 0] + m[1, 1] + m[2, 2]
-        if t > 0:
-            t = np.sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t
-            q[0] = (m[2, 1] - m[1, 2]) * t; q[1] = (m[0, 2] - m[2, 0]) * t; q[2] = (m[1, 0] - m[0, 1]) * t
-        else:
-            i = 0
-            if m[1, 1] > m[0, 0]: i = 1
-            if m[2, 2] > m[i, i]: i = 2
-            j = (i + 1) % 3; k = (j + 1) % 3
-            t = np.sqrt(m[i, i] - m[j, j] - m[k, k] + 1.0); q[i] = 0.5 * t; t = 0.5 / t
-            q[3] = (m[k, j] - m[j, k]) * t; q[j] = (m[j, i] + m[i, j]) * t; q[k] = (m[k, i] + m[i, k]) * t
-        nrm = np.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2])
-        if nrm < np.finfo(float).eps:
-            mx = np.abs(q[:3]).max()
-            nrm = mx * np.sqrt(((q[:3] / mx) ** 2).sum()) if mx > 0 else 0.0
-        if nrm != 0.0:
-            ang = 2.0 * np.arctan2(nrm, abs(q[3]))
-            if q[3] < 0: nrm = -nrm
-            axis = q[:3] / nrm
-        else:
-            ang, axis = 0.0, np.array([1.0, 0.0, 0.0])
+    """(N,3,3) rotations -> (N,4) quaternions (x,y,z,w).  Vectorised over N; every element goes through exactly the scalar
+    operations of the Eigen closed forms (same order, same roundings as oracle.rot_to_quat)."""
+    m = np.asarray(R, np.float64).reshape(-1, 3, 3)
+    N = m.shape[0]
+    q = np.empty((N, 4))
+    tr = m[:, 0, 0] + m[:, 1, 1] + m[:, 2, 2]
+    pos = tr > 0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        # trace > 0 branch
+        t = np.sqrt(np.where(pos, tr, 0.0) + 1.0)
+        ti = 0.5 / t
+        qa = np.stack([(m[:, 2, 1] - m[:, 1, 2]) * ti, (m[:, 0, 2] - m[:, 2, 0]) * ti, (m[:, 1, 0] - m[:, 0, 1]) * ti, 0.5 * t], 1)
+        # otherwise: largest diagonal entry i, then j, k cyclic
+        i = np.where(m[:, 1, 1] > m[:, 0, 0], 1, 0)
+        ar = np.arange(N)
+        i = np.where(m[:, 2, 2] > m[ar, i, i], 2, i)
+        j = (i + 1) % 3
+        k = (j + 1) % 3
+        t2 = np.sqrt(np.where(pos, 1.0, m[ar, i, i] - m[ar, j, j] - m[ar, k, k] + 1.0))
+        t2i = 0.5 / t2
+        qb = np.empty((N, 4))
+        qb[ar, i] = 0.5 * t2
+        qb[:, 3] = (m[ar, k, j] - m[ar, j, k]) * t2i
+        qb[ar, j] = (m[ar, j, i] + m[ar, i, j]) * t2i
+        qb[ar, k] = (m[ar, k, i] + m[ar, i, k]) * t2i
+        q = np.where(pos[:, None], qa, qb)
+        # Quaternion -> AngleAxis -> Quaternion
+        nrm = np.sqrt(q[:, 0] * q[:, 0] + q[:, 1] * q[:, 1] + q[:, 2] * q[:, 2])
+        tiny = nrm < np.finfo(float).eps
+        if tiny.any():
+            mx = np.abs(q[:, :3]).max(1)
+            safe = np.where(mx > 0, mx, 1.0)
+            alt = np.where(mx > 0, mx * np.sqrt(((q[:, :3] / safe[:, None]) ** 2).sum(1)), 0.0)
+            nrm = np.where(tiny, alt, nrm)
+        nz = nrm != 0.0
+        # transcendental functions through libm, one element at a time: numpy's vector loops may differ from it by an ulp
+        ang = np.array([2.0 * math.atan2(a, b) if z else 0.0 for a, b, z in zip(nrm, np.abs(q[:, 3]), nz)])
+        sgn = np.where(q[:, 3] < 0, -nrm, nrm)
+        axis = np.where(nz[:, None], q[:, :3] / np.where(nz, sgn, 1.0)[:, None], np.array([1.0, 0.0, 0.0])[None, :])
         ha = 0.5 * ang
-        out[n, 3] = np.cos(ha); out[n, :3] = np.sin(ha) * axis
+        out = np.empty((N, 4))
+        out[:, 3] = [math.cos(h) for h in ha]
+        out[:, :3] = np.array([math.sin(h) for h in ha])[:, None] * axis
     return out
 
 
 def quat_to_rot(q):
+    """(N,4) quaternions (x,y,z,w) -> (N,3,3) (Eigen Quaternion::toRotationMatrix), vectorised over N."""
     q = np.asarray(q, np.float64).reshape(-1, 4)
+    x, y, z, w = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    tx, ty, tz = 2 * x, 2 * y, 2 * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
     out = np.empty((q.shape[0], 3, 3))
-    for n, (x, y, z, w) in enumerate(q):
-        tx, ty, tz = 2 * x, 2 * y, 2 * z
-        twx, twy, twz = tx * w, ty * w, tz * w
-        txx, txy, txz = tx * x, ty * x, tz * x
-        tyy, tyz, tzz = ty * y, tz * y, tz * z
-        out[n] = [[1 - (tyy + tzz), txy - twz, txz + twy],
-                  [txy + twz, 1 - (txx + tzz), tyz - twx],
-                  [txz - twy, tyz + twx, 1 - (txx + tyy)]]
+    out[:, 0, 0] = 1 - (tyy + tzz); out[:, 0, 1] = txy - twz; out[:, 0, 2] = txz + twy
+    out[:, 1, 0] = txy + twz; out[:, 1, 1] = 1 - (txx + tzz); out[:, 1, 2] = tyz - twx
+    out[:, 2, 0] = txz - twy; out[:, 2, 1] = tyz + twx; out[:, 2, 2] = 1 - (txx + tyy)
     return out
 
 

@@ -47,39 +47,44 @@ namespace {
 //   implementation tuned for speed would do - the "fastest CPU" number the GPU speed-up is quoted against.
 // Results do not depend on the style: work is split by index range and partial sums are added in thread order.
 struct Pool {
+    // workers spin on a generation counter (a tuned CPU implementation keeps its workers hot between the evaluations of one
+    // optimize(); condition-variable wake-ups cost more than an evaluation's share of work on a many-core host)
     std::vector<std::thread> th;
-    std::mutex mu;
-    std::condition_variable cv_go, cv_done;
+    std::atomic<int> gen{0}, pending{0}, active{0};
+    std::atomic<bool> stop{false};
     std::function<void(int)> job;
-    int active = 0, gen = 0, pending = 0;
-    bool stop = false;
     explicit Pool(int n) {
         for (int i = 0; i < n; ++i) th.emplace_back([this, i] { loop(i); });
     }
     ~Pool() {
-        { std::lock_guard<std::mutex> l(mu); stop = true; ++gen; }
-        cv_go.notify_all();
+        stop.store(true);
+        gen.fetch_add(1);
         for (auto& t : th) t.join();
     }
     void loop(int id) {
         int seen = 0;
         for (;;) {
-            std::unique_lock<std::mutex> l(mu);
-            cv_go.wait(l, [&] { return gen != seen; });
-            seen = gen;
-            if (stop) return;
-            if (id >= active) continue;
-            l.unlock();
-            job(id);
-            l.lock();
-            if (--pending == 0) cv_done.notify_one();
+            int spins = 0;
+            while (gen.load(std::memory_order_acquire) == seen) {
+                if (++spins > 20000) { std::this_thread::sleep_for(std::chrono::microseconds(50)); }
+                else __builtin_ia32_pause();
+            }
+            seen = gen.load(std::memory_order_acquire);
+            if (stop.load()) return;
+            if (id + 1 < active.load(std::memory_order_acquire)) {
+                job(id + 1);
+                pending.fetch_sub(1, std::memory_order_acq_rel);
+            }
         }
     }
-    void run(int n, const std::function<void(int)>& f) {   // f(0..n-1), n <= th.size()
-        std::unique_lock<std::mutex> l(mu);
-        job = f; active = n; pending = n; ++gen;
-        cv_go.notify_all();
-        cv_done.wait(l, [&] { return pending == 0; });
+    void run(int n, const std::function<void(int)>& f) {   // f(0..n-1), n <= th.size(); the caller runs share 0 itself
+        job = f;
+        active.store(n, std::memory_order_release);
+        pending.store(n - 1, std::memory_order_release);
+        gen.fetch_add(1, std::memory_order_acq_rel);
+        f(0);
+        while (pending.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+        active.store(0, std::memory_order_release);
     }
 };
 Pool* g_pool = nullptr;
@@ -91,7 +96,7 @@ nn_override_fn g_nn_override = nullptr;   // e.g. oracle/_ref's nanoflann KD-tre
 void parallel_for(int nthreads, const std::function<void(int)>& f) {
     if (nthreads <= 1) { f(0); return; }
     if (g_persistent_pool) {
-        if (!g_pool || (int)g_pool->th.size() < nthreads) { delete g_pool; g_pool = new Pool(std::max(nthreads, (int)std::thread::hardware_concurrency())); }
+        if (!g_pool || (int)g_pool->th.size() != nthreads - 1) { delete g_pool; g_pool = new Pool(nthreads - 1); }   // worker i runs share i + 1
         g_pool->run(nthreads, f);
         return;
     }
@@ -1102,7 +1107,10 @@ int orc_optimize(const orc_model* m, int num_parts, const int* part_map, const d
 }
 
 // ---- knobs of the timed baseline (bench.py): threading style and the nearest-neighbour implementation
-void orc_set_threading(int persistent_pool, int parallel_nn) { g_persistent_pool = persistent_pool; g_parallel_nn = parallel_nn; }
+void orc_set_threading(int persistent_pool, int parallel_nn) {
+    g_persistent_pool = persistent_pool; g_parallel_nn = parallel_nn;
+    if (!persistent_pool) { delete g_pool; g_pool = nullptr; }      // no idle spinners outside the tuned mode
+}
 void orc_set_nn_override(void* fn) { g_nn_override = (nn_override_fn)fn; }
 int orc_hardware_concurrency() { return (int)std::thread::hardware_concurrency(); }
 

@@ -174,6 +174,27 @@ class OracleModel:
         return dict(p=p, q=q.reshape(self.J, 4), w=w, stats=st, trace_cost=tc, trace_acc=ta, corr=corr,
                     cloud=cloud.reshape(self.V, 3))
 
+    def batch_runner(self, part_map, num_parts, data, labels, copies, opt: Options, p, q, w, aggregate=1, nworkers=1):
+        """`copies` copies of one frame marshalled ONCE; returns a zero-argument callable that runs one optimize() per copy,
+        one per core (the timed CPU baseline of the frame-batch configurations must not time numpy concatenations)."""
+        pm = np.ascontiguousarray(part_map, np.int32)
+        N = len(labels)
+        offs = (np.arange(copies + 1, dtype=np.int64) * N).astype(np.int32)
+        dat = np.ascontiguousarray(np.tile(np.asarray(data, np.float64).reshape(-1, 3), (copies, 1)))
+        lab = np.ascontiguousarray(np.tile(np.asarray(labels, np.int32), copies))
+        P0 = np.tile(np.asarray(p, np.float64).reshape(1, 3), (copies, 1)); Q0 = np.tile(np.asarray(q, np.float64).reshape(1, -1), (copies, 1))
+        W0 = np.tile(np.asarray(w, np.float64).reshape(1, -1), (copies, 1))
+        st = (Stats * copies)()
+        keep = (pm, offs, dat, lab, P0, Q0, W0, st)
+
+        def run():
+            Pc, Qc, Wc = P0.copy(), Q0.copy(), W0.copy()
+            lib().orc_optimize_batch(self.h, C.c_int(num_parts), iptr(pm), C.c_int(copies), dptr(dat), iptr(lab), iptr(offs), C.byref(opt),
+                                     C.c_int(aggregate), C.c_int(nworkers), dptr(Pc), dptr(Qc), dptr(Wc), st)
+            return Pc, Qc, Wc
+        run._keep = keep
+        return run
+
     def optimize_batch(self, part_map, num_parts, datas, labels, opt: Options, p, q, w, aggregate=1, nworkers=1):
         """Independent frames on independent cores (one single-threaded optimize() per worker)."""
         F = len(datas)

@@ -1,29 +1,39 @@
 #!/bin/bash
 # Reproduces the rocprofv3 artefacts under profiles/ on an MI355X box (run through gpurun from the repo root):
-#   kernel traces (--kernel-trace --stats) and, in separate passes, the FETCH_SIZE / WRITE_SIZE counters for the two
-#   bench configurations, plus the SQ counters of the evaluation kernel.  Output: gpurun_out/prof_<tag>/ and *.txt / *.json.
+#   kernel traces (--kernel-trace --stats) and, in separate passes, the FETCH_SIZE / WRITE_SIZE counters for the bench
+#   configurations, plus SQ counters of the evaluation, solve and nearest-neighbour kernels.  A frame batch runs as frame
+#   groups, so every summary is PER LAUNCH SHAPE (tools/rocpd_stats.py, pmc_summary.py, pmc_counters.py group by grid);
+#   the instrumented pass of bench.py uses the same shapes as the graph replay.
+# Output: gpurun_out/prof_<tag>/ and gpurun_out/<round>_*.txt / *.json (copy what is to be judged into profiles/).
 set -u
+RND=${RND:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
-for F in 1 64; do
-  tag=$([ $F = 1 ] && echo single_frame || echo 64_frames)
+COMMON="--no-cpu-baseline --no-throughput-config --no-label-stage --no-render-stage --no-shard --saturation-frames 0 --regions 3"
+for F in ${FRAMES:-1 64}; do
+  nfg=$(python -c "print($F if $F < 48 else ($F + 1) // 2)")     # frames per launch: two frame groups from 48 frames on
   steps=$([ $F = 1 ] && echo 25 || echo 5)
-  cmd="python $R/bench.py --frames $F --steps $steps --warmup 2 --no-cpu-baseline --no-throughput-config --no-label-stage --no-render-stage"
-  rocprofv3 --kernel-trace --stats -d $O/prof_kt_$tag -o p -- $cmd > $O/prof_kt_$tag.log 2>&1
-  python $R/tools/rocpd_stats.py $(find $O/prof_kt_$tag -name "*.db" | head -1) > $O/r01_rocprof_kernel_trace_$tag.txt
+  cmd="python $R/bench.py --frames $F --steps $steps --warmup 2 $COMMON"
+  rocprofv3 --kernel-trace --stats -d $O/prof_kt_$F -o p -- $cmd > $O/prof_kt_$F.log 2>&1
+  python $R/tools/rocpd_stats.py $(find $O/prof_kt_$F -name "*.db" | head -1) > $O/${RND}_rocprof_kernel_trace_${F}_frames.txt
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $ctr -d $O/prof_pmc_${tag}_$ctr -o p -- $cmd > $O/prof_pmc_${tag}_$ctr.log 2>&1
+    rocprofv3 --pmc $ctr -d $O/prof_pmc_${F}_$ctr -o p -- $cmd > $O/prof_pmc_${F}_$ctr.log 2>&1
   done
-  python $R/tools/pmc_summary.py $(find $O/prof_pmc_${tag}_FETCH_SIZE -name "*.db" | head -1) $(find $O/prof_pmc_${tag}_WRITE_SIZE -name "*.db" | head -1) \
-      "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --frames $F" $O/r01_pmc_$tag.json > /dev/null
+  python $R/tools/pmc_summary.py $(find $O/prof_pmc_${F}_FETCH_SIZE -name "*.db" | head -1) $(find $O/prof_pmc_${F}_WRITE_SIZE -name "*.db" | head -1) \
+      "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --frames $F ($nfg frames per launch)" $O/${RND}_pmc_${nfg}_frames_per_launch.json > /dev/null
 done
-cmd="python $R/bench.py --frames 64 --steps 3 --warmup 1 --no-cpu-baseline --no-throughput-config --no-label-stage --no-render-stage"
-: > $O/r01_pmc_eval_sq_counters_64_frames.txt
-for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH SQ_WAIT_ANY"; do
-  n=$(echo $set | cut -d" " -f1)
-  rocprofv3 --pmc $set -d $O/prof_sq_$n -o p -- $cmd > $O/prof_sq_$n.log 2>&1
-  python $R/tools/pmc_counters.py $(find $O/prof_sq_$n -name "*.db" | head -1) k_eval >> $O/r01_pmc_eval_sq_counters_64_frames.txt
-done
-ls -la $O/*.txt $O/*.json
+if [ "${SQ:-1}" = 1 ]; then
+  for F in ${SQ_FRAMES:-1 64}; do
+    cmd="python $R/bench.py --frames $F --steps 3 --warmup 1 $COMMON"
+    out=$O/${RND}_pmc_sq_counters_${F}_frames.txt
+    : > $out
+    for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH SQ_WAIT_ANY"; do
+      n=$(echo $set | cut -d" " -f1)
+      rocprofv3 --pmc $set -d $O/prof_sq_${F}_$n -o p -- $cmd > $O/prof_sq_${F}_$n.log 2>&1
+      python $R/tools/pmc_counters.py $(find $O/prof_sq_${F}_$n -name "*.db" | head -1) k_eval k_solve k_nn k_reduce >> $out
+    done
+  done
+fi
+ls -la $O/${RND}_*
