@@ -12,7 +12,7 @@ import numpy as np
 import scipy.sparse as sp
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libavatar_hip.so")
+LIB_PATH = os.environ.get("AVT_LIB", os.path.join(_HERE, "csrc", "libavatar_hip.so"))   # AVT_LIB: instrumented builds (tools/)
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
