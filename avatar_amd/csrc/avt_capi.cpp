@@ -21,7 +21,6 @@ int avt_eval_set_attributes();
 int avt_render_enqueue(avt_ctx* c, int nframes, const int* d_vertex_part, unsigned long long* d_zkey, unsigned char* d_label, int* d_block,
                        double fx, double fy, double cx, double cy, int width, int height);
 void avt_eval_report_occupancy(const AvtDims& d);
-bool avt_use_eval2(const AvtDims& d, int G);
 
 #define HIP_OK(expr)                                                                          \
     do {                                                                                      \
@@ -96,7 +95,6 @@ int check_launch(const char* what) {
 // the launch sequence of one optimize() over the resident frames
 void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStream_t stream) {
     c->fb.f0 = f0;
-    c->fb.rec_by16 = avt_use_eval2(c->dm.d, c->fb.G) ? 1 : 0;     // record layout follows the evaluation kernel that will read it
     c->cur_stream = stream;
     c->ran_icp_iters = 0;
     const int vis_init = o->enable_occlusion ? 0 : 1;

@@ -70,11 +70,7 @@ __global__ __launch_bounds__(256) void k_records(DeviceModel dm, FrameBuffers fb
     if (b * AVT_EVAL_PTS >= M) return;
     const int wv = t >> 6, ln = t & 63;
     const int ND = 3 * K + 11, RQ = d.rec_quad;
-    // layout 0 (k_eval): one region per wave quad, field F of point p4 at [F*4 + p4];  layout 1 (k_eval2): one region per
-    // batch, field F of point pi at [F*16 + pi] (16 consecutive doubles per field: one builder wave reads them, lane = point)
-    const int by16 = fb.rec_by16;
-    double* R = fb.rec + (((size_t)f * d.nb_max + b) * 4 + (by16 ? 0 : wv)) * RQ;
-    const int fstride = by16 ? 16 : 4, poff = by16 ? wv * 4 : 0;
+    double* R = fb.rec + (((size_t)f * d.nb_max + b) * 4 + wv) * RQ;
     for (int e = ln; e < ND * 4; e += 64) {
         const int field = e >> 2, pos = b * AVT_EVAL_PTS + wv * 4 + (e & 3);
         double v = 0.0;
@@ -87,27 +83,21 @@ __global__ __launch_bounds__(256) void k_records(DeviceModel dm, FrameBuffers fb
             } else if (field == 3 * K + 6) v = sqrt((double)fb.cnt[(size_t)f * V + m]);
             else v = dm.asg_w[(size_t)(field - (3 * K + 7)) * V + m];
         }
-        R[field * fstride + poff + (e & 3)] = v;
+        R[e] = v;
     }
-    int* RI = (int*)(R + ND * fstride);
+    int* RI = (int*)(R + ND * 4);
     for (int e = ln; e < 80; e += 64) {
         const int ifield = e >> 2, pos = b * AVT_EVAL_PTS + wv * 4 + (e & 3);
         int v = 0;
         if (pos < M) {
             const int m = fb.matched[(size_t)f * V + pos];
             if (ifield < 4) v = dm.asg_j[(size_t)ifield * V + m];
-            else if (by16) {   // k_eval2: four words of 4-bit masks, joint j at bits 4 (j & 7) of word j >> 3 (0 = not an ancestor)
-                if (ifield < 8)
-                    for (int a = 0; a < (int)dm.anc_n[m]; ++a) {
-                        const int w = (int)dm.anc[(size_t)a * V + m], jid = w & 0xff;
-                        if ((jid >> 3) == ifield - 4) v |= ((w >> 8) & 0xf) << (4 * (jid & 7));
-                    }
-            } else if (ifield - 4 < (int)dm.anc_n[m]) {
+            else if (ifield - 4 < (int)dm.anc_n[m]) {
                 v = (int)dm.anc[(size_t)(ifield - 4) * V + m];
                 v |= ((dm.parent[v & 0xff] + 1) << 16) | (dm.joint_col[v & 0xff] << 24);
             }
         }
-        RI[ifield * fstride + poff + (e & 3)] = v;
+        RI[e] = v;
     }
     if (t < 32) {   // tiles this batch's rows touch: J^T J skips the other tile pairs (k_eval)
         const int pos = b * AVT_EVAL_PTS + t;
@@ -303,37 +293,6 @@ __device__ __forceinline__ void mfma_batch6(const double* const (&base)[6], int 
     }
 }
 
-// One owned tile pair of the matrix phase, ownership dealt by the host (AvtDims::pair_own: the pairs that are live together
-// land on different waves; entry = pair | a_start << 5 | a_cnt << 12 | b_start << 17 | b_cnt << 24).  CH accumulator chains
-// (even / odd k-steps): v_mfma_f64_16x16x4_f64 issues in 16 clocks, its accumulator is ready after 64.
-template <int CH>
-__device__ __forceinline__ void contract_pair(const double* __restrict__ s_Jt, int own, int pm, int ln, v4f64* __restrict__ acc) {
-    constexpr int RS = AVT_EVAL_RS;
-    if (own >= 0 && ((pm >> (own & 31)) & 1)) {          // wave-uniform scalar branch, straight-line code inside
-        const int a_start = (own >> 5) & 127, a_cnt = (own >> 12) & 31, b_start = (own >> 17) & 127, b_cnt = (own >> 24) & 31;
-        const int c16 = ln & 15;
-        // tile column -> storage column (padding columns of a tile -> the all-zero column)
-        const double* pa = s_Jt + (size_t)(c16 < a_cnt ? a_start + c16 : (int)(3 + 3 * 24 + 10 + 1)) * RS + (ln >> 4);
-        const double* pb = s_Jt + (size_t)(c16 < b_cnt ? b_start + c16 : (int)(3 + 3 * 24 + 10 + 1)) * RS + (ln >> 4);
-        const bool diag = a_start == b_start;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            double fa[6], fbv[6];
-#pragma unroll
-            for (int ks = 0; ks < 6; ++ks) fa[ks] = pa[4 * (6 * h + ks)];
-            if (diag) {
-#pragma unroll
-                for (int ks = 0; ks < 6; ++ks) fbv[ks] = fa[ks];
-            } else {
-#pragma unroll
-                for (int ks = 0; ks < 6; ++ks) fbv[ks] = pb[4 * (6 * h + ks)];
-            }
-#pragma unroll
-            for (int ks = 0; ks < 6; ++ks) acc[ks & (CH - 1)] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks], fbv[ks], acc[ks & (CH - 1)], 0, 0, 0);
-        }
-    }
-}
-
 // =================================================================================================
 // k_eval.  1-D grid of nframes*G + nframes*ncomps workgroups of 256 threads = 4 waves (1-D on purpose: the hardware
 // deals workgroups to shader engines by linear id, and a 2-D grid whose x extent is a multiple of 16 would send all
@@ -448,10 +407,6 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm,
     v4f64 acc[MAXPW];
 #pragma unroll
     for (int i = 0; i < MAXPW; ++i) acc[i] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    int own[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) own[i] = wv == 0 ? d.pair_own[0][i] : (wv == 1 ? d.pair_own[1][i] : (wv == 2 ? d.pair_own[2][i] : d.pair_own[3][i]));
-    constexpr bool dealt = FIXED;            // the fixed-shape kernel is only launched for tiled layouts (launch_eval)
 
 #ifdef AVT_TIMING
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = clock64(); const long long wall0 = wall_clock64();
@@ -477,9 +432,13 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm,
         EPROBE(4);
         // MFMA phase: 12 k-steps of 4 rows
         wm |= (unsigned long long)pm;
-        if constexpr (FIXED) {                 // host-dealt ownership: the live pairs of a batch spread over the four waves
-#pragma unroll
-            for (int i = 0; i < 6; ++i) contract_pair<1>(s_Jt, own[i], pm, ln, &acc[i]);
+        if constexpr (FIXED) {
+            switch (wv) {
+                case 0: mfma_batch6<0>(fbase, pm, acc); break;
+                case 1: mfma_batch6<1>(fbase, pm, acc); break;
+                case 2: mfma_batch6<2>(fbase, pm, acc); break;
+                default: mfma_batch6<3>(fbase, pm, acc); break;
+            }
             EPROBE(1);
         } else {
 #pragma unroll 1
@@ -498,7 +457,7 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm,
     if (ln == 0 && f == fb.f0 && g == 0) { for (int k = 0; k < 8; ++k) fb.trace[(size_t)f * 64 + 16 + 8 * wv + k] = (double)tacc[k]; if (wv == 0) fb.trace[(size_t)f * 64 + 56] = (double)(wall_clock64() - wall0); }
 #endif
 #ifdef AVT_TIMELINE
-    if (t == 0 && g < 8) {   // where and when this workgroup ran (tools/eval_block_timeline.py)
+    if (t == 0 && g < 8) {   // where and when this workgroup ran (tools/eval_block_timeline.py, -DAVT_TIMELINE builds)
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -506,11 +465,25 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm,
         tr[0] = (double)wall0; tr[1] = (double)wall_clock64(); tr[2] = (double)((xcc & 0xf) * 65536 + (hw & 0xffff));
     }
 #endif
+    if (FIXED && ((wm >> 20) & 1)) {   // the four waves' shares of pair (5,5) are summed in wave order by wave 0 (wm is workgroup-uniform)
+        __syncthreads();
+        if (wv > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_Jt[(wv - 1) * 256 + r * 64 + ln] = acc[5][r];
+        }
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[5][r] += s_Jt[w * 256 + r * 64 + ln];
+        }
+    }
     // partial tiles out: element (row = (ln>>4) + 4*reg, col = ln&15) of pair p at [p][reg*64 + ln]
     double* part = fb.partial + (((size_t)f * G + g) * NPAIR) * 256;
 #pragma unroll
     for (int i = 0; i < MAXPW; ++i) {
-        const int p = dealt ? (i < 6 && own[i < 6 ? i : 0] >= 0 ? (own[i < 6 ? i : 0] & 31) : NPAIR) : wv + 4 * i;
+        const int p = wv + 4 * i;
         if (p < NPAIR && ((wm >> p) & 1)) {          // untouched pairs stay unwritten: k_reduce reads the mask
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[(size_t)p * 256 + r * 64 + ln] = acc[i][r];
@@ -519,299 +492,18 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm,
     if (t == 0) fb.wmask[(size_t)f * G + g] = wm;
 }
 
-// =================================================================================================
-// k_eval2 — the evaluation for FRAME BATCHES (SMPL dimensions, tiled column layout; few workgroups per frame, many batches
-// per workgroup).  Same grid, LDS tile, record stream, partial-tile output and prior workgroups as k_eval.  What changes:
-//   * Lanes are dealt to JOINT COLUMNS, not to ancestors.  Thread t of the workgroup owns (point t & 15, joint slot t >> 4);
-//     the 16 joint slots are the root plus the 5 joints of each of up to three live joint tiles (a second pass covers batches
-//     with more live tiles).  A lane writes the 3x3 rotation block of its joint if the joint is an ancestor of its point
-//     and ZEROS otherwise, so every real column of every live tile is written once per batch: no zeroing pass, no third
-//     barrier.  The records carry, instead of a list of ancestor words, four words of 4-bit masks indexed by joint.
-//   * Every wave sees all 16 points, four lanes per point; shaped rest position and the four carried points x_k are
-//     computed per wave in registers (cross-lane ds_bpermute, no LDS scratch).  k_eval gives every point 16 lanes of ONE
-//     wave and leaves most of them idle through most phases.
-//   * The shape block is split over all waves (lane = row sub < 3 of keys wave, wave + 4, wave + 8); the spare lanes
-//     (sub == 3) of wave 3 write the residual column and the root-translation block.
-//   * Matrix phase: pair ownership comes from the host (AvtDims::pair_own): the pairs that are live together land on
-//     different waves (k_eval's fixed W, W+4, .. deal left two waves with 3 k cycles and two with 15 k per workgroup, in-kernel
-//     probes, profiles/), and every pair runs as two accumulator chains (even / odd k-steps) summed at the very end:
-//     v_mfma_f64_16x16x4_f64 issues in 16 clocks but its accumulator is ready after 64 (tools/ubench/launch.hip).
-//   * The records of the next batch go to LDS at the start of the matrix phase (the builder is done with the old ones), so
-//     there are two workgroup barriers per batch: A (matrix phase done, records staged) and B (tile built).
-// Measured dead ends on the way (profiles/README.md): one builder wave + three contractor waves (a lone in-order wave
-// exposes every LDS round trip: slower than k_eval); one wave per kind of work with a zeroing pass and a third barrier
-// (the shape wave was the critical path).
-// =================================================================================================
-template <int CJ, int CK, int CH, int OCC>
-__global__ __launch_bounds__(256, OCC) void k_eval2(DeviceModel dm, FrameBuffers fb, int nframes) {
-    constexpr int J = CJ, K = CK, P = 3 + 3 * J + K, NT = (P + 16) / 16, NPAIR = NT * (NT + 1) / 2, RS = AVT_EVAL_RS, NC = P + 1;
-    static_assert(NT == 6 && J == 24 && K == 10, "written for the SMPL shape (6 column tiles; contract_pair's zero column)");
-    constexpr int ND = 3 * K + 11, RQ = 12 * K + 84, REC = 4 * RQ, REC2 = REC / 2;
-    static_assert(REC2 <= 512, "two record words per thread");
-    const AvtDims d = dm.d;
-    const int G = fb.G, t = threadIdx.x, id = blockIdx.x;
-    if (id >= nframes * G) {   // trailing workgroups: pose prior of the trial point, one (frame, GMM component) each
-        const int id2 = id - nframes * G, fp = id2 / d.ncomps + fb.f0;
-        extern __shared__ __attribute__((aligned(16))) char smem_prior[];
-        prior_component(dm, fb, fp, id2 % d.ncomps, 1 - fb.ctl[fp].cur_slot, (double*)smem_prior);
-        return;
-    }
-    const int f = id / G + fb.f0, g = id % G;
-    const AvtFrameCtl& ctl = fb.ctl[f];
-    const int wv = t >> 6, ln = t & 63, p = ln & 15, sub = ln >> 4, js = t >> 4;
-    const int S = AVT_EVAL_CHUNK(G);
-    auto next_batch = [&](int b) { const int b1 = b + 1; return (b1 % S) ? b1 : b1 - S + G * S; };
-    const int M = ctl.M;
-    const int try_slot = 1 - ctl.cur_slot;
-    const int nb = (M + AVT_EVAL_PTS - 1) / AVT_EVAL_PTS;
-
-    // the first batch's records do not depend on anything else this kernel loads: request them first
-    const d2v* recf = (const d2v*)(fb.rec + (size_t)f * d.nb_max * REC);
-    d2v pf0 = (d2v){0.0, 0.0}, pf1 = (d2v){0.0, 0.0};
-    int bm_next = 0;
-    auto prefetch = [&](int b) {
-        bm_next = fb.bmask[(size_t)f * d.nb_max + b];
-        const d2v* src = recf + (size_t)b * REC2;
-        pf0 = __builtin_nontemporal_load(src + t);
-        if (t + 256 < REC2) pf1 = __builtin_nontemporal_load(src + t + 256);
-    };
-    const int b0 = g * S;
-    if (b0 < nb) prefetch(b0);
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int npre = 15 * J + 3 * J * K, nprep = (npre + K + 3 + 1) & ~1;
-    double* s_prep = (double*)smem;                               // Rw o Jh G | w off
-    double* s_Jt = s_prep + nprep;                                // [NC + 1][RS]
-    double* s_rec = s_Jt + AVT_EVAL_TILE(NC + 1);                 // [REC] records of the batch, field-major [F][16]
-    int* s_tab = (int*)(s_rec + REC);                             // parent[32] | joint_col[32] | tile_joint[8][8]   (k_eval's scratch area)
-    double* s_ident = s_rec + REC + 48 + 192 + 144;               // (same offsets as k_eval: one LDS size for both)
-    const double* prep = fb.prep + ((size_t)f * 2 + try_slot) * d.prep_size;
-    for (int e = t; e < npre + K + 3; e += 256) s_prep[e] = prep[e < npre ? e : e + 4 * J];
-    if (t < 9) s_ident[t] = (t == 0 || t == 4 || t == 8) ? 1.0 : 0.0;
-    if (t < RS) s_Jt[(size_t)NC * RS + t] = 0.0;
-    if (t < J) { s_tab[t] = dm.parent[t]; s_tab[32 + t] = dm.joint_col[t]; }
-    if (t < 64) s_tab[64 + t] = ((t & 7) < 5 && (t >> 3) < NT) ? d.tile_joint[t >> 3][t & 7] : -1;
-    {   // records of the first batch
-        d2v* R2 = (d2v*)s_rec;
-        R2[t] = pf0;
-        if (t + 256 < REC2) R2[t + 256] = pf1;
-    }
-    int bw = __builtin_amdgcn_readfirstlane(bm_next);
-    if (b0 < nb && next_batch(b0) < nb) prefetch(next_batch(b0));
-    const double* Rw = s_prep;
-    const double* oo = s_prep + 9 * J;
-    const double* Jh = s_prep + 12 * J;
-    const double* Gm = s_prep + 15 * J;
-    const double* ww = s_prep + npre;
-    const double* off = ww + K;
-    int own[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) own[i] = wv == 0 ? d.pair_own[0][i] : (wv == 1 ? d.pair_own[1][i] : (wv == 2 ? d.pair_own[2][i] : d.pair_own[3][i]));
-    v4f64 acc[6][CH];
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int h = 0; h < CH; ++h) acc[i][h] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    const double* Rd = s_rec + p;                                 // field F of my point: Rd[F * 16]
-    const int* RI = (const int*)(s_rec + ND * 16) + p;            // int field I of my point: RI[I * 16]
-    // my joint slot: slot 0 = the root, slot 1 + 5 q + r = joint r of the q-th live joint tile (second pass: slot + 16)
-    const int q1 = js == 0 ? -1 : (js - 1) / 5, r1 = js == 0 ? 0 : (js - 1) % 5;
-    const int q2 = (js + 15) / 5, r2 = (js + 15) % 5;
-    unsigned wm = 0u;
-#ifdef AVT_TIMING
-    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = clock64(); const long long wall0 = wall_clock64();
-#endif
-
-    for (int b = b0; b < nb; b = next_batch(b)) {
-        __syncthreads();                                          // A: records staged, previous matrix phase done (first pass: tables too)
-        EPROBE(0);
-        const int tm = (unsigned)bw >> 24, pm = bw & 0xffffff;
-        // live joint tiles of this batch, in tile order (uniform)
-        int lt[5], nlt = 0;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) lt[i] = 0;
-#pragma unroll
-        for (int ti = 1; ti < NT; ++ti)
-            if ((tm >> ti) & 1) {
-#pragma unroll
-                for (int i = 0; i < 5; ++i) if (i == nlt) lt[i] = ti;
-                ++nlt;
-            }
-        // ---- every wave: shaped rest position (CalcShape, :249-272) and the carried points x_k (:508-514), in registers
-        double xh = 0.0;
-        if (sub < 3) {
-            double a = 0.0;
-#pragma unroll
-            for (int k = 0; k < K; ++k) a += Rd[(3 * k + sub) * 16] * ww[k];
-            xh = (a + Rd[(3 * K + sub) * 16]) - off[sub];
-        }
-        const double sc = Rd[(3 * K + 6) * 16];
-        double aw[4];
-        int aj[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) { aw[a] = Rd[(3 * K + 7 + a) * 16]; aj[a] = RI[a * 16]; }
-        const int nw0 = RI[4 * 16], nw1 = RI[5 * 16], nw2 = RI[6 * 16], nw3 = RI[7 * 16];
-        const double xh0 = __shfl(xh, p, 64), xh1 = __shfl(xh, p + 16, 64), xh2 = __shfl(xh, p + 32, 64);
-        double mx0, mx1, mx2;
-        {
-            const int k = sub == 0 ? aj[0] : (sub == 1 ? aj[1] : (sub == 2 ? aj[2] : aj[3]));
-            const double* Rk = Rw + 9 * k;
-            double rk[9];
-#pragma unroll
-            for (int e = 0; e < 9; ++e) rk[e] = Rk[e];
-            const double e0 = xh0 - Jh[3 * k], e1 = xh1 - Jh[3 * k + 1], e2 = xh2 - Jh[3 * k + 2];
-            mx0 = (rk[0] * e0 + rk[1] * e1 + rk[2] * e2) + oo[3 * k];
-            mx1 = (rk[3] * e0 + rk[4] * e1 + rk[5] * e2) + oo[3 * k + 1];
-            mx2 = (rk[6] * e0 + rk[7] * e1 + rk[8] * e2) + oo[3 * k + 2];
-        }
-        double xk[12];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) { xk[3 * a] = __shfl(mx0, p + 16 * a, 64); xk[3 * a + 1] = __shfl(mx1, p + 16 * a, 64); xk[3 * a + 2] = __shfl(mx2, p + 16 * a, 64); }
-        // ---- rotation columns of my joint slot: -2 sqrt(c) [l_j]_x R(-1,parent j) if j is an ancestor of my point, else zeros
-        const int npass = nlt > 3 ? 2 : 1;
-        for (int pass = 0; pass < npass; ++pass) {
-            const int q = pass ? q2 : q1, r = pass ? r2 : r1;
-            int j = -1;
-            if (q < 0) j = pass ? -1 : 0;
-            else if (q < nlt) {
-                const int ti = q == 0 ? lt[0] : (q == 1 ? lt[1] : (q == 2 ? lt[2] : (q == 3 ? lt[3] : lt[4])));
-                j = s_tab[64 + ti * 8 + r];
-            }
-            if (j >= 0) {
-                const int word = (j >> 3) == 0 ? nw0 : ((j >> 3) == 1 ? nw1 : ((j >> 3) == 2 ? nw2 : nw3));
-                const unsigned mask = ((unsigned)word >> (4 * (j & 7))) & 0xfu;
-                const int pj = s_tab[j], col = s_tab[32 + j];
-                const double* Rp = pj >= 0 ? Rw + 9 * pj : s_ident;
-                double rp[9];
-#pragma unroll
-                for (int e = 0; e < 9; ++e) rp[e] = Rp[e];
-                const double oj0 = oo[3 * j], oj1 = oo[3 * j + 1], oj2 = oo[3 * j + 2];
-                double X0 = 0.0, X1 = 0.0, X2 = 0.0, cj = 0.0;
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const double wa = (mask & (1u << a)) ? aw[a] : 0.0;      // select, not a branch
-                    X0 += wa * xk[3 * a]; X1 += wa * xk[3 * a + 1]; X2 += wa * xk[3 * a + 2];
-                    cj += wa;
-                }
-                const double m2 = mask ? -2.0 * sc : 0.0;                    // not an ancestor: the block is written as zeros
-                const double L0 = m2 * (X0 - cj * oj0), L1 = m2 * (X1 - cj * oj1), L2 = m2 * (X2 - cj * oj2);
-                double ov[9];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    ov[3 * c] = L1 * rp[6 + c] - L2 * rp[3 + c];
-                    ov[3 * c + 1] = L2 * rp[c] - L0 * rp[6 + c];
-                    ov[3 * c + 2] = L0 * rp[3 + c] - L1 * rp[c];
-                }
-                double* o0 = s_Jt + (size_t)col * RS + p * 3;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { o0[c * RS] = ov[3 * c]; o0[c * RS + 1] = ov[3 * c + 1]; o0[c * RS + 2] = ov[3 * c + 2]; }
-            }
-        }
-        // ---- shape block (:568-580): row `sub` of keys wv, wv+4, wv+8: (sum a_k Rw_k)[sub,:] D_k + sum a_k G_k[sub][k]
-        if (sub < 3) {
-            double tr[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int e9 = 3 * sub + c;
-                tr[c] = ((aw[0] * Rw[9 * aj[0] + e9] + aw[1] * Rw[9 * aj[1] + e9]) + aw[2] * Rw[9 * aj[2] + e9]) + aw[3] * Rw[9 * aj[3] + e9];
-            }
-            double sh[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int k = min(wv + 4 * i, K - 1);               // clamped: loads unconditional, the store guarded
-                const int e = sub * K + k;
-                const double D0 = Rd[(3 * k) * 16], D1 = Rd[(3 * k + 1) * 16], D2 = Rd[(3 * k + 2) * 16];
-                const double gs = ((aw[0] * Gm[aj[0] * 3 * K + e] + aw[1] * Gm[aj[1] * 3 * K + e]) + aw[2] * Gm[aj[2] * 3 * K + e]) + aw[3] * Gm[aj[3] * 3 * K + e];
-                sh[i] = sc * ((tr[0] * D0 + tr[1] * D1 + tr[2] * D2) + gs);
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-                if (wv + 4 * i < K) s_Jt[(size_t)(d.col_shape + wv + 4 * i) * RS + p * 3 + sub] = sh[i];
-        } else if (wv == 3) {
-            // ---- residual column sqrt(c) (x_m - dbar_m) and the identity root-translation block (:476-481)
-            double res[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                double xm = 0.0;
-#pragma unroll
-                for (int a = 0; a < 4; ++a) xm += aw[a] * xk[3 * a + c];
-                res[c] = sc * (xm - Rd[(3 * K + 3 + c) * 16]);
-            }
-            double* rc = s_Jt + (size_t)d.col_res * RS + p * 3;
-            rc[0] = res[0]; rc[1] = res[1]; rc[2] = res[2];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                double* tc = s_Jt + (size_t)(d.col_tr + c) * RS + p * 3;
-                tc[0] = c == 0 ? sc : 0.0; tc[1] = c == 1 ? sc : 0.0; tc[2] = c == 2 ? sc : 0.0;
-            }
-        }
-        EPROBE(3);
-        __syncthreads();                                          // B: the tile is built, the records are free
-        EPROBE(4);
-        // the next batch's records go to LDS now (published by barrier A), the one after that is requested
-        const int bn = next_batch(b);
-        if (bn < nb) {
-            d2v* R2 = (d2v*)s_rec;
-            R2[t] = pf0;
-            if (t + 256 < REC2) R2[t + 256] = pf1;
-            bw = __builtin_amdgcn_readfirstlane(bm_next);
-            if (next_batch(bn) < nb) prefetch(next_batch(bn));
-        }
-        EPROBE(2);
-        wm |= (unsigned)pm;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) contract_pair<CH>(s_Jt, own[i], pm, ln, &acc[i][0]);
-        EPROBE(1);
-    }
-#ifdef AVT_TIMING
-    if (ln == 0 && f == fb.f0 && g == 0) { for (int k = 0; k < 8; ++k) fb.trace[(size_t)f * 64 + 16 + 8 * wv + k] = (double)tacc[k]; if (wv == 0) fb.trace[(size_t)f * 64 + 56] = (double)(wall_clock64() - wall0); }
-#endif
-    // partial tiles out: element (row = (ln>>4) + 4*reg, col = ln&15) of pair p at [p][reg*64 + ln]; untouched pairs stay
-    // unwritten (k_reduce reads the mask)
-    double* part = fb.partial + (((size_t)f * G + g) * NPAIR) * 256;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int pp = own[i] & 31;
-        if (own[i] >= 0 && ((wm >> pp) & 1)) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double v = acc[i][0][r];
-                if constexpr (CH == 2) v += acc[i][1][r];
-                part[(size_t)pp * 256 + r * 64 + ln] = v;
-            }
-        }
-    }
-    if (t == 0) fb.wmask[(size_t)f * G + g] = (unsigned long long)wm;
-}
-
-static bool eval_fixed_shape(const AvtDims& d) { return d.J == 24 && d.K == 10 && d.tiled; }   // SMPL dimensions AND columns tiled by kinematic branch
+static bool eval_fixed_shape(const AvtDims& d) { return d.J == 24 && d.K == 10; }
 
 static size_t eval_lds_bytes(const AvtDims& d) {
     const size_t nprep = ((size_t)15 * d.J + 3 * d.J * d.K + d.K + 3 + 1) & ~(size_t)1;
     return sizeof(double) * (nprep + (size_t)AVT_EVAL_TILE(d.P + 2) + 4 * (size_t)d.rec_quad + 48 + 192 + 144 + 10);
 }
 
-// frame batches of SMPL-shaped models run k_eval2 (one builder wave, three contractor waves); a frame with >= 64 workgroups
-// of its own (one batch per workgroup: latency, not throughput) and generic skeletons keep k_eval.  AVT_EVAL=1 forces k_eval.
-bool avt_use_eval2(const AvtDims& d, int G) {
-    static const int force = getenv("AVT_EVAL") ? atoi(getenv("AVT_EVAL")) : 0;
-    if (!eval_fixed_shape(d) || force == 1) return false;
-    return force == 2 || G < 64;
-}
-
 void launch_eval(avt_ctx* c, int nframes) {
     const AvtDims& d = c->dm.d;
     dim3 grid((unsigned)nframes * (c->fb.G + std::max(0, d.ncomps)));
     const size_t lds = eval_lds_bytes(d);
-    static const int variant = getenv("AVT_EVAL2_VARIANT") ? atoi(getenv("AVT_EVAL2_VARIANT")) : 0;   // tuning knob
-    if (c->fb.rec_by16) {
-        switch (variant) {
-            case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval2<24, 10, 1, 3>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, nframes); break;
-            case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval2<24, 10, 1, 2>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, nframes); break;
-            case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval2<24, 10, 2, 3>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, nframes); break;
-            default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval2<24, 10, 2, 2>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, nframes); break;
-        }
-    } else if (eval_fixed_shape(d)) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<24, 10>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, nframes);
+    if (eval_fixed_shape(d)) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<24, 10>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, nframes);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<0, 0>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, nframes);
 }
 

@@ -43,13 +43,6 @@ struct AvtDims {
     int nb_max;              // eval batches a frame can have: ceil(V/16)
     int col_tr, col_shape, col_res;   // storage columns of the evaluation tile: root translation, first shape key, residual (avt_model.cpp)
     int tile_zpass[AVT_MAX_TILES];    // per tile: the 5-column zeroing passes of build_rows that overlap its storage columns (bit = pass)
-    // ---- k_eval2 (frame batches, tiled column layout only; tiled == 0 -> k_eval)
-    int tiled;                        // build_tile_layout grouped the columns by kinematic branch (else: plain order, every tile live)
-    int tile_joint[AVT_MAX_TILES][5]; // joints whose rotation columns live in tile ti (ti >= 1), -1 = none
-    // matrix-phase ownership: wave w contracts pairs pair_own[w][0..5]; entry = pair | a_start << 5 | a_cnt << 12 | b_start << 17 |
-    // b_cnt << 24 (storage-column range of the pair's two tiles), -1 = none.  Dealt so that the pairs that are live together
-    // (tile 0, the residual's tile, one limb tile) land on different waves.
-    int pair_own[4][6];
 };
 
 // prep block layout (doubles), one per frame per slot: what an evaluation needs about the skeleton state
@@ -163,7 +156,6 @@ struct FrameBuffers {
     int max_frames, max_points;   // per frame
     int G;                        // eval blocks per frame
     int f0;                       // first frame of the frame group a launch covers (grid frame index is relative to it)
-    int rec_by16;                 // matched-point record layout: 0 = per wave quad (k_eval), 1 = per batch of 16 (k_eval2)
     // raw inputs
     double* data_raw;     // [max_frames*max_points][3]
     int* labels_raw;      // [max_frames*max_points]

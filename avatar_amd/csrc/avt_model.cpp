@@ -52,9 +52,6 @@ static bool chol_lower(const double* A, int n, double* L) {
 static void build_tile_layout(avt_model* m, const int* parent) {
     AvtDims& d = m->d;
     const int V = d.V, J = d.J, K = d.K, P = d.P, NT = d.NT, NC = P + 1;
-    d.tiled = 0;
-    for (auto& row : d.tile_joint) for (int& v : row) v = -1;
-    for (auto& row : d.pair_own) for (int& v : row) v = -1;
     auto plain = [&]() {
         m->tile_col.assign((size_t)16 * NT, NC); m->tile_param.assign((size_t)16 * NT, -1);
         for (int tc = 0; tc < NC; ++tc) { m->tile_col[tc] = tc; m->tile_param[tc] = tc; }
@@ -126,40 +123,6 @@ static void build_tile_layout(avt_model* m, const int* parent) {
     for (int v = 0; v < V; ++v) m->vmask[v] = (unsigned char)(vm[v] | (1u << res_tile));
     m->vorder.resize(V); std::iota(m->vorder.begin(), m->vorder.end(), 0);
     std::stable_sort(m->vorder.begin(), m->vorder.end(), [&](int a, int b) { return m->vmask[a] < m->vmask[b]; });
-    // ---- tables of k_eval2
-    d.tiled = 1;
-    for (size_t gi = 0; gi < groups.size(); ++gi)
-        for (size_t i = 0; i < groups[gi].size() && i < 5; ++i) d.tile_joint[gi + 1][i] = groups[gi][i];
-    if (NT == 6) {
-        // storage-column range of every tile (contiguous by construction)
-        int tstart[AVT_MAX_TILES] = {0}, tcnt[AVT_MAX_TILES] = {0};
-        for (int ti = 0; ti < NT; ++ti) {
-            tstart[ti] = m->tile_col[16 * ti];
-            for (int i = 0; i < 16; ++i) tcnt[ti] += m->tile_col[16 * ti + i] < NC;
-        }
-        auto pair_index = [&](int a, int b) { if (a > b) std::swap(a, b); int p = 0; for (int t = 0; t < a; ++t) p += NT - t; return p + (b - a); };
-        auto entry = [&](int a, int b) {
-            if (a > b) std::swap(a, b);
-            return pair_index(a, b) | (tstart[a] << 5) | (tcnt[a] << 12) | (tstart[b] << 17) | (tcnt[b] << 24);
-        };
-        const int S = res_tile > 0 ? res_tile : 1;               // the tile that is live in every batch besides tile 0
-        std::vector<int> limbs;
-        for (int ti = 1; ti < NT; ++ti) if (ti != S) limbs.push_back(ti);
-        std::vector<std::vector<int>> own(4);
-        own[0].push_back(entry(0, 0)); own[1].push_back(entry(0, S)); own[2].push_back(entry(S, S));
-        for (int L : limbs) { own[3].push_back(entry(0, L)); own[0].push_back(entry(S, L)); own[1].push_back(entry(L, L)); }
-        // limb x limb pairs (rarely live: vertices weighted to two branches): to the least loaded waves
-        for (size_t i = 0; i < limbs.size(); ++i)
-            for (size_t k = i + 1; k < limbs.size(); ++k) {
-                int w = 0;
-                for (int c = 1; c < 4; ++c) if (own[c].size() < own[w].size()) w = c;
-                own[w].push_back(entry(limbs[i], limbs[k]));
-            }
-        bool fits = true;
-        for (int w = 0; w < 4; ++w) fits = fits && own[w].size() <= 6;
-        if (fits) { for (int w = 0; w < 4; ++w) for (size_t i = 0; i < own[w].size(); ++i) d.pair_own[w][i] = own[w][i]; }
-        else d.tiled = 0;
-    } else d.tiled = 0;
 }
 
 extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
