@@ -159,7 +159,8 @@ struct Filler {
 extern "C" {
 
 int avt_rtree_create(const avt_rtree_desc* d, int device, avt_rtree** out) {
-    if (!d || !out || d->n_nodes <= 0 || d->n_leafs < 0 || !d->feature || !d->links || (d->n_leafs > 0 && !d->leaf_data)) {
+    if (!d || !out || d->n_nodes <= 0 || d->n_leafs < 0 || d->n_leafs > d->n_nodes || d->num_parts <= 0 || d->num_parts > 255 || !d->feature ||
+        !d->links || (d->n_leafs > 0 && !d->leaf_data)) {
         avt_set_error("avt_rtree_create: bad descriptor");
         return 1;
     }
@@ -189,7 +190,7 @@ int avt_rtree_load(const char* path, int device, avt_rtree** out) {
     if (marker == 'R') {   // binary format
         uint32_t n = 0, nl = 0;
         int32_t np = 0;
-        if (!get(bin, n) || !get(bin, nl) || !get(bin, np) || np <= 0 || n == 0 || n > (1u << 28)) return fail("bad header");
+        if (!get(bin, n) || !get(bin, nl) || !get(bin, np) || np <= 0 || np > 255 || n == 0 || n > (1u << 28) || nl > n) return fail("bad header");
         rt->num_parts = np;
         rt->feature.assign(5 * (size_t)n, 0.f);
         rt->links.assign(3 * (size_t)n, -1);

@@ -311,9 +311,29 @@ def tracker_stage(api, synth, smpl, gm):
     for xyz, mask, bbox in frames[1:]:
         tr.subsample(xyz, mask, bbox)
     t_sub = (time.perf_counter() - t1) / (len(frames) - 1)
-    return {"workload": f"demo.cpp frame loop on 1280x720 renders: interval 3 ({npts} points per frame), 3 ICP x 10 GN iterations per frame, warm start",
-            "value": round(1.0 / dt, 1), "unit": "frames/s", "ms_per_frame": round(dt * 1e3, 3),
-            "of_which_host_subsampling_ms": round(t_sub * 1e3, 3), "gn_iterations_per_s": round(30.0 / dt, 1)}
+    res = {"workload": f"demo.cpp frame loop on 1280x720 renders: interval 3 ({npts} points per frame), 3 ICP x 10 GN iterations per frame, warm start",
+           "python_facade": {"value": round(1.0 / dt, 1), "unit": "frames/s", "ms_per_frame": round(dt * 1e3, 3),
+                             "of_which_host_subsampling_ms": round(t_sub * 1e3, 3), "gn_iterations_per_s": round(30.0 / dt, 1)}}
+    # the same loop in C++ (include/ark/FrameTracker.h through tests/cpp/tracker_demo): no Python in the frame path
+    exe = os.path.join(ROOT, "tests", "cpp", "tracker_demo")
+    if os.path.exists(exe):
+        import subprocess
+        import tempfile
+        from tests.test_gpu_facade import write_model_dir
+        from tests.test_gpu_tracker import write_sequence
+        with tempfile.TemporaryDirectory() as td:
+            write_model_dir(smpl, os.path.join(td, "model"))
+            write_sequence(os.path.join(td, "seq.bin"), [(x, m, b) for x, m, b in frames], 3, 3, 6, 1000)
+            r = subprocess.run([exe, os.path.join(td, "model"), os.path.join(td, "seq.bin"), os.path.join(td, "out.bin"), "5"],
+                               capture_output=True, text=True, timeout=600)
+            for line in r.stdout.splitlines():
+                if line.startswith("tracker_demo timing:"):
+                    ms = float(line.split(",")[1].split()[0])
+                    res["cpp_facade"] = {"value": round(1e3 / ms, 1), "unit": "frames/s", "ms_per_frame": round(ms, 4), "gn_iterations_per_s": round(30e3 / ms, 1)}
+            if "cpp_facade" not in res:
+                res["cpp_facade"] = {"error": (r.stdout + r.stderr)[-300:]}
+    res["value"], res["unit"] = res.get("cpp_facade", res["python_facade"]).get("value", res["python_facade"]["value"]), "frames/s"
+    return res
 
 
 def label_stage(synth, smpl, with_cpu):
@@ -424,18 +444,24 @@ def cpu_baselines(synth, smpl, r, opt, budget, F_batch):
     out["fastest_single_frame"] = name
     out["sample"] = (f"optimize() of frame 0 ({len(fr['labels'])} pts, {gn} GN iterations) repeated for about {budget:.0f} s in total over the "
                      f"modes listed; value = the fastest single-frame mode ({name}); CPU restatement of the sxyu/avatar algorithm, not Ceres")
-    # frame batches: one frame per core (inputs marshalled once, outside the timed calls)
-    nb = min(ncpu, 256)
-    run = om.batch_runner(pm, 24, fr["data"], fr["labels"], nb, opt, p0, q0, w0, aggregate=1, nworkers=ncpu)
-    run()
-    tt, reps = 0.0, 0
-    while tt < budget * 0.15 or reps < 1:
-        a = time.perf_counter()
+    # frame batches: one single-threaded optimize() per worker (inputs marshalled once, outside the timed calls), swept over
+    # the worker count: on a many-core host the copies compete for cache and memory bandwidth long before the cores run out
+    sweep_b, best_b = {}, (0.0, 1, 0)
+    for nw in sorted({min(ncpu, n) for n in (16, 32, 64, 128, 256)}):
+        run = om.batch_runner(pm, 24, fr["data"], fr["labels"], nw, opt, p0, q0, w0, aggregate=1, nworkers=nw)
         run()
-        tt += time.perf_counter() - a
-        reps += 1
-    out["batch_all_cores"] = {"value": round(reps * nb * gn / tt, 2), "unit": "GN iterations/s", "cores": ncpu,
-                              "sample": f"{reps} x {nb} copies of frame 0, one single-threaded optimize() per core"}
+        tt, reps = 0.0, 0
+        while tt < budget * 0.04 or reps < 1:
+            a = time.perf_counter()
+            run()
+            tt += time.perf_counter() - a
+            reps += 1
+        v = reps * nw * gn / tt
+        sweep_b[str(nw)] = round(v, 2)
+        if v > best_b[0]:
+            best_b = (v, nw, reps)
+    out["batch_all_cores"] = {"value": round(best_b[0], 2), "unit": "GN iterations/s", "cores": best_b[1], "by_workers": sweep_b,
+                              "sample": f"{best_b[2]} x {best_b[1]} copies of frame 0, one single-threaded optimize() per worker; best of the worker counts listed"}
     orc.set_nn_implementation("bruteforce")
     return out
 

@@ -137,6 +137,13 @@ class Avatar {
         w.assign(model.numShapeKeys(), 0.0);          // Avatar.cpp:12-20
         r.assign(model.numJoints(), Matrix3d());
     }
+    /** Copies carry the state (w, p, r and the derived clouds) like the reference's plain value type; the device context is
+     *  NOT shared: a copy creates its own on its first update() (one owner per avt_ctx, no double free). */
+    Avatar(const Avatar& o) : model(o.model), cloud(o.cloud), w(o.w), p(o.p), r(o.r), jointPos(o.jointPos), jointTrans(o.jointTrans), device(o.device) {}
+    Avatar& operator=(const Avatar& o) {
+        if (this != &o) { cloud = o.cloud; w = o.w; p = o.p; r = o.r; jointPos = o.jointPos; jointTrans = o.jointTrans; device = o.device; }
+        return *this;      // (`model` is a reference: both sides must already refer to the same model, as with the reference's type)
+    }
     ~Avatar() { if (ctx) avt_ctx_destroy(ctx); }
 
     /** Update joints and skin points from the current shape and pose (Avatar.cpp:22-75). */

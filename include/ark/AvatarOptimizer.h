@@ -16,6 +16,10 @@ class AvatarOptimizer {
         r.resize(ava.model.numJoints());
     }
     ~AvatarOptimizer() { if (ctx) avt_ctx_destroy(ctx); }
+    // holds references (ava, intrin, partMap) and owns a device context: not copyable (the reference's class holds the same
+    // references; copying it would alias the avatar it optimises)
+    AvatarOptimizer(const AvatarOptimizer&) = delete;
+    AvatarOptimizer& operator=(const AvatarOptimizer&) = delete;
 
     /** Begin full optimization on the target data cloud (AvatarOptimizer.cpp:1246-1517).  Precondition as in the
      *  reference: ava.update() has been called; postcondition: ava.p, ava.w, ava.r updated and ava.update()d. */

@@ -2,7 +2,13 @@
 #include <cstdio>
 #include "ark/Npz.h"
 int main(int argc, char** argv) {
-    auto z = ark::npz::load(argv[1]);
+    std::map<std::string, ark::npz::Array> z;
+    try {
+        z = ark::npz::load(argv[1]);
+    } catch (const std::exception& e) {      // a damaged file must end here, not in a crash
+        std::fprintf(stderr, "npz_check: %s\n", e.what());
+        return 3;
+    }
     for (auto& kv : z) {
         double s = 0;
         const size_t n = kv.second.size();

@@ -71,3 +71,35 @@ def test_npz_reader_cpu(smpl, tmp_path, compressed):
             acc += x
         assert first == flat[0] and last == flat[-1]
         assert abs(s - float(np.sum(flat))) <= 1e-9 * max(1.0, np.abs(flat).sum())
+
+
+def test_npz_reader_tolerates_foreign_members_and_rejects_damage(smpl, tmp_path):
+    """SMPL exports carry string / bool / object members next to the six arrays the model needs: they are skipped (cnpy
+    tolerates them too); a truncated or corrupted file ends in an error, never in an out-of-bounds read."""
+    mdir = tmp_path / "model"
+    os.makedirs(mdir)
+    keys = {k: smpl[k] for k in ("v_template", "f", "kintree_table", "J_regressor", "weights", "shapedirs")}
+    path = str(mdir / "model.npz")
+    np.savez(path, bs_style=np.array("lbs"), bs_type=np.array(["lrotmin"]), flag=np.array([True, False]), **keys)
+    exe = str(tmp_path / "npz_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(HERE, "cpp", "npz_check.cpp"), "-lz"])
+    r = subprocess.run([exe, path], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    names = {line.split()[0] for line in r.stdout.strip().splitlines()}
+    assert set(keys) <= names and "bs_style" not in names and "flag" not in names
+    raw = open(path, "rb").read()
+    rng = np.random.default_rng(0)
+    bad = [raw[:len(raw) // 2], raw[:-30], raw[:100], raw[len(raw) // 3:]]
+    for _ in range(6):                                   # random damage in the central directory / headers
+        b = bytearray(raw)
+        for pos in rng.integers(len(raw) - 2000, len(raw), 12):
+            b[pos] = int(rng.integers(0, 256))
+        bad.append(bytes(b))
+    for i, b in enumerate(bad):
+        q = str(tmp_path / f"bad{i}.npz")
+        open(q, "wb").write(b)
+        r = subprocess.run([exe, q], capture_output=True, text=True)
+        assert r.returncode in (0, 3), (i, r.returncode, r.stderr)      # clean result or a reported error; never a signal
+        if r.returncode == 3:
+            assert "npz" in r.stderr

@@ -187,3 +187,20 @@ def test_edge_cases(smpl, omodel, gmodel):
     p, q, w, st = ctx.optimize_batch([fr["data"]], [fr["labels"]], opt2, p0[None], q0[None], w0[None])
     assert np.array_equal(ctx.correspondences(0, len(fr["labels"])), ref["corr"])
     assert np.abs(ctx.cloud(0) - ref["cloud"]).max() < 1e-6
+
+
+def test_nn_full_size_against_nanoflann_goldens(smpl, omodel, gmodel):
+    """k_nn / k_compact at FULL size against the reference's own nanoflann output (38 k, 125 k dense, coarse 6-part map):
+    index arrays committed under tests/golden/, inputs regenerated from seeds.  Bit-exact."""
+    import os
+    import sys
+    from avatar_amd import api
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_nn_golden_full as mk
+    z = np.load(os.path.join(here, "golden", "nn_golden_full.npz"))
+    for k, c in enumerate(mk.CASES):
+        pm, npart, cloud, vis, data, labels = mk.case_inputs(smpl, omodel, c)
+        ctx = api.Context(gmodel, npart, pm, len(labels), 1, device=0)
+        got = ctx.nn(cloud, vis, data, labels)
+        assert np.array_equal(got, z[f"idx_{k}"]), (k, int((got != z[f"idx_{k}"]).sum()))

@@ -192,3 +192,46 @@ def test_large_batch_two_frame_groups_matches_oracle(smpl, omodel, gmodel):
         assert np.array_equal(ctx.correspondences(i, len(frs[i]["labels"])), ref["corr"])
         assert np.abs(ctx.cloud(i) - ref["cloud"]).max() < 1e-6
         assert st[i].gn_iterations == ref["stats"].gn_iterations and st[i].accepted_steps == ref["stats"].accepted_steps
+
+
+def test_512_frames_per_gpu_rendered_on_the_gpu(smpl, omodel, gmodel):
+    """BASELINE configs[3] / the saturation point DESIGN quotes: 512 independent ~30k-point frames resident on one GPU
+    (the per-GPU share of configs[3] is 64; 512 is where the frames-per-GPU curve flattens).  Frames come from the GPU
+    generator, exactly as bench.py makes them.  Checks: every frame finite and improved; bit-wise reproducible run to run;
+    frames at both ends of both frame groups against the oracle (correspondences bit-exact, vertices 1e-6); a frame's fit
+    does not depend on its neighbours in the batch (the same frame alone agrees to 1e-9: only the summation order of the
+    partial tiles differs with the launch shape)."""
+    from avatar_amd import api
+    F = 512
+    pm = synth.identity_part_map()
+    gts = [synth.sample_ground_truth(smpl, 2000 + f) for f in range(F)]
+    starts = [synth.perturb_start(*gts[f], 2000 + f) for f in range(F)]
+    ctx = api.Context(gmodel, 24, pm, 65536, F, device=0)
+    npts = ctx.render_frames(np.array([g[0] for g in gts]), np.array([g[1] for g in gts]), np.array([g[2] for g in gts]))
+    assert npts.min() > 5000 and npts.max() <= 65536
+    p0 = np.array([s[1] for s in starts]); w0 = np.array([s[0] for s in starts])
+    q0 = api.rot_to_quat(np.array([s[2] for s in starts]).reshape(-1, 3, 3)).reshape(F, 24, 4)
+    ctx.state_upload(p0, q0, w0)
+    opt = Options.demo()
+    assert ctx.launch_shape()[:2] == (2, 256)
+    ctx.optimize_resident(opt)
+    p, q, w, st = ctx.state_download()
+    ctx.state_reset(); ctx.optimize_resident(opt)
+    p2, q2, w2, _ = ctx.state_download()
+    assert np.array_equal(p, p2) and np.array_equal(q, q2) and np.array_equal(w, w2)
+    assert np.isfinite(p).all() and np.isfinite(q).all() and np.isfinite(w).all()
+    assert all(s.gn_iterations == 10 and s.final_cost <= s.initial_cost and s.num_correspondences > 0 for s in st)
+    assert np.abs(np.linalg.norm(q, axis=2) - 1.0).max() < 1e-9
+    for i in (0, 255, 256, 511):
+        d, l = ctx.frame_download(i)
+        assert len(l) == npts[i]
+        ref = omodel.optimize(pm, 24, d, l, opt, p0[i], q0[i], w0[i], aggregate=1)
+        assert np.array_equal(ctx.correspondences(i, len(l)), ref["corr"])
+        assert np.abs(ctx.cloud(i) - ref["cloud"]).max() < 1e-6
+        assert st[i].accepted_steps == ref["stats"].accepted_steps
+        assert np.abs(p[i] - ref["p"]).max() < 1e-7 and np.abs(q[i] - ref["q"]).max() < 1e-7
+    one = api.Context(gmodel, 24, pm, 65536, 1, device=0)
+    for i in (3, 300):
+        d, l = ctx.frame_download(i)
+        pa, qa, wa, _ = one.optimize_batch([d], [l], opt, p0[i][None], q0[i][None], w0[i][None])
+        assert np.abs(pa[0] - p[i]).max() < 1e-9 and np.abs(qa[0] - q[i]).max() < 1e-9 and np.abs(wa[0] - w[i]).max() < 1e-8

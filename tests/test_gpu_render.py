@@ -45,3 +45,38 @@ def test_render_then_optimize_resident(smpl, omodel, gmodel):
     ref = omodel.optimize(pm, 24, data, lab, opt, p0, q0, w0, aggregate=1)
     assert np.array_equal(ctx.correspondences(0, len(lab)), ref["corr"])
     assert np.abs(ctx.cloud(0) - ref["cloud"]).max() < 1e-6
+
+
+def test_gpu_frames_against_the_painters_order_oracle(smpl, gmodel):
+    """Row f1 against an oracle of the REFERENCE's renderer (oracle/render_oracle.cpp: painter's order, scanline fills,
+    AvatarHelpers.cpp:61-303), not against the product's own host twin: the GPU generator resolves visibility with a
+    z-buffer, so the comparison is per pixel with a disagreement budget (silhouette rim, self-occlusions): see
+    tests/test_render_oracle_cpu.py for the measured numbers."""
+    from avatar_amd import api
+    from oracle import render_oracle as ro
+    pm = synth.identity_part_map()
+    k = synth.K4A_INTRIN
+    vp = pm[synth.main_joint(smpl)]
+    seeds = (0, 1, 7)
+    gts = [synth.sample_ground_truth(smpl, s) for s in seeds]
+    ctx = api.Context(gmodel, 24, pm, 60000, len(seeds), device=0)
+    ctx.render_frames(np.array([g[0] for g in gts]), np.array([g[1] for g in gts]), np.array([g[2] for g in gts]))
+    cloud, _, _ = ctx.lbs_update(np.array([g[0] for g in gts]), np.array([g[1] for g in gts]), np.array([g[2] for g in gts]))
+    ctx.render_frames(np.array([g[0] for g in gts]), np.array([g[1] for g in gts]), np.array([g[2] for g in gts]))
+    for f in range(len(seeds)):
+        data_g, lab_g = ctx.frame_download(f)
+        depth_p, mask_p = ro.render(cloud[f], smpl["f"], vp, k, k["width"], k["height"])
+        # GPU points back to pixels (exact: X = (c - cx) z / fx in float)
+        z = data_g[:, 2].astype(np.float32)
+        cols = np.rint(data_g[:, 0].astype(np.float32) * np.float32(k["fx"]) / z + np.float32(k["cx"])).astype(int)
+        rows = np.rint(-data_g[:, 1].astype(np.float32) * np.float32(k["fy"]) / z + np.float32(k["cy"])).astype(int)
+        fg_g = np.zeros(depth_p.shape, bool); fg_g[rows, cols] = True
+        assert fg_g.sum() == len(lab_g)                              # one point per pixel
+        fg_p = depth_p > 0
+        both = fg_g & fg_p
+        iou = both.sum() / (fg_g | fg_p).sum()
+        dz = np.abs(z - depth_p[rows, cols])[fg_p[rows, cols]]
+        same = (lab_g == mask_p[rows, cols])[fg_p[rows, cols]].mean()
+        assert iou > 0.92 and (fg_g & ~fg_p).sum() < 0.01 * fg_g.sum()
+        assert np.median(dz) < 1e-3 and np.percentile(dz, 95) < 1e-2
+        assert same > 0.97

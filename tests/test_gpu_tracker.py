@@ -76,3 +76,74 @@ def test_tracker_sequence_matches_oracle(smpl, omodel, gmodel):
     # tracking loss: an (almost) empty mask flips the tracker back to reinit
     empty = np.full_like(frames[0][1], 255)
     assert not tr.process(frames[0][0], empty, (0, 0, 719, 1279)) and tr.reinit
+
+
+def write_sequence(path, frames, interval, frame_icp, reinit_icp, reinit_cnz):
+    """sequence.bin of tests/cpp/tracker_demo.cpp: header, then per frame bbox + XYZ map (float32) + part mask (uint8)."""
+    import struct
+    H, W = frames[0][1].shape
+    with open(path, "wb") as f:
+        f.write(struct.pack("7i", len(frames), W, H, interval, frame_icp, reinit_icp, reinit_cnz))
+        for xyz, mask, bbox in frames:
+            f.write(struct.pack("4i", *[int(v) for v in bbox]))
+            f.write(np.ascontiguousarray(xyz, np.float32).tobytes()); f.write(np.ascontiguousarray(mask, np.uint8).tobytes())
+
+
+@pytest.mark.gpu
+def test_cpp_frame_tracker_matches_oracle(smpl, omodel, tmp_path):
+    """include/ark/FrameTracker.h (the demo.cpp:215-290 loop in C++ over the C ABI) on a rendered sequence, against the
+    oracle mirror of the same protocol; an empty frame in the middle must flip it to reinit and the next frame must
+    reinitialise (centroid start, reinit ICP budget)."""
+    import os
+    import subprocess
+    from oracle import oracle as orc
+    from tests.test_gpu_facade import write_model_dir
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(here, "cpp", "tracker_demo")
+    assert os.path.exists(exe), "tests/cpp/tracker_demo not built (make -C avatar_amd/csrc facade)"
+    mdir = str(tmp_path / "model")
+    write_model_dir(smpl, mdir)
+    seq = _sequence(smpl, 3)
+    frames = []
+    for xyz, mask, gt in seq:
+        ys, xs = np.nonzero(mask != 255)
+        frames.append((xyz, mask, (ys.min(), xs.min(), ys.max(), xs.max())))
+    empty = (seq[0][0], np.full_like(seq[0][1], 255), (0, 0, 719, 1279))
+    order = [frames[0], frames[1], empty, frames[2]]
+    spath, opath = str(tmp_path / "seq.bin"), str(tmp_path / "out.bin")
+    write_sequence(spath, order, 6, 2, 3, 1000)
+    r = subprocess.run([exe, mdir, spath, opath], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(opath, "rb").read()
+    V, off, got = 6890, 0, []
+    for _ in order:
+        fitted = int(np.frombuffer(raw, np.int32, 1, off)[0]); off += 4
+        if fitted:
+            cloud = np.frombuffer(raw, np.float64, 3 * V, off).reshape(V, 3); off += 8 * 3 * V
+            pw = np.frombuffer(raw, np.float64, 13, off); off += 8 * 13
+            got.append((cloud, pw[:3], pw[3:]))
+        else:
+            got.append(None)
+    assert got[2] is None and all(g is not None for g in (got[0], got[1], got[3]))
+    # oracle mirror
+    from avatar_amd.tracker import FrameTracker
+
+    class _Opt:
+        numParts = 24
+    sub = FrameTracker.__new__(FrameTracker); sub.opt = _Opt(); sub.interval = 6
+    pm = synth.identity_part_map()
+    o_w = np.zeros(10); o_p = np.zeros(3); o_R = np.tile(np.eye(3), (24, 1, 1)); reinit = True
+    for k, (xyz, mask, bbox) in enumerate(order):
+        data, labels = sub.subsample(xyz, mask, bbox)
+        if len(labels) < 1000 // 36:
+            reinit = True
+            continue
+        icp = 2
+        if reinit:
+            o_p = data.mean(0); o_w = np.zeros(10); o_R = np.tile(np.eye(3), (24, 1, 1))
+            o_R[0] = np.array([[-1.0, 0, 0], [0, 1.0, 0], [0, 0, -1.0]]); reinit = False; icp = 3
+        ref = omodel.optimize(pm, 24, data, labels, Options.demo(icp_iters=icp), o_p, orc.rot_to_quat(o_R), o_w, aggregate=1)
+        o_p, o_w, o_R = ref["p"], ref["w"], orc.quat_to_rot(ref["q"])
+        cloud, p, w = got[k]
+        assert np.abs(cloud - ref["cloud"]).max() < 1e-5, k
+        assert np.abs(p - ref["p"]).max() < 1e-6 and np.abs(w - ref["w"]).max() < 1e-5

@@ -61,6 +61,20 @@ def test_oracle_nn_live_against_reference_build(smpl, omodel):
     assert np.array_equal(ref, omodel.nn(pm, 24, cloud, vis, fr["data"], fr["labels"]))
 
 
+def test_oracle_nn_full_size_against_nanoflann_goldens(smpl, omodel):
+    """The oracle's ordered brute-force search against the reference's nanoflann KD-tree at FULL size (38 k, 125 k dense and
+    a coarse 6-part map): inputs regenerated from seeds, reference index arrays committed (tests/golden/nn_golden_full.npz,
+    made by tests/golden/make_nn_golden_full.py in the build container)."""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_nn_golden_full as mk
+    z = np.load(os.path.join(HERE, "golden", "nn_golden_full.npz"))
+    assert int(z["ncase"]) == len(mk.CASES)
+    for k, c in enumerate(mk.CASES):
+        pm, npart, cloud, vis, data, labels = mk.case_inputs(smpl, omodel, c)
+        assert len(labels) == int(z[f"n_{k}"])
+        assert np.array_equal(omodel.nn(pm, npart, cloud, vis, data, labels), z[f"idx_{k}"]), k
+
+
 # ------------------------------------------------------------------------------------------------ LBS known answers
 def test_lbs_known_answers(smpl, omodel):
     J0 = omodel.joint_regression()[0][0]
