@@ -36,4 +36,6 @@ if [ "${SQ:-1}" = 1 ]; then
     done
   done
 fi
+# the rocpd databases are tens of MiB each: only the summaries travel back (gpurun merges at most 64 MiB)
+rm -rf $O/prof_kt_* $O/prof_pmc_* $O/prof_sq_*
 ls -la $O/${RND}_*
