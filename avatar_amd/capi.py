@@ -161,7 +161,7 @@ def load_library():
         "avt_model_dims": [vp, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p],
         "avt_model_main_joint": [vp, c_int_p],
         "avt_model_joint_regression": [vp, c_double_p, c_double_p],
-        "avt_model_tile_layout": [vp, c_int_p, c_int_p, C.POINTER(C.c_ubyte), c_int_p],
+        "avt_model_tile_layout": [vp, c_int_p, c_int_p, C.POINTER(C.c_ushort), c_int_p],
         "avt_ctx_create": [C.c_int, vp, C.c_int, c_int_p, C.c_int, C.c_int, C.POINTER(vp)],
         "avt_ctx_destroy": [vp],
         "avt_sync": [vp],

@@ -104,12 +104,13 @@ __global__ __launch_bounds__(256) void k_records(DeviceModel dm, FrameBuffers fb
         int bm = (t < 16 && pos < M) ? (int)dm.vmask[fb.matched[(size_t)f * V + pos]] : 0;
 #pragma unroll
         for (int s = 16; s >= 1; s >>= 1) bm |= __shfl_xor(bm, s, 64);
-        // word: bits 24..31 live tiles; bits 0..23 live tile pairs in upper-triangle order (lane p = pair p; used when NT <= 6)
+        // word (NT <= 8): bits 24..31 live tiles; bits 0..23 live tile pairs in upper-triangle order (lane p = pair p; used when
+        // NT <= 6).  NT > 8: the live tiles in the low 16 bits.
         int p = t, ti = 0;
         while (ti < d.NT && p >= d.NT - ti) { p -= d.NT - ti; ++ti; }
         const bool live = t < 24 && ti < d.NT && ((bm >> ti) & (bm >> (ti + p)) & 1);
         const unsigned long long bal = __ballot(live);
-        if (t == 0) fb.bmask[(size_t)f * d.nb_max + b] = (int)(bal & 0xffffffu) | (bm << 24);
+        if (t == 0) fb.bmask[(size_t)f * d.nb_max + b] = d.NT > 8 ? (bm & 0xffff) : ((int)(bal & 0xffffffu) | (bm << 24));
     }
 }
 
@@ -137,9 +138,10 @@ __device__ __forceinline__ void stage_records(double* __restrict__ Rrec, int RQ2
     }
 }
 
-template <int CJ, int CK>
+template <int CJ, int CK, int MT>
 __device__ __forceinline__ void build_rows(const AvtDims& d, const EvalTables& T, double* __restrict__ s_Jt, const double* __restrict__ Rrec,
-                                           double* __restrict__ s_xhat, double* __restrict__ s_xk, double* __restrict__ s_T, int qw, int ln, int zmask) {
+                                           double* __restrict__ s_xhat, double* __restrict__ s_xk, double* __restrict__ s_T, int qw, int ln,
+                                           unsigned long long zmask) {
     constexpr bool FIXED = CJ != 0;
     constexpr int RS = AVT_EVAL_RS;
     const int J = FIXED ? CJ : d.J, K = FIXED ? CK : d.K, P = 3 + 3 * J + K, NC = P + 1;
@@ -149,7 +151,7 @@ __device__ __forceinline__ void build_rows(const AvtDims& d, const EvalTables& T
     if (ln < 60) {   // zero my wave's 12 rows of every column of the batch's live tiles: 5 columns x 12 rows per pass (the stride is odd: 8-byte stores)
         double* z = s_Jt + (size_t)(ln / 12) * RS + qw * 12 + (ln % 12);
 #pragma unroll
-        for (int pass = 0; pass < (16 * AVT_MAX_TILES + 4) / 5; ++pass)
+        for (int pass = 0; pass < (16 * MT + 4) / 5; ++pass)
             if ((zmask >> pass) & 1) {          // wave-uniform: some column of this pass lies in a live tile
                 if (5 * pass + ln / 12 < NC) z[pass * 5 * RS] = 0.0;
             }
@@ -310,15 +312,17 @@ __device__ __forceinline__ void mfma_batch6(const double* const (&base)[6], int 
 //     also maps tile coordinates back to parameter indices); tile pairs the batch does not touch are skipped.
 // CJ/CK != 0: dimensions fixed at compile time (SMPL: 24 joints, 10 shape keys); 0: taken from the model.
 // =================================================================================================
-template <int CJ, int CK>
-__global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm, FrameBuffers fb, int nframes) {
+// MT = column tiles the instantiation is sized for (accumulators per wave, zeroing passes): 6 for the SMPL shape, 8 for
+// generic skeletons of up to 128 columns, AVT_MAX_TILES (11) up to 176 columns (SMPL-H)
+template <int CJ, int CK, int MT = (CJ != 0 ? 6 : 8)>
+__global__ __launch_bounds__(256, (CJ != 0) ? 3 : (MT > 8 ? 1 : 2)) void k_eval(DeviceModel dm, FrameBuffers fb, int nframes) {
     constexpr bool FIXED = CJ != 0;
     const AvtDims d = dm.d;
     const int J = FIXED ? CJ : d.J, K = FIXED ? CK : d.K, P = 3 + 3 * J + K;
     const int NT = FIXED ? (3 + 3 * CJ + CK + 16) / 16 : d.NT, NPAIR = NT * (NT + 1) / 2;
     static_assert(!FIXED || (3 + 3 * CJ + CK + 16) / 16 == 6, "fixed-shape path is written for 6 column tiles");
     constexpr int RS = AVT_EVAL_RS;
-    constexpr int MAXPW = FIXED ? 6 : (AVT_MAX_TILES * (AVT_MAX_TILES + 1) / 2 + 3) / 4;
+    constexpr int MAXPW = FIXED ? 6 : (MT * (MT + 1) / 2 + 3) / 4;
     const int G = fb.G, t = threadIdx.x;
     const int id = blockIdx.x;
     if (id >= nframes * G) {   // trailing workgroups: pose prior of the trial point, one (frame, GMM component) each
@@ -412,21 +416,21 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm,
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = clock64(); const long long wall0 = wall_clock64();
 #endif
     // tile pairs this workgroup accumulated into: only those partial tiles are written, k_reduce reads the mask
-    unsigned long long wm = FIXED ? 0ull : ~0ull;
+    unsigned long long wm = FIXED ? 0ull : ~0ull;     // generic shapes write every pair (k_reduce treats pairs >= 64 as written)
     for (int b = g * S; b < nb; b = next_batch(b)) {
         __syncthreads();  // previous batch's MFMA reads are done (also covers the prep staging on the first pass)
         EPROBE(0);
         // ---- wave-local from here to the next barrier ------------------------------------------------------
         stage_records<NPF>(s_rec + (size_t)wv * RQ, RQ2, ln, pf);
         const int bw = __builtin_amdgcn_readfirstlane(bm_next);   // live tiles / tile pairs of this batch (k_records)
-        const int tm = (unsigned)bw >> 24, pm = bw & 0xffffff;
+        const int tm = NT > 8 ? (bw & 0xffff) : (int)((unsigned)bw >> 24), pm = bw & 0xffffff;
         if (next_batch(b) < nb) prefetch(next_batch(b));
         // zeroing passes (5 consecutive storage columns each) that touch a live tile (AvtDims::tile_zpass, avt_model.cpp)
-        int zmask = 0;
+        unsigned long long zmask = 0ull;
 #pragma unroll
-        for (int ti = 0; ti < AVT_MAX_TILES; ++ti)
+        for (int ti = 0; ti < MT; ++ti)
             if (ti < NT && ((tm >> ti) & 1)) zmask |= d.tile_zpass[ti];
-        build_rows<CJ, CK>(d, tabs, s_Jt, s_rec + (size_t)wv * RQ, s_xhat, s_xk, s_T, wv, ln, zmask);
+        build_rows<CJ, CK, MT>(d, tabs, s_Jt, s_rec + (size_t)wv * RQ, s_xhat, s_xk, s_T, wv, ln, zmask);
         EPROBE(3);
         __syncthreads();
         EPROBE(4);
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 2) void k_eval(DeviceModel dm,
 #pragma unroll
     for (int i = 0; i < MAXPW; ++i) {
         const int p = wv + 4 * i;
-        if (p < NPAIR && ((wm >> p) & 1)) {          // untouched pairs stay unwritten: k_reduce reads the mask
+        if (p < NPAIR && (p >= 64 || ((wm >> (p & 63)) & 1))) {   // untouched pairs stay unwritten: k_reduce reads the mask
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[(size_t)p * 256 + r * 64 + ln] = acc[i][r];
         }
@@ -504,7 +508,8 @@ void launch_eval(avt_ctx* c, int nframes) {
     dim3 grid((unsigned)nframes * (c->fb.G + std::max(0, d.ncomps)));
     const size_t lds = eval_lds_bytes(d);
     if (eval_fixed_shape(d)) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<24, 10>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, nframes);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<0, 0>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, nframes);
+    else if (d.NT <= 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<0, 0, 8>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, nframes);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<0, 0, AVT_MAX_TILES>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, nframes);
 }
 
 void avt_eval_report_occupancy(const AvtDims& d) {
@@ -516,5 +521,6 @@ void avt_eval_report_occupancy(const AvtDims& d) {
 int avt_eval_set_attributes() {
     // the fixed-shape kernel needs < 64 KB of dynamic LDS: leave its attribute alone (raising the cap costs residency);
     // the generic shape may need more.
-    return hipFuncSetAttribute((const void*)k_eval<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess;
+    return hipFuncSetAttribute((const void*)k_eval<0, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_eval<0, 0, AVT_MAX_TILES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess;
 }

@@ -20,7 +20,8 @@
                               // operand fetches of two k-steps into ds_read2_b64, which is banked modulo 32 in 16-lane groups - an even
                               // stride makes columns c and c+8 collide (2-way), an odd one is conflict-free (plain ds_read_b64 too)
 #define AVT_EVAL_TILE(ncols) ((((ncols) * AVT_EVAL_RS) + 1) & ~1)   // doubles of a tile of ncols columns, kept even (16-byte alignment of what follows)
-#define AVT_MAX_TILES 8       // ceil((P+1)/16) <= 8  (J<=32, K<=16)
+#define AVT_MAX_TILES 11      // ceil((P+1)/16) with P <= 175 (k_solve: one 4x4 block of the bordered system per lane of <= 1024 threads)
+#define AVT_MAX_P 175
 #define AVT_MAX_COMPS 16      // GMM components
 #define AVT_MAX_GROUPS 4      // frame groups of one optimize() running on separate streams
 #define AVT_PRIOR_STRIDE (2 + 3 * AVT_MAX_JOINTS)   // doubles per (frame, component) of prior scratch
@@ -42,7 +43,7 @@ struct AvtDims {
     int rec_quad;            // doubles per 4-point matched-point record (avt_eval.hip): 12K + 84
     int nb_max;              // eval batches a frame can have: ceil(V/16)
     int col_tr, col_shape, col_res;   // storage columns of the evaluation tile: root translation, first shape key, residual (avt_model.cpp)
-    int tile_zpass[AVT_MAX_TILES];    // per tile: the 5-column zeroing passes of build_rows that overlap its storage columns (bit = pass)
+    unsigned long long tile_zpass[AVT_MAX_TILES];   // per tile: the 5-column zeroing passes of build_rows that overlap its storage columns (bit = pass)
 };
 
 // prep block layout (doubles), one per frame per slot: what an evaluation needs about the skeleton state
@@ -61,7 +62,7 @@ __host__ __device__ inline int prep_off_off(const AvtDims& d) { return 19 * d.J 
 __host__ __device__ inline int prep_total(const AvtDims& d) { return ((19 * d.J + 3 * d.J * d.K + d.K + 3) + 7) & ~7; }
 
 // LDS scratch of k_solve's skeleton pass (avt_lm.hip): offsets in doubles; the host-built work items (DeviceModel::
-// fk_items) address it with 13-bit offsets
+// fk_items) address it with 14-bit offsets
 struct PrepLayout {
     int rot, Rw, o, jp, dv, H, Sp, S, jsr, jsrb, ident, zero, w, x0;
     int ndoubles;   // even
@@ -83,7 +84,7 @@ __host__ __device__ inline PrepLayout prep_layout(int J, int K, int xsize) {
     L.ident = o; o += 9;
     L.zero = o; o += 3;
     L.w = o; o += K;
-    L.x0 = o; o += 2 * xsize;
+    L.x0 = o;                 // (unused since round 2: both state slots are staged in their own LDS area)
     L.ndoubles = (o + 1) & ~1;
     L.nitems = J * (12 + 3 * K);
     return L;
@@ -134,7 +135,7 @@ struct DeviceModel {
     int* tile_param;      // [16*NT] tile column -> parameter index (P = residual), -1 = padding
     int* joint_col;       // [J] storage column of the joint's first rotation parameter
     int* vorder;          // [V] vertices ordered by the set of tiles their rows touch, then by id
-    unsigned char* vmask; // [V] that set (bit = tile)
+    unsigned short* vmask; // [V] that set (bit = tile)
     int* fk_items;        // [J*(12+3K)][2] per-level work items of k_solve's skeleton pass (see avt_lm.hip), grouped by level
     int* fk_level_off;    // [nlevels+1] offsets into fk_items
     double* jsr_base;     // [3J] initialJointPos
@@ -204,8 +205,8 @@ struct avt_model {
     std::vector<double> shape_planes, lbs_w, asg_w, jsr_base, jsr, S, Sp;
     std::vector<int> lbs_j, asg_j, mesh_soa, parent, main_joint, jlevel, fk_items, fk_level_off;
     std::vector<int> tile_col, tile_param, joint_col, vorder;
-    std::vector<unsigned char> anc_n, vmask;
-    std::vector<unsigned short> anc;
+    std::vector<unsigned char> anc_n;
+    std::vector<unsigned short> anc, vmask;
     std::vector<double> prior_mean, prior_prec, prior_L, prior_clog;
 };
 

@@ -11,6 +11,8 @@
 // per 4 pivots, every lane keeps its own copy of its column's diagonal block instead of reading a published one,
 // back-substitution four unknowns at a time with cross-lane v_readlane, the skeleton pass from LDS only, and no global
 // load inside any sequential loop.  -DAVT_TIMING adds s_memtime probes (tools/kernel_timing_probe.py).
+#include <algorithm>
+
 #include "avt_device.h"
 
 #ifdef AVT_TIMING
@@ -23,19 +25,19 @@
 // Skeleton pass: state x=(p,q,w) -> prep block (PrepareForEvaluation, AvatarOptimizer.cpp:283-325), LDS only.
 //   B      : double scratch laid out by prep_layout(J,K) (avt_internal.h);
 //   items  : host-built work items of the level-parallel pass, two 32-bit words each:
-//            word0 = rp | v << 13 | stride_code << 26,  word1 = add | out << 13   (offsets into B)
+//            word0 = rp | v << 14 | stride_code << 28,  word1 = add | out << 14   (offsets into B)
 //            B[out] = (B[rp] B[v] + B[rp+1] B[v+st] + B[rp+2] B[v+2st]) + B[add]
 //            which is a world-rotation entry (R(-1,pa) rot_j), a world-origin entry (o_pa + R(-1,pa)(J_j - J_pa)) or a
 //            shape-table entry (H_pa + R(-1,pa) Sp_j) depending on the offsets (:303-324); the root uses the identity.
 // prep_stage_constants() runs at kernel start (its global loads hide behind the LM decision and the factorisation),
 // prep_set_state() installs the state, prep_run() does the pass and writes the prep block.
 // -------------------------------------------------------------------------------------------------
+template <int NTH>
 __device__ __forceinline__ void prep_stage_constants(const DeviceModel& dm, const PrepLayout& L, double* __restrict__ B,
-                                                     int2* __restrict__ items, int* __restrict__ level,
-                                                     const double* __restrict__ xboth) {
+                                                     int2* __restrict__ items, int* __restrict__ level) {
     const AvtDims& d = dm.d;
     const int J = d.J, K = d.K, t = threadIdx.x;
-    for (int e = t; e < 3 * J * K; e += 256) {
+    for (int e = t; e < 3 * J * K; e += NTH) {
         B[L.Sp + e] = dm.Sp[e];
         B[L.S + e] = dm.S[e];
         B[L.jsr + e] = dm.jsr[e];
@@ -43,9 +45,8 @@ __device__ __forceinline__ void prep_stage_constants(const DeviceModel& dm, cons
     if (t < 3 * J) B[L.jsrb + t] = dm.jsr_base[t];
     if (t < 9) B[L.ident + t] = (t == 0 || t == 4 || t == 8) ? 1.0 : 0.0;
     if (t < 3) B[L.zero + t] = 0.0;
-    for (int e = t; e < 2 * d.xsize; e += 256) B[L.x0 + e] = xboth[e];
     const int2* gi = (const int2*)dm.fk_items;
-    for (int e = t; e < L.nitems; e += 256) items[e] = gi[e];
+    for (int e = t; e < L.nitems; e += NTH) items[e] = gi[e];
     if (t <= d.nlevels) level[t] = dm.fk_level_off[t];
     if (t < J) level[AVT_MAX_JOINTS + 2 + t] = dm.parent[t];     // parents follow the level offsets
 }
@@ -60,6 +61,7 @@ __device__ __forceinline__ void prep_set_state(const AvtDims& d, const PrepLayou
 }
 
 // callers: a barrier separates prep_set_state() from prep_run()
+template <int NTH>
 __device__ void prep_run(const DeviceModel& dm, const PrepLayout& L, double* __restrict__ B, const int2* __restrict__ items,
                          const int* __restrict__ level, const double* __restrict__ q, double* __restrict__ prep) {
     const AvtDims d = dm.d;
@@ -89,11 +91,11 @@ __device__ void prep_run(const DeviceModel& dm, const PrepLayout& L, double* __r
     // one tree level per barrier
     for (int lv = 0; lv < d.nlevels; ++lv) {
         const int lo = level[lv], hi = level[lv + 1];
-        for (int idx = lo + t; idx < hi; idx += 256) {
+        for (int idx = lo + t; idx < hi; idx += NTH) {
             const int2 it = items[idx];
-            const int rp = it.x & 0x1fff, v = (it.x >> 13) & 0x1fff, scode = (unsigned)it.x >> 26;
+            const int rp = it.x & 0x3fff, v = (it.x >> 14) & 0x3fff, scode = (unsigned)it.x >> 28;
             const int st = scode == 3 ? K : (scode == 2 ? 3 : scode);
-            const int add = it.y & 0x1fff, out = (unsigned)it.y >> 13;
+            const int add = it.y & 0x3fff, out = (unsigned)it.y >> 14;
             B[out] = (B[rp] * B[v] + B[rp + 1] * B[v + st] + B[rp + 2] * B[v + 2 * st]) + B[add];
         }
         __syncthreads();
@@ -102,15 +104,15 @@ __device__ void prep_run(const DeviceModel& dm, const PrepLayout& L, double* __r
     if (threadIdx.x == 0) prep[d.prep_size - 2] = (double)clock64();
 #endif
     const double off0 = B[L.jp], off1 = B[L.jp + 1], off2 = B[L.jp + 2];
-    for (int e = t; e < 9 * J; e += 256) prep[prep_off_Rw(d) + e] = B[L.Rw + e];
-    for (int e = t; e < 3 * J; e += 256) {
+    for (int e = t; e < 9 * J; e += NTH) prep[prep_off_Rw(d) + e] = B[L.Rw + e];
+    for (int e = t; e < 3 * J; e += NTH) {
         prep[prep_off_o(d) + e] = B[L.o + e];
         const int c = e % 3;
         prep[prep_off_Jh(d) + e] = B[L.jp + e] - (c == 0 ? off0 : (c == 1 ? off1 : off2));   // root at origin (:270-272)
     }
     // G[j] = H[j] - Rw[j]*S[j]  (shape block of :568-580); the index split divides by K: constant for SMPL
     auto g_table = [&](const int KK) {
-        for (int e = t; e < 3 * J * KK; e += 256) {
+        for (int e = t; e < 3 * J * KK; e += NTH) {
             const int j = e / (3 * KK), r = (e / KK) % 3, k = e % KK;
             const double* Rj = B + L.Rw + 9 * j;
             const double* S = B + L.S + j * 3 * KK;
@@ -118,7 +120,7 @@ __device__ void prep_run(const DeviceModel& dm, const PrepLayout& L, double* __r
         }
     };
     if (K == 10) g_table(10); else g_table(K);
-    for (int e = t; e < 4 * J; e += 256) prep[prep_off_q(d) + e] = q[e];
+    for (int e = t; e < 4 * J; e += NTH) prep[prep_off_q(d) + e] = q[e];
     if (t < K) prep[prep_off_w(d) + t] = B[L.w + t];
     if (t < 3) prep[prep_off_off(d) + t] = (t == 0 ? off0 : (t == 1 ? off1 : off2));
 }
@@ -146,7 +148,10 @@ __global__ __launch_bounds__(256 * Q) void k_reduce(DeviceModel dm, FrameBuffers
     const int lane = threadIdx.x & 63;
     const unsigned long long wmine = (glo + lane < ghi) ? fb.wmask[(size_t)f * G + glo + lane] : 0ull;
     unsigned long long live = ~0ull;
-    if constexpr (Q == 1) live = __ballot((int)((wmine >> blockIdx.x) & 1ull));
+    // (the mask has 64 bits; only skeletons with more than 64 tile pairs - evaluated by the generic kernel, which writes
+    // every pair - have pairs beyond it)
+    const bool masked = blockIdx.x < 64;
+    if constexpr (Q == 1) live = masked ? __ballot((int)((wmine >> (blockIdx.x & 63)) & 1ull)) : ~0ull;
     double a = 0.0;
     int g = glo;
 #define AVT_REDUCE_ROUND(NLD)                                                                        \
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256 * Q) void k_reduce(DeviceModel dm, FrameBuffers
         const int ng = ghi - glo;
 #pragma unroll
         for (int u = 0; u < 32; ++u) v[u] = (u < ng) ? __builtin_nontemporal_load(part + (size_t)(glo + u) * st) : 0.0;
-        const unsigned long long wrote = __ballot((int)((wmine >> blockIdx.x) & 1ull));
+        const unsigned long long wrote = masked ? __ballot((int)((wmine >> (blockIdx.x & 63)) & 1ull)) : ~0ull;
 #pragma unroll
         for (int u = 0; u < 32; ++u) a += ((wrote >> u) & 1ull) ? v[u] : 0.0;
         g = ghi;
@@ -213,6 +218,13 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // Lane l keeps W(P,l), W(P,l+64) and the running sums acc_l = sum_{k>i} W(k,l) delta_k in registers.  Per step the
 // four values W(P,.) - acc of the block cross the wave by v_readlane, the 4x4 triangular system is solved by every lane
 // alike, and each lane adds the block's contribution to its sums.
+// Block (pivot block kb, row block bi >= kb) of W: square storage [kb][bi] (every block addressable, the never-written ones
+// zeroed: the SMPL shape) or packed lower triangle (systems above 88 columns: the square does not fit the LDS).
+template <bool TRI>
+__device__ __forceinline__ int wblk(int kb, int bi, int NB) {
+    return TRI ? kb * NB - (kb * (kb - 1)) / 2 + (bi - kb) : kb * NB + bi;
+}
+
 template <int NBC>
 __device__ __forceinline__ void backsub_blocked(const double* __restrict__ Lblk, const double* __restrict__ s_R, int NBrt, int P, int t,
                                                 double* __restrict__ s_delta) {
@@ -268,10 +280,53 @@ __device__ __forceinline__ void backsub_blocked(const double* __restrict__ Lblk,
     }
 }
 
+// The same back substitution for the packed-triangle storage and up to 192 unknowns (three columns per lane of the wave):
+// plain loop, W(k,l) = 0 for l >= k by a select instead of by stored zeros.
+__device__ __forceinline__ void backsub_tri(const double* __restrict__ Lblk, const double* __restrict__ s_R, int NB, int P, int t,
+                                            double* __restrict__ s_delta) {
+    auto blockp = [&](int kb, int bi) { return Lblk + (size_t)wblk<true>(kb, bi, NB) * 18; };
+    double wp[3], acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { const int l = t + 64 * c; wp[c] = (l < P) ? blockp(l >> 2, P >> 2)[(P & 3) * 4 + (l & 3)] : 0.0; }
+    for (int kb = NB - 1; kb >= 0; --kb) {
+        const int base = 4 * kb;
+        const d2v* Wd = (const d2v*)blockp(kb, kb);
+        const d2v a = Wd[2], bq = Wd[4], cq = Wd[6], e = Wd[7];
+        const double w10 = a.x, w20 = bq.x, w21 = bq.y, w30 = cq.x, w31 = cq.y, w32 = e.x;
+        const d2v* Rq = (const d2v*)(s_R + base);
+        const double r0 = Rq[0].x, r1 = Rq[0].y, r2 = Rq[1].x, r3 = Rq[1].y;
+        const int own = base >> 6;                                  // which of my columns holds unknown `base`
+        const double u = (own == 0 ? wp[0] - acc[0] : (own == 1 ? wp[1] - acc[1] : wp[2] - acc[2]));
+        const double u0 = readlane_f64(u, base & 63), u1 = readlane_f64(u, (base + 1) & 63);
+        const double u2 = readlane_f64(u, (base + 2) & 63), u3 = readlane_f64(u, (base + 3) & 63);
+        const double d3 = r3 * u3;
+        const double d2 = r2 * fma(-w32, d3, u2);
+        const double d1 = r1 * fma(-w21, d2, fma(-w31, d3, u1));
+        const double d0 = r0 * fma(-w10, d1, fma(-w20, d2, fma(-w30, d3, u0)));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int l = t + 64 * c, cb = l >> 2;                  // my column l lives in pivot block cb; rows of block kb matter if kb > cb
+            if (l < P && kb > cb) {
+                const double* bp = blockp(cb, kb) + (l & 3);
+                acc[c] += fma(bp[0], d0, bp[4] * d1) + fma(bp[8], d2, bp[12] * d3);
+            } else if (l < P && kb == cb) {                          // inside the diagonal block: strictly lower part only
+                const double* bp = blockp(cb, cb) + (l & 3);
+                const int li = l & 3;
+                acc[c] += (li < 1 ? bp[4] * d1 : 0.0) + (li < 2 ? bp[8] * d2 : 0.0) + (li < 3 ? bp[12] * d3 : 0.0);
+            }
+        }
+        if (t == 0) { d2v* o = (d2v*)(s_delta + base); o[0] = (d2v){d0, d1}; o[1] = (d2v){d2, d3}; }
+    }
+}
+
 // =================================================================================================
-// k_solve.  grid (nframes), block 256.
+// k_solve<NTH, TRI>.  grid (nframes), block NTH.  <256, false>: systems of up to 88 columns (SMPL: 86), one 4x4 block per
+// lane of 256 threads, the factor in a square LDS array whose unused blocks read as zeros.  <1024, true>: up to 176 columns
+// (SMPL-H: 170): the same algorithm on 16 waves, the factor as a packed lower triangle (990 blocks = 139 KB), the skeleton
+// scratch overlaid on it once the back substitution is done.
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, int mode) {
+template <int NTH, bool TRI>
+__global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb, int mode) {
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, P = d.P, HS = d.HS;
     const int f = blockIdx.x + fb.f0, t = threadIdx.x;
@@ -282,11 +337,14 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
     // block is 16 doubles + 2 of padding (144 B), so lanes reading different blocks spread over the LDS banks; row P
     // carries L^-1 rhs
     double* Lblk = (double*)smem;
-    double* s_W = Lblk + (size_t)NBk * NBk * 18;            // [2][NB][18]  scratch: reciprocal pivots, later the new quaternions
-    double* s_D = s_W + 2 * (size_t)NBk * 18;               // [2][18]   diagonal block of the next panel column (double-buffered)
-    double* s_delta = s_D + 36;                             // [HS]
+    const size_t nblk = TRI ? (size_t)NBk * (NBk + 1) / 2 : (size_t)NBk * NBk;
+    double* s_W = Lblk + nblk * 18;                         // [max(HS, 4J) + 2]  reciprocal pivots, later the new quaternions
+    double* s_delta = s_W + ((max(HS, 4 * J) + 3) & ~1);    // [HS]
+    double* s_x = s_delta + HS + 2;                         // [2][xsize] both state slots
     const PrepLayout L = prep_layout(J, K, d.xsize);
-    double* B = s_delta + HS + 2;                           // skeleton scratch (+ both state slots)
+    // skeleton scratch: behind the factor (SMPL shape: staged at kernel start, hidden behind the factorisation) or ON it
+    // (triangular shape: the factor is dead once the back substitution is done)
+    double* B = TRI ? Lblk : s_x + ((2 * d.xsize + 1) & ~1);
     int2* s_items = (int2*)(B + L.ndoubles);
     int* s_level = (int*)(s_items + L.nitems);
     __shared__ int s_failf[2];
@@ -294,11 +352,12 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
     double* x0 = fb.x + ((size_t)f * 2) * xs;
     double* prep0 = fb.prep + ((size_t)f * 2) * d.prep_size;
 
-    // everything that does not depend on the LM decision is requested now: skeleton constants and both state slots
-    prep_stage_constants(dm, L, B, s_items, s_level, x0);
-    if (mode != SOLVE_INIT && mode != SOLVE_LAST) {   // the never-written blocks of the factor must read as zeros (back substitution)
+    // everything that does not depend on the LM decision is requested now: both state slots and the skeleton constants
+    for (int e = t; e < 2 * xs; e += NTH) s_x[e] = x0[e];
+    if (!TRI || mode == SOLVE_INIT) prep_stage_constants<NTH>(dm, L, B, s_items, s_level);
+    if (!TRI && mode != SOLVE_INIT && mode != SOLVE_LAST) {   // the never-written blocks of the factor must read as zeros (back substitution)
         d2v* z = (d2v*)Lblk;
-        for (int e = t; e < NBk * NBk * 9; e += 256) z[e] = (d2v){0.0, 0.0};
+        for (int e = t; e < NBk * NBk * 9; e += NTH) z[e] = (d2v){0.0, 0.0};
     }
 
     if (mode == SOLVE_INIT) {
@@ -311,11 +370,11 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
         }
         __syncthreads();
         if (t == 0) { ctl.cost_const = 0.5 * a; ctl.try_valid = 1; }
-        const double* xc = B + L.x0 + cur * xs;
-        for (int e = t; e < xs; e += 256) x0[(size_t)tr * xs + e] = xc[e];
+        const double* xc = s_x + cur * xs;
+        for (int e = t; e < xs; e += NTH) x0[(size_t)tr * xs + e] = xc[e];
         prep_set_state(d, L, B, xc + 3, xc + 3 + 4 * J, xc);
         __syncthreads();
-        prep_run(dm, L, B, s_items, s_level, xc + 3, prep0 + (size_t)tr * d.prep_size);
+        prep_run<NTH>(dm, L, B, s_items, s_level, xc + 3, prep0 + (size_t)tr * d.prep_size);
         return;
     }
     TPROBE(0);
@@ -331,16 +390,20 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
         bi = r0; bj = rem;
     }
     const double* H0 = fb.Hraw + ((size_t)f * 2) * HS * HS;
-    d2v hraw[2][4][2], hdiag[2][4][2];       // my block, and the diagonal block of my block column
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl)
+    // my block, and the diagonal block of my block column: of BOTH slots, requested before the decision (SMPL shape) - or of
+    // the chosen slot only, after it (1024-thread shape: 128 registers per lane)
+    constexpr int NSL = TRI ? 1 : 2;
+    d2v hraw[NSL][4][2], hdiag[NSL][4][2];
+    auto load_blocks = [&](int slot, int into) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const d2v* src = (const d2v*)(H0 + (size_t)sl * HS * HS + (size_t)(4 * max(bi, 0) + r) * HS + 4 * max(bj, 0));
-            hraw[sl][r][0] = src[0]; hraw[sl][r][1] = src[1];
-            const d2v* srd = (const d2v*)(H0 + (size_t)sl * HS * HS + (size_t)(4 * max(bj, 0) + r) * HS + 4 * max(bj, 0));
-            hdiag[sl][r][0] = srd[0]; hdiag[sl][r][1] = srd[1];
+            const d2v* src = (const d2v*)(H0 + (size_t)slot * HS * HS + (size_t)(4 * max(bi, 0) + r) * HS + 4 * max(bj, 0));
+            hraw[into][r][0] = src[0]; hraw[into][r][1] = src[1];
+            const d2v* srd = (const d2v*)(H0 + (size_t)slot * HS * HS + (size_t)(4 * max(bj, 0) + r) * HS + 4 * max(bj, 0));
+            hdiag[into][r][0] = srd[0]; hdiag[into][r][1] = srd[1];
         }
+    };
+    if constexpr (!TRI) { load_blocks(0, 0); load_blocks(1, 1); }
     const double hpp0 = H0[(size_t)P * HS + P], hpp1 = H0[(size_t)HS * HS + (size_t)P * HS + P];
     const double lm_up = fb.params->lm_up, lm_down = fb.params->lm_down, lm_min = fb.params->lm_min, lm_max = fb.params->lm_max;   // same round trip
     const int cur0 = ctl.cur_slot, try_valid = ctl.try_valid, comp_cur0 = ctl.comp_cur;
@@ -364,7 +427,7 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
     }
     __syncthreads();   // the staged state slots are visible; every lane has read the control block
     const int try0 = 1 - cur0;
-    const double* xt = B + L.x0 + try0 * xs;
+    const double* xt = s_x + try0 * xs;
     double cost = 0.5 * (try0 ? hpp1 : hpp0) + cost_const;
     int comp_try = -1;
     if (sbp > 0.0 && d.ncomps > 0) {
@@ -402,7 +465,7 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
 
     // ---- b. the damped system of the current point, straight into registers (second, short round trip: the
     // precision block and gradient of the chosen GMM component, read-only data) ------------------------------
-    const double* xc = B + L.x0 + cur * xs;
+    const double* xc = s_x + cur * xs;
     const double* pri = fb.prior + (((size_t)f * 2 + cur) * AVT_MAX_COMPS + (comp >= 0 ? comp : 0)) * AVT_PRIOR_STRIDE;
     const bool use_pose = sbp > 0.0 && d.ncomps > 0 && comp >= 0;
     const int n = d.ndims;
@@ -419,7 +482,8 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
         gq[c] = use_pose ? pri[2 + pc] : 0.0;
         xq[c] = xc[3 + 4 * J + sk];
     }
-    auto assemble = [&](int rb, const d2v (&h)[2][4][2], double (&out)[4][4]) {
+    if constexpr (TRI) load_blocks(cur, 0);
+    auto assemble = [&](int rb, const d2v (&h)[NSL][4][2], double (&out)[4][4]) {
         double prv[4][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -435,7 +499,7 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int row = 4 * rb + r, col = 4 * bj + c;
-                const d2v hv = cur ? h[1][r][c >> 1] : h[0][r][c >> 1];
+                const d2v hv = (!TRI && cur) ? h[NSL - 1][r][c >> 1] : h[0][r][c >> 1];
                 double v = (c & 1) ? hv.y : hv.x;
                 const int pc = col - 6, sk = col - (3 + 3 * J), pr_ = row - 6;
                 const bool in_pose_c = use_pose && pc >= 0 && pc < n;
@@ -494,7 +558,7 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
             const bool real1 = 4 * kb + 1 < P, real2 = 4 * kb + 2 < P, real3 = 4 * kb + 3 < P;   // 4*kb < P always
             const int bad = (int)!(P0 > 0.0) | ((int)real1 & (int)!(P1 > 0.0)) | ((int)real2 & (int)!(P2 > 0.0)) | ((int)real3 & (int)!(P3 > 0.0));
             if (bad) s_failf[kb & 1] = 1;
-            d2v* Wo = (d2v*)(Lblk + ((size_t)kb * NB + bi) * 18);
+            d2v* Wo = (d2v*)(Lblk + (size_t)wblk<TRI>(kb, bi, NB) * 18);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double w0 = a4[r][0];
@@ -513,8 +577,8 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
         }
         __syncthreads();                                    // W and 1/d of pivot block kb are visible
         if (bj > kb) {
-            const d2v* Wi = (const d2v*)(Lblk + ((size_t)kb * NB + bi) * 18);
-            const d2v* Wj = (const d2v*)(Lblk + ((size_t)kb * NB + bj) * 18);
+            const d2v* Wi = (const d2v*)(Lblk + (size_t)wblk<TRI>(kb, bi, NB) * 18);
+            const d2v* Wj = (const d2v*)(Lblk + (size_t)wblk<TRI>(kb, bj, NB) * 18);
             const d2v* Rq = (const d2v*)(s_R + 4 * kb);
             d2v wv[4][2], wj[4][2], lv[4][2];
             // column-block operands first: the diagonal copy and its factorisation are the critical chain
@@ -561,10 +625,15 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
     if (ok) {
         // ---- back substitution by wave 0 (the other waves wait at the barrier)
         if (t < 64) {
-            if (NB == 22) backsub_blocked<22>(Lblk, s_R, NB, P, t, s_delta);
+            if constexpr (TRI) backsub_tri(Lblk, s_R, NB, P, t, s_delta);
+            else if (NB == 22) backsub_blocked<22>(Lblk, s_R, NB, P, t, s_delta);
             else backsub_blocked<0>(Lblk, s_R, NB, P, t, s_delta);
         }
         __syncthreads();
+        if constexpr (TRI) {   // the factor is dead: the skeleton constants take its place
+            prep_stage_constants<NTH>(dm, L, B, s_items, s_level);
+            __syncthreads();
+        }
         TPROBE(4);
         // retraction (FakeQuaternionParameterization::Plus, :123-143): the new trial point goes to global memory for
         // the kernels that follow and straight into the skeleton scratch
@@ -592,8 +661,9 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
             for (int e = 0; e < 4; ++e) { qn[e] = qo[e]; qs[e] = qo[e]; }
         }
     } else {
-        for (int e = t; e < xs; e += 256) xn[e] = xc[e];
-        for (int e = t; e < 4 * J; e += 256) s_qnew[e] = xc[3 + e];
+        for (int e = t; e < xs; e += NTH) xn[e] = xc[e];
+        for (int e = t; e < 4 * J; e += NTH) s_qnew[e] = xc[3 + e];
+        if constexpr (TRI) { __syncthreads(); prep_stage_constants<NTH>(dm, L, B, s_items, s_level); __syncthreads(); }
         prep_set_state(d, L, B, xc + 3, xc + 3 + 4 * J, xc);
         lambda = fmin(lambda * lm_up, lm_max);
     }
@@ -601,7 +671,7 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
     __syncthreads();
     TPROBE(5);
     // ---- d. skeleton tables of the new trial point ----------------------------------------------------
-    prep_run(dm, L, B, s_items, s_level, s_qnew, prep0 + (size_t)ntry * d.prep_size);
+    prep_run<NTH>(dm, L, B, s_items, s_level, s_qnew, prep0 + (size_t)ntry * d.prep_size);
     TPROBE(6);
 #ifdef AVT_TIMING
     __syncthreads();
@@ -609,10 +679,16 @@ __global__ __launch_bounds__(256) void k_solve(DeviceModel dm, FrameBuffers fb, 
 #endif
 }
 
+static bool solve_big(const AvtDims& d) { return d.HS / 4 > 22; }      // more than 253 blocks: the 1024-thread triangular shape
+
 static size_t solve_lds_bytes(const AvtDims& d) {
     const int HS = d.HS, NB = HS / 4;
     const PrepLayout L = prep_layout(d.J, d.K, d.xsize);
-    return sizeof(double) * ((size_t)NB * NB * 18 + 2 * (size_t)NB * 18 + 36 + HS + 2 + L.ndoubles) + sizeof(int) * (2 * (size_t)L.nitems + 2 * AVT_MAX_JOINTS + 4) + 64;
+    const size_t nblk = solve_big(d) ? (size_t)NB * (NB + 1) / 2 : (size_t)NB * NB;
+    const size_t prep_bytes = sizeof(double) * (size_t)L.ndoubles + sizeof(int) * (2 * (size_t)L.nitems + 2 * AVT_MAX_JOINTS + 4);
+    const size_t fixed = sizeof(double) * (((std::max(HS, 4 * d.J) + 3) & ~1) + HS + 2 + ((2 * d.xsize + 1) & ~1));
+    const size_t factor = sizeof(double) * nblk * 18;
+    return (solve_big(d) ? std::max(factor, prep_bytes) + fixed : factor + fixed + prep_bytes) + 64;
 }
 
 void launch_reduce(avt_ctx* c, int nframes) {
@@ -623,9 +699,11 @@ void launch_reduce(avt_ctx* c, int nframes) {
 
 void launch_solve(avt_ctx* c, int nframes, int mode) {
     const AvtDims& d = c->dm.d;
-    hipLaunchKernelGGL(k_solve, dim3(nframes), dim3(256), solve_lds_bytes(d), c->cur_stream, c->dm, c->fb, mode);
+    if (solve_big(d)) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<1024, true>), dim3(nframes), dim3(1024), solve_lds_bytes(d), c->cur_stream, c->dm, c->fb, mode);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256, false>), dim3(nframes), dim3(256), solve_lds_bytes(d), c->cur_stream, c->dm, c->fb, mode);
 }
 
 int avt_solve_set_attributes() {
-    return hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess;
+    return hipFuncSetAttribute((const void*)k_solve<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_solve<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess;
 }

@@ -59,7 +59,7 @@ static void build_tile_layout(avt_model* m, const int* parent) {
         for (int j = 0; j < J; ++j) m->joint_col[j] = 3 + 3 * j;
         d.col_tr = 0; d.col_shape = 3 + 3 * J; d.col_res = P;
         m->vorder.resize(V); std::iota(m->vorder.begin(), m->vorder.end(), 0);
-        m->vmask.assign(V, (unsigned char)((1u << NT) - 1));
+        m->vmask.assign(V, (unsigned short)((1u << NT) - 1));
     };
     if (6 + K > 16 || NT > 8) { plain(); return; }
     std::vector<std::vector<int>> children(J), groups;
@@ -89,10 +89,10 @@ static void build_tile_layout(avt_model* m, const int* parent) {
     for (size_t gi = 0; gi < groups.size(); ++gi)
         for (int j : groups[gi]) tile_of[j] = (int)gi + 1;
     // tiles a vertex touches (without the residual's tile), from its ancestor list
-    std::vector<unsigned char> vm(V, 1);
+    std::vector<unsigned short> vm(V, 1);
     std::vector<int> touched(NT, 0);
     for (int v = 0; v < V; ++v) {
-        for (int a = 0; a < m->anc_n[v]; ++a) vm[v] |= (unsigned char)(1u << tile_of[m->anc[(size_t)a * V + v] & 0xff]);
+        for (int a = 0; a < m->anc_n[v]; ++a) vm[v] |= (unsigned short)(1u << tile_of[m->anc[(size_t)a * V + v] & 0xff]);
         for (int ti = 0; ti < NT; ++ti) touched[ti] += (vm[v] >> ti) & 1;
     }
     int res_tile = 0;
@@ -120,7 +120,7 @@ static void build_tile_layout(avt_model* m, const int* parent) {
         if (res_tile == (int)gi + 1) d.col_res = put((int)gi + 1, fill, P);
     }
     m->vmask.resize(V);
-    for (int v = 0; v < V; ++v) m->vmask[v] = (unsigned char)(vm[v] | (1u << res_tile));
+    for (int v = 0; v < V; ++v) m->vmask[v] = (unsigned short)(vm[v] | (1u << res_tile));
     m->vorder.resize(V); std::iota(m->vorder.begin(), m->vorder.end(), 0);
     std::stable_sort(m->vorder.begin(), m->vorder.end(), [&](int a, int b) { return m->vmask[a] < m->vmask[b]; });
 }
@@ -129,11 +129,11 @@ extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
     if (!desc || !out) { avt_set_error("avt_model_create: null argument"); return 1; }
     const int V = desc->num_points, J = desc->num_joints, K = desc->num_shape_keys, F = desc->num_faces;
     if (V <= 0 || J <= 0 || J > AVT_MAX_JOINTS || K < 0 || K > AVT_MAX_SHAPE || F < 0) {
-        avt_set_error("avt_model_create: unsupported dimensions (J<=32, K<=16)");
+        avt_set_error("avt_model_create: unsupported dimensions (J<=64, K<=16)");
         return 1;
     }
-    if (3 + 3 * J + K > 87) {  // the register-blocked LDL^T of k_solve maps one 4x4 block per lane of a 256-thread workgroup
-        avt_set_error("avt_model_create: 3+3J+K must be <= 87 in this build (SMPL: 85)");
+    if (3 + 3 * J + K > AVT_MAX_P) {  // k_solve maps one 4x4 block of the bordered system per lane: 256 threads up to P = 87, 1024 up to 175
+        avt_set_error("avt_model_create: 3+3J+K must be <= 175 in this build (SMPL: 85, SMPL-H: 169)");
         return 1;
     }
     if (desc->parent[0] != -1) { avt_set_error("avt_model_create: parent[0] must be -1 (AvatarModel.cpp:41)"); return 1; }
@@ -158,10 +158,10 @@ extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
     // entries, 3 world-origin entries and 3K shape-table entries, each one B[out] = B[rp..rp+2] . B[v, v+st, v+2st] + B[add]
     {
         const PrepLayout L = prep_layout(J, K, d.xsize);
-        if (L.ndoubles >= 8192) { delete m; avt_set_error("avt_model_create: skeleton scratch exceeds the 13-bit item offsets"); return 1; }
+        if (L.ndoubles >= 16384) { delete m; avt_set_error("avt_model_create: skeleton scratch exceeds the 14-bit item offsets"); return 1; }
         auto item = [&](int rp, int v, int scode, int add, int out) {
-            m->fk_items.push_back(rp | (v << 13) | (scode << 26));
-            m->fk_items.push_back(add | (out << 13));
+            m->fk_items.push_back(rp | (v << 14) | (scode << 28));
+            m->fk_items.push_back(add | (out << 14));
         };
         m->fk_level_off.assign(d.nlevels + 1, 0);
         for (int lv = 0; lv < d.nlevels; ++lv) {
@@ -246,7 +246,7 @@ extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
     m->anc.assign((size_t)AVT_ANC_MAX * V, 0);
     int anc_max = 0;
     for (int v = 0; v < V; ++v) {
-        unsigned mask[AVT_MAX_JOINTS] = {0};
+        unsigned mask[AVT_MAX_JOINTS] = {0};     // per joint: which of the <= 4 assigned joints lie under it
         for (size_t a = 0; a < assigned[v].size(); ++a)
             for (int j = assigned[v][a].second; j != -1; j = desc->parent[j]) mask[j] |= 1u << a;
         int n = 0;
@@ -265,7 +265,7 @@ extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
         int lo = d.P + 1, hi = -1;
         if (ti < d.NT)
             for (int i = 0; i < 16; ++i) { const int c = m->tile_col[ti * 16 + i]; if (c <= d.P) { lo = std::min(lo, c); hi = std::max(hi, c); } }
-        d.tile_zpass[ti] = hi >= lo ? (int)(((2u << (hi / 5)) - 1u) & ~((1u << (lo / 5)) - 1u)) : 0;
+        d.tile_zpass[ti] = hi >= lo ? (((2ull << (hi / 5)) - 1ull) & ~((1ull << (lo / 5)) - 1ull)) : 0ull;
     }
 
     // mesh SoA
@@ -378,7 +378,7 @@ extern "C" const char* avt_kernel_name(int k) {
     return (k >= 0 && k < AVT_K_COUNT) ? names[k] : "?";
 }
 
-extern "C" int avt_model_tile_layout(const avt_model* m, int* ntiles, int* tile_param, unsigned char* vertex_tiles, int* vertex_order) {
+extern "C" int avt_model_tile_layout(const avt_model* m, int* ntiles, int* tile_param, unsigned short* vertex_tiles, int* vertex_order) {
     if (!m) { avt_set_error("avt_model_tile_layout: null model"); return 1; }
     if (ntiles) *ntiles = m->d.NT;
     if (tile_param) std::copy(m->tile_param.begin(), m->tile_param.end(), tile_param);

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AVT_MAX_JOINTS 32   /* SMPL: 24 */
+#define AVT_MAX_JOINTS 64   /* SMPL: 24, SMPL-H: 52; additionally 3 + 3J + K <= 175 (avt_model_create) */
 #define AVT_MAX_SHAPE 16    /* SMPL: 10 */
 #define AVT_MAX_ASSIGN 4    /* AvatarOptimizer.cpp:164 MAX_ASSIGN */
 #define AVT_MAX_PARTS 64
@@ -118,7 +118,7 @@ int avt_model_joint_regression(const avt_model* m, double* initial_joint_pos_3xJ
  * AvatarOptimizer.cpp:620-629): `tile_param[16*ntiles]` = parameter index of every tile column (P = residual, -1 = padding),
  * `vertex_tiles[V]` = bit mask of the 16-column tiles a vertex's residual rows touch, `vertex_order[V]` = the order in which
  * matched vertices are batched (by tile set, then id).  Any pointer may be NULL; *ntiles = ceil((P+1)/16). */
-int avt_model_tile_layout(const avt_model* m, int* ntiles, int* tile_param, unsigned char* vertex_tiles, int* vertex_order);
+int avt_model_tile_layout(const avt_model* m, int* ntiles, int* tile_param, unsigned short* vertex_tiles, int* vertex_order);
 
 /* ---- context: one HIP device + stream + persistent buffers.  `part_map` (>= J entries) and `num_parts`
  * are the AvatarOptimizer ctor arguments (AvatarOptimizer.h:14, AvatarOptimizer.cpp:1213-1244). */

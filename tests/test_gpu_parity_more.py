@@ -97,7 +97,7 @@ def test_model_with_twelve_shape_keys_keeps_the_plain_column_order(smpl):
     m2["shapedirs"] = np.ascontiguousarray(np.concatenate([smpl["shapedirs"], extra], axis=2))
     gm, om = api.AvatarModel(m2), orc.OracleModel(m2)
     lib = capi.load_library()
-    nt = ctypes.c_int(); tp = np.zeros(16 * 8, np.int32)
+    nt = ctypes.c_int(); tp = np.zeros(16 * 11, np.int32)
     assert lib.avt_model_tile_layout(gm.h, ctypes.byref(nt), capi.iptr(tp), None, None) == 0
     assert nt.value == 6 and np.array_equal(tp[:88], np.arange(88)) and np.all(tp[88:96] == -1)
     fr = synth.make_frame(smpl, 18)

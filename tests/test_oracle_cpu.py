@@ -298,8 +298,8 @@ def test_tile_layout_of_the_evaluation_kernel(smpl):
     V, J, K = arr.V, 24, 10
     P = 3 + 3 * J + K
     nt = ctypes.c_int()
-    tp = np.full(16 * 8, -7, np.int32); vt = np.zeros(V, np.uint8); vo = np.zeros(V, np.int32)
-    assert lib.avt_model_tile_layout(h, ctypes.byref(nt), capi.iptr(tp), vt.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), capi.iptr(vo)) == 0
+    tp = np.full(16 * 11, -7, np.int32); vt = np.zeros(V, np.uint16); vo = np.zeros(V, np.int32)
+    assert lib.avt_model_tile_layout(h, ctypes.byref(nt), capi.iptr(tp), vt.ctypes.data_as(ctypes.POINTER(ctypes.c_ushort)), capi.iptr(vo)) == 0
     NT = nt.value
     assert NT == (P + 1 + 15) // 16 == 6
     tp = tp[:16 * NT]
