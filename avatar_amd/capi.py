@@ -18,7 +18,7 @@ c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
 c_ubyte_p = C.POINTER(C.c_ubyte)
 
-AVT_K_NAMES = ["lbs", "visibility", "bucket", "nn", "aggregate", "prepare", "eval", "reduce", "solve"]
+AVT_K_NAMES = ["lbs", "visibility", "bucket", "nn", "aggregate", "prepare", "eval", "reduce", "solve", "decide"]
 AVT_K_COUNT = len(AVT_K_NAMES)
 
 

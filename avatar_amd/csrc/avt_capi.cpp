@@ -114,7 +114,7 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
             { ProfScope ps(c, AVT_K_EVAL); launch_eval(c, nf); }
             { ProfScope ps(c, AVT_K_REDUCE); launch_reduce(c, nf); }
         }
-        if (o->max_iters_per_icp > 0) { ProfScope ps(c, AVT_K_SOLVE); launch_solve(c, nf, SOLVE_LAST); }
+        if (o->max_iters_per_icp > 0) { ProfScope ps(c, AVT_K_DECIDE); launch_solve(c, nf, SOLVE_LAST); }
         { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 1, vis_init); }   // :1494-1497
         c->ran_icp_iters++;
     }

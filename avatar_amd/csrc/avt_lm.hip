@@ -325,8 +325,11 @@ __device__ __forceinline__ void backsub_tri(const double* __restrict__ Lblk, con
 // (SMPL-H: 170): the same algorithm on 16 waves, the factor as a packed lower triangle (990 blocks = 139 KB), the skeleton
 // scratch overlaid on it once the back substitution is done.
 // =================================================================================================
-template <int NTH, bool TRI>
-__global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb, int mode) {
+// MODE (SOLVE_INIT / FIRST / NORMAL / LAST) is a template parameter so that the four roles are four symbols in a kernel trace
+// (their durations differ six-fold) and the short ones do not carry the factorisation's code.
+template <int NTH, bool TRI, int MODE>
+__global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) {
+    constexpr int mode = MODE;
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, P = d.P, HS = d.HS;
     const int f = blockIdx.x + fb.f0, t = threadIdx.x;
@@ -697,13 +700,29 @@ void launch_reduce(avt_ctx* c, int nframes) {
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<1>), dim3(d.NPAIR, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
 }
 
-void launch_solve(avt_ctx* c, int nframes, int mode) {
-    const AvtDims& d = c->dm.d;
-    if (solve_big(d)) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<1024, true>), dim3(nframes), dim3(1024), solve_lds_bytes(d), c->cur_stream, c->dm, c->fb, mode);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256, false>), dim3(nframes), dim3(256), solve_lds_bytes(d), c->cur_stream, c->dm, c->fb, mode);
+template <int NTH, bool TRI>
+static void launch_solve_shape(avt_ctx* c, int nframes, int mode, size_t lds) {
+    switch (mode) {
+        case SOLVE_INIT: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<NTH, TRI, SOLVE_INIT>), dim3(nframes), dim3(NTH), lds, c->cur_stream, c->dm, c->fb); break;
+        case SOLVE_FIRST: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<NTH, TRI, SOLVE_FIRST>), dim3(nframes), dim3(NTH), lds, c->cur_stream, c->dm, c->fb); break;
+        case SOLVE_LAST: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<NTH, TRI, SOLVE_LAST>), dim3(nframes), dim3(NTH), lds, c->cur_stream, c->dm, c->fb); break;
+        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<NTH, TRI, SOLVE_NORMAL>), dim3(nframes), dim3(NTH), lds, c->cur_stream, c->dm, c->fb); break;
+    }
 }
 
-int avt_solve_set_attributes() {
-    return hipFuncSetAttribute((const void*)k_solve<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess ||
-           hipFuncSetAttribute((const void*)k_solve<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess;
+void launch_solve(avt_ctx* c, int nframes, int mode) {
+    const AvtDims& d = c->dm.d;
+    if (solve_big(d)) launch_solve_shape<1024, true>(c, nframes, mode, solve_lds_bytes(d));
+    else launch_solve_shape<256, false>(c, nframes, mode, solve_lds_bytes(d));
 }
+
+template <int NTH, bool TRI>
+static int solve_attr() {
+    const int cap = 160 * 1024 - 512;
+    return hipFuncSetAttribute((const void*)k_solve<NTH, TRI, SOLVE_INIT>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_solve<NTH, TRI, SOLVE_FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_solve<NTH, TRI, SOLVE_NORMAL>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_solve<NTH, TRI, SOLVE_LAST>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess;
+}
+
+int avt_solve_set_attributes() { return solve_attr<256, false>() || solve_attr<1024, true>(); }

@@ -39,7 +39,7 @@ LIMITER = {
     "reduce": "L2 round trips (partial tiles live in L2/MALL)",
     "nn": "fp64 VALU (8 flop per candidate) with LDS broadcast reads",
     "lbs": "HBM/L2 streaming of the shape planes", "bucket": "LDS + global atomics", "visibility": "launch latency",
-    "aggregate": "launch latency / gathers", "prepare": "latency (skeleton pass)",
+    "aggregate": "launch latency / gathers", "prepare": "latency (skeleton pass)", "decide": "launch latency",
 }
 
 
@@ -48,7 +48,7 @@ def algorithmic_bytes_per_gn_iter(N, V, K, P):
     return 24 * N + 4 * N + 24 * V * (K + 1) + 48 * V + 24 * V + 8 * P * (P + 1)
 
 
-KERNEL_SYMBOL = {"eval": "k_eval", "solve": "k_solve", "reduce": "k_reduce", "nn": "k_nn", "lbs": "k_lbs"}   # symbol-name fragments
+KERNEL_SYMBOL = {"eval": "k_eval", "solve": "ELi2EEv11DeviceModel", "reduce": "k_reduce", "nn": "k_nn", "lbs": "k_lbs"}   # symbol-name fragments (solve: k_solve<.., SOLVE_NORMAL>)
 
 
 def pmc_traffic(frames_per_launch, kernel_class):

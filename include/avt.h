@@ -94,7 +94,7 @@ typedef struct avt_stats {
 /* Per-kernel-class device timings (ms, HIP events on the context's stream) accumulated between
  * avt_profile_begin / avt_profile_end.  Profiling inserts event records around every launch. */
 enum { AVT_K_LBS = 0, AVT_K_VISIBILITY, AVT_K_BUCKET, AVT_K_NN, AVT_K_AGGREGATE, AVT_K_PREPARE,
-       AVT_K_EVAL, AVT_K_REDUCE, AVT_K_SOLVE, AVT_K_COUNT };
+       AVT_K_EVAL, AVT_K_REDUCE, AVT_K_SOLVE /* the full LM solves */, AVT_K_DECIDE /* the closing accept/reject */, AVT_K_COUNT };
 typedef struct avt_profile {
     double ms[AVT_K_COUNT];
     int launches[AVT_K_COUNT];

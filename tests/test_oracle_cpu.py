@@ -260,7 +260,7 @@ def test_abi_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(capi.Options) == 8 * 2 + 4 * 6 + 8 * 5
     assert ctypes.sizeof(capi.Stats) == 8 * 3 + 4 * 4
-    assert ctypes.sizeof(capi.Profile) == 8 * capi.AVT_K_COUNT + 4 * capi.AVT_K_COUNT + 4
+    assert ctypes.sizeof(capi.Profile) == (12 * capi.AVT_K_COUNT + 7) // 8 * 8          # doubles, ints, tail padding to 8
 
 
 def test_model_create_host_side(smpl, omodel):
