@@ -69,19 +69,20 @@ __global__ __launch_bounds__(256) void k_records(DeviceModel dm, FrameBuffers fb
     const int M = fb.ctl[f].M;
     if (b * AVT_EVAL_PTS >= M) return;
     const int wv = t >> 6, ln = t & 63;
-    const int ND = 3 * K + 11, RQ = d.rec_quad;
+    const int ND = 3 * K + 11, RQ = d.rec_quad, RV = RQ >> 2;
     double* R = fb.rec + (((size_t)f * d.nb_max + b) * 4 + wv) * RQ;
+    // everything but the mean data point and sqrt(count) is a property of the vertex: copied from its contiguous static record
+    // (DeviceModel::vrec; lanes of one point read consecutive doubles)
     for (int e = ln; e < ND * 4; e += 64) {
         const int field = e >> 2, pos = b * AVT_EVAL_PTS + wv * 4 + (e & 3);
         double v = 0.0;
         if (pos < M) {
             const int m = fb.matched[(size_t)f * V + pos];
-            if (field < 3 * (K + 1)) v = dm.shape_planes[(size_t)field * V + m];
-            else if (field < 3 * K + 6) {       // mean data point of the vertex (AvatarOptimizer.cpp:1419-1431), from the NN kernel's fixed-point sums
+            if (field >= 3 * (K + 1) && field < 3 * K + 6) {   // mean data point of the vertex (AvatarOptimizer.cpp:1419-1431), from the NN kernel's fixed-point sums
                 const int k = field - 3 * (K + 1);
                 v = fb.ctl[f].centre[k] + ((double)fb.fsum[((size_t)f * 3 + k) * V + m] / AVT_FIX_SCALE) / (double)fb.cnt[(size_t)f * V + m];
             } else if (field == 3 * K + 6) v = sqrt((double)fb.cnt[(size_t)f * V + m]);
-            else v = dm.asg_w[(size_t)(field - (3 * K + 7)) * V + m];
+            else v = dm.vrec[(size_t)m * RV + field];
         }
         R[e] = v;
     }
@@ -91,11 +92,7 @@ __global__ __launch_bounds__(256) void k_records(DeviceModel dm, FrameBuffers fb
         int v = 0;
         if (pos < M) {
             const int m = fb.matched[(size_t)f * V + pos];
-            if (ifield < 4) v = dm.asg_j[(size_t)ifield * V + m];
-            else if (ifield - 4 < (int)dm.anc_n[m]) {
-                v = (int)dm.anc[(size_t)(ifield - 4) * V + m];
-                v |= ((dm.parent[v & 0xff] + 1) << 16) | (dm.joint_col[v & 0xff] << 24);
-            }
+            v = ((const int*)(dm.vrec + (size_t)m * RV + ND))[ifield];
         }
         RI[e] = v;
     }

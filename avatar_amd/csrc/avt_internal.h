@@ -136,6 +136,9 @@ struct DeviceModel {
     int* joint_col;       // [J] storage column of the joint's first rotation parameter
     int* vorder;          // [V] vertices ordered by the set of tiles their rows touch, then by id
     unsigned short* vmask; // [V] that set (bit = tile)
+    // the state-independent part of a matched point's record, one contiguous block per vertex (what k_records gathers: 33 shape-plane
+    // values, 4 weights, 4 joints and 16 ancestor words would otherwise be 57 scattered 8-byte reads per matched point)
+    double* vrec;         // [V][rec_quad / 4] = record fields of the vertex, the mean-data-point and sqrt(count) fields zero
     int* fk_items;        // [J*(12+3K)][2] per-level work items of k_solve's skeleton pass (see avt_lm.hip), grouped by level
     int* fk_level_off;    // [nlevels+1] offsets into fk_items
     double* jsr_base;     // [3J] initialJointPos
@@ -202,7 +205,7 @@ struct FrameBuffers {
 struct avt_model {
     AvtDims d;
     // host copies (used by avt_ctx_create to build the device model and by accessors)
-    std::vector<double> shape_planes, lbs_w, asg_w, jsr_base, jsr, S, Sp;
+    std::vector<double> shape_planes, lbs_w, asg_w, jsr_base, jsr, S, Sp, vrec;
     std::vector<int> lbs_j, asg_j, mesh_soa, parent, main_joint, jlevel, fk_items, fk_level_off;
     std::vector<int> tile_col, tile_param, joint_col, vorder;
     std::vector<unsigned char> anc_n;

@@ -268,6 +268,25 @@ extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
         d.tile_zpass[ti] = hi >= lo ? (((2ull << (hi / 5)) - 1ull) & ~((1ull << (lo / 5)) - 1ull)) : 0ull;
     }
 
+    // per-vertex static records (field order of the matched-point records, avt_eval.hip): 3(K+1) shape-plane values, 3 zeros
+    // (mean data point), 1 zero (sqrt count), 4 weights; then 20 ints: 4 assigned joints, 16 ancestor words
+    // joint | mask << 8 | (parent + 1) << 16 | storage column << 24
+    {
+        const int RV = d.rec_quad / 4, ND = 3 * K + 11;
+        m->vrec.assign((size_t)V * RV, 0.0);
+        for (int v = 0; v < V; ++v) {
+            double* r = &m->vrec[(size_t)v * RV];
+            for (int fld = 0; fld < 3 * (K + 1); ++fld) r[fld] = m->shape_planes[(size_t)fld * V + v];
+            for (int a = 0; a < 4; ++a) r[3 * K + 7 + a] = m->asg_w[(size_t)a * V + v];
+            int* ri = (int*)(r + ND);
+            for (int a = 0; a < 4; ++a) ri[a] = m->asg_j[(size_t)a * V + v];
+            for (int a = 0; a < (int)m->anc_n[v]; ++a) {
+                const int w = (int)m->anc[(size_t)a * V + v], j = w & 0xff;
+                ri[4 + a] = w | ((desc->parent[j] + 1) << 16) | (m->joint_col[j] << 24);
+            }
+        }
+    }
+
     // mesh SoA
     m->mesh_soa.assign((size_t)3 * F, 0);
     for (int f = 0; f < F; ++f)
