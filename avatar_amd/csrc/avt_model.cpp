@@ -7,11 +7,13 @@
 //     deduplicated ancestor lists and the shape tables S, Sp;
 //   * GaussianMixture::load factorisations (GaussianMixture.cpp:44-76): Cholesky of the precision, consts.
 // and lays everything out SoA for coalesced device access.
+#include <exception>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <memory>
 #include <numeric>
 
 #include "avt_internal.h"
@@ -125,7 +127,7 @@ static void build_tile_layout(avt_model* m, const int* parent) {
     std::stable_sort(m->vorder.begin(), m->vorder.end(), [&](int a, int b) { return m->vmask[a] < m->vmask[b]; });
 }
 
-extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
+static int avt_model_create_impl(const avt_model_desc* desc, avt_model** out) {
     if (!desc || !out) { avt_set_error("avt_model_create: null argument"); return 1; }
     const int V = desc->num_points, J = desc->num_joints, K = desc->num_shape_keys, F = desc->num_faces;
     if (V <= 0 || J <= 0 || J > AVT_MAX_JOINTS || K < 0 || K > AVT_MAX_SHAPE || F < 0) {
@@ -139,7 +141,8 @@ extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
     if (desc->parent[0] != -1) { avt_set_error("avt_model_create: parent[0] must be -1 (AvatarModel.cpp:41)"); return 1; }
     for (int j = 1; j < J; ++j)
         if (desc->parent[j] < 0 || desc->parent[j] >= j) { avt_set_error("avt_model_create: parent[] must be topologically sorted"); return 1; }
-    avt_model* m = new avt_model();
+    std::unique_ptr<avt_model> holder(new avt_model());      // released to the caller only on success (also on an exception)
+    avt_model* m = holder.get();
     AvtDims& d = m->d;
     d.V = V; d.J = J; d.K = K; d.F = F; d.P = 3 + 3 * J + K;
     d.NT = (d.P + 1 + AVT_TILE - 1) / AVT_TILE;
@@ -158,7 +161,7 @@ extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
     // entries, 3 world-origin entries and 3K shape-table entries, each one B[out] = B[rp..rp+2] . B[v, v+st, v+2st] + B[add]
     {
         const PrepLayout L = prep_layout(J, K, d.xsize);
-        if (L.ndoubles >= 16384) { delete m; avt_set_error("avt_model_create: skeleton scratch exceeds the 14-bit item offsets"); return 1; }
+        if (L.ndoubles >= 16384) { avt_set_error("avt_model_create: skeleton scratch exceeds the 14-bit item offsets"); return 1; }
         auto item = [&](int rp, int v, int scode, int add, int out) {
             m->fk_items.push_back(rp | (v << 14) | (scode << 28));
             m->fk_items.push_back(add | (out << 14));
@@ -205,13 +208,13 @@ extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
         }
         for (int i = b; i < e; ++i) {
             const int j = desc->weights_row[i];
-            if (j < 0 || j >= J) { delete m; avt_set_error("avt_model_create: weight row out of range"); return 1; }
+            if (j < 0 || j >= J) { avt_set_error("avt_model_create: weight row out of range"); return 1; }
             m->lbs_w[(size_t)(i - b) * V + v] = desc->weights_val[i];
             m->lbs_j[(size_t)(i - b) * V + v] = j;
             if (desc->weights_val[i] > 1e-12) assigned[v].push_back({desc->weights_val[i], j});
         }
         std::sort(assigned[v].begin(), assigned[v].end(), std::greater<std::pair<double, int>>());
-        if (assigned[v].empty()) { delete m; avt_set_error("avt_model_create: vertex without skinning weights"); return 1; }
+        if (assigned[v].empty()) { avt_set_error("avt_model_create: vertex without skinning weights"); return 1; }
         for (size_t a = 0; a < assigned[v].size(); ++a) {
             m->asg_w[a * V + v] = assigned[v][a].first;
             m->asg_j[a * V + v] = assigned[v][a].second;
@@ -252,7 +255,7 @@ extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
         int n = 0;
         for (int j = 0; j < J; ++j)
             if (mask[j]) {
-                if (n >= AVT_ANC_MAX) { delete m; avt_set_error("avt_model_create: more than 16 ancestors on a vertex"); return 1; }
+                if (n >= AVT_ANC_MAX) { avt_set_error("avt_model_create: more than 16 ancestors on a vertex"); return 1; }
                 m->anc[(size_t)n * V + v] = (unsigned short)(j | (mask[j] << 8));
                 ++n;
             }
@@ -292,17 +295,17 @@ extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
     for (int f = 0; f < F; ++f)
         for (int c = 0; c < 3; ++c) {
             const int idx = desc->mesh[3 * f + c];
-            if (idx < 0 || idx >= V) { delete m; avt_set_error("avt_model_create: mesh index out of range"); return 1; }
+            if (idx < 0 || idx >= V) { avt_set_error("avt_model_create: mesh index out of range"); return 1; }
             m->mesh_soa[(size_t)c * F + f] = idx;
         }
 
     // GMM (GaussianMixture.cpp:12-77)
     d.ncomps = desc->prior_ncomps > 0 ? desc->prior_ncomps : 0;
-    if (d.ncomps > AVT_MAX_COMPS) { delete m; avt_set_error("avt_model_create: more than 16 GMM components"); return 1; }
+    if (d.ncomps > AVT_MAX_COMPS) { avt_set_error("avt_model_create: more than 16 GMM components"); return 1; }
     d.ndims = d.ncomps ? desc->prior_ndims : 0;
     if (d.ncomps) {
         const int n = d.ndims;
-        if (n != 3 * (J - 1)) { delete m; avt_set_error("avt_model_create: prior_ndims must be 3*(J-1)"); return 1; }
+        if (n != 3 * (J - 1)) { avt_set_error("avt_model_create: prior_ndims must be 3*(J-1)"); return 1; }
         m->prior_mean.assign(desc->prior_mean, desc->prior_mean + (size_t)d.ncomps * n);
         m->prior_prec.assign((size_t)d.ncomps * n * n, 0.0);
         m->prior_L.assign((size_t)d.ncomps * n * n, 0.0);
@@ -313,7 +316,7 @@ extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
         for (int c = 0; c < d.ncomps; ++c) {
             m->prior_clog[c] = std::log(desc->prior_weight[c]) - log_sqrt_2_pi_n;
             if (!chol_lower(desc->prior_cov + (size_t)c * n * n, n, L.data())) {
-                delete m; avt_set_error("avt_model_create: prior covariance not positive definite (\"Decomposition failed!\")");
+                avt_set_error("avt_model_create: prior covariance not positive definite (\"Decomposition failed!\")");
                 return 1;
             }
             std::fill(Li.begin(), Li.end(), 0.0);  // L^-1 by forward substitution
@@ -331,7 +334,7 @@ extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
                     prec[(size_t)i * n + j] = s;
                 }
             if (!chol_lower(prec, n, &m->prior_L[(size_t)c * n * n])) {
-                delete m; avt_set_error("avt_model_create: precision factorisation failed");
+                avt_set_error("avt_model_create: precision factorisation failed");
                 return 1;
             }
             double det = 1.0;
@@ -352,7 +355,7 @@ extern "C" int avt_model_create(const avt_model_desc* desc, avt_model** out) {
                 }
         }
     }
-    *out = m;
+    *out = holder.release();
     return 0;
 }
 
@@ -405,3 +408,12 @@ extern "C" int avt_model_tile_layout(const avt_model* m, int* ntiles, int* tile_
     if (vertex_order) std::copy(m->vorder.begin(), m->vorder.end(), vertex_order);
     return 0;
 }
+
+// ---- exported entry points of the functions above: no C++ exception crosses the C ABI
+extern "C" {
+int avt_model_create(const avt_model_desc* desc, avt_model** out) {
+    try { return avt_model_create_impl(desc, out); }
+    catch (const std::exception& e) { avt_set_error(std::string("avt_model_create: ") + e.what()); return 1; }
+    catch (...) { avt_set_error("avt_model_create: unknown exception"); return 1; }
+}
+}  // extern "C"

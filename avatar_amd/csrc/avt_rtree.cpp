@@ -3,6 +3,7 @@
 // (RTree::postProcess, RTree.cpp:3422-3449), which the reference also runs on the host.
 #include "avt_rtree.h"
 
+#include <exception>
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -158,7 +159,7 @@ struct Filler {
 
 extern "C" {
 
-int avt_rtree_create(const avt_rtree_desc* d, int device, avt_rtree** out) {
+static int avt_rtree_create_impl(const avt_rtree_desc* d, int device, avt_rtree** out) {
     if (!d || !out || d->n_nodes <= 0 || d->n_leafs < 0 || d->n_leafs > d->n_nodes || d->num_parts <= 0 || d->num_parts > 255 || !d->feature ||
         !d->links || (d->n_leafs > 0 && !d->leaf_data)) {
         avt_set_error("avt_rtree_create: bad descriptor");
@@ -178,7 +179,7 @@ int avt_rtree_create(const avt_rtree_desc* d, int device, avt_rtree** out) {
     return 0;
 }
 
-int avt_rtree_load(const char* path, int device, avt_rtree** out) {
+static int avt_rtree_load_impl(const char* path, int device, avt_rtree** out) {
     if (!path || !out) { avt_set_error("avt_rtree_load: null argument"); return 1; }
     std::ifstream bin(path, std::ios::in | std::ios::binary);
     if (!bin) { avt_set_error(std::string("avt_rtree_load: cannot open ") + path); return 1; }
@@ -253,7 +254,7 @@ int avt_rtree_load(const char* path, int device, avt_rtree** out) {
     return 0;
 }
 
-int avt_rtree_export(const avt_rtree* rt, const char* path) {
+static int avt_rtree_export_impl(const avt_rtree* rt, const char* path) {
     std::ofstream ofs(path, std::ios::out | std::ios::binary);
     if (!ofs) { avt_set_error(std::string("avt_rtree_export: cannot open ") + path); return 1; }
     const int n = (int)(rt->links.size() / 3), np = rt->num_parts;
@@ -312,7 +313,7 @@ int avt_rtree_get(const avt_rtree* rt, float* feature, int* links, float* leaf_d
     return 0;
 }
 
-int avt_rtree_images_upload(avt_rtree* rt, int n_images, int rows, int cols, const float* depth) {
+static int avt_rtree_images_upload_impl(avt_rtree* rt, int n_images, int rows, int cols, const float* depth) {
     if (!rt || !depth || n_images <= 0 || rows <= 0 || cols <= 0) { avt_set_error("avt_rtree_images_upload: bad arguments"); return 1; }
     const size_t pixels = (size_t)n_images * rows * cols;
     if (reserve_images(rt, pixels)) return 1;
@@ -344,7 +345,7 @@ int avt_rtree_sync(avt_rtree* rt) {
     return 0;
 }
 
-int avt_rtree_predict_best(avt_rtree* rt, const float* depth, int rows, int cols, int interval, int tlx, int tly, int brx, int bry, int fill,
+static int avt_rtree_predict_best_impl(avt_rtree* rt, const float* depth, int rows, int cols, int interval, int tlx, int tly, int brx, int bry, int fill,
                            unsigned char* labels_out) {
     if (!rt || !depth || !labels_out) { avt_set_error("avt_rtree_predict_best: null argument"); return 1; }
     if (roi_ok(rows, cols, interval, tlx, tly, brx, bry)) return 1;
@@ -353,7 +354,7 @@ int avt_rtree_predict_best(avt_rtree* rt, const float* depth, int rows, int cols
     return avt_rtree_labels_download(rt, 0, labels_out);
 }
 
-int avt_rtree_predict(avt_rtree* rt, const float* depth, int rows, int cols, float* dist_out) {
+static int avt_rtree_predict_impl(avt_rtree* rt, const float* depth, int rows, int cols, float* dist_out) {
     if (!rt || !depth || !dist_out || rows <= 0 || cols <= 0) { avt_set_error("avt_rtree_predict: bad arguments"); return 1; }
     if (avt_rtree_images_upload(rt, 1, rows, cols, depth)) return 1;
     const size_t n = (size_t)rt->num_parts * rows * cols;
@@ -367,7 +368,7 @@ int avt_rtree_predict(avt_rtree* rt, const float* depth, int rows, int cols, flo
     return rc;
 }
 
-int avt_rtree_post_process(const avt_rtree* rt, unsigned char* image, int rows, int cols, double* com_pre, int com_pre_valid, int interval, int tlx,
+static int avt_rtree_post_process_impl(const avt_rtree* rt, unsigned char* image, int rows, int cols, double* com_pre, int com_pre_valid, int interval, int tlx,
                            int tly, int brx, int bry, double dist_to_pre_weight) {
     if (!rt || !image || !com_pre) { avt_set_error("avt_rtree_post_process: null argument"); return 1; }
     if (roi_ok(rows, cols, interval, tlx, tly, brx, bry)) return 1;
@@ -429,4 +430,51 @@ int avt_rtree_post_process(const avt_rtree* rt, unsigned char* image, int rows, 
     return 0;
 }
 
+}  // extern "C"
+
+// ---- exported entry points of the functions above: no C++ exception crosses the C ABI
+extern "C" {
+int avt_rtree_create(const avt_rtree_desc* d, int device, avt_rtree** out) {
+    try { return avt_rtree_create_impl(d, device, out); }
+    catch (const std::exception& e) { avt_set_error(std::string("avt_rtree_create: ") + e.what()); return 1; }
+    catch (...) { avt_set_error("avt_rtree_create: unknown exception"); return 1; }
+}
+
+int avt_rtree_load(const char* path, int device, avt_rtree** out) {
+    try { return avt_rtree_load_impl(path, device, out); }
+    catch (const std::exception& e) { avt_set_error(std::string("avt_rtree_load: ") + e.what()); return 1; }
+    catch (...) { avt_set_error("avt_rtree_load: unknown exception"); return 1; }
+}
+
+int avt_rtree_export(const avt_rtree* rt, const char* path) {
+    try { return avt_rtree_export_impl(rt, path); }
+    catch (const std::exception& e) { avt_set_error(std::string("avt_rtree_export: ") + e.what()); return 1; }
+    catch (...) { avt_set_error("avt_rtree_export: unknown exception"); return 1; }
+}
+
+int avt_rtree_images_upload(avt_rtree* rt, int n_images, int rows, int cols, const float* depth) {
+    try { return avt_rtree_images_upload_impl(rt, n_images, rows, cols, depth); }
+    catch (const std::exception& e) { avt_set_error(std::string("avt_rtree_images_upload: ") + e.what()); return 1; }
+    catch (...) { avt_set_error("avt_rtree_images_upload: unknown exception"); return 1; }
+}
+
+int avt_rtree_predict_best(avt_rtree* rt, const float* depth, int rows, int cols, int interval, int tlx, int tly, int brx, int bry, int fill,
+                           unsigned char* labels_out) {
+    try { return avt_rtree_predict_best_impl(rt, depth, rows, cols, interval, tlx, tly, brx, bry, fill, labels_out); }
+    catch (const std::exception& e) { avt_set_error(std::string("avt_rtree_predict_best: ") + e.what()); return 1; }
+    catch (...) { avt_set_error("avt_rtree_predict_best: unknown exception"); return 1; }
+}
+
+int avt_rtree_predict(avt_rtree* rt, const float* depth, int rows, int cols, float* dist_out) {
+    try { return avt_rtree_predict_impl(rt, depth, rows, cols, dist_out); }
+    catch (const std::exception& e) { avt_set_error(std::string("avt_rtree_predict: ") + e.what()); return 1; }
+    catch (...) { avt_set_error("avt_rtree_predict: unknown exception"); return 1; }
+}
+
+int avt_rtree_post_process(const avt_rtree* rt, unsigned char* image, int rows, int cols, double* com_pre, int com_pre_valid, int interval, int tlx,
+                           int tly, int brx, int bry, double dist_to_pre_weight) {
+    try { return avt_rtree_post_process_impl(rt, image, rows, cols, com_pre, com_pre_valid, interval, tlx, tly, brx, bry, dist_to_pre_weight); }
+    catch (const std::exception& e) { avt_set_error(std::string("avt_rtree_post_process: ") + e.what()); return 1; }
+    catch (...) { avt_set_error("avt_rtree_post_process: unknown exception"); return 1; }
+}
 }  // extern "C"
