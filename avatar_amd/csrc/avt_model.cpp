@@ -202,7 +202,6 @@ static int avt_model_create_impl(const avt_model_desc* desc, avt_model** out) {
     for (int v = 0; v < V; ++v) {
         const int b = desc->weights_colptr[v], e = desc->weights_colptr[v + 1];
         if (e - b > AVT_MAX_ASSIGN) {
-            delete m;
             avt_set_error("avt_model_create: more than 4 skinning weights on a vertex (MAX_ASSIGN, AvatarOptimizer.cpp:164)");
             return 1;
         }
