@@ -366,3 +366,31 @@ def test_frame_sharding_world_size_2_gloo(tmp_path):
                         "--master-port", "29731", script], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "SHARD_OK" in r.stdout
+
+
+def test_model_create_error_paths_report_and_release(smpl):
+    """avt_model_create failures (every one of them frees the half-built model exactly once and leaves a message)."""
+    lib = capi.load_library()
+    h = ctypes.c_void_p()
+
+    def create(m):
+        arr = capi.ModelArrays(m)
+        d = arr.desc()
+        rc = lib.avt_model_create(ctypes.byref(d), ctypes.byref(h))
+        return rc, lib.avt_last_error().decode()
+    W = np.array(smpl["weights"], np.float64)
+    W5 = W.copy(); W5[7] = 0.0; W5[7, :5] = 0.2                      # five skinning weights on one vertex
+    rc, msg = create(dict(smpl, weights=W5))
+    assert rc != 0 and "4 skinning weights" in msg
+    W0 = W.copy(); W0[11] = 0.0                                       # a vertex without weights
+    rc, msg = create(dict(smpl, weights=W0))
+    assert rc != 0 and "without skinning weights" in msg
+    f = np.array(smpl["f"]).copy(); f[3, 1] = 10 ** 6                 # mesh index out of range
+    rc, msg = create(dict(smpl, f=f))
+    assert rc != 0 and "mesh index" in msg
+    cov = np.array(smpl["prior_cov"]).copy(); cov[2] = -cov[2]        # covariance not positive definite
+    rc, msg = create(dict(smpl, prior_cov=cov))
+    assert rc != 0 and "positive definite" in msg
+    rc, msg = create(smpl)                                            # and the library is still fine afterwards
+    assert rc == 0
+    lib.avt_model_destroy(h)
