@@ -37,18 +37,13 @@ __device__ __forceinline__ void quat_to_rot(const double* q, double* R) {
 // Forward kinematics shared by Avatar::update (Avatar.cpp:41-64) and PrepareForEvaluation
 // (AvatarOptimizer.cpp:303-315): world rotation Rw[j] = Rw[parent]*rot[j], origin o[j] = o[parent] +
 // Rw[parent]*(jp[j]-jp[parent]), root at p.  All arrays live in LDS; must be called by every thread of the
-// block (contains barriers).  rot[J][9], jp[J][3] are inputs; lvl[J+1] is LDS scratch.  Joints are processed
-// one tree level per barrier (SMPL: 9 levels instead of 24 sequential joints).
+// block (contains barriers).  rot[J][9], jp[J][3] are inputs; lvl[J+1] holds the joints' tree depths and the deepest level
+// (staged by the caller from DeviceModel::jlevel / AvtDims::nlevels).  Joints are processed one tree level per barrier
+// (SMPL: 9 levels instead of 24 sequential joints).
 __device__ __forceinline__ void fk_chain(int J, const int* __restrict__ parent, const double* rot, const double* jp,
                                          const double* p, double* Rw, double* o, int* lvl) {
     const int t = threadIdx.x;
-    if (t == 0) {
-        int mx = 0;
-        lvl[0] = 0;
-        for (int j = 1; j < J; ++j) { lvl[j] = lvl[parent[j]] + 1; mx = max(mx, lvl[j]); }
-        lvl[J] = mx;
-    }
-    __syncthreads();
+    // lvl[0..J-1] = tree depth of every joint (host-computed), lvl[J] = deepest level: staged by the caller before its last barrier
     const int nl = lvl[J];
     for (int L = 0; L <= nl; ++L) {
         for (int idx = t; idx < 12 * J; idx += blockDim.x) {

@@ -130,6 +130,7 @@ struct DeviceModel {
     unsigned short* anc;  // [AVT_ANC_MAX][V]
     int* mesh;            // [3][F] SoA
     int* parent;          // [J]
+    int* jlevel;          // [J] depth of the joint in the kinematic tree (root 0)
     // column layout of the evaluation tile (build_tile_layout, avt_model.cpp)
     int* tile_col;        // [16*NT] tile column -> storage column (P+1 = the all-zero column for padding)
     int* tile_param;      // [16*NT] tile column -> parameter index (P = residual), -1 = padding

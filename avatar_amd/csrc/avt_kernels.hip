@@ -24,7 +24,8 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
     if (from_state) xs = fb.x + ((size_t)f * 2 + fb.ctl[f].cur_slot) * d.xsize;
     if (t < K) s_w[t] = from_state ? xs[3 + 4 * J + t] : w_in[(size_t)f * K + t];
     if (t < 3) s_p[t] = from_state ? xs[t] : p_in[(size_t)f * 3 + t];
-    if (t < J) s_parent[t] = dm.parent[t];
+    if (t < J) { s_parent[t] = dm.parent[t]; s_lvl[t] = dm.jlevel[t]; }
+    if (t == 0) s_lvl[J] = d.nlevels - 1;
     if (from_state) {
         if (t < J) quat_to_rot(xs + 3 + 4 * t, s_rot + 9 * t);
     } else {
