@@ -205,6 +205,7 @@ def load_library():
         "avt_shard_broadcast_model": [vp, C.c_int, C.POINTER(ModelDesc), C.POINTER(vp)],
         "avt_shard_scatter_frames": [vp, vp, C.c_int, C.c_int, c_double_p, c_int_p, c_int_p, c_double_p, c_double_p, c_double_p],
         "avt_shard_gather_enqueue": [vp, vp, C.c_int],
+        "avt_shard_gather_wait": [vp],
         "avt_shard_gather_download": [vp, vp, C.c_int, c_double_p, c_double_p, c_double_p, C.POINTER(Stats)],
         "avt_shard_gather_results": [vp, vp, C.c_int, c_double_p, c_double_p, c_double_p, C.POINTER(Stats)],
         "avt_shard_barrier": [vp, vp],
@@ -231,6 +232,6 @@ EXPORTED_SYMBOLS = [
     # include/avt_shard.h
     "avt_shard_owner", "avt_shard_local_count", "avt_shard_local_index", "avt_shard_global_frame", "avt_model_pack_size", "avt_model_pack",
     "avt_model_unpack", "avt_shard_unique_id", "avt_shard_create", "avt_shard_destroy", "avt_shard_rank", "avt_shard_world", "avt_shard_backend",
-    "avt_shard_broadcast_model", "avt_shard_scatter_frames", "avt_shard_gather_enqueue", "avt_shard_gather_download",
+    "avt_shard_broadcast_model", "avt_shard_scatter_frames", "avt_shard_gather_enqueue", "avt_shard_gather_wait", "avt_shard_gather_download",
     "avt_shard_gather_results", "avt_shard_barrier",
 ]

@@ -106,15 +106,20 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
         { ProfScope ps(c, AVT_K_NN); launch_nn(c, nf); }
         { ProfScope ps(c, AVT_K_AGGREGATE); launch_finalize(c, nf); launch_records(c, nf); }
         { ProfScope ps(c, AVT_K_PREPARE); launch_solve(c, nf, SOLVE_INIT); }
-        { ProfScope ps(c, AVT_K_EVAL); launch_eval(c, nf); }
+        { ProfScope ps(c, AVT_K_EVAL); launch_eval(c, nf, false); }
         { ProfScope ps(c, AVT_K_REDUCE); launch_reduce(c, nf); }
         for (int it = 1; it <= std::max(1, o->max_iters_per_icp); ++it) {
             { ProfScope ps(c, AVT_K_SOLVE); launch_solve(c, nf, it == 1 ? SOLVE_FIRST : SOLVE_NORMAL); }
             if (o->max_iters_per_icp == 0) break;
-            { ProfScope ps(c, AVT_K_EVAL); launch_eval(c, nf); }
-            { ProfScope ps(c, AVT_K_REDUCE); launch_reduce(c, nf); }
+            if (it < o->max_iters_per_icp) {
+                { ProfScope ps(c, AVT_K_EVAL); launch_eval(c, nf, false); }
+                { ProfScope ps(c, AVT_K_REDUCE); launch_reduce(c, nf); }
+            } else {   // no solve follows the last trial point: its cost alone, and the accept test inside the reduction
+                ProfScope ps(c, AVT_K_DECIDE);
+                launch_eval(c, nf, true);
+                launch_reduce(c, nf, true);
+            }
         }
-        if (o->max_iters_per_icp > 0) { ProfScope ps(c, AVT_K_DECIDE); launch_solve(c, nf, SOLVE_LAST); }
         { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 1, vis_init); }   // :1494-1497
         c->ran_icp_iters++;
     }
@@ -689,13 +694,26 @@ int avt_get_posed(avt_ctx* c, int frame, double* cloud, double* joint_pos, doubl
 int avt_get_normal_equations(avt_ctx* c, int frame, double* H, double* g, double* cost) {
     AVT_API_GUARD_BEGIN
     if (!c || frame < 0 || frame >= c->nframes) { avt_set_error("avt_get_normal_equations: bad argument"); return 1; }
+    if (!c->frames_valid || !c->state_valid || c->ran_icp_iters <= 0) { avt_set_error("avt_get_normal_equations: no optimize call has run on the resident frames"); return 1; }
     const AvtDims& d = c->dm.d;
     HIP_OK(hipSetDevice(c->device));
+    // optimize() does not build the system of its last trial point (only that point's cost is needed): evaluate the data term
+    // at the CURRENT point here - trial point := current point (SOLVE_INIT), one full evaluation, one reduction - with the
+    // correspondences of the last ICP iteration.  The current point, its cost and the LM state are left untouched.
+    const int G_keep = c->fb.G;
+    c->fb.G = choose_G(c->nframes);
+    c->fb.f0 = 0;
+    c->cur_stream = c->stream;
+    launch_solve(c, c->nframes, SOLVE_INIT);
+    launch_eval(c, c->nframes, false);
+    launch_reduce(c, c->nframes, false);
+    c->fb.G = G_keep;
+    if (check_launch("avt_get_normal_equations")) return 1;
     HIP_OK(hipStreamSynchronize(c->stream));
     AvtFrameCtl ctl;
     HIP_OK(hipMemcpy(&ctl, c->fb.ctl + frame, sizeof(ctl), hipMemcpyDeviceToHost));
     std::vector<double> buf((size_t)d.HS * d.HS);
-    HIP_OK(hipMemcpy(buf.data(), c->fb.Hraw + ((size_t)frame * 2 + ctl.cur_slot) * buf.size(), buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(buf.data(), c->fb.Hraw + ((size_t)frame * 2 + (1 - ctl.cur_slot)) * buf.size(), buf.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int r = 0; r < d.P; ++r) {
         if (H) for (int q = 0; q < d.P; ++q) H[(size_t)r * d.P + q] = buf[(size_t)r * d.HS + q];
         if (g) g[r] = buf[(size_t)d.P * d.HS + r];

@@ -135,7 +135,9 @@ __device__ __forceinline__ void stage_records(double* __restrict__ Rrec, int RQ2
     }
 }
 
-template <int CJ, int CK, int MT>
+// COST: only the residual column is built (the last evaluation of an ICP iteration is followed by no solve: the accept test
+// needs sum c|r|^2 of the trial point and nothing else; same instructions for that column, hence the same bits).
+template <int CJ, int CK, int MT, bool COST>
 __device__ __forceinline__ void build_rows(const AvtDims& d, const EvalTables& T, double* __restrict__ s_Jt, const double* __restrict__ Rrec,
                                            double* __restrict__ s_xhat, double* __restrict__ s_xk, double* __restrict__ s_T, int qw, int ln,
                                            unsigned long long zmask) {
@@ -178,13 +180,13 @@ __device__ __forceinline__ void build_rows(const AvtDims& d, const EvalTables& T
         xk[0] = (Rk[0] * e0 + Rk[1] * e1 + Rk[2] * e2) + oo[3 * k];
         xk[1] = (Rk[3] * e0 + Rk[4] * e1 + Rk[5] * e2) + oo[3 * k + 1];
         xk[2] = (Rk[6] * e0 + Rk[7] * e1 + Rk[8] * e2) + oo[3 * k + 2];
-    } else if (slot < 13) {
+    } else if (!COST && slot < 13) {
         const int e9 = slot - 4;
         s_T[pi * 9 + e9] = ((aw[0] * Rw[9 * aj[0] + e9] + aw[1] * Rw[9 * aj[1] + e9]) + aw[2] * Rw[9 * aj[2] + e9]) + aw[3] * Rw[9 * aj[3] + e9];
     }
     wave_sync();
     const double* xk = s_xk + pi * 12;
-    const int aword = RI[(4 + slot) * 4 + p4];
+    const int aword = COST ? 0 : RI[(4 + slot) * 4 + p4];
     if (aword != 0) {   // rotation block of ancestor j: -2 sqrt(c) [l_j]_x R(-1,parent j)
         const int j = aword & 0xff;
         const unsigned mask = ((unsigned)aword >> 8) & 0xffu;
@@ -226,7 +228,7 @@ __device__ __forceinline__ void build_rows(const AvtDims& d, const EvalTables& T
     for (int it = 0; it < NSH; ++it) {
         const int e = slot + 16 * it;
         shv[it] = 0.0;
-        if (e < 3 * K) {
+        if (!COST && e < 3 * K) {
             const int r = e / K, k = e - r * K;
             const double* Tr = s_T + pi * 9 + 3 * r;
             const double gs = ((aw[0] * Gm[aj[0] * 3 * K + e] + aw[1] * Gm[aj[1] * 3 * K + e]) + aw[2] * Gm[aj[2] * 3 * K + e]) + aw[3] * Gm[aj[3] * 3 * K + e];
@@ -244,13 +246,13 @@ __device__ __forceinline__ void build_rows(const AvtDims& d, const EvalTables& T
 #pragma unroll
     for (int it = 0; it < NSH; ++it) {
         const int e = slot + 16 * it;
-        if (e < 3 * K) {
+        if (!COST && e < 3 * K) {
             const int r = e / K, k = e - r * K;
             s_Jt[(size_t)(d.col_shape + k) * RS + pi * 3 + r] = shv[it];
         }
     }
     if (slot < 3) s_Jt[(size_t)d.col_res * RS + pi * 3 + slot] = resv;
-    else if (slot < 6) {   // identity root-translation block (:476-481)
+    else if (!COST && slot < 6) {   // identity root-translation block (:476-481)
         const int r = slot - 3;
         s_Jt[(size_t)(d.col_tr + r) * RS + pi * 3 + r] = sc;
     }
@@ -311,7 +313,8 @@ __device__ __forceinline__ void mfma_batch6(const double* const (&base)[6], int 
 // =================================================================================================
 // MT = column tiles the instantiation is sized for (accumulators per wave, zeroing passes): 6 for the SMPL shape, 8 for
 // generic skeletons of up to 128 columns, AVT_MAX_TILES (11) up to 176 columns (SMPL-H)
-template <int CJ, int CK, int MT = (CJ != 0 ? 6 : 8)>
+// COST: the evaluation behind which no solve follows - residual column and tile pair (res, res) only (see build_rows)
+template <int CJ, int CK, int MT, bool COST>
 __global__ __launch_bounds__(256, (CJ != 0) ? 3 : (MT > 8 ? 1 : 2)) void k_eval(DeviceModel dm, FrameBuffers fb, int nframes) {
     constexpr bool FIXED = CJ != 0;
     const AvtDims d = dm.d;
@@ -420,14 +423,15 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : (MT > 8 ? 1 : 2)) void k_eval(
         // ---- wave-local from here to the next barrier ------------------------------------------------------
         stage_records<NPF>(s_rec + (size_t)wv * RQ, RQ2, ln, pf);
         const int bw = __builtin_amdgcn_readfirstlane(bm_next);   // live tiles / tile pairs of this batch (k_records)
-        const int tm = NT > 8 ? (bw & 0xffff) : (int)((unsigned)bw >> 24), pm = bw & 0xffffff;
+        // (COST: only the tile of the residual column and its diagonal pair)
+        const int tm = COST ? (1 << d.res_tile) : (NT > 8 ? (bw & 0xffff) : (int)((unsigned)bw >> 24)), pm = COST ? (1 << d.res_pair) : (bw & 0xffffff);
         if (next_batch(b) < nb) prefetch(next_batch(b));
         // zeroing passes (5 consecutive storage columns each) that touch a live tile (AvtDims::tile_zpass, avt_model.cpp)
         unsigned long long zmask = 0ull;
 #pragma unroll
         for (int ti = 0; ti < MT; ++ti)
             if (ti < NT && ((tm >> ti) & 1)) zmask |= d.tile_zpass[ti];
-        build_rows<CJ, CK, MT>(d, tabs, s_Jt, s_rec + (size_t)wv * RQ, s_xhat, s_xk, s_T, wv, ln, zmask);
+        build_rows<CJ, CK, MT, COST>(d, tabs, s_Jt, s_rec + (size_t)wv * RQ, s_xhat, s_xk, s_T, wv, ln, zmask);
         EPROBE(3);
         __syncthreads();
         EPROBE(4);
@@ -500,24 +504,29 @@ static size_t eval_lds_bytes(const AvtDims& d) {
     return sizeof(double) * (nprep + (size_t)AVT_EVAL_TILE(d.P + 2) + 4 * (size_t)d.rec_quad + 48 + 192 + 144 + 10);
 }
 
-void launch_eval(avt_ctx* c, int nframes) {
+// cost_only: the last evaluation of an ICP iteration (launch_reduce(.., decide = true) follows)
+void launch_eval(avt_ctx* c, int nframes, bool cost_only) {
     const AvtDims& d = c->dm.d;
     dim3 grid((unsigned)nframes * (c->fb.G + std::max(0, d.ncomps)));
     const size_t lds = eval_lds_bytes(d);
-    if (eval_fixed_shape(d)) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<24, 10>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, nframes);
-    else if (d.NT <= 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<0, 0, 8>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, nframes);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<0, 0, AVT_MAX_TILES>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, nframes);
+#define AVT_EVAL_LAUNCH(...) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<__VA_ARGS__>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, nframes)
+    if (eval_fixed_shape(d)) { if (cost_only) AVT_EVAL_LAUNCH(24, 10, 6, true); else AVT_EVAL_LAUNCH(24, 10, 6, false); }
+    else if (d.NT <= 8) { if (cost_only) AVT_EVAL_LAUNCH(0, 0, 8, true); else AVT_EVAL_LAUNCH(0, 0, 8, false); }
+    else { if (cost_only) AVT_EVAL_LAUNCH(0, 0, AVT_MAX_TILES, true); else AVT_EVAL_LAUNCH(0, 0, AVT_MAX_TILES, false); }
+#undef AVT_EVAL_LAUNCH
 }
 
 void avt_eval_report_occupancy(const AvtDims& d) {
     int nb = -1;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_eval<24, 10>, 256, eval_lds_bytes(d));
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_eval<24, 10, 6, false>, 256, eval_lds_bytes(d));
     fprintf(stderr, "[avt] k_eval<24,10>: dynamic LDS %zu B, occupancy query -> %d blocks/CU (%s)\n", eval_lds_bytes(d), nb, hipGetErrorString(e));
 }
 
 int avt_eval_set_attributes() {
     // the fixed-shape kernel needs < 64 KB of dynamic LDS: leave its attribute alone (raising the cap costs residency);
     // the generic shape may need more.
-    return hipFuncSetAttribute((const void*)k_eval<0, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
-           hipFuncSetAttribute((const void*)k_eval<0, 0, AVT_MAX_TILES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess;
+    return hipFuncSetAttribute((const void*)k_eval<0, 0, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_eval<0, 0, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_eval<0, 0, AVT_MAX_TILES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_eval<0, 0, AVT_MAX_TILES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess;
 }

@@ -43,6 +43,7 @@ struct AvtDims {
     int rec_quad;            // doubles per 4-point matched-point record (avt_eval.hip): 12K + 84
     int nb_max;              // eval batches a frame can have: ceil(V/16)
     int col_tr, col_shape, col_res;   // storage columns of the evaluation tile: root translation, first shape key, residual (avt_model.cpp)
+    int res_tile, res_pair;  // the column tile that holds the residual column and the index of its diagonal tile pair
     unsigned long long tile_zpass[AVT_MAX_TILES];   // per tile: the 5-column zeroing passes of build_rows that overlap its storage columns (bit = pass)
 };
 
@@ -249,7 +250,7 @@ struct avt_ctx {
 void avt_set_error(const std::string& s);
 
 // kernel launch wrappers (avt_kernels.hip / avt_nn.hip)
-enum { SOLVE_INIT = 0, SOLVE_FIRST = 1, SOLVE_NORMAL = 2, SOLVE_LAST = 3 };
+enum { SOLVE_INIT = 0, SOLVE_FIRST = 1, SOLVE_NORMAL = 2 };
 void launch_lbs(avt_ctx* c, int nframes, const double* x_state_or_null, const double* w, const double* p, const double* R,
                 int from_state, int vis_init /* -1: leave bookkeeping alone; 0/1: reset it, visibility flags to this value */);
 void launch_visibility(avt_ctx* c, int nframes, int enable);
@@ -257,8 +258,8 @@ void launch_bucket(avt_ctx* c, int nframes, bool clear_after);
 void launch_state_reset(avt_ctx* c, int nframes);
 void launch_nn(avt_ctx* c, int nframes);
 void launch_finalize(avt_ctx* c, int nframes);
-void launch_eval(avt_ctx* c, int nframes);
+void launch_eval(avt_ctx* c, int nframes, bool cost_only = false);
 void launch_records(avt_ctx* c, int nframes);
-void launch_reduce(avt_ctx* c, int nframes);
+void launch_reduce(avt_ctx* c, int nframes, bool decide = false);
 void launch_solve(avt_ctx* c, int nframes, int mode);
 void launch_pack_results(avt_ctx* c, int nframes, double* out, int stride);

@@ -134,12 +134,56 @@ __device__ void prep_run(const DeviceModel& dm, const PrepLayout& L, double* __r
 //   The tile is written to both triangles of the dense (HS x HS) symmetric block; row/column P carry J^T r and
 //   sum c|r|^2.  (The GMM pose prior of the trial point is evaluated by extra workgroups of k_eval, avt_prior.h.)
 // =================================================================================================
-template <int Q>
+// Accept / reject of the LAST trial point of an ICP iteration (no further solve follows): run by the one lane of the final
+// k_reduce launch that has just summed H(P,P) = sum c|r|^2 of the trial point - the same rule k_solve applies at the start of
+// every other iteration (AvatarOptimizer.cpp:1486's accept test in the LM form of DESIGN section 4), without a launch of its own.
+__device__ __forceinline__ void lm_decide_last(const DeviceModel& dm, const FrameBuffers& fb, int f, double hpp_try) {
+    const AvtDims& d = dm.d;
+    AvtFrameCtl& ctl = fb.ctl[f];
+    const int J = d.J, K = d.K, xs = d.xsize;
+    const int cur0 = ctl.cur_slot, try0 = 1 - cur0, try_valid = ctl.try_valid;
+    const double sbp = ctl.sbp, sbs = ctl.sbs, cost_cur0 = ctl.cost_cur;
+    double lambda = ctl.lambda;
+    double cost = 0.5 * hpp_try + ctl.cost_const;
+    int comp_try = -1;
+    if (sbp > 0.0 && d.ncomps > 0) {   // strict '<' in ascending component order (GaussianMixture.cpp:103)
+        double best = 1.7976931348623157e308;
+        double pr[AVT_MAX_COMPS];
+#pragma unroll
+        for (int c = 0; c < AVT_MAX_COMPS; ++c)
+            pr[c] = (c < d.ncomps) ? fb.prior[(((size_t)f * 2 + try0) * AVT_MAX_COMPS + c) * AVT_PRIOR_STRIDE] : 0.0;
+#pragma unroll
+        for (int c = 0; c < AVT_MAX_COMPS; ++c)
+            if (c < d.ncomps && pr[c] < best) { best = pr[c]; comp_try = c; }
+        cost += 0.5 * sbp * sbp * best;
+    }
+    if (sbs > 0.0) {
+        const double* xt = fb.x + ((size_t)f * 2 + try0) * xs;
+        double a = 0.0;
+        for (int k = 0; k < K; ++k) { const double r = xt[3 + 4 * J + k] * sbs; a += r * r; }
+        cost += 0.5 * a;
+    }
+    bool accepted = false;
+    if (try_valid) {
+        if (cost < cost_cur0) { accepted = true; lambda = fmax(lambda * fb.params->lm_down, fb.params->lm_min); }
+        else lambda = fmin(lambda * fb.params->lm_up, fb.params->lm_max);
+    }
+    const double cost_cur = accepted ? cost : cost_cur0;
+    if (accepted) { ctl.cur_slot = try0; ctl.cost_cur = cost; ctl.comp_cur = comp_try; ctl.accepted += 1; }
+    const int it = ctl.gn_iterations + 1;
+    ctl.gn_iterations = it;
+    if (it < 40) fb.trace[(size_t)f * 64 + it] = cost_cur;
+    ctl.lambda = lambda;
+}
+
+template <int Q, bool DECIDE>
 __global__ __launch_bounds__(256 * Q) void k_reduce(DeviceModel dm, FrameBuffers fb) {
+    __builtin_amdgcn_s_setprio(3);
     const AvtDims d = dm.d;
     const int f = blockIdx.y + fb.f0, t = threadIdx.x & 255, q = threadIdx.x >> 8, NPAIR = d.NPAIR, NT = d.NT, P = d.P, HS = d.HS;
     const int G = fb.G, glo = (G * q) / Q, ghi = (G * (q + 1)) / Q;
-    const double* part = fb.partial + ((size_t)f * G * NPAIR + blockIdx.x) * 256 + t;
+    const int pair = DECIDE ? d.res_pair : (int)blockIdx.x;     // DECIDE: grid (1, frames), only the pair that holds H(P,P)
+    const double* part = fb.partial + ((size_t)f * G * NPAIR + pair) * 256 + t;
     const size_t st = (size_t)NPAIR * 256;
     // which of my workgroups g wrote this pair (k_eval skips the tile pairs its batches never touch): lane l asks for
     // g = glo + l, the ballot makes the answer wave-uniform (ghi - glo <= 64 in both launch shapes).  Q = 1 (frame batches)
@@ -150,8 +194,8 @@ __global__ __launch_bounds__(256 * Q) void k_reduce(DeviceModel dm, FrameBuffers
     unsigned long long live = ~0ull;
     // (the mask has 64 bits; only skeletons with more than 64 tile pairs - evaluated by the generic kernel, which writes
     // every pair - have pairs beyond it)
-    const bool masked = blockIdx.x < 64;
-    if constexpr (Q == 1) live = masked ? __ballot((int)((wmine >> (blockIdx.x & 63)) & 1ull)) : ~0ull;
+    const bool masked = pair < 64;
+    if constexpr (Q == 1) live = masked ? __ballot((int)((wmine >> (pair & 63)) & 1ull)) : ~0ull;
     double a = 0.0;
     int g = glo;
 #define AVT_REDUCE_ROUND(NLD)                                                                        \
@@ -165,7 +209,7 @@ __global__ __launch_bounds__(256 * Q) void k_reduce(DeviceModel dm, FrameBuffers
         const int ng = ghi - glo;
 #pragma unroll
         for (int u = 0; u < 32; ++u) v[u] = (u < ng) ? __builtin_nontemporal_load(part + (size_t)(glo + u) * st) : 0.0;
-        const unsigned long long wrote = masked ? __ballot((int)((wmine >> (blockIdx.x & 63)) & 1ull)) : ~0ull;
+        const unsigned long long wrote = masked ? __ballot((int)((wmine >> (pair & 63)) & 1ull)) : ~0ull;
 #pragma unroll
         for (int u = 0; u < 32; ++u) a += ((wrote >> u) & 1ull) ? v[u] : 0.0;
         g = ghi;
@@ -183,12 +227,14 @@ __global__ __launch_bounds__(256 * Q) void k_reduce(DeviceModel dm, FrameBuffers
 #pragma unroll
             for (int i = 0; i < Q - 1; ++i) a += s_q[i][t];
         }
-        int p = blockIdx.x, ti = 0;
+        int p = pair, ti = 0;
         while (p >= NT - ti) { p -= NT - ti; ++ti; }
         const int tj = ti + p;
         // tile coordinates -> parameter indices (the evaluation tile has its own column order, avt_model.cpp)
         const int r = dm.tile_param[ti * 16 + ((t >> 4) & 3) + 4 * (t >> 6)], c = dm.tile_param[tj * 16 + (t & 15)];
-        if (r >= 0 && c >= 0) {
+        if constexpr (DECIDE) {   // nothing reads the system of this trial point: only the accept test
+            if (r == P && c == P) lm_decide_last(dm, fb, f, a);
+        } else if (r >= 0 && c >= 0) {
             double* H = fb.Hraw + ((size_t)f * 2 + try_slot) * HS * HS;
             H[(size_t)r * HS + c] = a;
             if (ti != tj) H[(size_t)c * HS + r] = a;
@@ -325,11 +371,12 @@ __device__ __forceinline__ void backsub_tri(const double* __restrict__ Lblk, con
 // (SMPL-H: 170): the same algorithm on 16 waves, the factor as a packed lower triangle (990 blocks = 139 KB), the skeleton
 // scratch overlaid on it once the back substitution is done.
 // =================================================================================================
-// MODE (SOLVE_INIT / FIRST / NORMAL / LAST) is a template parameter so that the four roles are four symbols in a kernel trace
+// MODE (SOLVE_INIT / FIRST / NORMAL) is a template parameter so that the three roles are three symbols in a kernel trace
 // (their durations differ six-fold) and the short ones do not carry the factorisation's code.
 template <int NTH, bool TRI, int MODE>
 __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) {
     constexpr int mode = MODE;
+    __builtin_amdgcn_s_setprio(3);   // one dependency chain per frame: issue ahead of the evaluation waves of another frame group on this CU
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, P = d.P, HS = d.HS;
     const int f = blockIdx.x + fb.f0, t = threadIdx.x;
@@ -358,7 +405,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     // everything that does not depend on the LM decision is requested now: both state slots and the skeleton constants
     for (int e = t; e < 2 * xs; e += NTH) s_x[e] = x0[e];
     if (!TRI || mode == SOLVE_INIT) prep_stage_constants<NTH>(dm, L, B, s_items, s_level);
-    if (!TRI && mode != SOLVE_INIT && mode != SOLVE_LAST) {   // the never-written blocks of the factor must read as zeros (back substitution)
+    if (!TRI && mode != SOLVE_INIT) {   // the never-written blocks of the factor must read as zeros (back substitution)
         d2v* z = (d2v*)Lblk;
         for (int e = t; e < NBk * NBk * 9; e += NTH) z[e] = (d2v){0.0, 0.0};
     }
@@ -461,9 +508,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         if (mode == SOLVE_FIRST) ctl.cost_initial = cost;
         else { it += 1; ctl.gn_iterations = it; if (accepted) ctl.accepted += 1; }
         if (it < 40) fb.trace[(size_t)f * 64 + it] = cost_cur;
-        if (mode == SOLVE_LAST) ctl.lambda = lambda;
     }
-    if (mode == SOLVE_LAST) return;
     TPROBE(1);
 
     // ---- b. the damped system of the current point, straight into registers (second, short round trip: the
@@ -694,10 +739,17 @@ static size_t solve_lds_bytes(const AvtDims& d) {
     return (solve_big(d) ? std::max(factor, prep_bytes) + fixed : factor + fixed + prep_bytes) + 64;
 }
 
-void launch_reduce(avt_ctx* c, int nframes) {
+// decide = the launch behind the LAST evaluation of an ICP iteration: the lane that sums H(P,P) also takes the accept / reject decision
+void launch_reduce(avt_ctx* c, int nframes, bool decide) {
     const AvtDims& d = c->dm.d;
-    if (c->fb.G >= 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<4>), dim3(d.NPAIR, nframes), dim3(1024), 0, c->cur_stream, c->dm, c->fb);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<1>), dim3(d.NPAIR, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
+    const dim3 grid(decide ? 1 : d.NPAIR, nframes);
+    if (c->fb.G >= 64) {
+        if (decide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<4, true>), grid, dim3(1024), 0, c->cur_stream, c->dm, c->fb);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<4, false>), grid, dim3(1024), 0, c->cur_stream, c->dm, c->fb);
+    } else {
+        if (decide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<1, true>), grid, dim3(256), 0, c->cur_stream, c->dm, c->fb);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<1, false>), grid, dim3(256), 0, c->cur_stream, c->dm, c->fb);
+    }
 }
 
 template <int NTH, bool TRI>
@@ -705,7 +757,6 @@ static void launch_solve_shape(avt_ctx* c, int nframes, int mode, size_t lds) {
     switch (mode) {
         case SOLVE_INIT: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<NTH, TRI, SOLVE_INIT>), dim3(nframes), dim3(NTH), lds, c->cur_stream, c->dm, c->fb); break;
         case SOLVE_FIRST: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<NTH, TRI, SOLVE_FIRST>), dim3(nframes), dim3(NTH), lds, c->cur_stream, c->dm, c->fb); break;
-        case SOLVE_LAST: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<NTH, TRI, SOLVE_LAST>), dim3(nframes), dim3(NTH), lds, c->cur_stream, c->dm, c->fb); break;
         default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<NTH, TRI, SOLVE_NORMAL>), dim3(nframes), dim3(NTH), lds, c->cur_stream, c->dm, c->fb); break;
     }
 }
@@ -721,8 +772,7 @@ static int solve_attr() {
     const int cap = 160 * 1024 - 512;
     return hipFuncSetAttribute((const void*)k_solve<NTH, TRI, SOLVE_INIT>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
            hipFuncSetAttribute((const void*)k_solve<NTH, TRI, SOLVE_FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
-           hipFuncSetAttribute((const void*)k_solve<NTH, TRI, SOLVE_NORMAL>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
-           hipFuncSetAttribute((const void*)k_solve<NTH, TRI, SOLVE_LAST>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess;
+           hipFuncSetAttribute((const void*)k_solve<NTH, TRI, SOLVE_NORMAL>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess;
 }
 
 int avt_solve_set_attributes() { return solve_attr<256, false>() || solve_attr<1024, true>(); }

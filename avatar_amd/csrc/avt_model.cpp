@@ -263,6 +263,10 @@ static int avt_model_create_impl(const avt_model_desc* desc, avt_model** out) {
     }
     d.anc_max = anc_max;
     build_tile_layout(m, desc->parent);
+    d.res_tile = 0;
+    for (int tc = 0; tc < 16 * d.NT; ++tc) if (m->tile_param[tc] == d.P) d.res_tile = tc / 16;
+    d.res_pair = 0;
+    for (int i = 0; i < d.res_tile; ++i) d.res_pair += d.NT - i;
     for (int ti = 0; ti < AVT_MAX_TILES; ++ti) {
         int lo = d.P + 1, hi = -1;
         if (ti < d.NT)

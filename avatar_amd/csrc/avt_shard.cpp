@@ -222,6 +222,9 @@ struct avt_shard {
     double* d_send = nullptr; double* d_recv = nullptr; size_t gather_cap = 0;   // doubles per rank block
     void* d_stage = nullptr; size_t stage_cap = 0;                              // scatter / broadcast staging, bytes
     void* d_stage2 = nullptr; size_t stage2_cap = 0;
+    // the all-gather runs on `stream`, behind the packing kernel on the context's stream and beside whatever that stream does next
+    hipEvent_t ev_packed = nullptr, ev_gathered = nullptr;
+    bool gather_in_flight = false;
 };
 
 #define NCCL_OK(s, expr)                                                                                       \
@@ -277,8 +280,12 @@ extern "C" int avt_shard_create(int device, int rank, int world, const char id[A
         delete s;
         return 1;
     }
-    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
-        avt_set_error("avt_shard_create: hipStreamCreate failed");
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_packed, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_gathered, hipEventDisableTiming) != hipSuccess) {
+        avt_set_error("avt_shard_create: stream / event creation failed");
+        if (s->ev_packed) (void)hipEventDestroy(s->ev_packed);
+        if (s->stream) (void)hipStreamDestroy(s->stream);
         a->CommDestroy(s->comm);
         delete s;
         return 1;
@@ -297,6 +304,8 @@ extern "C" void avt_shard_destroy(avt_shard* s) {
     if (s->comm) s->api->CommDestroy(s->comm);
     for (void* p : {(void*)s->d_send, (void*)s->d_recv, s->d_stage, s->d_stage2})
         if (p) (void)hipFree(p);
+    if (s->ev_packed) (void)hipEventDestroy(s->ev_packed);
+    if (s->ev_gathered) (void)hipEventDestroy(s->ev_gathered);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -449,16 +458,31 @@ extern "C" int avt_shard_gather_enqueue(avt_shard* s, avt_ctx* c, int B) {
     const size_t blk = (size_t)per * stride;
     if (s->gather_cap < blk) {
         HIP_OK(hipStreamSynchronize(c->stream));
+        HIP_OK(hipStreamSynchronize(s->stream));
         if (s->d_send) HIP_OK(hipFree(s->d_send));
         if (s->d_recv) HIP_OK(hipFree(s->d_recv));
-        s->d_send = s->d_recv = nullptr; s->gather_cap = 0;
+        s->d_send = s->d_recv = nullptr; s->gather_cap = 0; s->gather_in_flight = false;
         HIP_OK(hipMalloc((void**)&s->d_send, blk * 8));
         HIP_OK(hipMalloc((void**)&s->d_recv, blk * 8 * W));
         HIP_OK(hipMemset(s->d_send, 0, blk * 8));
         s->gather_cap = blk;
     }
+    // ctx stream: [previous all-gather has read the send block] -> pack;  shard stream: [packed] -> all-gather.  The exchange
+    // of step k therefore overlaps the optimisation of step k+1 and the ranks never wait for each other inside a step.
+    if (s->gather_in_flight) HIP_OK(hipStreamWaitEvent(c->stream, s->ev_gathered, 0));
     if (nloc) launch_pack_results(c, nloc, s->d_send, stride);
-    NCCL_OK(s, s->api->AllGather(s->d_send, s->d_recv, blk, ncclDouble, s->comm, c->stream));
+    HIP_OK(hipEventRecord(s->ev_packed, c->stream));
+    HIP_OK(hipStreamWaitEvent(s->stream, s->ev_packed, 0));
+    NCCL_OK(s, s->api->AllGather(s->d_send, s->d_recv, blk, ncclDouble, s->comm, s->stream));
+    HIP_OK(hipEventRecord(s->ev_gathered, s->stream));
+    s->gather_in_flight = true;
+    return 0;
+}
+
+extern "C" int avt_shard_gather_wait(avt_shard* s) {
+    if (!s) { avt_set_error("avt_shard_gather_wait: null argument"); return 1; }
+    HIP_OK(hipSetDevice(s->device));
+    HIP_OK(hipStreamSynchronize(s->stream));
     return 0;
 }
 
@@ -470,8 +494,8 @@ extern "C" int avt_shard_gather_download(avt_shard* s, avt_ctx* c, int B, double
     if (s->gather_cap < blk || !s->d_recv) { avt_set_error("avt_shard_gather_download: nothing was gathered"); return 1; }
     HIP_OK(hipSetDevice(s->device));
     std::vector<double> host(blk * W);
-    HIP_OK(hipMemcpyAsync(host.data(), s->d_recv, host.size() * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpyAsync(host.data(), s->d_recv, host.size() * 8, hipMemcpyDeviceToHost, s->stream));   // behind the all-gather
+    HIP_OK(hipStreamSynchronize(s->stream));
     for (int f = 0; f < B; ++f) {
         const double* x = &host[(size_t)(f % W) * blk + (size_t)(f / W) * stride];
         if (p) std::copy(x, x + 3, p + 3 * (size_t)f);

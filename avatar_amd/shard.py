@@ -114,6 +114,10 @@ class Shard:
     def gather_enqueue(self, ctx, num_frames):
         _check(self._lib.avt_shard_gather_enqueue(self.h, ctx.h, C.c_int(num_frames)))
 
+    def gather_wait(self):
+        """Blocks until the last enqueued all-gather is complete (it runs on the shard's own stream)."""
+        _check(self._lib.avt_shard_gather_wait(self.h))
+
     def gather_download(self, ctx, num_frames):
         m = ctx.model
         p = np.empty((num_frames, 3)); q = np.empty((num_frames, m.numJoints() * 4)); w = np.empty((num_frames, m.numShapeKeys()))

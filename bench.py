@@ -75,7 +75,7 @@ def _max_over_ranks(x, torch, dist, world, backend):
 def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, rank, world, local_rank, dense, shard=None, regions=REGIONS):
     """Times `steps` optimize() calls over this rank's F resident frames, `regions` times; returns the per-config dict.
     Global frame g = rank + world * i is frame i of this rank (avt_shard partition); with a shard handle every step also
-    enqueues the result all-gather (RCCL, device buffers) behind optimize()."""
+    enqueues the result all-gather (RCCL, device buffers; on the shard's stream, beside the next step's optimize())."""
     V, J, K, P = gm.numPoints(), gm.numJoints(), gm.numShapeKeys(), gm.arrays.P
     pm = synth.identity_part_map()
     B = F * world
@@ -99,10 +99,12 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
         ctx.state_reset()                 # device-side reinstall of the start state (asynchronous, no host transfer)
         ctx.optimize_resident(opt)        # asynchronous on the context's stream (one hipGraph replay)
         if shard is not None:
-            shard.gather_enqueue(ctx, B)  # ncclAllGather of (p, q, w, stats) of all B frames, same stream, no host sync
+            shard.gather_enqueue(ctx, B)  # ncclAllGather of (p, q, w, stats) of all B frames on the shard's stream, no host sync
 
     def full_sync():
         ctx.sync()
+        if shard is not None:
+            shard.gather_wait()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -137,6 +139,8 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
         for _ in range(steps):
             step()
         ctx.sync()
+        if shard is not None:
+            shard.gather_wait()           # the last step's all-gather (shard stream) is inside the region
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         times.append(_max_over_ranks(t1 - t0, torch, dist, world, args.backend))

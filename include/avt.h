@@ -180,7 +180,9 @@ int avt_get_cloud(avt_ctx* c, int frame, double* cloud_3xV);       /* ava.cloud 
  * (AvatarOptimizer.cpp:1494-1497, Avatar.cpp:22-75): a caller refreshes its Avatar from these instead of running
  * update() a second time.  Any pointer may be NULL. */
 int avt_get_posed(avt_ctx* c, int frame, double* cloud_3xV, double* joint_pos_3xJ, double* joint_trans_12xJ);
-/* data-term Gauss-Newton normal equations J^T J (P x P) and J^T r (P) at the current point + its objective */
+/* data-term Gauss-Newton normal equations J^T J (P x P) and J^T r (P) at the current point + its objective.  Evaluated by
+ * this call (optimize() itself never builds the system of its last trial point) with the correspondences of the last ICP
+ * iteration, for all resident frames; the fit, its cost and the LM state are not changed. */
 int avt_get_normal_equations(avt_ctx* c, int frame, double* H /* P x P */, double* g /* P */, double* cost);
 
 /* diagnostics: 64 doubles per frame (objective after every GN iteration; with -DAVT_TIMING builds also in-kernel

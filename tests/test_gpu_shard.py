@@ -72,6 +72,16 @@ def test_scatter_optimize_gather_equals_plain_path(smpl, gmodel, one_rank_shard)
     for f in range(B):
         assert stg[f].final_cost == sta[f].final_cost and stg[f].num_correspondences == sta[f].num_correspondences
         assert stg[f].gn_iterations == 4 and stg[f].matched_model_points == sta[f].matched_model_points
+    # the exchange of one step runs on the shard's stream beside the next step: after reset -> optimize -> enqueue, three
+    # times without any host synchronisation, the gathered block is the last step's (= the same results again)
+    for _ in range(3):
+        ctx_b.state_reset()
+        ctx_b.optimize_resident(opt)
+        one_rank_shard.gather_enqueue(ctx_b, B)
+    one_rank_shard.gather_wait()
+    pg2, qg2, wg2, stg2 = one_rank_shard.gather_download(ctx_b, B)
+    assert np.array_equal(pg2, pa) and np.array_equal(qg2, qa) and np.array_equal(wg2, wa)
+    assert all(stg2[f].final_cost == sta[f].final_cost for f in range(B))
     one_rank_shard.barrier(ctx_b)
 
 
