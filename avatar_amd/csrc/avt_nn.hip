@@ -12,7 +12,8 @@
 // (pcx/pcy/pcz written by k_lbs).  A workgroup owns 256 consecutive bucketed data points (one per lane);
 // the candidate range of the parts those points span is contiguous in the part-sorted model arrays and is
 // streamed through LDS in tiles of 1024 candidates (24 KB).  Lanes of a wave almost always share a part, so
-// the LDS reads are broadcasts.  Work is fp64-VALU bound: 8 flops + compare/select per candidate.
+// the LDS reads are broadcasts.  Work is fp64-VALU bound: 8 flops + one v_min_f64 per candidate, one compare/select per
+// group of 8 candidates (the position inside the winning group is resolved after the scan).
 //
 // The kernel also accumulates, per matched model vertex, the correspondence count and the fixed-point
 // (2^40, frame-centred) sum of its data points with integer atomics: order-independent, hence bit-wise
@@ -64,7 +65,19 @@ __global__ __launch_bounds__(256) void k_nn(DeviceModel dm, FrameBuffers fb) {
     const double* pcy = fb.vcy + (size_t)f * V;
     const double* pcz = fb.vcz + (size_t)f * V;
     double best = 1.7976931348623157e308;  // numeric_limits<double>::max(), KNNResultSet::init
-    int bi = 0x7fffffff;
+    // The scan keeps the smallest distance and the START of the group of NN_GROUP candidates that first reached it (one compare
+    // and one select per group instead of per candidate); which member of that group it was is settled once, after the scan.
+    // Equivalent to one ascending scan with strict '<': a group replaces the running minimum only if its own minimum is
+    // strictly smaller, and inside the group the first member that attains it wins.
+    constexpr int NN_GROUP = 8;
+    int gpos = -1;                          // absolute position (part-sorted arrays) of the winning group's first candidate
+    auto dist2 = [&](double cx, double cy, double cz) {
+        const double d0 = a0 - cx, d1 = a1 - cy, d2 = a2 - cz;
+        double r = d0 * d0;                 // (0 + d0*d0) == d0*d0 exactly
+        r = r + d1 * d1;
+        r = r + d2 * d2;
+        return r;
+    };
     for (int tb = cb; tb < ce; tb += NN_TILE) {
         const int tn = min(NN_TILE, ce - tb);
         __syncthreads();
@@ -77,36 +90,39 @@ __global__ __launch_bounds__(256) void k_nn(DeviceModel dm, FrameBuffers fb) {
         __syncthreads();
         if (active) {
             const int b = max(my_b, tb) - tb, e = min(my_e, tb + tn) - tb;
-            // lane `sub` of the query's LANES-lane group scans candidates b+sub, b+sub+LANES, ... in ascending order;
-            // four candidates per trip are evaluated independently (ILP) and compared in order (same strict-'<' result)
+            // lane `sub` of the query's LANES-lane group scans candidates b+sub, b+sub+LANES, ... in ascending order
             int c = b + sub;
-            for (; c + 3 * LANES < e; c += 4 * LANES) {
-                double r[4];
+            for (; c + (NN_GROUP - 1) * LANES < e; c += NN_GROUP * LANES) {
+                double r[NN_GROUP];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int cu = c + u * LANES;
-                    const double d0 = a0 - c_x[cu];
-                    const double d1 = a1 - c_y[cu];
-                    const double d2 = a2 - c_z[cu];
-                    double ru = d0 * d0;          // (0 + d0*d0) == d0*d0 exactly
-                    ru = ru + d1 * d1;
-                    ru = ru + d2 * d2;
-                    r[u] = ru;
-                }
+                for (int u = 0; u < NN_GROUP; ++u) r[u] = dist2(c_x[c + u * LANES], c_y[c + u * LANES], c_z[c + u * LANES]);
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (r[u] < best) { best = r[u]; bi = tb + c + u * LANES; }
+                for (int w = 1; w < NN_GROUP; w <<= 1)
+#pragma unroll
+                    for (int u = 0; u + w < NN_GROUP; u += 2 * w) r[u] = __builtin_fmin(r[u], r[u + w]);
+                gpos = (r[0] < best) ? tb + c : gpos;
+                best = __builtin_fmin(best, r[0]);
             }
-            for (; c < e; c += LANES) {
-                const double d0 = a0 - c_x[c];
-                const double d1 = a1 - c_y[c];
-                const double d2 = a2 - c_z[c];
-                double r = d0 * d0;
-                r = r + d1 * d1;
-                r = r + d2 * d2;
-                if (r < best) { best = r; bi = tb + c; }
+            for (; c < e; c += LANES) {     // the tail of the range: groups of one
+                const double r = dist2(c_x[c], c_y[c], c_z[c]);
+                gpos = (r < best) ? tb + c : gpos;
+                best = __builtin_fmin(best, r);
             }
         }
+    }
+    // which member of the winning group: the first whose distance IS the minimum (same operations on the same values, read
+    // back from the part-sorted arrays: the group's tile may have left the LDS)
+    int bi = 0x7fffffff;
+    if (gpos >= 0) {
+        double r[NN_GROUP];
+#pragma unroll
+        for (int u = 0; u < NN_GROUP; ++u) {
+            const int pos = min(gpos + u * LANES, my_e - 1);
+            r[u] = dist2(pcx[pos], pcy[pos], pcz[pos]);
+        }
+#pragma unroll
+        for (int u = NN_GROUP - 1; u >= 0; --u)
+            if (gpos + u * LANES < my_e && r[u] == best) bi = gpos + u * LANES;
     }
     // combine the 4 sub-scans: smallest distance, ties to the lowest candidate position — exactly the winner of
     // one ascending scan with strict '<'
