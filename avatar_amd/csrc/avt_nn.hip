@@ -23,6 +23,58 @@
 #define NN_TILE 1024
 
 
+// round-to-nearest-even of x (|x| < 2^51) as an integer: the low mantissa bits of x + 1.5*2^52 (what __double2ll_rn
+// returns, in two instructions instead of a conversion sequence)
+__device__ __forceinline__ long long rint_to_ll(double x) {
+    const double C = 6755399441055744.0;
+    return __double_as_longlong(x + C) - __double_as_longlong(C);
+}
+
+// ---- correspondence bookkeeping.  Neighbouring pixels usually hit the same model vertex, so runs of equal
+// vertices among the wave's consecutive queries are merged first (segmented inclusive scan over the query lanes,
+// integer adds: order-independent) and only the last lane of each run issues the global atomics (which are what this
+// costs: a scan over runs of at most 8 queries with DPP row shifts instead of LDS permutes measured slower).
+template <int LANES>
+__device__ __forceinline__ void nn_record(const FrameBuffers& fb, const AvtFrameCtl& ctl, int f, int V, size_t base, int s, bool active, int sub,
+                                          int bi, double a0, double a1, double a2) {
+    const bool qlane = active && sub == 0;
+    const int m = (qlane && bi != 0x7fffffff) ? fb.vcid[(size_t)f * V + bi] : -1;
+    if (qlane) {
+        fb.corr_sorted[base + s] = m;
+        fb.corr[base + fb.dorig[base + s]] = m;
+    }
+    int cnt = (m >= 0) ? 1 : 0;
+    long long s0q = 0, s1q = 0, s2q = 0;
+    if (m >= 0) {
+        s0q = rint_to_ll((a0 - ctl.centre[0]) * AVT_FIX_SCALE);
+        s1q = rint_to_ll((a1 - ctl.centre[1]) * AVT_FIX_SCALE);
+        s2q = rint_to_ll((a2 - ctl.centre[2]) * AVT_FIX_SCALE);
+    }
+    const int ql = lane_id() / LANES;                     // index of my query among the wave's 64/LANES queries
+    const int mprev = __shfl_up(m, LANES, 64);
+    bool head = (ql == 0) || (mprev != m);
+#pragma unroll
+    for (int dq = 1; dq < 64 / LANES; dq <<= 1) {
+        const int d = dq * LANES;
+        const int c_up = __shfl_up(cnt, d, 64);
+        const long long a_up = __shfl_up(s0q, d, 64), b_up = __shfl_up(s1q, d, 64), e_up = __shfl_up(s2q, d, 64);
+        const int h_up = __shfl_up((int)head, d, 64);
+        if (ql >= dq) {
+            if (!head) { cnt += c_up; s0q += a_up; s1q += b_up; s2q += e_up; }
+            head = head || (h_up != 0);
+        }
+    }
+    const int mnext = __shfl_down(m, LANES, 64);
+    const bool tail = (ql == 64 / LANES - 1) || (mnext != m);
+    if (sub == 0 && m >= 0 && tail) {
+        atomicAdd(fb.cnt + (size_t)f * V + m, cnt);
+        unsigned long long* fs = (unsigned long long*)(fb.fsum + (size_t)f * 3 * V);
+        atomicAdd(fs + m, (unsigned long long)s0q);
+        atomicAdd(fs + (size_t)V + m, (unsigned long long)s1q);
+        atomicAdd(fs + 2 * (size_t)V + m, (unsigned long long)s2q);
+    }
+}
+
 // LANES lanes cooperate on one query (4: low-latency single-frame shape; 1: throughput shape for large batches)
 template <int LANES>
 __global__ __launch_bounds__(256) void k_nn(DeviceModel dm, FrameBuffers fb) {
@@ -132,45 +184,87 @@ __global__ __launch_bounds__(256) void k_nn(DeviceModel dm, FrameBuffers fb) {
         const int oi = __shfl_xor(bi, m, 64);
         if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
-    // ---- correspondence bookkeeping.  Neighbouring pixels usually hit the same model vertex, so runs of equal
-    // vertices among the wave's consecutive queries are merged first (segmented inclusive scan over the query lanes,
-    // integer adds: order-independent) and only the last lane of each run issues the global atomics.
-    const bool qlane = active && sub == 0;
-    const int m = (qlane && bi != 0x7fffffff) ? fb.vcid[(size_t)f * V + bi] : -1;
-    if (qlane) {
-        fb.corr_sorted[base + s] = m;
-        fb.corr[base + fb.dorig[base + s]] = m;
-    }
-    int cnt = (m >= 0) ? 1 : 0;
-    long long s0q = 0, s1q = 0, s2q = 0;
-    if (m >= 0) {
-        s0q = __double2ll_rn((a0 - ctl.centre[0]) * AVT_FIX_SCALE);
-        s1q = __double2ll_rn((a1 - ctl.centre[1]) * AVT_FIX_SCALE);
-        s2q = __double2ll_rn((a2 - ctl.centre[2]) * AVT_FIX_SCALE);
-    }
-    const int ql = lane_id() / LANES;                     // index of my query among the wave's 64/LANES queries
-    const int mprev = __shfl_up(m, LANES, 64);
-    bool head = (ql == 0) || (mprev != m);
+    nn_record<LANES>(fb, ctl, f, V, base, s, active, sub, bi, a0, a1, a2);
+}
+
+// -------------------------------------------------------------------------------------------------
+// k_nn_part: the throughput shape (frame batches).  A workgroup owns up to 256 consecutive bucketed data points of ONE part
+// (one per lane), so every lane scans the same candidates: the part's visible model points are read with SCALAR loads
+// (constant address space: k_compact wrote them in an earlier kernel) straight into the VALU's scalar operand - no LDS
+// tile, no barrier, no per-lane range arithmetic; what remains per candidate is 8 flops and one v_min_f64.  Same distance
+// expression, same strict '<' in ascending candidate order, hence the same index as k_nn and nanoflann.
+// grid: (upper bound of sum_q ceil(points of part q / 256), frames): lane l of every wave looks at part l, a wave prefix sum
+// of the parts' workgroup counts maps blockIdx.x to (part, chunk).
+// -------------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(4))) double* nn_cptr;
+
+__global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb) {
+    const int f = blockIdx.y + fb.f0, t = threadIdx.x, lane = t & 63;
+    const int V = dm.d.V, np = dm.d.num_parts;
+    const AvtFrameCtl& ctl = fb.ctl[f];
+    const int* po = fb.part_off + (size_t)f * (np + 1);
+    const int po_l = (lane <= np) ? po[min(lane, np)] : 0, po_n = (lane < np) ? po[lane + 1] : 0;
+    const int nbq = (lane < np) ? (po_n - po_l + 255) >> 8 : 0;
+    int incl = nbq;
 #pragma unroll
-    for (int dq = 1; dq < 64 / LANES; dq <<= 1) {
-        const int d = dq * LANES;
-        const int c_up = __shfl_up(cnt, d, 64);
-        const long long a_up = __shfl_up(s0q, d, 64), b_up = __shfl_up(s1q, d, 64), e_up = __shfl_up(s2q, d, 64);
-        const int h_up = __shfl_up((int)head, d, 64);
-        if (ql >= dq) {
-            if (!head) { cnt += c_up; s0q += a_up; s1q += b_up; s2q += e_up; }
-            head = head || (h_up != 0);
+    for (int sft = 1; sft < 64; sft <<= 1) { const int v = __shfl_up(incl, sft, 64); if (lane >= sft) incl += v; }
+    const int excl = incl - nbq, blk = blockIdx.x;
+    const unsigned long long hit = __ballot(lane < np && blk >= excl && blk < incl);
+    if (hit == 0ull) return;                                  // past the last chunk of the last part (grid is an upper bound)
+    const int q = __ffsll((long long)hit) - 1;
+    const int s_beg = __shfl(po_l, q, 64) + (blk - __shfl(excl, q, 64)) * 256, s_end = __shfl(po_n, q, 64);
+    const size_t base = (size_t)f * fb.max_points;
+    const int s = s_beg + t;
+    const bool active = s < s_end;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (active) { a0 = fb.dx[base + s]; a1 = fb.dy[base + s]; a2 = fb.dz[base + s]; }
+    const int pb = __builtin_amdgcn_readfirstlane(dm.part_start[q]);
+    const int pe = pb + __builtin_amdgcn_readfirstlane(fb.vcount[(size_t)f * np + q]);   // visible candidates of the part
+    const nn_cptr cx = (nn_cptr)(uintptr_t)(fb.vcx + (size_t)f * V), cy = (nn_cptr)(uintptr_t)(fb.vcy + (size_t)f * V),
+                  cz = (nn_cptr)(uintptr_t)(fb.vcz + (size_t)f * V);
+    auto dist2 = [&](double px, double py, double pz) {
+        const double d0 = a0 - px, d1 = a1 - py, d2 = a2 - pz;
+        double r = d0 * d0;
+        r = r + d1 * d1;
+        r = r + d2 * d2;
+        return r;
+    };
+    constexpr int NN_GROUP = 4;
+    double best = 1.7976931348623157e308;
+    int gpos = -1;
+    int c = pb;
+    for (; c + NN_GROUP <= pe; c += NN_GROUP) {
+        double r[NN_GROUP];
+#pragma unroll
+        for (int u = 0; u < NN_GROUP; ++u) r[u] = dist2(cx[c + u], cy[c + u], cz[c + u]);
+#pragma unroll
+        for (int w = 1; w < NN_GROUP; w <<= 1)
+#pragma unroll
+            for (int u = 0; u + w < NN_GROUP; u += 2 * w) r[u] = __builtin_fmin(r[u], r[u + w]);
+        gpos = (r[0] < best) ? c : gpos;
+        best = __builtin_fmin(best, r[0]);
+    }
+    for (; c < pe; ++c) {
+        const double r = dist2(cx[c], cy[c], cz[c]);
+        gpos = (r < best) ? c : gpos;
+        best = __builtin_fmin(best, r);
+    }
+    int bi = 0x7fffffff;
+    if (gpos >= 0) {      // the first member of the winning group whose distance is the minimum
+        const double* pcx = fb.vcx + (size_t)f * V;
+        const double* pcy = fb.vcy + (size_t)f * V;
+        const double* pcz = fb.vcz + (size_t)f * V;
+        double r[NN_GROUP];
+#pragma unroll
+        for (int u = 0; u < NN_GROUP; ++u) {
+            const int pos = min(gpos + u, pe - 1);
+            r[u] = dist2(pcx[pos], pcy[pos], pcz[pos]);
         }
+#pragma unroll
+        for (int u = NN_GROUP - 1; u >= 0; --u)
+            if (gpos + u < pe && r[u] == best) bi = gpos + u;
     }
-    const int mnext = __shfl_down(m, LANES, 64);
-    const bool tail = (ql == 64 / LANES - 1) || (mnext != m);
-    if (sub == 0 && m >= 0 && tail) {
-        atomicAdd(fb.cnt + (size_t)f * V + m, cnt);
-        unsigned long long* fs = (unsigned long long*)(fb.fsum + (size_t)f * 3 * V);
-        atomicAdd(fs + m, (unsigned long long)s0q);
-        atomicAdd(fs + (size_t)V + m, (unsigned long long)s1q);
-        atomicAdd(fs + 2 * (size_t)V + m, (unsigned long long)s2q);
-    }
+    nn_record<1>(fb, ctl, f, V, base, s, active, 0, bi, a0, a1, a2);
 }
 
 // Visible model points of every part, compacted in ascending vertex order inside the part's segment of the
@@ -218,7 +312,7 @@ void launch_nn(avt_ctx* c, int nframes) {
     const int maxN = c->launch_maxN;
     if (maxN <= 0) return;
     hipLaunchKernelGGL(k_compact, dim3(c->dm.d.num_parts, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
-    // few queries: 4 lanes per query (more workgroups, shorter scans); many: one lane per query
+    // few queries: 4 lanes per query (more workgroups, shorter scans); many: one lane per query, one part per workgroup
     if ((long long)nframes * maxN <= 400000) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn<4>), dim3((maxN + 63) / 64, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn<1>), dim3((maxN + 255) / 256, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
+    else hipLaunchKernelGGL(k_nn_part, dim3((maxN + 255) / 256 + c->dm.d.num_parts, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
 }
