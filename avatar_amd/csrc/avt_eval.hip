@@ -115,16 +115,38 @@ void launch_records(avt_ctx* c, int nframes) {
     hipLaunchKernelGGL(k_records, dim3(c->dm.d.nb_max + c->fb.const_used, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
 }
 
+// lane N of every row of 16 lanes (= the 16 slots of one point) -> all lanes of that row: a DPP operand modifier
+// (v_mov_b32_dpp row_newbcast, tools/ubench/dpp_bcast.hip), no LDS round trip.  Must run with the source lanes switched on.
+template <int N>
+__device__ __forceinline__ double row_bcast(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + N, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int N>
+__device__ __forceinline__ int row_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xf, 0xf, false); }
+// lane l <- lane l - SH of its row (0.0 where that leaves the row)
+template <int SH>
+__device__ __forceinline__ double row_shr(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + SH, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + SH, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
 // What a wave needs to turn the records of its 4 points into rows of the tile: the skeleton tables staged in LDS
 struct EvalTables {
     const double *Rw, *oo, *Jh, *Gm, *ww, *off, *ident;
 };
 
-// One wave, 4 points x 16 slots (after stage_records put the wave's records in LDS): my 12 rows of the tile zeroed, shaped rest position,
-// the <= 4 carried points x_k, then one lane per (point, ancestor) writes the rotation block; shape block, residual
-// column and translation block follow.  Everything is wave-local (LDS operations of one wave execute in order), so the
-// caller needs no workgroup barrier around it.  qw = the wave's point quad (rows 12*qw..12*qw+11 of the tile), R = the
-// wave's record region, s_xhat / s_xk / s_T = scratch of the 16 points this wave's workgroup (or producer group) builds.
+// One wave, 4 points x 16 slots (after stage_records put the wave's records in LDS): my 12 rows of the live tiles zeroed, then
+// every sum over a point's data is spread over the point's 16 lanes (= one DPP row) and what a lane computed reaches the
+// others by DPP row broadcasts / row shifts - registers, no LDS round trip: the per-point scalars, the shaped rest position
+// (lane k: shape key k, row scan), the blended rotation (lane e9), the <= 4 carried points x_k (lane 3a + c); then one lane
+// per (point, ancestor) writes the rotation block, lane k the three rows of shape key k, lanes 0..5 the residual column and
+// the translation block.  The only LDS traffic left is the records, the skeleton tables and the tile itself.  Everything is
+// wave-local (LDS operations of one wave execute in order), so the caller needs no workgroup barrier around it.
+// qw = the wave's point quad (rows 12*qw..12*qw+11 of the tile), Rrec = the wave's record region.
 template <int NPF>
 __device__ __forceinline__ void stage_records(double* __restrict__ Rrec, int RQ2, int ln, const d2v (&pf)[NPF]) {
     d2v* R2 = (d2v*)Rrec;
@@ -139,8 +161,7 @@ __device__ __forceinline__ void stage_records(double* __restrict__ Rrec, int RQ2
 // needs sum c|r|^2 of the trial point and nothing else; same instructions for that column, hence the same bits).
 template <int CJ, int CK, int MT, bool COST>
 __device__ __forceinline__ void build_rows(const AvtDims& d, const EvalTables& T, double* __restrict__ s_Jt, const double* __restrict__ Rrec,
-                                           double* __restrict__ s_xhat, double* __restrict__ s_xk, double* __restrict__ s_T, int qw, int ln,
-                                           unsigned long long zmask) {
+                                           int qw, int ln, unsigned long long zmask) {
     constexpr bool FIXED = CJ != 0;
     constexpr int RS = AVT_EVAL_RS;
     const int J = FIXED ? CJ : d.J, K = FIXED ? CK : d.K, P = 3 + 3 * J + K, NC = P + 1;
@@ -158,34 +179,61 @@ __device__ __forceinline__ void build_rows(const AvtDims& d, const EvalTables& T
     wave_sync();
     const double* R = Rrec;
     const int* RI = (const int*)(R + ND * 4);
-    if (slot < 3) {   // shaped rest position, root-subtracted (CalcShape, :249-272)
-        double a = 0.0;
-#pragma unroll
-        for (int k = 0; k < (FIXED ? CK : AVT_MAX_SHAPE); ++k)
-            if (k < K) a += R[(3 * k + slot) * 4 + p4] * ww[k];
-        s_xhat[pi * 3 + slot] = (a + R[(3 * K + slot) * 4 + p4]) - off[slot];
+    // ---- per-point scalars: one LDS read per lane, handed to the point's 16 lanes by DPP broadcasts ----------------------
+    double pv = 0.0;
+    int piv = 0;
+    if (slot < 5) pv = R[(3 * K + 6 + slot) * 4 + p4];           // sqrt(count), the 4 weights
+    else if (slot < 9) piv = RI[(slot - 5) * 4 + p4];            // the 4 assigned joints
+    const double sc = row_bcast<0>(pv);
+    const double aw[4] = {row_bcast<1>(pv), row_bcast<2>(pv), row_bcast<3>(pv), row_bcast<4>(pv)};
+    const int aj[4] = {row_bcast<5>(piv), row_bcast<6>(piv), row_bcast<7>(piv), row_bcast<8>(piv)};
+    // ---- shaped rest position, root-subtracted (CalcShape, :249-272): lane k holds shape key k's term of each coordinate,
+    // the 16 lanes are summed by a row scan (fixed order), lane c < 3 adds the base cloud and subtracts the root offset
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    if (slot < K) {
+        const double wk = ww[slot];
+        t0 = R[(3 * slot) * 4 + p4] * wk; t1 = R[(3 * slot + 1) * 4 + p4] * wk; t2 = R[(3 * slot + 2) * 4 + p4] * wk;
     }
-    wave_sync();
-    const double sc = R[(3 * K + 6) * 4 + p4];
-    double aw[4];
-    int aj[4];
+    t0 += row_shr<8>(t0); t1 += row_shr<8>(t1); t2 += row_shr<8>(t2);
+    t0 += row_shr<4>(t0); t1 += row_shr<4>(t1); t2 += row_shr<4>(t2);
+    t0 += row_shr<2>(t0); t1 += row_shr<2>(t1); t2 += row_shr<2>(t2);
+    t0 += row_shr<1>(t0); t1 += row_shr<1>(t1); t2 += row_shr<1>(t2);
+    const double s0 = row_bcast<15>(t0), s1 = row_bcast<15>(t1), s2 = row_bcast<15>(t2);
+    double xh = 0.0;
+    if (slot < 3) xh = ((slot == 0 ? s0 : (slot == 1 ? s1 : s2)) + R[(3 * K + slot) * 4 + p4]) - off[slot];
+    const double xh0 = row_bcast<0>(xh), xh1 = row_bcast<1>(xh), xh2 = row_bcast<2>(xh);
+    if constexpr (!COST) {
+        // ---- shape block (:568-580): (sum a_k Rw_k) D_k + sum a_k G_k.  Lane e9 < 9 blends entry e9 of the rotation, all
+        // nine entries reach every lane by broadcast, lane k < K writes the three rows of shape key k
+        double tb = 0.0;
+        if (slot < 9) tb = ((aw[0] * Rw[9 * aj[0] + slot] + aw[1] * Rw[9 * aj[1] + slot]) + aw[2] * Rw[9 * aj[2] + slot]) + aw[3] * Rw[9 * aj[3] + slot];
+        const double Tb[9] = {row_bcast<0>(tb), row_bcast<1>(tb), row_bcast<2>(tb), row_bcast<3>(tb), row_bcast<4>(tb),
+                              row_bcast<5>(tb), row_bcast<6>(tb), row_bcast<7>(tb), row_bcast<8>(tb)};
+        if (slot < K) {
+            const double D0 = R[(3 * slot) * 4 + p4], D1 = R[(3 * slot + 1) * 4 + p4], D2 = R[(3 * slot + 2) * 4 + p4];
+            double shv[3];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) { aw[a] = R[(3 * K + 7 + a) * 4 + p4]; aj[a] = RI[a * 4 + p4]; }
-    // x_k = R(-1,k)(x^ - J^_k) + t(-1,k) for the <=4 assigned joints (:508-514); blended rotation T = sum a_k Rw_k
-    if (slot < 4) {
-        const int k = aj[slot];
-        const double* Rk = Rw + 9 * k;
-        const double e0 = s_xhat[pi * 3] - Jh[3 * k], e1 = s_xhat[pi * 3 + 1] - Jh[3 * k + 1], e2 = s_xhat[pi * 3 + 2] - Jh[3 * k + 2];
-        double* xk = s_xk + (pi * 4 + slot) * 3;
-        xk[0] = (Rk[0] * e0 + Rk[1] * e1 + Rk[2] * e2) + oo[3 * k];
-        xk[1] = (Rk[3] * e0 + Rk[4] * e1 + Rk[5] * e2) + oo[3 * k + 1];
-        xk[2] = (Rk[6] * e0 + Rk[7] * e1 + Rk[8] * e2) + oo[3 * k + 2];
-    } else if (!COST && slot < 13) {
-        const int e9 = slot - 4;
-        s_T[pi * 9 + e9] = ((aw[0] * Rw[9 * aj[0] + e9] + aw[1] * Rw[9 * aj[1] + e9]) + aw[2] * Rw[9 * aj[2] + e9]) + aw[3] * Rw[9 * aj[3] + e9];
+            for (int r = 0; r < 3; ++r) {
+                const int e = r * K + slot;
+                const double gs = ((aw[0] * Gm[aj[0] * 3 * K + e] + aw[1] * Gm[aj[1] * 3 * K + e]) + aw[2] * Gm[aj[2] * 3 * K + e]) + aw[3] * Gm[aj[3] * 3 * K + e];
+                shv[r] = sc * ((Tb[3 * r] * D0 + Tb[3 * r + 1] * D1 + Tb[3 * r + 2] * D2) + gs);
+            }
+            double* o = s_Jt + (size_t)(d.col_shape + slot) * RS + pi * 3;
+            o[0] = shv[0]; o[1] = shv[1]; o[2] = shv[2];
+        }
     }
-    wave_sync();
-    const double* xk = s_xk + pi * 12;
+    // ---- x_k = R(-1,k)(x^ - J^_k) + t(-1,k) for the <=4 assigned joints (:508-514): lane 3a + c computes coordinate c of
+    // carried point a; the twelve values reach every lane of the point by broadcast
+    double xkv = 0.0;
+    if (slot < 12) {
+        const int a = slot / 3, c = slot - 3 * a;
+        const int k = a == 0 ? aj[0] : (a == 1 ? aj[1] : (a == 2 ? aj[2] : aj[3]));
+        const double* Rk = Rw + 9 * k + 3 * c;
+        const double e0 = xh0 - Jh[3 * k], e1 = xh1 - Jh[3 * k + 1], e2 = xh2 - Jh[3 * k + 2];
+        xkv = (Rk[0] * e0 + Rk[1] * e1 + Rk[2] * e2) + oo[3 * k + c];
+    }
+    const double xkr[12] = {row_bcast<0>(xkv), row_bcast<1>(xkv), row_bcast<2>(xkv), row_bcast<3>(xkv), row_bcast<4>(xkv), row_bcast<5>(xkv),
+                            row_bcast<6>(xkv), row_bcast<7>(xkv), row_bcast<8>(xkv), row_bcast<9>(xkv), row_bcast<10>(xkv), row_bcast<11>(xkv)};
     const int aword = COST ? 0 : RI[(4 + slot) * 4 + p4];
     if (aword != 0) {   // rotation block of ancestor j: -2 sqrt(c) [l_j]_x R(-1,parent j)
         const int j = aword & 0xff;
@@ -194,11 +242,9 @@ __device__ __forceinline__ void build_rows(const AvtDims& d, const EvalTables& T
         // the tables do not alias and would otherwise re-load the tables after every store (one LDS round trip each)
         const int pj = (aword >> 16) & 0xff;
         const double* Rp = pj ? Rw + 9 * (pj - 1) : T.ident;
-        double rp[9], xkr[12];
+        double rp[9];
 #pragma unroll
         for (int e = 0; e < 9; ++e) rp[e] = Rp[e];
-#pragma unroll
-        for (int e = 0; e < 12; ++e) xkr[e] = xk[e];
         const double oj0 = oo[3 * j], oj1 = oo[3 * j + 1], oj2 = oo[3 * j + 2];
         double X0 = 0.0, X1 = 0.0, X2 = 0.0, cj = 0.0;
 #pragma unroll
@@ -220,78 +266,34 @@ __device__ __forceinline__ void build_rows(const AvtDims& d, const EvalTables& T
 #pragma unroll
         for (int c = 0; c < 3; ++c) { o0[c * RS] = ov[3 * c]; o0[c * RS + 1] = ov[3 * c + 1]; o0[c * RS + 2] = ov[3 * c + 2]; }
     }
-    // shape block (:568-580): (sum a_k Rw_k) D_k + sum a_k G_k; residual column; identity translation block.
-    // All values first, all stores afterwards (see the rotation block).
-    constexpr int NSH = (3 * (FIXED ? CK : AVT_MAX_SHAPE) + 15) / 16;
-    double shv[NSH];
-#pragma unroll
-    for (int it = 0; it < NSH; ++it) {
-        const int e = slot + 16 * it;
-        shv[it] = 0.0;
-        if (!COST && e < 3 * K) {
-            const int r = e / K, k = e - r * K;
-            const double* Tr = s_T + pi * 9 + 3 * r;
-            const double gs = ((aw[0] * Gm[aj[0] * 3 * K + e] + aw[1] * Gm[aj[1] * 3 * K + e]) + aw[2] * Gm[aj[2] * 3 * K + e]) + aw[3] * Gm[aj[3] * 3 * K + e];
-            const double a = (Tr[0] * R[(3 * k) * 4 + p4] + Tr[1] * R[(3 * k + 1) * 4 + p4] + Tr[2] * R[(3 * k + 2) * 4 + p4]) + gs;
-            shv[it] = sc * a;
-        }
-    }
-    double resv = 0.0;
-    if (slot < 3) {          // residual column: sqrt(c) (x_m - dbar_m)
+    // residual column sqrt(c) (x_m - dbar_m); identity root-translation block (:476-481)
+    if (slot < 3) {
         double xm = 0.0;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) xm += aw[a] * xk[3 * a + slot];
-        resv = sc * (xm - R[(3 * K + 3 + slot) * 4 + p4]);
-    }
-#pragma unroll
-    for (int it = 0; it < NSH; ++it) {
-        const int e = slot + 16 * it;
-        if (!COST && e < 3 * K) {
-            const int r = e / K, k = e - r * K;
-            s_Jt[(size_t)(d.col_shape + k) * RS + pi * 3 + r] = shv[it];
-        }
-    }
-    if (slot < 3) s_Jt[(size_t)d.col_res * RS + pi * 3 + slot] = resv;
-    else if (!COST && slot < 6) {   // identity root-translation block (:476-481)
+        for (int a = 0; a < 4; ++a) xm += aw[a] * (slot == 0 ? xkr[3 * a] : (slot == 1 ? xkr[3 * a + 1] : xkr[3 * a + 2]));
+        s_Jt[(size_t)d.col_res * RS + pi * 3 + slot] = sc * (xm - R[(3 * K + 3 + slot) * 4 + p4]);
+    } else if (!COST && slot < 6) {
         const int r = slot - 3;
         s_Jt[(size_t)(d.col_tr + r) * RS + pi * 3 + r] = sc;
     }
 }
 
-// upper-triangular tile pairs of the 6x6 tile grid, in the order k_reduce / k_solve decode them
-__device__ constexpr int PAIR6_TI[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
-__device__ constexpr int PAIR6_TJ[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
-
-// SMPL shape (6 column tiles, 21 tile pairs, 12 k-steps per batch = 252 matrix instructions when every tile is live):
-// wave W owns pairs W, W+4, .., W+16 and k-steps 3W..3W+2 of the last pair (5,5), 63 instructions per wave and batch.
-// A and B operands are the same kind of fragment (lane l: tile column (l&15) -> its storage column, row k0 + (l>>4)), so
-// a pair costs 24 LDS reads (12 on the diagonal).  pm = the batch's live tile pairs (bit p): one wave-uniform scalar
-// branch per pair (matrix instructions ignore EXEC), the 12 k-steps of a live pair are straight-line code.
-template <int W>
-__device__ __forceinline__ void mfma_batch6(const double* const (&base)[6], int pm, v4f64 (&acc)[6]) {
+// SMPL shape (6 column tiles, 21 tile pairs, 12 k-steps per batch = 252 matrix instructions when every tile is live): a wave
+// owns the five pairs the host dealt it (AvtDims::pair_deal: even expected loads, avt_model.cpp) and k-steps 3W..3W+2 of the
+// split pair.  A and B operands are the same kind of fragment (lane l: tile column (l&15) -> its storage column, row
+// k0 + (l>>4)), so a pair costs 24 LDS reads (12 on the diagonal).  pm = the batch's live tile pairs (bit p): one wave-uniform
+// scalar branch per pair (matrix instructions ignore EXEC), the 12 k-steps of a live pair are straight-line code.
+template <bool DIAG>
+__device__ __forceinline__ void mfma_pair(const double* __restrict__ a, const double* __restrict__ b, v4f64& acc) {
+    constexpr int NK = AVT_EVAL_ROWS / 4;
+    double fa[NK], fbv[NK];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int p = W + 4 * i;
-        if ((pm >> p) & 1) {                 // one scalar branch per live pair, straight-line code inside
-            constexpr int NK = AVT_EVAL_ROWS / 4;
-            const int ti = PAIR6_TI[p], tj = PAIR6_TJ[p];
-            double fa[NK], fbv[NK];
-#pragma unroll
-            for (int ks = 0; ks < NK; ++ks) {
-                fa[ks] = base[ti][4 * ks];
-                fbv[ks] = (ti != tj) ? base[tj][4 * ks] : fa[ks];
-            }
-#pragma unroll
-            for (int ks = 0; ks < NK; ++ks) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks], fbv[ks], acc[i], 0, 0, 0);
-        }
+    for (int ks = 0; ks < NK; ++ks) {
+        fa[ks] = a[4 * ks];
+        fbv[ks] = DIAG ? fa[ks] : b[4 * ks];
     }
-    if ((pm >> 20) & 1) {
 #pragma unroll
-        for (int ks = 3 * W; ks < 3 * W + 3; ++ks) {
-            const double f = base[5][4 * ks];
-            acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(f, f, acc[5], 0, 0, 0);
-        }
-    }
+    for (int ks = 0; ks < NK; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks], fbv[ks], acc, 0, 0, 0);
 }
 
 // =================================================================================================
@@ -369,20 +371,30 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : (MT > 8 ? 1 : 2)) void k_eval(
     double* s_prep = (double*)smem;                               // Rw o Jh G | w off
     double* s_Jt = s_prep + nprep;                                // [NC + 1][RS]
     double* s_rec = s_Jt + AVT_EVAL_TILE(NC + 1);                 // [4 waves][RQ]
-    double* s_xhat = s_rec + 4 * RQ;                              // [16][3]
-    double* s_xk = s_xhat + 48;                                   // [16][4][3]
-    double* s_T = s_xk + 192;                                     // [16][9]  blended rotation per point
-    double* s_ident = s_T + 144;                                  // [9]  R(-1,parent of the root) = I
+    double* s_ident = s_rec + 4 * RQ;                             // [9]  R(-1,parent of the root) = I
 
     const double* prep = fb.prep + ((size_t)f * 2 + try_slot) * d.prep_size;
     for (int e = t; e < npre + K + 3; e += 256) s_prep[e] = prep[e < npre ? e : e + 4 * J];
     if (t < 9) s_ident[t] = (t == 0 || t == 4 || t == 8) ? 1.0 : 0.0;
     if (t < RS) s_Jt[(size_t)NC * RS + t] = 0.0;
     // MFMA operand fragments: lane l reads storage column tile_col[tile*16 + (l&15)] (padding -> the zero column), rows k0 + (l>>4)
-    const double* fbase[6];
+    // six-tile shape: my wave's five dealt pairs (pair index = bit of the batch word, operand fragments, diagonal or not) and my
+    // k-steps of the split pair
+    int dp_bit[6];
+    bool dp_diag[6];
+    const double *dp_a[6], *dp_b[6];
     if constexpr (FIXED) {
+        const int wvs = __builtin_amdgcn_readfirstlane(wv);
+        const unsigned mydeal = wvs == 0 ? d.pair_deal[0] : (wvs == 1 ? d.pair_deal[1] : (wvs == 2 ? d.pair_deal[2] : d.pair_deal[3]));
 #pragma unroll
-        for (int ti = 0; ti < 6; ++ti) fbase[ti] = s_Jt + (size_t)dm.tile_col[ti * 16 + (ln & 15)] * RS + (ln >> 4);
+        for (int i = 0; i < 6; ++i) {
+            dp_bit[i] = i < 5 ? (int)((mydeal >> (5 * i)) & 31u) : d.pair_split;
+            dp_diag[i] = (mydeal >> (25 + i)) & 1u;
+            const int k0 = i < 5 ? 0 : 12 * wvs;     // the split pair: rows 12 W .. 12 W + 11
+            // storage columns of my fragments, per wave and dealt pair, from the host (twelve independent loads)
+            dp_a[i] = s_Jt + (size_t)dm.deal_col[((wvs * 6 + i) * 2 + 0) * 16 + (ln & 15)] * RS + (ln >> 4) + k0;
+            dp_b[i] = s_Jt + (size_t)dm.deal_col[((wvs * 6 + i) * 2 + 1) * 16 + (ln & 15)] * RS + (ln >> 4) + k0;
+        }
     }
     const double* Rw = s_prep;                                    // prep_off_Rw = 0
     const double* oo = s_prep + 9 * J;
@@ -422,6 +434,9 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : (MT > 8 ? 1 : 2)) void k_eval(
         EPROBE(0);
         // ---- wave-local from here to the next barrier ------------------------------------------------------
         stage_records<NPF>(s_rec + (size_t)wv * RQ, RQ2, ln, pf);
+#ifdef AVT_TIMING
+        wave_sync(); __builtin_amdgcn_s_waitcnt(0); EPROBE(2);      // records-wait: the prefetched records have arrived and sit in LDS
+#endif
         const int bw = __builtin_amdgcn_readfirstlane(bm_next);   // live tiles / tile pairs of this batch (k_records)
         // (COST: only the tile of the residual column and its diagonal pair)
         const int tm = COST ? (1 << d.res_tile) : (NT > 8 ? (bw & 0xffff) : (int)((unsigned)bw >> 24)), pm = COST ? (1 << d.res_pair) : (bw & 0xffffff);
@@ -431,18 +446,25 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : (MT > 8 ? 1 : 2)) void k_eval(
 #pragma unroll
         for (int ti = 0; ti < MT; ++ti)
             if (ti < NT && ((tm >> ti) & 1)) zmask |= d.tile_zpass[ti];
-        build_rows<CJ, CK, MT, COST>(d, tabs, s_Jt, s_rec + (size_t)wv * RQ, s_xhat, s_xk, s_T, wv, ln, zmask);
+        build_rows<CJ, CK, MT, COST>(d, tabs, s_Jt, s_rec + (size_t)wv * RQ, wv, ln, zmask);
         EPROBE(3);
         __syncthreads();
         EPROBE(4);
         // MFMA phase: 12 k-steps of 4 rows
         wm |= (unsigned long long)pm;
         if constexpr (FIXED) {
-            switch (wv) {
-                case 0: mfma_batch6<0>(fbase, pm, acc); break;
-                case 1: mfma_batch6<1>(fbase, pm, acc); break;
-                case 2: mfma_batch6<2>(fbase, pm, acc); break;
-                default: mfma_batch6<3>(fbase, pm, acc); break;
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+                if ((pm >> dp_bit[i]) & 1) {             // one scalar branch per live pair, straight-line code inside
+                    if (dp_diag[i]) mfma_pair<true>(dp_a[i], dp_a[i], acc[i]);
+                    else mfma_pair<false>(dp_a[i], dp_b[i], acc[i]);
+                }
+            if ((pm >> dp_bit[5]) & 1) {
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    const double fa = dp_a[5][4 * ks], fbv = dp_b[5][4 * ks];
+                    acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fbv, acc[5], 0, 0, 0);
+                }
             }
             EPROBE(1);
         } else {
@@ -459,7 +481,7 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : (MT > 8 ? 1 : 2)) void k_eval(
     }
 #ifdef AVT_TIMING
     EPROBE(5);
-    if (ln == 0 && f == fb.f0 && g == 0) { for (int k = 0; k < 8; ++k) fb.trace[(size_t)f * 64 + 16 + 8 * wv + k] = (double)tacc[k]; if (wv == 0) fb.trace[(size_t)f * 64 + 56] = (double)(wall_clock64() - wall0); }
+    if (!COST && ln == 0 && f == fb.f0 && g == 0) { for (int k = 0; k < 8; ++k) fb.trace[(size_t)f * 64 + 16 + 8 * wv + k] = (double)tacc[k]; if (wv == 0) fb.trace[(size_t)f * 64 + 56] = (double)(wall_clock64() - wall0); }
 #endif
 #ifdef AVT_TIMELINE
     if (t == 0 && g < 8) {   // where and when this workgroup ran (tools/eval_block_timeline.py, -DAVT_TIMELINE builds)
@@ -470,7 +492,7 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : (MT > 8 ? 1 : 2)) void k_eval(
         tr[0] = (double)wall0; tr[1] = (double)wall_clock64(); tr[2] = (double)((xcc & 0xf) * 65536 + (hw & 0xffff));
     }
 #endif
-    if (FIXED && ((wm >> 20) & 1)) {   // the four waves' shares of pair (5,5) are summed in wave order by wave 0 (wm is workgroup-uniform)
+    if (FIXED && ((wm >> d.pair_split) & 1)) {   // the four waves' shares of the split pair are summed in wave order by wave 0 (wm is workgroup-uniform)
         __syncthreads();
         if (wv > 0) {
 #pragma unroll
@@ -488,7 +510,8 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : (MT > 8 ? 1 : 2)) void k_eval(
     double* part = fb.partial + (((size_t)f * G + g) * NPAIR) * 256;
 #pragma unroll
     for (int i = 0; i < MAXPW; ++i) {
-        const int p = wv + 4 * i;
+        int p = wv + 4 * i;
+        if constexpr (FIXED) p = (i < 5 || wv == 0) ? dp_bit[i] : NPAIR;     // my dealt pairs; wave 0 also writes the split pair
         if (p < NPAIR && (p >= 64 || ((wm >> (p & 63)) & 1))) {   // untouched pairs stay unwritten: k_reduce reads the mask
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[(size_t)p * 256 + r * 64 + ln] = acc[i][r];
@@ -501,7 +524,7 @@ static bool eval_fixed_shape(const AvtDims& d) { return d.J == 24 && d.K == 10; 
 
 static size_t eval_lds_bytes(const AvtDims& d) {
     const size_t nprep = ((size_t)15 * d.J + 3 * d.J * d.K + d.K + 3 + 1) & ~(size_t)1;
-    return sizeof(double) * (nprep + (size_t)AVT_EVAL_TILE(d.P + 2) + 4 * (size_t)d.rec_quad + 48 + 192 + 144 + 10);
+    return sizeof(double) * (nprep + (size_t)AVT_EVAL_TILE(d.P + 2) + 4 * (size_t)d.rec_quad + 10);
 }
 
 // cost_only: the last evaluation of an ICP iteration (launch_reduce(.., decide = true) follows)

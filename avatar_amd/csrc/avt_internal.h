@@ -44,6 +44,10 @@ struct AvtDims {
     int nb_max;              // eval batches a frame can have: ceil(V/16)
     int col_tr, col_shape, col_res;   // storage columns of the evaluation tile: root translation, first shape key, residual (avt_model.cpp)
     int res_tile, res_pair;  // the column tile that holds the residual column and the index of its diagonal tile pair
+    // six-tile evaluation (SMPL shape): which wave contracts which tile pair - pair_deal[wave] (five 5-bit pair indices each; 20 pairs), and the pair
+    // whose 12 k-steps are split over the four waves; dealt on the host so that the waves' expected loads are even (avt_model.cpp)
+    unsigned pair_deal[4];   // wave w: five 5-bit pair indices, pair i at bits 5i..5i+4; bit 25+i: pair i is diagonal (i = 5: the split pair)
+    int pair_split;
     unsigned long long tile_zpass[AVT_MAX_TILES];   // per tile: the 5-column zeroing passes of build_rows that overlap its storage columns (bit = pass)
 };
 
@@ -134,6 +138,7 @@ struct DeviceModel {
     int* jlevel;          // [J] depth of the joint in the kinematic tree (root 0)
     // column layout of the evaluation tile (build_tile_layout, avt_model.cpp)
     int* tile_col;        // [16*NT] tile column -> storage column (P+1 = the all-zero column for padding)
+    int* deal_col;        // [4 waves][6 pairs][2 operands][16] six-tile shape: storage columns of the A / B fragments of the wave's dealt pairs (5) and the split pair
     int* tile_param;      // [16*NT] tile column -> parameter index (P = residual), -1 = padding
     int* joint_col;       // [J] storage column of the joint's first rotation parameter
     int* vorder;          // [V] vertices ordered by the set of tiles their rows touch, then by id
@@ -209,7 +214,7 @@ struct avt_model {
     // host copies (used by avt_ctx_create to build the device model and by accessors)
     std::vector<double> shape_planes, lbs_w, asg_w, jsr_base, jsr, S, Sp, vrec;
     std::vector<int> lbs_j, asg_j, mesh_soa, parent, main_joint, jlevel, fk_items, fk_level_off;
-    std::vector<int> tile_col, tile_param, joint_col, vorder;
+    std::vector<int> tile_col, tile_param, joint_col, vorder, deal_col;
     std::vector<unsigned char> anc_n;
     std::vector<unsigned short> anc, vmask;
     std::vector<double> prior_mean, prior_prec, prior_L, prior_clog;

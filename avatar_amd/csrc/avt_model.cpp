@@ -9,6 +9,7 @@
 // and lays everything out SoA for coalesced device access.
 #include <exception>
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <functional>
@@ -125,6 +126,71 @@ static void build_tile_layout(avt_model* m, const int* parent) {
     for (int v = 0; v < V; ++v) m->vmask[v] = (unsigned short)(vm[v] | (1u << res_tile));
     m->vorder.resize(V); std::iota(m->vorder.begin(), m->vorder.end(), 0);
     std::stable_sort(m->vorder.begin(), m->vorder.end(), [&](int a, int b) { return m->vmask[a] < m->vmask[b]; });
+}
+
+// Which wave of k_eval's workgroup contracts which of the 21 tile pairs of the six-tile layout.  The pairs a batch of 16
+// matched points touches depend on the tiles of its vertices (vmask), and a wave works through its live pairs one after
+// the other (12 dependent matrix instructions each): the phase lasts as long as the busiest wave.  One pair - the most
+// frequent one - is split four ways by k-steps; the other 20 are dealt 5 per wave by descending frequency onto the wave
+// with the least expected load, then improved by pairwise swaps against the batches of the model's own vertex order
+// (mean over batches of the busiest wave's pair count).  Deterministic; the default p mod 4 deal when NT != 6.
+static void deal_tile_pairs(avt_model* m) {
+    AvtDims& d = m->d;
+    for (int w = 0; w < 4; ++w) d.pair_deal[w] = 0;
+    for (int p = 0; p < 20; ++p) d.pair_deal[p % 4] |= (unsigned)p << (5 * (p / 4));
+    d.pair_split = 20;
+    if (d.NT != 6) return;
+    const int V = d.V, NP = 21;
+    int pti[NP], ptj[NP];
+    for (int i = 0, p = 0; i < 6; ++i) for (int j = i; j < 6; ++j, ++p) { pti[p] = i; ptj[p] = j; }
+    std::vector<std::array<unsigned char, NP>> live;
+    for (int b = 0; b < V; b += 16) {
+        unsigned mask = 0;
+        for (int v = b; v < std::min(V, b + 16); ++v) mask |= m->vmask[m->vorder[v]];
+        std::array<unsigned char, NP> l{};
+        for (int p = 0; p < NP; ++p) l[p] = ((mask >> pti[p]) & (mask >> ptj[p]) & 1u) ? 1 : 0;
+        live.push_back(l);
+    }
+    std::vector<double> freq(NP, 0.0);
+    for (auto& l : live) for (int p = 0; p < NP; ++p) freq[p] += l[p];
+    std::vector<int> order(NP);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return freq[a] > freq[b]; });
+    int owner[NP];                                   // wave of every pair, 4 = split
+    owner[order[0]] = 4;
+    double wload[4] = {0, 0, 0, 0};
+    int wcount[4] = {0, 0, 0, 0};
+    for (int k = 1; k < NP; ++k) {
+        int best = -1;
+        for (int w = 0; w < 4; ++w) if (wcount[w] < 5 && (best < 0 || wload[w] < wload[best])) best = w;
+        owner[order[k]] = best; wload[best] += freq[order[k]]; ++wcount[best];
+    }
+    auto cost = [&]() {
+        long long total4 = 0;                         // 4 x (sum over batches of the busiest wave's load), the split pair counts 1/4
+        for (auto& l : live) {
+            int c[4] = {0, 0, 0, 0}, split = 0;
+            for (int p = 0; p < NP; ++p) if (l[p]) { if (owner[p] == 4) split = 1; else c[owner[p]] += 4; }
+            total4 += std::max(std::max(c[0], c[1]), std::max(c[2], c[3])) + split;
+        }
+        return total4;
+    };
+    long long cur = cost();
+    for (bool improved = true; improved;) {
+        improved = false;
+        for (int a = 0; a < NP; ++a)
+            for (int b = a + 1; b < NP; ++b) {
+                if (owner[a] == owner[b]) continue;
+                std::swap(owner[a], owner[b]);
+                const long long c = cost();
+                if (c < cur) { cur = c; improved = true; } else std::swap(owner[a], owner[b]);
+            }
+    }
+    int fill[4] = {0, 0, 0, 0};
+    for (int w = 0; w < 4; ++w) d.pair_deal[w] = 0;
+    for (int p = 0; p < NP; ++p) {
+        if (owner[p] == 4) d.pair_split = p;
+        else d.pair_deal[owner[p]] |= (unsigned)p << (5 * fill[owner[p]]++);
+    }
 }
 
 static int avt_model_create_impl(const avt_model_desc* desc, avt_model** out) {
@@ -267,6 +333,19 @@ static int avt_model_create_impl(const avt_model_desc* desc, avt_model** out) {
     for (int tc = 0; tc < 16 * d.NT; ++tc) if (m->tile_param[tc] == d.P) d.res_tile = tc / 16;
     d.res_pair = 0;
     for (int i = 0; i < d.res_tile; ++i) d.res_pair += d.NT - i;
+    deal_tile_pairs(m);
+    m->deal_col.assign(4 * 6 * 2 * 16, d.P + 1);
+    if (d.NT == 6)
+        for (int w = 0; w < 4; ++w)
+            for (int i = 0; i < 6; ++i) {
+                int p = i < 5 ? (int)((d.pair_deal[w] >> (5 * i)) & 31u) : d.pair_split, ti = 0;
+                while (p >= 6 - ti) { p -= 6 - ti; ++ti; }
+                if (p == 0) d.pair_deal[w] |= 1u << (25 + i);      // bits 25..30: pair i of the wave (30: the split pair) is a diagonal one
+                for (int l = 0; l < 16; ++l) {
+                    m->deal_col[((w * 6 + i) * 2 + 0) * 16 + l] = m->tile_col[ti * 16 + l];
+                    m->deal_col[((w * 6 + i) * 2 + 1) * 16 + l] = m->tile_col[(ti + p) * 16 + l];
+                }
+            }
     for (int ti = 0; ti < AVT_MAX_TILES; ++ti) {
         int lo = d.P + 1, hi = -1;
         if (ti < d.NT)

@@ -2,7 +2,7 @@
 Needs the instrumented library: make -C avatar_amd/csrc libavatar_hip_timing.so, then
     AVT_LIB=avatar_amd/csrc/libavatar_hip_timing.so python tools/eval_phase_probe.py [frames]
 Phases (cycles summed over the workgroup's batches): A-wait (barrier before the builder: the other waves' matrix phase) |
-mfma (the wave's own matrix phase) | build (records -> rows of the tile) | B-wait (barrier before the matrix phase)."""
+mfma (the wave's own matrix phase) | records-wait (the prefetched records arrive and go to LDS) | build (rows of the tile) | B-wait (barrier before the matrix phase)."""
 import ctypes as C
 import os
 import sys
@@ -26,8 +26,8 @@ for i in range(2):
 g, nfg, G = ctx.launch_shape()
 lib = capi.load_library(); buf = np.zeros(64)
 lib.avt_debug_trace(ctx.h, 0, buf.ctypes.data_as(C.POINTER(C.c_double)))
-names = ['A-wait', 'mfma', '-', 'build', 'B-wait', '-', '-', '-']
-print(f"F={F} groups={g} frames/launch={nfg} G={G}; last evaluation launch, workgroup 0 of frame 0; wall {buf[56] / 100.0:.2f} us")
+names = ['A-wait', 'mfma', 'records-wait', 'build', 'B-wait', '-', '-', '-']
+print(f"F={F} groups={g} frames/launch={nfg} G={G}; last full evaluation launch, workgroup 0 of frame 0; wall {buf[56] / 100.0:.2f} us")
 for wv in range(4):
     t = buf[16 + 8 * wv:24 + 8 * wv]
     print(f"  wave {wv}: total {t.sum():8.0f} cycles | " + " | ".join(f"{n} {v:7.0f}" for n, v in zip(names, t) if n != '-'))
