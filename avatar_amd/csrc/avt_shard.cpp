@@ -222,9 +222,7 @@ struct avt_shard {
     double* d_send = nullptr; double* d_recv = nullptr; size_t gather_cap = 0;   // doubles per rank block
     void* d_stage = nullptr; size_t stage_cap = 0;                              // scatter / broadcast staging, bytes
     void* d_stage2 = nullptr; size_t stage2_cap = 0;
-    // the all-gather runs on `stream`, behind the packing kernel on the context's stream and beside whatever that stream does next
-    hipEvent_t ev_packed = nullptr, ev_gathered = nullptr;
-    bool gather_in_flight = false;
+    hipStream_t gather_stream = nullptr;   // the stream the last all-gather was enqueued on
 };
 
 #define NCCL_OK(s, expr)                                                                                       \
@@ -280,12 +278,8 @@ extern "C" int avt_shard_create(int device, int rank, int world, const char id[A
         delete s;
         return 1;
     }
-    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&s->ev_packed, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s->ev_gathered, hipEventDisableTiming) != hipSuccess) {
-        avt_set_error("avt_shard_create: stream / event creation failed");
-        if (s->ev_packed) (void)hipEventDestroy(s->ev_packed);
-        if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+        avt_set_error("avt_shard_create: hipStreamCreate failed");
         a->CommDestroy(s->comm);
         delete s;
         return 1;
@@ -304,8 +298,6 @@ extern "C" void avt_shard_destroy(avt_shard* s) {
     if (s->comm) s->api->CommDestroy(s->comm);
     for (void* p : {(void*)s->d_send, (void*)s->d_recv, s->d_stage, s->d_stage2})
         if (p) (void)hipFree(p);
-    if (s->ev_packed) (void)hipEventDestroy(s->ev_packed);
-    if (s->ev_gathered) (void)hipEventDestroy(s->ev_gathered);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -461,28 +453,26 @@ extern "C" int avt_shard_gather_enqueue(avt_shard* s, avt_ctx* c, int B) {
         HIP_OK(hipStreamSynchronize(s->stream));
         if (s->d_send) HIP_OK(hipFree(s->d_send));
         if (s->d_recv) HIP_OK(hipFree(s->d_recv));
-        s->d_send = s->d_recv = nullptr; s->gather_cap = 0; s->gather_in_flight = false;
+        s->d_send = s->d_recv = nullptr; s->gather_cap = 0;
         HIP_OK(hipMalloc((void**)&s->d_send, blk * 8));
         HIP_OK(hipMalloc((void**)&s->d_recv, blk * 8 * W));
         HIP_OK(hipMemset(s->d_send, 0, blk * 8));
         s->gather_cap = blk;
     }
-    // ctx stream: [previous all-gather has read the send block] -> pack;  shard stream: [packed] -> all-gather.  The exchange
-    // of step k therefore overlaps the optimisation of step k+1 and the ranks never wait for each other inside a step.
-    if (s->gather_in_flight) HIP_OK(hipStreamWaitEvent(c->stream, s->ev_gathered, 0));
+    // Packing kernel and all-gather go behind optimize() on the context's stream.  Measured on one MI355X (bench.py, one frame
+    // per step, 0.62 ms): this costs 6 us per step; putting the all-gather on the shard's own stream instead - so that the
+    // exchange of step k overlaps step k+1 - costs 25 us, because the event record / cross-stream wait the hand-over needs
+    // sit in the context stream's critical path (double-buffering the send block and waiting on the host: 24 us).
     if (nloc) launch_pack_results(c, nloc, s->d_send, stride);
-    HIP_OK(hipEventRecord(s->ev_packed, c->stream));
-    HIP_OK(hipStreamWaitEvent(s->stream, s->ev_packed, 0));
-    NCCL_OK(s, s->api->AllGather(s->d_send, s->d_recv, blk, ncclDouble, s->comm, s->stream));
-    HIP_OK(hipEventRecord(s->ev_gathered, s->stream));
-    s->gather_in_flight = true;
+    NCCL_OK(s, s->api->AllGather(s->d_send, s->d_recv, blk, ncclDouble, s->comm, c->stream));
+    s->gather_stream = c->stream;
     return 0;
 }
 
 extern "C" int avt_shard_gather_wait(avt_shard* s) {
     if (!s) { avt_set_error("avt_shard_gather_wait: null argument"); return 1; }
     HIP_OK(hipSetDevice(s->device));
-    HIP_OK(hipStreamSynchronize(s->stream));
+    if (s->gather_stream) HIP_OK(hipStreamSynchronize(s->gather_stream));
     return 0;
 }
 
@@ -494,8 +484,8 @@ extern "C" int avt_shard_gather_download(avt_shard* s, avt_ctx* c, int B, double
     if (s->gather_cap < blk || !s->d_recv) { avt_set_error("avt_shard_gather_download: nothing was gathered"); return 1; }
     HIP_OK(hipSetDevice(s->device));
     std::vector<double> host(blk * W);
-    HIP_OK(hipMemcpyAsync(host.data(), s->d_recv, host.size() * 8, hipMemcpyDeviceToHost, s->stream));   // behind the all-gather
-    HIP_OK(hipStreamSynchronize(s->stream));
+    HIP_OK(hipMemcpyAsync(host.data(), s->d_recv, host.size() * 8, hipMemcpyDeviceToHost, c->stream));   // behind the all-gather
+    HIP_OK(hipStreamSynchronize(c->stream));
     for (int f = 0; f < B; ++f) {
         const double* x = &host[(size_t)(f % W) * blk + (size_t)(f / W) * stride];
         if (p) std::copy(x, x + 3, p + 3 * (size_t)f);

@@ -115,7 +115,7 @@ class Shard:
         _check(self._lib.avt_shard_gather_enqueue(self.h, ctx.h, C.c_int(num_frames)))
 
     def gather_wait(self):
-        """Blocks until the last enqueued all-gather is complete (it runs on the shard's own stream)."""
+        """Blocks until the last enqueued all-gather is complete."""
         _check(self._lib.avt_shard_gather_wait(self.h))
 
     def gather_download(self, ctx, num_frames):

@@ -35,11 +35,12 @@ REGIONS = 15                   # the K-step timed region is repeated this many t
 # SURVEY.md §8(d) prescribes, it is NOT what bounds the latency-bound kernels
 LIMITER = {
     "solve": "latency: one workgroup per frame walking an 85-pivot LDL^T dependency chain (working set in LDS/L2)",
-    "eval": "instruction issue / LDS latency of the row builder; fp64 MFMA contraction behind it",
+    "eval": "LDS pipe and dependent-latency chains of the row builder at three workgroups per CU; fp64 MFMA contraction behind it",
     "reduce": "L2 round trips (partial tiles live in L2/MALL)",
-    "nn": "fp64 VALU (8 flop per candidate) with LDS broadcast reads",
+    "nn": "fp64 VALU issue (8 flop + one v_min per candidate, candidates through scalar loads)",
     "lbs": "HBM/L2 streaming of the shape planes", "bucket": "LDS + global atomics", "visibility": "launch latency",
-    "aggregate": "launch latency / gathers", "prepare": "latency (skeleton pass)", "decide": "launch latency",
+    "aggregate": "launch latency / gathers", "prepare": "latency (skeleton pass)",
+    "decide": "cost-only evaluation of the last trial point + accept test inside its reduction",
 }
 
 
@@ -48,7 +49,8 @@ def algorithmic_bytes_per_gn_iter(N, V, K, P):
     return 24 * N + 4 * N + 24 * V * (K + 1) + 48 * V + 24 * V + 8 * P * (P + 1)
 
 
-KERNEL_SYMBOL = {"eval": "k_eval", "solve": "ELi2EEv11DeviceModel", "reduce": "k_reduce", "nn": "k_nn", "lbs": "k_lbs"}   # symbol-name fragments (solve: k_solve<.., SOLVE_NORMAL>)
+# symbol-name fragments (eval: the full evaluation k_eval<.., false>; solve: k_solve<.., SOLVE_NORMAL>; reduce: k_reduce<Q, false>)
+KERNEL_SYMBOL = {"eval": "Lb0EEv11DeviceModel12FrameBuffersi", "solve": "ELi2EEv11DeviceModel", "reduce": "ELb0EEv11DeviceModel12FrameBuffers.kd", "nn": "k_nn", "lbs": "k_lbs"}
 
 
 def pmc_traffic(frames_per_launch, kernel_class):
@@ -75,7 +77,7 @@ def _max_over_ranks(x, torch, dist, world, backend):
 def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, rank, world, local_rank, dense, shard=None, regions=REGIONS):
     """Times `steps` optimize() calls over this rank's F resident frames, `regions` times; returns the per-config dict.
     Global frame g = rank + world * i is frame i of this rank (avt_shard partition); with a shard handle every step also
-    enqueues the result all-gather (RCCL, device buffers; on the shard's stream, beside the next step's optimize())."""
+    enqueues the result all-gather (RCCL, device buffers) behind optimize()."""
     V, J, K, P = gm.numPoints(), gm.numJoints(), gm.numShapeKeys(), gm.arrays.P
     pm = synth.identity_part_map()
     B = F * world
@@ -99,7 +101,7 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
         ctx.state_reset()                 # device-side reinstall of the start state (asynchronous, no host transfer)
         ctx.optimize_resident(opt)        # asynchronous on the context's stream (one hipGraph replay)
         if shard is not None:
-            shard.gather_enqueue(ctx, B)  # ncclAllGather of (p, q, w, stats) of all B frames on the shard's stream, no host sync
+            shard.gather_enqueue(ctx, B)  # ncclAllGather of (p, q, w, stats) of all B frames behind optimize() on the same stream, no host sync
 
     def full_sync():
         ctx.sync()
@@ -140,7 +142,7 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
             step()
         ctx.sync()
         if shard is not None:
-            shard.gather_wait()           # the last step's all-gather (shard stream) is inside the region
+            shard.gather_wait()           # the last step's all-gather is inside the region
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         times.append(_max_over_ranks(t1 - t0, torch, dist, world, args.backend))

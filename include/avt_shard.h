@@ -68,13 +68,11 @@ int avt_shard_broadcast_model(avt_shard* s, int root, const avt_model_desc* desc
 int avt_shard_scatter_frames(avt_shard* s, avt_ctx* ctx, int root, int num_frames, const double* data, const int* labels,
                              const int* frame_offsets, const double* p, const double* q, const double* w);
 
-/* ---- result gather.  Enqueues, without host synchronisation, the packing of this rank's resident frames on ctx's stream
- * and, behind it on the shard's own stream, one ncclAllGather into a device buffer owned by the shard: inside a loop the
- * exchange of one step runs beside the next avt_optimize_resident and the ranks do not wait for each other within a step
- * (the next packing waits for the previous all-gather to have read the send block).  avt_shard_gather_wait blocks the
- * host until the last enqueued all-gather is complete.  avt_shard_gather_download waits likewise and copies out, for ALL
- * num_frames frames in global frame order: p (3), q (4J), w (K) and stats (any pointer may be NULL).
- * avt_shard_gather_results = enqueue + download. */
+/* ---- result gather.  Enqueues, on ctx's stream and without host synchronisation, the packing of this rank's resident
+ * frames and one ncclAllGather into a device buffer owned by the shard (so it can sit inside a timed loop behind
+ * avt_optimize_resident).  avt_shard_gather_wait blocks the host until the last enqueued all-gather is complete;
+ * avt_shard_gather_download waits likewise and copies out, for ALL num_frames frames in global frame order: p (3), q (4J),
+ * w (K) and stats (any pointer may be NULL).  avt_shard_gather_results = enqueue + download. */
 int avt_shard_gather_enqueue(avt_shard* s, avt_ctx* ctx, int num_frames);
 int avt_shard_gather_wait(avt_shard* s);
 int avt_shard_gather_download(avt_shard* s, avt_ctx* ctx, int num_frames, double* p, double* q, double* w, avt_stats* stats);
