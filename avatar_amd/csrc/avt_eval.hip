@@ -354,13 +354,20 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : (MT > 8 ? 1 : 2)) void k_eval(
             pf[i] = (idx < RQ2) ? __builtin_nontemporal_load(src + idx) : (d2v){0.0, 0.0};
         }
     };
-    // a workgroup takes chunks of S consecutive batches (consecutive matched points share their live tiles), chunk g, g+G, ...
-    const int S = AVT_EVAL_CHUNK(G);
-    auto next_batch = [&](int b) { const int b1 = b + 1; return (b1 % S) ? b1 : b1 - S + G * S; };
-    if (g * S < d.nb_max) prefetch(g * S);
+    // Which batches a workgroup takes.  Few frames (G >= 64, one or two batches per workgroup): batch g, g+G - known without
+    // the frame's batch count, so the first records are requested before anything else arrives.  Frame batches (G < 64): the
+    // CONTIGUOUS range k_solve INIT dealt it by estimated cost (eval_ranges: the kernel lasts as long as its busiest
+    // workgroup; with strided chunks the busiest workgroup of a 150-batch frame at G = 24 had 8 batches against a mean of
+    // 6.25); consecutive matched points share their live tiles, so fewer partial tiles are written as well.
+    const bool strided = G >= 64;
+    if (strided && g < d.nb_max) prefetch(g);
     const int M = ctl.M;
     const int try_slot = 1 - ctl.cur_slot;
     const int nb = (M + AVT_EVAL_PTS - 1) / AVT_EVAL_PTS;
+    const int* er = fb.erange + (size_t)f * AVT_ERANGE + g;       // cost-balanced contiguous ranges (eval_ranges, avt_lm.hip)
+    const int b_first = strided ? g : er[0], b_end = strided ? nb : er[1];
+    const int b_step = strided ? G : 1;
+    if (!strided && b_first < b_end) prefetch(b_first);
 
     // LDS: the skeleton tables of the trial point (prep block without the quaternions), the transposed tile with one
     // extra all-zero column that stands in for the padding columns P+1.. of the last column tile, the records of the
@@ -429,7 +436,7 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : (MT > 8 ? 1 : 2)) void k_eval(
 #endif
     // tile pairs this workgroup accumulated into: only those partial tiles are written, k_reduce reads the mask
     unsigned long long wm = FIXED ? 0ull : ~0ull;     // generic shapes write every pair (k_reduce treats pairs >= 64 as written)
-    for (int b = g * S; b < nb; b = next_batch(b)) {
+    for (int b = b_first; b < b_end; b += b_step) {
         __syncthreads();  // previous batch's MFMA reads are done (also covers the prep staging on the first pass)
         EPROBE(0);
         // ---- wave-local from here to the next barrier ------------------------------------------------------
@@ -440,7 +447,7 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : (MT > 8 ? 1 : 2)) void k_eval(
         const int bw = __builtin_amdgcn_readfirstlane(bm_next);   // live tiles / tile pairs of this batch (k_records)
         // (COST: only the tile of the residual column and its diagonal pair)
         const int tm = COST ? (1 << d.res_tile) : (NT > 8 ? (bw & 0xffff) : (int)((unsigned)bw >> 24)), pm = COST ? (1 << d.res_pair) : (bw & 0xffffff);
-        if (next_batch(b) < nb) prefetch(next_batch(b));
+        if (b + b_step < b_end) prefetch(b + b_step);
         // zeroing passes (5 consecutive storage columns each) that touch a live tile (AvtDims::tile_zpass, avt_model.cpp)
         unsigned long long zmask = 0ull;
 #pragma unroll

@@ -12,14 +12,11 @@
 #define AVT_TILE 16           // MFMA f64 16x16x4 tile edge
 #define AVT_EVAL_PTS 16       // model points per eval batch (48 Jacobian rows)
 #define AVT_EVAL_ROWS (3 * AVT_EVAL_PTS)
-#ifndef AVT_EVAL_CHUNK_BATCH
-#define AVT_EVAL_CHUNK_BATCH 2
-#endif
-#define AVT_EVAL_CHUNK(G) ((G) >= 64 ? 1 : AVT_EVAL_CHUNK_BATCH)   // consecutive batches a workgroup takes before striding by G chunks (few live tile pairs per workgroup)
 #define AVT_EVAL_RS 49        // LDS row stride (doubles) of the transposed Jacobian tile.  ODD on purpose: the compiler pairs the MFMA
                               // operand fetches of two k-steps into ds_read2_b64, which is banked modulo 32 in 16-lane groups - an even
                               // stride makes columns c and c+8 collide (2-way), an odd one is conflict-free (plain ds_read_b64 too)
 #define AVT_EVAL_TILE(ncols) ((((ncols) * AVT_EVAL_RS) + 1) & ~1)   // doubles of a tile of ncols columns, kept even (16-byte alignment of what follows)
+#define AVT_ERANGE 66         // G + 1 entries per frame for G < 64 (FrameBuffers::erange)
 #define AVT_MAX_TILES 11      // ceil((P+1)/16) with P <= 175 (k_solve: one 4x4 block of the bordered system per lane of <= 1024 threads)
 #define AVT_MAX_P 175
 #define AVT_MAX_COMPS 16      // GMM components
@@ -198,6 +195,7 @@ struct FrameBuffers {
     double* prep;         // [max_frames][2][prep_size]
     double* rec;          // [max_frames][nb_max][4][rec_quad] matched-point records (k_records)
     int* bmask;           // [max_frames][nb_max] tiles touched by each batch of 16 matched points
+    int* erange;          // [max_frames][AVT_ERANGE] frame batches (G < 64): evaluation workgroup g takes batches [erange[g], erange[g+1]) (k_solve INIT)
     double* partial;      // [max_frames][G][NPAIR][256]
     unsigned long long* wmask;   // [max_frames][G] tile pairs workgroup g of the frame wrote to `partial` (bit = pair); k_reduce skips the rest
     double* Hraw;         // [max_frames][2][HS*HS] reduced data-term [J|r]^T W [J|r] (full symmetric) per state slot

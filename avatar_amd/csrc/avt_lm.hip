@@ -244,6 +244,56 @@ __global__ __launch_bounds__(256 * Q) void k_reduce(DeviceModel dm, FrameBuffers
 
 typedef double d2v __attribute__((ext_vector_type(2)));
 
+// Frame batches: the matched-point batches of a frame are dealt to its G evaluation workgroups as CONTIGUOUS ranges of equal
+// estimated cost (a batch costs a fixed part for the row builder plus one unit per live tile pair of its matrix phase: hip
+// batches touch ten pairs, torso batches three), so that the workgroups of a frame finish together - k_eval lasts as long as
+// its busiest workgroup.  erange[g] = the first batch whose cost prefix reaches g/G of the frame's total.  Deterministic.
+// s_pre: AVT_ERANGE_CAP + 1 ints of LDS scratch.
+#define AVT_ERANGE_CAP 1024                          // batches a frame can have here (V <= 16384); beyond: equal counts
+template <int NTH>
+__device__ __forceinline__ void eval_ranges(const AvtDims& d, const FrameBuffers& fb, int f, int t, int* __restrict__ s_pre) {
+    constexpr int CAP = AVT_ERANGE_CAP;
+    __shared__ int s_wsum[NTH / 64];
+    const int nb = (fb.ctl[f].M + AVT_EVAL_PTS - 1) / AVT_EVAL_PTS, G = fb.G;
+    int* out = fb.erange + (size_t)f * AVT_ERANGE;
+    if (nb > CAP) {
+        for (int g = t; g <= G; g += NTH) out[g] = (int)(((long long)g * nb) / G);
+        return;
+    }
+    // inclusive prefix sums of the batch costs: PER = ceil(CAP / NTH) consecutive batches per thread, wave scan, wave totals
+    constexpr int PER = (CAP + NTH - 1) / NTH;
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int b = t * PER + i;
+        int c = 0;
+        if (b < nb) {
+            const int w = fb.bmask[(size_t)f * d.nb_max + b];
+            const int tiles = __popc(w & 0xffff);
+            c = 16 + (d.NT > 8 ? tiles * (tiles + 1) / 2 : __popc(w & 0xffffff));
+        }
+        sum += c; loc[i] = sum;
+    }
+    int incl = sum;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) { const int v = __shfl_up(incl, sft, 64); if ((t & 63) >= sft) incl += v; }
+    if ((t & 63) == 63) s_wsum[t >> 6] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int w = 0; w < (t >> 6); ++w) base += s_wsum[w];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { const int b = t * PER + i; if (b < CAP) s_pre[b + 1] = base + loc[i]; }
+    if (t == 0) s_pre[0] = 0;
+    __syncthreads();
+    const long long total = s_pre[min(nb, CAP)];
+    for (int g = t; g <= G; g += NTH) {
+        const long long want = (total * g) / G;            // first batch b with prefix(b) = s_pre[b] >= want
+        int lo = 0, hi = nb;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pre[mid] >= want) hi = mid; else lo = mid + 1; }
+        out[g] = g == G ? nb : lo;
+    }
+}
+
 // reciprocal off the slow path: v_rcp_f64 (~2^-26 relative) + one cubic Newton step (error e^3)
 __device__ __forceinline__ double fast_rcp(double d) {
     const double r0 = __builtin_amdgcn_rcp(d);
@@ -420,6 +470,8 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         }
         __syncthreads();
         if (t == 0) { ctl.cost_const = 0.5 * a; ctl.try_valid = 1; }
+        // frame batches: which batches each evaluation workgroup takes (scratch: the end of the factor's area, unused here)
+        if (fb.G < 64) eval_ranges<NTH>(d, fb, f, t, (int*)(Lblk + nblk * 18) - (AVT_ERANGE_CAP + 2));
         const double* xc = s_x + cur * xs;
         for (int e = t; e < xs; e += NTH) x0[(size_t)tr * xs + e] = xc[e];
         prep_set_state(d, L, B, xc + 3, xc + 3 + 4 * J, xc);
