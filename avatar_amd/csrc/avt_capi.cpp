@@ -58,7 +58,12 @@ int choose_groups(int nframes) {
 }
 
 int choose_G(int nframes) {
-    const int g = std::max(2, std::min(128, 768 / std::max(1, nframes)));   // 3 k_eval workgroups per CU when there are enough frames
+    // k_eval workgroups per frame.  Up to 64 frames per launch: 768 workgroups = one resident round at 3 per CU (more rounds
+    // cost more in partial tiles and prologues than they balance: 128 frames per group 645 k against 609 k GN it/s with twice as
+    // many).  From 128 frames per launch on: 1536, two rounds, so that the hardware's dispatch evens out frames with different
+    // numbers of matched points (512 frames: 747 k -> 774 k GN it/s; three rounds: 770 k).
+    const int target = nframes >= 128 ? 1536 : 768;
+    const int g = std::max(2, std::min(128, target / std::max(1, nframes)));
     if (const char* e = getenv("AVT_G")) return std::max(1, std::min(g, atoi(e)));   // tuning knob, never above the allocation
     return g;
 }
