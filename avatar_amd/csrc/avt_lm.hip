@@ -415,6 +415,126 @@ __device__ __forceinline__ void backsub_tri(const double* __restrict__ Lblk, con
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// LDL^T with the trailing matrix in MFMA accumulators (the 256-thread solve, systems of up to 95 columns; measured in
+// isolation in tools/ubench/ldlt_mfma.hip: 1620 clocks per 4-pivot round against 1900 for the register-blocked rounds).
+// The lower triangle of the bordered system lives as 21 tiles of 16x16 in the accumulators of the 4 waves: wave w holds tile
+// row rA = 5 - w (columns 0..rA) and, for w >= 2, tile row rB = w - 2 (columns 0..rB).  Two barriers per round:
+//   phase 1 (threads 0..95, one matrix row each): factor the 4x4 diagonal block of the published panel, W row = raw L^-T,
+//            stored in the layout the back substitution reads (Lblk[kb][row block][18]);
+//   phase 2 (all waves): A = W(:,k) and B = -W(:,k)/d_k fragments straight from Lblk / s_R, one v_mfma_f64_16x16x4_f64 per
+//            live tile (next panel's block column first), publish the next panel's 4 columns from the accumulators.
+// -------------------------------------------------------------------------------------------------
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+#define MF_PB_STRIDE 4
+#define MF_PB_DOUBLES (96 * MF_PB_STRIDE)
+
+template <int W, int CBN>
+__device__ __forceinline__ void mf_publish(const v4f64 (&accA)[6], const v4f64 (&accB)[2], int jq, double* __restrict__ PB, int ln) {
+    constexpr int rA = 5 - W, rB = W - 2;
+    const int k = ln >> 4, c16 = ln & 15;
+    if ((c16 >> 2) == jq) {
+        if constexpr (CBN <= rA) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) PB[(16 * rA + 4 * v + k) * MF_PB_STRIDE + (ln & 3)] = accA[CBN][v];
+        }
+        if constexpr (CBN < 2 && CBN <= rB) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) PB[(16 * rB + 4 * v + k) * MF_PB_STRIDE + (ln & 3)] = accB[CBN < 2 ? CBN : 0][v];
+        }
+    }
+}
+
+// one round = 4 pivots (columns 16 CB + 4 jq ..); CBN = block column of the next panel = first block column still live
+template <int W, int CB, int CBN>
+__device__ __forceinline__ bool mf_round(v4f64 (&accA)[6], v4f64 (&accB)[2], int jq, double* __restrict__ PB,
+                                           double* __restrict__ Lblk, double* __restrict__ s_R, int* __restrict__ s_fail, int P, int NB, int NR, int t) {
+    constexpr int rA = 5 - W, rB = W - 2;
+    const int ln = t & 63, k = ln >> 4, c16 = ln & 15, kb = 4 * CB + jq;
+    __syncthreads();                                         // the panel of this round is published
+    if (W < 2 && t < 96) {
+        const d2v* PB2 = (const d2v*)PB;
+        const d2v q0 = PB2[(4 * kb) * 2], q1 = PB2[(4 * kb + 1) * 2], q2a = PB2[(4 * kb + 2) * 2], q2b = PB2[(4 * kb + 2) * 2 + 1];
+        const d2v q3a = PB2[(4 * kb + 3) * 2], q3b = PB2[(4 * kb + 3) * 2 + 1];
+        const d2v s01 = PB2[t * 2], s23 = PB2[t * 2 + 1];
+        const double D00 = q0.x, D10 = q1.x;
+        double D11 = q1.y, D20 = q2a.x, D21 = q2a.y, D22 = q2b.x, D30 = q3a.x, D31 = q3a.y, D32 = q3b.x, D33 = q3b.y;
+        const double r0 = fast_rcp(D00), l10 = D10 * r0, l20 = D20 * r0, l30 = D30 * r0;
+        D11 = fma(-l10, D10, D11); D21 = fma(-l20, D10, D21); D31 = fma(-l30, D10, D31);
+        D22 = fma(-l20, D20, D22); D32 = fma(-l30, D20, D32); D33 = fma(-l30, D30, D33);
+        const double r1 = fast_rcp(D11), l21 = D21 * r1, l31 = D31 * r1;
+        D22 = fma(-l21, D21, D22); D32 = fma(-l31, D21, D32); D33 = fma(-l31, D31, D33);
+        const double r2 = fast_rcp(D22), l32 = D32 * r2;
+        D33 = fma(-l32, D32, D33);
+        const double r3 = fast_rcp(D33);
+        const bool real1 = 4 * kb + 1 < P, real2 = 4 * kb + 2 < P, real3 = 4 * kb + 3 < P;
+        const bool bad = !(D00 > 0.0) | (real1 & !(D11 > 0.0)) | (real2 & !(D22 > 0.0)) | (real3 & !(D33 > 0.0));
+        const double w0 = s01.x, w1 = fma(-w0, l10, s01.y), w2 = fma(-w1, l21, fma(-w0, l20, s23.x));
+        const double w3 = fma(-w2, l32, fma(-w1, l31, fma(-w0, l30, s23.y)));
+        const int rr = t - 4 * kb;     // row inside the trailing part; the diagonal block keeps its strictly lower part
+        if (rr >= 0 && (t >> 2) < NB) {     // (rows past the matrix have no block)
+            d2v* Wo = (d2v*)(Lblk + ((size_t)kb * NB + (t >> 2)) * 18 + (t & 3) * 4);
+            Wo[0] = (d2v){rr < 1 ? 0.0 : w0, rr < 2 ? 0.0 : w1};
+            Wo[1] = (d2v){rr < 3 ? 0.0 : w2, rr < 4 ? 0.0 : w3};
+        }
+        if (t == 0) {
+            d2v* Ro = (d2v*)(s_R + 4 * kb);
+            Ro[0] = (d2v){r0, real1 ? r1 : 0.0}; Ro[1] = (d2v){real2 ? r2 : 0.0, real3 ? r3 : 0.0};
+            if (bad) *s_fail = 1;
+        }
+    }
+    __syncthreads();                                         // W rows, reciprocal pivots and the failure flag are visible
+    // ---- fragments: lane (c16, k) holds row 16 b + c16, pivot k of the round
+    const double* Wk = Lblk + (size_t)kb * NB * 18 + (c16 >> 2) * 18 + (c16 & 3) * 4 + k;
+    double fw[6];
+#pragma unroll
+    for (int c = CBN; c <= rA; ++c) fw[c] = (4 * c + (c16 >> 2) < NB) ? Wk[c * 4 * 18] : 0.0;     // (rows past the matrix: zero)
+    constexpr bool useB = rB >= 0 && CBN <= rB;
+    double fAB = 0.0;
+    if constexpr (useB) fAB = (4 * (rB > 0 ? rB : 0) + (c16 >> 2) < NB) ? Wk[(rB > 0 ? rB : 0) * 4 * 18] : 0.0;
+    const double rk = s_R[4 * kb + k];
+    if (*s_fail) return false;
+    if (kb + 1 >= NR) return true;
+    if constexpr (CBN <= rA) {
+        double fb[6];
+#pragma unroll
+        for (int c = CBN; c <= rA; ++c) fb[c] = fw[c] * -rk;
+        const double fA = fw[rA];
+        accA[CBN] = __builtin_amdgcn_mfma_f64_16x16x4f64(fA, fb[CBN], accA[CBN], 0, 0, 0);
+        if constexpr (useB) {
+#pragma unroll
+            for (int c = CBN; c <= rB; ++c) accB[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fAB, fb[c], accB[c], 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = CBN + 1; c <= rA; ++c) accA[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fA, fb[c], accA[c], 0, 0, 0);
+    }
+    mf_publish<W, CBN>(accA, accB, (jq + 1) & 3, PB, ln);
+    return true;
+}
+
+template <int W, int CB>
+__device__ __forceinline__ bool mf_block_column(v4f64 (&accA)[6], v4f64 (&accB)[2], double* __restrict__ PB,
+                                                  double* __restrict__ Lblk, double* __restrict__ s_R, int* s_fail, int P, int NB, int NR, int t) {
+#pragma unroll 1
+    for (int jq = 0; jq < 3; ++jq) {
+        if (4 * CB + jq >= NR) return true;
+        if (!mf_round<W, CB, CB>(accA, accB, jq, PB, Lblk, s_R, s_fail, P, NB, NR, t)) return false;
+    }
+    if (4 * CB + 3 >= NR) return true;
+    return mf_round<W, CB, (CB < 5 ? CB + 1 : 5)>(accA, accB, 3, PB, Lblk, s_R, s_fail, P, NB, NR, t);
+}
+
+template <int W>
+__device__ __forceinline__ bool mf_rounds(v4f64 (&accA)[6], v4f64 (&accB)[2], double* __restrict__ PB,
+                                            double* __restrict__ Lblk, double* __restrict__ s_R, int* s_fail, int P, int NB, int t) {
+    const int NR = (P + 3) >> 2;          // rounds: pivots 0..P-1
+    mf_publish<W, 0>(accA, accB, 0, PB, t & 63);
+    return mf_block_column<W, 0>(accA, accB, PB, Lblk, s_R, s_fail, P, NB, NR, t) && mf_block_column<W, 1>(accA, accB, PB, Lblk, s_R, s_fail, P, NB, NR, t) &&
+           mf_block_column<W, 2>(accA, accB, PB, Lblk, s_R, s_fail, P, NB, NR, t) && mf_block_column<W, 3>(accA, accB, PB, Lblk, s_R, s_fail, P, NB, NR, t) &&
+           mf_block_column<W, 4>(accA, accB, PB, Lblk, s_R, s_fail, P, NB, NR, t) && mf_block_column<W, 5>(accA, accB, PB, Lblk, s_R, s_fail, P, NB, NR, t);
+}
+
+
 // =================================================================================================
 // k_solve<NTH, TRI>.  grid (nframes), block NTH.  <256, false>: systems of up to 88 columns (SMPL: 86), one 4x4 block per
 // lane of 256 threads, the factor in a square LDS array whose unused blocks read as zeros.  <1024, true>: up to 176 columns
@@ -438,7 +558,8 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     // carries L^-1 rhs
     double* Lblk = (double*)smem;
     const size_t nblk = TRI ? (size_t)NBk * (NBk + 1) / 2 : (size_t)NBk * NBk;
-    double* s_W = Lblk + nblk * 18;                         // [max(HS, 4J) + 2]  reciprocal pivots, later the new quaternions
+    double* s_PB = Lblk + nblk * 18;                        // (256-thread shape) [96][4] the four panel columns of a round
+    double* s_W = s_PB + (TRI ? 0 : MF_PB_DOUBLES);         // [max(HS, 4J) + 2]  reciprocal pivots, later the new quaternions
     double* s_delta = s_W + ((max(HS, 4 * J) + 3) & ~1);    // [HS]
     double* s_x = s_delta + HS + 2;                         // [2][xsize] both state slots
     const PrepLayout L = prep_layout(J, K, d.xsize);
@@ -505,7 +626,26 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
             hdiag[into][r][0] = srd[0]; hdiag[into][r][1] = srd[1];
         }
     };
-    if constexpr (!TRI) { load_blocks(0, 0); load_blocks(1, 1); }
+    // 256-thread shape: the system goes straight into the MFMA accumulator layout - wave w owns tile row rA = 5 - w (tile
+    // slots 0..5) and, for w >= 2, tile row rB = w - 2 (slots 6, 7); lane (g4 = l >> 4, c16 = l & 15) holds rows 4v + g4 of
+    // column c16 of a tile.  Raw data-term entries of BOTH slots are requested now (indices clamped, selected later).
+    const int mf_wv = t >> 6, mf_g4 = (t >> 4) & 3, mf_c16 = t & 15, mf_rA = 5 - mf_wv, mf_rB = mf_wv - 2;
+    // (six tile slots per wave: slot s <= rA is tile (rA, s), the slots behind are tiles (rB, 0..rB))
+    double mraw[TRI ? 1 : 2][TRI ? 1 : 6][4];
+    if constexpr (!TRI) {
+#pragma unroll
+        for (int ti = 0; ti < 6; ++ti) {
+            const bool first = ti <= mf_rA;
+            const int rb = first ? mf_rA : max(mf_rB, 0), cb = first ? ti : ti - mf_rA - 1;
+            const bool own = first || cb <= mf_rB;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = min(16 * rb + 4 * v + mf_g4, HS - 1), col = min(16 * cb + mf_c16, HS - 1);
+                mraw[0][ti][v] = own ? H0[(size_t)row * HS + col] : 0.0;
+                mraw[1][ti][v] = own ? H0[(size_t)HS * HS + (size_t)row * HS + col] : 0.0;
+            }
+        }
+    }
     const double hpp0 = H0[(size_t)P * HS + P], hpp1 = H0[(size_t)HS * HS + (size_t)P * HS + P];
     const double lm_up = fb.params->lm_up, lm_down = fb.params->lm_down, lm_min = fb.params->lm_min, lm_max = fb.params->lm_max;   // same round trip
     const int cur0 = ctl.cur_slot, try_valid = ctl.try_valid, comp_cur0 = ctl.comp_cur;
@@ -616,106 +756,156 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
                 out[r][c] = inside ? (row < P ? vh : -vg) : ((row == col) ? 1.0 : 0.0);
             }
     };
-    double a4[4][4], dg[4][4];
-    assemble(bi, hraw, a4);
-    assemble(bj, hdiag, dg);    // private copy of the diagonal block of my column (its lower triangle is what is used)
-    TPROBE(2);
-
-    // ---- c. register-blocked LDL^T, four pivots and ONE barrier per round ---------------------------------------------
-    //  (1) the lanes owning the pivot block column (bj == kb) take the factorisation D = Ld diag(d) Ld^T of their PRIVATE
-    //      copy of the diagonal block and publish their own block of W = A Ld^-T; the diagonal lane also publishes 1/d;
-    //  (2) after the barrier every trailing lane (bj > kb) reads W of its row block and of its column block and
-    //      applies the rank-4 update A -= W_i diag(1/d) W_j^T to its block and to its copy of its column's
-    //      diagonal block (same operands, +40 FMAs, no extra LDS traffic) - so nobody ever publishes or reads a
-    //      diagonal block, and the next round's panel can start without a second barrier.
-    // Measured on MI355X (tools/ubench/ldlt.hip), clocks per round: two barriers + published diagonal + W and L
-    // stored 2520; W only 2215; private diagonal copies 2030; with the factorisation hoisted (below) 1900.  The rounds are
-    // bound by LDS traffic and latency, not by the FMAs.
-    // (A look-ahead variant that rebuilt the diagonal block from a published copy measured slower, 2770.)
-    double* s_R = s_W;                                      // [HS] reciprocal pivots
-    // D = Ld diag(d) Ld^T of my diagonal-block copy.  Every lane factors its copy right after updating it - wasted work
-    // unless its column is the next panel, but it keeps the rcp chain in the same straight-line block as the 64
-    // independent FMAs of the lane's own block update, where its latency hides (2030 -> 1900 clocks per round).
-    double l10, l20, l30, l21, l31, l32, r0, r1, r2, r3, P0, P1, P2, P3;
-#define AVT_FACTOR_DG() do {                                                                                       \
-        const double D00 = dg[0][0], D10 = dg[1][0];                                                                \
-        double D11 = dg[1][1], D20 = dg[2][0], D21 = dg[2][1], D22 = dg[2][2], D30 = dg[3][0], D31 = dg[3][1], D32 = dg[3][2], D33 = dg[3][3]; \
-        P0 = D00; r0 = fast_rcp(D00); l10 = D10 * r0; l20 = D20 * r0; l30 = D30 * r0;                              \
-        D11 = fma(-l10, D10, D11); D21 = fma(-l20, D10, D21); D31 = fma(-l30, D10, D31);                            \
-        D22 = fma(-l20, D20, D22); D32 = fma(-l30, D20, D32); D33 = fma(-l30, D30, D33);                            \
-        P1 = D11; r1 = fast_rcp(D11); l21 = D21 * r1; l31 = D31 * r1;                                               \
-        D22 = fma(-l21, D21, D22); D32 = fma(-l31, D21, D32); D33 = fma(-l31, D31, D33);                            \
-        P2 = D22; r2 = fast_rcp(D22); l32 = D32 * r2; D33 = fma(-l32, D32, D33);                                    \
-        P3 = D33; r3 = fast_rcp(D33);                                                                               \
-    } while (0)
-    AVT_FACTOR_DG();
-    if (t < 2) s_failf[t] = 0;
     bool fail = false;
-    __syncthreads();
-    for (int kb = 0; kb < NB; ++kb) {
-        if (kb > 0 && s_failf[(kb - 1) & 1]) { fail = true; break; }
-        if (bj == kb) {
-            const bool real1 = 4 * kb + 1 < P, real2 = 4 * kb + 2 < P, real3 = 4 * kb + 3 < P;   // 4*kb < P always
-            const int bad = (int)!(P0 > 0.0) | ((int)real1 & (int)!(P1 > 0.0)) | ((int)real2 & (int)!(P2 > 0.0)) | ((int)real3 & (int)!(P3 > 0.0));
-            if (bad) s_failf[kb & 1] = 1;
-            d2v* Wo = (d2v*)(Lblk + (size_t)wblk<TRI>(kb, bi, NB) * 18);
+    double* s_R = s_W;                                      // [HS] reciprocal pivots
+    if constexpr (!TRI) {
+        // ---- b'. the damped system in the MFMA accumulator layout (same element formula as `assemble` above, same bits) ----
+        v4f64 tile[6];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double w0 = a4[r][0];
-                const double w1 = fma(-w0, l10, a4[r][1]);
-                const double w2 = fma(-w1, l21, fma(-w0, l20, a4[r][2]));
-                const double w3 = fma(-w2, l32, fma(-w1, l31, fma(-w0, l30, a4[r][3])));
-                // (the diagonal block keeps its strictly lower part only: nobody but the back substitution reads it)
-                const bool dgb = bi == kb;
-                Wo[2 * r] = (d2v){(dgb && r < 1) ? 0.0 : w0, (dgb && r < 2) ? 0.0 : w1};
-                Wo[2 * r + 1] = (d2v){(dgb && r < 3) ? 0.0 : w2, dgb ? 0.0 : w3};
+        for (int ti = 0; ti < 6; ++ti) {
+            const bool first = ti <= mf_rA;
+            const int rb = first ? mf_rA : max(mf_rB, 0), cb = first ? ti : ti - mf_rA - 1;
+            const bool own = first || cb <= mf_rB;
+            const int col = 16 * cb + mf_c16, pc = col - 6, sk = col - (3 + 3 * J);
+            const int pcc = min(max(pc, 0), max(n - 1, 0)), skc = min(max(sk, 0), max(K - 1, 0));
+            const double gqc = use_pose ? pri[2 + pcc] : 0.0, xqc = xc[3 + 4 * J + skc];
+            const bool in_pose_c = use_pose && pc >= 0 && pc < n;
+            const bool shape_c = sbs > 0.0 && sk >= 0 && col < P;
+            v4f64 out;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = 16 * rb + 4 * v + mf_g4, pr_ = row - 6, prc = min(max(pr_, 0), max(n - 1, 0));
+                const double prv = use_pose ? Pr[(size_t)prc * n + pcc] : 0.0;
+                const double v0 = cur ? mraw[TRI ? 0 : 1][TRI ? 0 : ti][v] : mraw[0][TRI ? 0 : ti][v];
+                double vh = v0;
+                vh += (in_pose_c && pr_ >= 0 && pr_ < n) ? sc2 * prv : 0.0;
+                if (row == col) { vh += shape_c ? sbs * sbs : 0.0; vh += lambda * vh; }
+                double vg = v0;
+                vg += in_pose_c ? gs * gqc : 0.0;
+                vg += shape_c ? sbs * (xqc * sbs) : 0.0;
+                const bool inside = row <= P && col < P;
+                const double val = inside ? (row < P ? vh : -vg) : ((row == col) ? 1.0 : 0.0);
+                out[v] = own ? val : 0.0;
             }
-            if (bi == kb) {   // reciprocal pivots; 0 for the rhs / padding rows (only the back substitution reads those)
-                d2v* Ro = (d2v*)(s_R + 4 * kb);
-                Ro[0] = (d2v){r0, real1 ? r1 : 0.0}; Ro[1] = (d2v){real2 ? r2 : 0.0, real3 ? r3 : 0.0};
+            tile[ti] = out;
+        }
+        TPROBE(2);
+        // ---- c'. LDL^T, four pivots and two barriers per round, the trailing matrix in the accumulators (mf_rounds) ----
+        if (t == 0) s_failf[0] = 0;
+        bool okf;
+        const v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
+        switch (mf_wv) {
+            case 0: { v4f64 accA[6] = {tile[0], tile[1], tile[2], tile[3], tile[4], tile[5]}, accB[2] = {z4, z4};
+                      okf = mf_rounds<0>(accA, accB, s_PB, Lblk, s_R, &s_failf[0], P, NB, t); break; }
+            case 1: { v4f64 accA[6] = {tile[0], tile[1], tile[2], tile[3], tile[4], z4}, accB[2] = {z4, z4};
+                      okf = mf_rounds<1>(accA, accB, s_PB, Lblk, s_R, &s_failf[0], P, NB, t); break; }
+            case 2: { v4f64 accA[6] = {tile[0], tile[1], tile[2], tile[3], z4, z4}, accB[2] = {tile[4], z4};
+                      okf = mf_rounds<2>(accA, accB, s_PB, Lblk, s_R, &s_failf[0], P, NB, t); break; }
+            default: { v4f64 accA[6] = {tile[0], tile[1], tile[2], z4, z4, z4}, accB[2] = {tile[3], tile[4]};
+                       okf = mf_rounds<3>(accA, accB, s_PB, Lblk, s_R, &s_failf[0], P, NB, t); break; }
+        }
+        fail = !okf;
+    } else {
+        double a4[4][4], dg[4][4];
+        assemble(bi, hraw, a4);
+        assemble(bj, hdiag, dg);    // private copy of the diagonal block of my column (its lower triangle is what is used)
+        TPROBE(2);
+
+        // ---- c. register-blocked LDL^T, four pivots and ONE barrier per round ---------------------------------------------
+        //  (1) the lanes owning the pivot block column (bj == kb) take the factorisation D = Ld diag(d) Ld^T of their PRIVATE
+        //      copy of the diagonal block and publish their own block of W = A Ld^-T; the diagonal lane also publishes 1/d;
+        //  (2) after the barrier every trailing lane (bj > kb) reads W of its row block and of its column block and
+        //      applies the rank-4 update A -= W_i diag(1/d) W_j^T to its block and to its copy of its column's
+        //      diagonal block (same operands, +40 FMAs, no extra LDS traffic) - so nobody ever publishes or reads a
+        //      diagonal block, and the next round's panel can start without a second barrier.
+        // Measured on MI355X (tools/ubench/ldlt.hip), clocks per round: two barriers + published diagonal + W and L
+        // stored 2520; W only 2215; private diagonal copies 2030; with the factorisation hoisted (below) 1900.  The rounds are
+        // bound by LDS traffic and latency, not by the FMAs.
+        // (A look-ahead variant that rebuilt the diagonal block from a published copy measured slower, 2770.)
+        // D = Ld diag(d) Ld^T of my diagonal-block copy.  Every lane factors its copy right after updating it - wasted work
+        // unless its column is the next panel, but it keeps the rcp chain in the same straight-line block as the 64
+        // independent FMAs of the lane's own block update, where its latency hides (2030 -> 1900 clocks per round).
+        double l10, l20, l30, l21, l31, l32, r0, r1, r2, r3, P0, P1, P2, P3;
+#define AVT_FACTOR_DG() do {                                                                                       \
+            const double D00 = dg[0][0], D10 = dg[1][0];                                                                \
+            double D11 = dg[1][1], D20 = dg[2][0], D21 = dg[2][1], D22 = dg[2][2], D30 = dg[3][0], D31 = dg[3][1], D32 = dg[3][2], D33 = dg[3][3]; \
+            P0 = D00; r0 = fast_rcp(D00); l10 = D10 * r0; l20 = D20 * r0; l30 = D30 * r0;                              \
+            D11 = fma(-l10, D10, D11); D21 = fma(-l20, D10, D21); D31 = fma(-l30, D10, D31);                            \
+            D22 = fma(-l20, D20, D22); D32 = fma(-l30, D20, D32); D33 = fma(-l30, D30, D33);                            \
+            P1 = D11; r1 = fast_rcp(D11); l21 = D21 * r1; l31 = D31 * r1;                                               \
+            D22 = fma(-l21, D21, D22); D32 = fma(-l31, D21, D32); D33 = fma(-l31, D31, D33);                            \
+            P2 = D22; r2 = fast_rcp(D22); l32 = D32 * r2; D33 = fma(-l32, D32, D33);                                    \
+            P3 = D33; r3 = fast_rcp(D33);                                                                               \
+        } while (0)
+        AVT_FACTOR_DG();
+        if (t < 2) s_failf[t] = 0;
+        __syncthreads();
+        for (int kb = 0; kb < NB; ++kb) {
+            if (kb > 0 && s_failf[(kb - 1) & 1]) { fail = true; break; }
+            if (bj == kb) {
+                const bool real1 = 4 * kb + 1 < P, real2 = 4 * kb + 2 < P, real3 = 4 * kb + 3 < P;   // 4*kb < P always
+                const int bad = (int)!(P0 > 0.0) | ((int)real1 & (int)!(P1 > 0.0)) | ((int)real2 & (int)!(P2 > 0.0)) | ((int)real3 & (int)!(P3 > 0.0));
+                if (bad) s_failf[kb & 1] = 1;
+                d2v* Wo = (d2v*)(Lblk + (size_t)wblk<TRI>(kb, bi, NB) * 18);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double w0 = a4[r][0];
+                    const double w1 = fma(-w0, l10, a4[r][1]);
+                    const double w2 = fma(-w1, l21, fma(-w0, l20, a4[r][2]));
+                    const double w3 = fma(-w2, l32, fma(-w1, l31, fma(-w0, l30, a4[r][3])));
+                    // (the diagonal block keeps its strictly lower part only: nobody but the back substitution reads it)
+                    const bool dgb = bi == kb;
+                    Wo[2 * r] = (d2v){(dgb && r < 1) ? 0.0 : w0, (dgb && r < 2) ? 0.0 : w1};
+                    Wo[2 * r + 1] = (d2v){(dgb && r < 3) ? 0.0 : w2, dgb ? 0.0 : w3};
+                }
+                if (bi == kb) {   // reciprocal pivots; 0 for the rhs / padding rows (only the back substitution reads those)
+                    d2v* Ro = (d2v*)(s_R + 4 * kb);
+                    Ro[0] = (d2v){r0, real1 ? r1 : 0.0}; Ro[1] = (d2v){real2 ? r2 : 0.0, real3 ? r3 : 0.0};
+                }
+            }
+            __syncthreads();                                    // W and 1/d of pivot block kb are visible
+            if (bj > kb) {
+                const d2v* Wi = (const d2v*)(Lblk + (size_t)wblk<TRI>(kb, bi, NB) * 18);
+                const d2v* Wj = (const d2v*)(Lblk + (size_t)wblk<TRI>(kb, bj, NB) * 18);
+                const d2v* Rq = (const d2v*)(s_R + 4 * kb);
+                d2v wv[4][2], wj[4][2], lv[4][2];
+                // column-block operands first: the diagonal copy and its factorisation are the critical chain
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { wj[r][0] = Wj[2 * r]; wj[r][1] = Wj[2 * r + 1]; }
+                const d2v ra = Rq[0], rb = Rq[1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { wv[r][0] = Wi[2 * r]; wv[r][1] = Wi[2 * r + 1]; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { lv[r][0].x = wj[r][0].x * ra.x; lv[r][0].y = wj[r][0].y * ra.y; lv[r][1].x = wj[r][1].x * rb.x; lv[r][1].y = wj[r][1].y * rb.y; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int cc = 0; cc <= r; ++cc) {
+                        double v = dg[r][cc];
+                        v = fma(-wj[r][0].x, lv[cc][0].x, v);
+                        v = fma(-wj[r][0].y, lv[cc][0].y, v);
+                        v = fma(-wj[r][1].x, lv[cc][1].x, v);
+                        v = fma(-wj[r][1].y, lv[cc][1].y, v);
+                        dg[r][cc] = v;
+                    }
+                AVT_FACTOR_DG();
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        double v = a4[r][cc];
+                        v = fma(-wv[r][0].x, lv[cc][0].x, v);
+                        v = fma(-wv[r][0].y, lv[cc][0].y, v);
+                        v = fma(-wv[r][1].x, lv[cc][1].x, v);
+                        v = fma(-wv[r][1].y, lv[cc][1].y, v);
+                        a4[r][cc] = v;
+                    }
             }
         }
-        __syncthreads();                                    // W and 1/d of pivot block kb are visible
-        if (bj > kb) {
-            const d2v* Wi = (const d2v*)(Lblk + (size_t)wblk<TRI>(kb, bi, NB) * 18);
-            const d2v* Wj = (const d2v*)(Lblk + (size_t)wblk<TRI>(kb, bj, NB) * 18);
-            const d2v* Rq = (const d2v*)(s_R + 4 * kb);
-            d2v wv[4][2], wj[4][2], lv[4][2];
-            // column-block operands first: the diagonal copy and its factorisation are the critical chain
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { wj[r][0] = Wj[2 * r]; wj[r][1] = Wj[2 * r + 1]; }
-            const d2v ra = Rq[0], rb = Rq[1];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { wv[r][0] = Wi[2 * r]; wv[r][1] = Wi[2 * r + 1]; }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { lv[r][0].x = wj[r][0].x * ra.x; lv[r][0].y = wj[r][0].y * ra.y; lv[r][1].x = wj[r][1].x * rb.x; lv[r][1].y = wj[r][1].y * rb.y; }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int cc = 0; cc <= r; ++cc) {
-                    double v = dg[r][cc];
-                    v = fma(-wj[r][0].x, lv[cc][0].x, v);
-                    v = fma(-wj[r][0].y, lv[cc][0].y, v);
-                    v = fma(-wj[r][1].x, lv[cc][1].x, v);
-                    v = fma(-wj[r][1].y, lv[cc][1].y, v);
-                    dg[r][cc] = v;
-                }
-            AVT_FACTOR_DG();
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    double v = a4[r][cc];
-                    v = fma(-wv[r][0].x, lv[cc][0].x, v);
-                    v = fma(-wv[r][0].y, lv[cc][0].y, v);
-                    v = fma(-wv[r][1].x, lv[cc][1].x, v);
-                    v = fma(-wv[r][1].y, lv[cc][1].y, v);
-                    a4[r][cc] = v;
-                }
-        }
-    }
 #undef AVT_FACTOR_DG
-    if (!fail && s_failf[(NB - 1) & 1]) fail = true;
+        if (!fail && s_failf[(NB - 1) & 1]) fail = true;
+
+    }
     __syncthreads();
     TPROBE(3);
     const bool ok = !fail;
@@ -788,7 +978,7 @@ static size_t solve_lds_bytes(const AvtDims& d) {
     const size_t prep_bytes = sizeof(double) * (size_t)L.ndoubles + sizeof(int) * (2 * (size_t)L.nitems + 2 * AVT_MAX_JOINTS + 4);
     const size_t fixed = sizeof(double) * (((std::max(HS, 4 * d.J) + 3) & ~1) + HS + 2 + ((2 * d.xsize + 1) & ~1));
     const size_t factor = sizeof(double) * nblk * 18;
-    return (solve_big(d) ? std::max(factor, prep_bytes) + fixed : factor + fixed + prep_bytes) + 64;
+    return (solve_big(d) ? std::max(factor, prep_bytes) + fixed : factor + sizeof(double) * MF_PB_DOUBLES + fixed + prep_bytes) + 64;
 }
 
 // decide = the launch behind the LAST evaluation of an ICP iteration: the lane that sums H(P,P) also takes the accept / reject decision
