@@ -1,0 +1,28 @@
+"""In-kernel phase timing (clock64, thread 0) of the last k_solve launch of an optimize() call.
+Needs the instrumented library: make -C avatar_amd/csrc libavatar_hip_timing_lm.so, then
+    AVT_LIB=avatar_amd/csrc/libavatar_hip_timing_lm.so python tools/solve_phase_probe.py [frames]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from avatar_amd import api, capi, synth  # noqa: E402
+from avatar_amd.capi import Options  # noqa: E402
+
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+smpl = synth.load_model(0); gm = api.AvatarModel(smpl)
+frs = [synth.make_frame(smpl, s % 8) for s in range(min(F, 8))]
+frs = [frs[s % len(frs)] for s in range(F)]
+pm = synth.identity_part_map()
+ctx = api.Context(gm, 24, pm, 60000, F)
+p0 = np.array([f['start'][1] for f in frs]); q0 = np.array([api.rot_to_quat(f['start'][2]) for f in frs]); w0 = np.array([f['start'][0] for f in frs])
+opt = Options.demo()
+for i in range(2):
+    ctx.optimize_batch([f['data'] for f in frs], [f['labels'] for f in frs], opt, p0, q0, w0)
+lib = capi.load_library(); buf = np.zeros(64)
+lib.avt_debug_trace(ctx.h, 0, buf.ctypes.data_as(C.POINTER(C.c_double)))
+s = np.diff(buf[40:47])
+print("F=%d k_solve (last full solve of frame 0), shader clocks: loads + LM decision %.0f | system assembly %.0f | LDL^T %.0f | back substitution %.0f | retraction %.0f | skeleton pass %.0f | total %.0f"
+      % (F, s[0], s[1], s[2], s[3], s[4], s[5], buf[46] - buf[40]))
