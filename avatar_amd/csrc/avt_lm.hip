@@ -426,6 +426,16 @@ __device__ __forceinline__ void backsub_tri(const double* __restrict__ Lblk, con
 //            live tile (next panel's block column first), publish the next panel's 4 columns from the accumulators.
 // -------------------------------------------------------------------------------------------------
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+#ifdef AVT_TIMING
+__device__ long long g_mf_phase[8];     // waves 0 and 3, lane 0, workgroup 0: clocks at barrier A, row phase, barrier B, matrix phase (summed over rounds and launches)
+extern "C" void avt_debug_mf_phases(long long* out8, int reset) {
+    if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_mf_phase), sizeof(long long) * 8);
+    if (reset) { long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mf_phase), z, sizeof z); }
+}
+#define MFP(i) do { if ((t & 63) == 0 && (W == 0 || W == 3) && blockIdx.x == 0) { const long long _n = clock64(); g_mf_phase[(W == 0 ? 0 : 4) + (i)] += _n - _tl; _tl = _n; } } while (0)
+#else
+#define MFP(i) do {} while (0)
+#endif
 #define MF_PB_STRIDE 4
 #define MF_PB_DOUBLES (96 * MF_PB_STRIDE)
 
@@ -451,7 +461,11 @@ __device__ __forceinline__ bool mf_round(v4f64 (&accA)[6], v4f64 (&accB)[2], int
                                            double* __restrict__ Lblk, double* __restrict__ s_R, int* __restrict__ s_fail, int P, int NB, int NR, int t) {
     constexpr int rA = 5 - W, rB = W - 2;
     const int ln = t & 63, k = ln >> 4, c16 = ln & 15, kb = 4 * CB + jq;
+#ifdef AVT_TIMING
+    long long _tl = clock64();
+#endif
     __syncthreads();                                         // the panel of this round is published
+    MFP(0);
     if (W < 2 && t < 96) {
         const d2v* PB2 = (const d2v*)PB;
         const d2v q0 = PB2[(4 * kb) * 2], q1 = PB2[(4 * kb + 1) * 2], q2a = PB2[(4 * kb + 2) * 2], q2b = PB2[(4 * kb + 2) * 2 + 1];
@@ -483,7 +497,9 @@ __device__ __forceinline__ bool mf_round(v4f64 (&accA)[6], v4f64 (&accB)[2], int
             if (bad) *s_fail = 1;
         }
     }
+    MFP(1);
     __syncthreads();                                         // W rows, reciprocal pivots and the failure flag are visible
+    MFP(2);
     // ---- fragments: lane (c16, k) holds row 16 b + c16, pivot k of the round
     const double* Wk = Lblk + (size_t)kb * NB * 18 + (c16 >> 2) * 18 + (c16 & 3) * 4 + k;
     double fw[6];
@@ -509,6 +525,7 @@ __device__ __forceinline__ bool mf_round(v4f64 (&accA)[6], v4f64 (&accB)[2], int
         for (int c = CBN + 1; c <= rA; ++c) accA[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fA, fb[c], accA[c], 0, 0, 0);
     }
     mf_publish<W, CBN>(accA, accB, (jq + 1) & 3, PB, ln);
+    MFP(3);
     return true;
 }
 

@@ -26,3 +26,15 @@ lib.avt_debug_trace(ctx.h, 0, buf.ctypes.data_as(C.POINTER(C.c_double)))
 s = np.diff(buf[40:47])
 print("F=%d k_solve (last full solve of frame 0), shader clocks: loads + LM decision %.0f | system assembly %.0f | LDL^T %.0f | back substitution %.0f | retraction %.0f | skeleton pass %.0f | total %.0f"
       % (F, s[0], s[1], s[2], s[3], s[4], s[5], buf[46] - buf[40]))
+
+try:
+    lib.avt_debug_mf_phases.argtypes = [C.POINTER(C.c_longlong), C.c_int]
+    lib.avt_debug_mf_phases(None, 1)
+    ctx.optimize_batch([f['data'] for f in frs], [f['labels'] for f in frs], opt, p0, q0, w0)
+    ph = (C.c_longlong * 8)()
+    lib.avt_debug_mf_phases(ph, 0)
+    n = 10.0 * 22       # full solves of the call x rounds
+    print("LDL^T rounds of workgroup 0, clocks per round: wave 0: barrier A %.0f | row phase %.0f | barrier B %.0f | matrix phase %.0f   wave 3: %.0f | %.0f | %.0f | %.0f"
+          % tuple(v / n for v in ph))
+except AttributeError:
+    pass
