@@ -242,6 +242,54 @@ __global__ __launch_bounds__(256 * Q) void k_reduce(DeviceModel dm, FrameBuffers
     }
 }
 
+// k_reduce_strip<DECIDE, NS>: the few-frames shape (G >= 64) of the reduction.  One workgroup per tile pair pulls G x 2 KB =
+// 256 KB of partial tiles through one CU (k_reduce<4>: 7.3 us per launch on one frame); here a pair is NS workgroups on NS CUs,
+// each reducing a strip of 256 / NS tile elements (contiguous in every partial tile): 1024 threads = EL elements x NSL slices of
+// the G workgroups, <= 8 loads per thread in flight together with the written-masks, the slice sums added in fixed order
+// through LDS.  grid (NS NPAIR, frames) - DECIDE: (NS, frames), only the pair that holds H(P,P).  5.0 us per launch on one frame.
+template <bool DECIDE, int NS>
+__global__ __launch_bounds__(1024) void k_reduce_strip(DeviceModel dm, FrameBuffers fb) {
+    __builtin_amdgcn_s_setprio(3);
+    constexpr int EL = 256 / NS, NSL = 1024 / EL, NLD = (128 + NSL - 1) / NSL;     // elements per strip, slices, loads per thread (G <= 128)
+    const AvtDims d = dm.d;
+    const int f = blockIdx.y + fb.f0, el = threadIdx.x % EL, slice = threadIdx.x / EL, strip = blockIdx.x % NS;
+    const int NPAIR = d.NPAIR, NT = d.NT, P = d.P, HS = d.HS;
+    const int pair = DECIDE ? d.res_pair : (int)(blockIdx.x / NS);
+    const int e = strip * EL + el;                       // element of the tile: (row = (e >> 4 & 3) + 4 (e >> 6), col = e & 15)
+    const int G = fb.G, glo = (G * slice) / NSL, ghi = (G * (slice + 1)) / NSL;
+    const double* part = fb.partial + ((size_t)f * G * NPAIR + pair) * 256 + e;
+    const size_t st = (size_t)NPAIR * 256;
+    const unsigned long long* wm = fb.wmask + (size_t)f * G;
+    double v[NLD];
+    unsigned long long m[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int g = min(glo + u, G - 1);
+        v[u] = __builtin_nontemporal_load(part + (size_t)g * st);
+        m[u] = wm[g];
+    }
+    double a = 0.0;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) a += (glo + u < ghi && (pair >= 64 || ((m[u] >> (pair & 63)) & 1ull))) ? v[u] : 0.0;
+    __shared__ double s_q[NSL - 1][EL];
+    if (slice > 0) s_q[slice - 1][el] = a;
+    __syncthreads();
+    if (slice != 0) return;
+#pragma unroll
+    for (int i = 0; i < NSL - 1; ++i) a += s_q[i][el];
+    int p = pair, ti = 0;
+    while (p >= NT - ti) { p -= NT - ti; ++ti; }
+    const int tj = ti + p;
+    const int r = dm.tile_param[ti * 16 + ((e >> 4) & 3) + 4 * (e >> 6)], c = dm.tile_param[tj * 16 + (e & 15)];
+    if constexpr (DECIDE) {
+        if (r == P && c == P) lm_decide_last(dm, fb, f, a);
+    } else if (r >= 0 && c >= 0) {
+        double* H = fb.Hraw + ((size_t)f * 2 + (1 - fb.ctl[f].cur_slot)) * HS * HS;
+        H[(size_t)r * HS + c] = a;
+        if (ti != tj) H[(size_t)c * HS + r] = a;
+    }
+}
+
 typedef double d2v __attribute__((ext_vector_type(2)));
 
 // Frame batches: the matched-point batches of a frame are dealt to its G evaluation workgroups as CONTIGUOUS ranges of equal
@@ -1002,9 +1050,13 @@ static size_t solve_lds_bytes(const AvtDims& d) {
 void launch_reduce(avt_ctx* c, int nframes, bool decide) {
     const AvtDims& d = c->dm.d;
     const dim3 grid(decide ? 1 : d.NPAIR, nframes);
-    if (c->fb.G >= 64) {
-        if (decide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<4, true>), grid, dim3(1024), 0, c->cur_stream, c->dm, c->fb);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<4, false>), grid, dim3(1024), 0, c->cur_stream, c->dm, c->fb);
+    if (c->fb.G >= 64) {      // few frames: four workgroups per pair (k_reduce_strip)
+        const int ns = nframes == 1 ? 8 : 4;     // measured, one frame: 2 / 4 / 8 / 16 strips 0.582 / 0.556 / 0.543 / 0.560 ms per step; eight frames: 0.817 / 0.778 / 0.800 / 0.915
+        const dim3 grid4(decide ? ns : ns * d.NPAIR, nframes);
+#define AVT_RS(NS) do { if (decide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_strip<true, NS>), grid4, dim3(1024), 0, c->cur_stream, c->dm, c->fb); \
+                        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_strip<false, NS>), grid4, dim3(1024), 0, c->cur_stream, c->dm, c->fb); } while (0)
+        if (ns == 8) AVT_RS(8); else AVT_RS(4);
+#undef AVT_RS
     } else {
         if (decide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<1, true>), grid, dim3(256), 0, c->cur_stream, c->dm, c->fb);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<1, false>), grid, dim3(256), 0, c->cur_stream, c->dm, c->fb);
