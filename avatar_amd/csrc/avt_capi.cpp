@@ -104,10 +104,14 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
     c->ran_icp_iters = 0;
     const int vis_init = o->enable_occlusion ? 0 : 1;
     c->lbs_cleared = true;
-    { ProfScope ps(c, AVT_K_BUCKET); launch_bucket(c, nf, o->icp_iters <= 0); }   // k_finalize restores the cursors
-    { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 1, vis_init); }   // ava.update() precondition (:1356)
+    // The two passes of the data bucketing ride in the trailing workgroups of the two launches they do not depend on (the label
+    // histogram beside the skinning, the scatter beside the visibility pass of the first ICP iteration): two launches fewer on
+    // the dependency chain; k_finalize restores the cursors.  (No ICP iteration: the stand-alone launches, cursors cleared.)
+    const bool fuse_bucket = o->icp_iters > 0;
+    if (!fuse_bucket) { ProfScope ps(c, AVT_K_BUCKET); launch_bucket(c, nf, true); }
+    { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 1, vis_init, fuse_bucket); }   // ava.update() precondition (:1356)
     for (int icp = 0; icp < o->icp_iters; ++icp) {
-        { ProfScope ps(c, AVT_K_VISIBILITY); launch_visibility(c, nf, o->enable_occlusion); }
+        { ProfScope ps(c, AVT_K_VISIBILITY); launch_visibility(c, nf, o->enable_occlusion, fuse_bucket && icp == 0); }
         { ProfScope ps(c, AVT_K_NN); launch_nn(c, nf); }
         { ProfScope ps(c, AVT_K_AGGREGATE); launch_finalize(c, nf); launch_records(c, nf); }
         { ProfScope ps(c, AVT_K_PREPARE); launch_solve(c, nf, SOLVE_INIT); }

@@ -4,6 +4,96 @@
 #include "avt_device.h"
 
 // =================================================================================================
+// Data bucketing by body-part label (the data-side counterpart of AvatarOptimizer.cpp:1274-1293): a
+// two-pass counting sort over many workgroups.  Pass 1 histograms labels (LDS atomics, then one global atomic
+// per (workgroup, part)); pass 2 reserves a range per (workgroup, part) and scatters.  The order of points
+// INSIDE a part bucket is not deterministic, and nothing downstream depends on it: the nearest neighbour of a
+// point does not depend on its neighbours, the correspondence sums are order-independent integer atomics and
+// every floating-point reduction over data points runs in original index order.
+// =================================================================================================
+#define BUCKET_TILE 2048
+
+__device__ __forceinline__ void bucket_count_block(const DeviceModel& dm, const FrameBuffers& fb, int f, int bx) {
+    const int t = threadIdx.x, np = dm.d.num_parts;
+    const int N = fb.ctl[f].N;
+    const int s0 = bx * BUCKET_TILE;
+    if (s0 >= N) return;
+    __shared__ int hist[AVT_MAX_PARTS + 1];
+    if (t <= np) hist[t] = 0;
+    __syncthreads();
+    const int* lab = fb.labels_raw + (size_t)f * fb.max_points;
+#pragma unroll
+    for (int u = 0; u < BUCKET_TILE / 256; ++u) {
+        const int i = s0 + u * 256 + t;
+        if (i < N) {
+            int q = lab[i];
+            if (q < 0 || q >= np) q = np;
+            atomicAdd(&hist[q], 1);
+        }
+    }
+    __syncthreads();
+    if (t <= np && hist[t]) atomicAdd(fb.part_cnt + (size_t)f * 2 * (AVT_MAX_PARTS + 1) + t, hist[t]);
+}
+
+__global__ __launch_bounds__(256) void k_bucket_count(DeviceModel dm, FrameBuffers fb) { bucket_count_block(dm, fb, blockIdx.y + fb.f0, blockIdx.x); }
+
+__device__ __forceinline__ void bucket_scatter_block(const DeviceModel& dm, const FrameBuffers& fb, int f, int bx) {
+    const int t = threadIdx.x, np = dm.d.num_parts;
+    AvtFrameCtl& ctl = fb.ctl[f];
+    const int N = ctl.N;
+    const int s0 = bx * BUCKET_TILE;
+    const size_t base = (size_t)f * fb.max_points;
+    __shared__ int hist[AVT_MAX_PARTS + 1], poff[AVT_MAX_PARTS + 2], bbase[AVT_MAX_PARTS + 1];
+    int* pcnt = fb.part_cnt + (size_t)f * 2 * (AVT_MAX_PARTS + 1);
+    int* cursor = pcnt + (AVT_MAX_PARTS + 1);
+    if (t <= np) hist[t] = 0;
+    if (t == 0) {
+        int acc = 0;
+        for (int q = 0; q <= np; ++q) { poff[q] = acc; acc += pcnt[q]; }
+        poff[np + 1] = acc;
+    }
+    __syncthreads();
+    if (bx == 0) {
+        if (t <= np) fb.part_off[(size_t)f * (np + 1) + t] = poff[t];
+        if (t < 3 && N > 0) ctl.centre[t] = fb.data_raw[3 * base + t];
+    }
+    if (s0 >= N) return;
+    const int* lab = fb.labels_raw + base;
+    int qs[BUCKET_TILE / 256];
+#pragma unroll
+    for (int u = 0; u < BUCKET_TILE / 256; ++u) {
+        const int i = s0 + u * 256 + t;
+        int q = -1;
+        if (i < N) {
+            q = lab[i];
+            if (q < 0 || q >= np) q = np;
+            atomicAdd(&hist[q], 1);
+        }
+        qs[u] = q;
+    }
+    __syncthreads();
+    if (t <= np) {
+        bbase[t] = hist[t] ? poff[t] + atomicAdd(cursor + t, hist[t]) : 0;
+        hist[t] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < BUCKET_TILE / 256; ++u) {
+        const int i = s0 + u * 256 + t;
+        const int q = qs[u];
+        if (q < 0) continue;
+        const int pos = bbase[q] + atomicAdd(&hist[q], 1);
+        fb.dx[base + pos] = fb.data_raw[3 * (base + i)];
+        fb.dy[base + pos] = fb.data_raw[3 * (base + i) + 1];
+        fb.dz[base + pos] = fb.data_raw[3 * (base + i) + 2];
+        fb.dorig[base + pos] = i;
+        if (q == np) fb.corr[base + i] = -1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bucket_scatter(DeviceModel dm, FrameBuffers fb) { bucket_scatter_block(dm, fb, blockIdx.y + fb.f0, blockIdx.x); }
+
+// =================================================================================================
 // Avatar::update()  (Avatar.cpp:22-75)
 // grid (ceil(V/256), nframes), block 256.  Joint matrices are staged in LDS (<= 32 joints x 24 doubles),
 // the per-vertex loads are SoA and fully coalesced: 3(K+1) shape planes + 4 (weight, joint) pairs in,
@@ -11,10 +101,13 @@
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, const double* __restrict__ w_in,
                                              const double* __restrict__ p_in, const double* __restrict__ R_in,
-                                             int from_state, int vis_init) {
+                                             int from_state, int vis_init, int nlbs) {
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, V = d.V;
     const int f = blockIdx.y + fb.f0, t = threadIdx.x;
+    // trailing workgroups of the grid (the first launch of optimize() only): the label histogram of the data points - it depends
+    // on nothing this kernel computes, and riding here saves a launch on the dependency chain
+    if ((int)blockIdx.x >= nlbs) { bucket_count_block(dm, fb, f, (int)blockIdx.x - nlbs); return; }
     __shared__ double s_rot[AVT_MAX_JOINTS * 9], s_Rw[AVT_MAX_JOINTS * 9], s_o[AVT_MAX_JOINTS * 3], s_jp[AVT_MAX_JOINTS * 3];
     __shared__ double s_T[AVT_MAX_JOINTS * 12];  // jointTrans, column-major 3x4 per joint (Avatar.h:215)
     __shared__ double s_w[AVT_MAX_SHAPE], s_p[3];
@@ -107,18 +200,23 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
     }
 }
 
-void launch_lbs(avt_ctx* c, int nframes, const double*, const double* w, const double* p, const double* R, int from_state, int vis_init) {
-    dim3 grid((c->dm.d.V + 255) / 256, nframes);
-    hipLaunchKernelGGL(k_lbs, grid, dim3(256), 0, c->cur_stream, c->dm, c->fb, w, p, R, from_state, vis_init);
+// with_bucket_count: also histogram the data labels (first half of launch_bucket) in trailing workgroups
+void launch_lbs(avt_ctx* c, int nframes, const double*, const double* w, const double* p, const double* R, int from_state, int vis_init, bool with_bucket_count) {
+    const int nlbs = (c->dm.d.V + 255) / 256;
+    const int nb = with_bucket_count ? std::max(1, (c->launch_maxN + BUCKET_TILE - 1) / BUCKET_TILE) : 0;
+    dim3 grid(nlbs + nb, nframes);
+    hipLaunchKernelGGL(k_lbs, grid, dim3(256), 0, c->cur_stream, c->dm, c->fb, w, p, R, from_state, vis_init, nlbs);
 }
 
 // =================================================================================================
 // back-face visibility (AvatarOptimizer.cpp:1349-1367): a face whose ((p2-p1)x(p1-p3)).z > 1e-4 marks its
 // three vertices visible.  `visible` is cleared (or set, when occlusion is off) by a memset node first.
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_visibility(DeviceModel dm, FrameBuffers fb) {
+__global__ __launch_bounds__(256) void k_visibility(DeviceModel dm, FrameBuffers fb, int nvis) {
     const int F = dm.d.F, V = dm.d.V;
     const int f = blockIdx.y + fb.f0;
+    // trailing workgroups (first ICP iteration only): the scatter pass of the data bucketing (its histogram rode in k_lbs)
+    if ((int)blockIdx.x >= nvis) { bucket_scatter_block(dm, fb, f, (int)blockIdx.x - nvis); return; }
     const int face = blockIdx.x * 256 + threadIdx.x;
     if (face >= F) return;
     const int i1 = dm.mesh[face], i2 = dm.mesh[(size_t)F + face], i3 = dm.mesh[2 * (size_t)F + face];
@@ -134,98 +232,16 @@ __global__ __launch_bounds__(256) void k_visibility(DeviceModel dm, FrameBuffers
     }
 }
 
-void launch_visibility(avt_ctx* c, int nframes, int enable) {
+// with_bucket_scatter: also run the scatter pass of the data bucketing (second half of launch_bucket) in trailing workgroups
+void launch_visibility(avt_ctx* c, int nframes, int enable, bool with_bucket_scatter) {
     const int V = c->dm.d.V;
     if (!c->lbs_cleared) (void)hipMemsetAsync(c->fb.visible + (size_t)c->fb.f0 * V, enable ? 0 : 1, (size_t)nframes * V, c->cur_stream);
+    const int nb = with_bucket_scatter ? std::max(1, (c->launch_maxN + BUCKET_TILE - 1) / BUCKET_TILE) : 0;
     if (enable) {
-        dim3 grid((c->dm.d.F + 255) / 256, nframes);
-        hipLaunchKernelGGL(k_visibility, grid, dim3(256), 0, c->cur_stream, c->dm, c->fb);
-    }
-}
-
-// =================================================================================================
-// Data bucketing by body-part label (the data-side counterpart of AvatarOptimizer.cpp:1274-1293): a
-// two-pass counting sort over many workgroups.  Pass 1 histograms labels (LDS atomics, then one global atomic
-// per (workgroup, part)); pass 2 reserves a range per (workgroup, part) and scatters.  The order of points
-// INSIDE a part bucket is not deterministic, and nothing downstream depends on it: the nearest neighbour of a
-// point does not depend on its neighbours, the correspondence sums are order-independent integer atomics and
-// every floating-point reduction over data points runs in original index order.
-// =================================================================================================
-#define BUCKET_TILE 2048
-
-__global__ __launch_bounds__(256) void k_bucket_count(DeviceModel dm, FrameBuffers fb) {
-    const int f = blockIdx.y + fb.f0, t = threadIdx.x, np = dm.d.num_parts;
-    const int N = fb.ctl[f].N;
-    const int s0 = blockIdx.x * BUCKET_TILE;
-    if (s0 >= N) return;
-    __shared__ int hist[AVT_MAX_PARTS + 1];
-    if (t <= np) hist[t] = 0;
-    __syncthreads();
-    const int* lab = fb.labels_raw + (size_t)f * fb.max_points;
-#pragma unroll
-    for (int u = 0; u < BUCKET_TILE / 256; ++u) {
-        const int i = s0 + u * 256 + t;
-        if (i < N) {
-            int q = lab[i];
-            if (q < 0 || q >= np) q = np;
-            atomicAdd(&hist[q], 1);
-        }
-    }
-    __syncthreads();
-    if (t <= np && hist[t]) atomicAdd(fb.part_cnt + (size_t)f * 2 * (AVT_MAX_PARTS + 1) + t, hist[t]);
-}
-
-__global__ __launch_bounds__(256) void k_bucket_scatter(DeviceModel dm, FrameBuffers fb) {
-    const int f = blockIdx.y + fb.f0, t = threadIdx.x, np = dm.d.num_parts;
-    AvtFrameCtl& ctl = fb.ctl[f];
-    const int N = ctl.N;
-    const int s0 = blockIdx.x * BUCKET_TILE;
-    const size_t base = (size_t)f * fb.max_points;
-    __shared__ int hist[AVT_MAX_PARTS + 1], poff[AVT_MAX_PARTS + 2], bbase[AVT_MAX_PARTS + 1];
-    int* pcnt = fb.part_cnt + (size_t)f * 2 * (AVT_MAX_PARTS + 1);
-    int* cursor = pcnt + (AVT_MAX_PARTS + 1);
-    if (t <= np) hist[t] = 0;
-    if (t == 0) {
-        int acc = 0;
-        for (int q = 0; q <= np; ++q) { poff[q] = acc; acc += pcnt[q]; }
-        poff[np + 1] = acc;
-    }
-    __syncthreads();
-    if (blockIdx.x == 0) {
-        if (t <= np) fb.part_off[(size_t)f * (np + 1) + t] = poff[t];
-        if (t < 3 && N > 0) ctl.centre[t] = fb.data_raw[3 * base + t];
-    }
-    if (s0 >= N) return;
-    const int* lab = fb.labels_raw + base;
-    int qs[BUCKET_TILE / 256];
-#pragma unroll
-    for (int u = 0; u < BUCKET_TILE / 256; ++u) {
-        const int i = s0 + u * 256 + t;
-        int q = -1;
-        if (i < N) {
-            q = lab[i];
-            if (q < 0 || q >= np) q = np;
-            atomicAdd(&hist[q], 1);
-        }
-        qs[u] = q;
-    }
-    __syncthreads();
-    if (t <= np) {
-        bbase[t] = hist[t] ? poff[t] + atomicAdd(cursor + t, hist[t]) : 0;
-        hist[t] = 0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < BUCKET_TILE / 256; ++u) {
-        const int i = s0 + u * 256 + t;
-        const int q = qs[u];
-        if (q < 0) continue;
-        const int pos = bbase[q] + atomicAdd(&hist[q], 1);
-        fb.dx[base + pos] = fb.data_raw[3 * (base + i)];
-        fb.dy[base + pos] = fb.data_raw[3 * (base + i) + 1];
-        fb.dz[base + pos] = fb.data_raw[3 * (base + i) + 2];
-        fb.dorig[base + pos] = i;
-        if (q == np) fb.corr[base + i] = -1;
+        const int nvis = (c->dm.d.F + 255) / 256;
+        hipLaunchKernelGGL(k_visibility, dim3(nvis + nb, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb, nvis);
+    } else if (nb) {
+        hipLaunchKernelGGL(k_bucket_scatter, dim3(nb, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
     }
 }
 
