@@ -129,7 +129,7 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
                 launch_reduce(c, nf, true);
             }
         }
-        { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 1, vis_init); }   // :1494-1497
+        { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 2, vis_init); }   // :1494-1497 (2: from the skeleton tables of the current point)
         c->ran_icp_iters++;
     }
     c->lbs_cleared = false;

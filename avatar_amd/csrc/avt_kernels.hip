@@ -113,29 +113,39 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
     __shared__ double s_w[AVT_MAX_SHAPE], s_p[3];
     __shared__ int s_parent[AVT_MAX_JOINTS], s_lvl[AVT_MAX_JOINTS + 1];
 
-    const double* xs = nullptr;
-    if (from_state) xs = fb.x + ((size_t)f * 2 + fb.ctl[f].cur_slot) * d.xsize;
-    if (t < K) s_w[t] = from_state ? xs[3 + 4 * J + t] : w_in[(size_t)f * K + t];
-    if (t < 3) s_p[t] = from_state ? xs[t] : p_in[(size_t)f * 3 + t];
-    if (t < J) { s_parent[t] = dm.parent[t]; s_lvl[t] = dm.jlevel[t]; }
-    if (t == 0) s_lvl[J] = d.nlevels - 1;
-    if (from_state) {
-        if (t < J) quat_to_rot(xs + 3 + 4 * t, s_rot + 9 * t);
+    if (from_state == 2) {
+        // from the skeleton tables k_solve made for the current point (its world rotations, joint origins and rest joints are
+        // what the forward kinematics below would recompute): no chain of tree levels on the way to the vertices
+        const double* pp = fb.prep + ((size_t)f * 2 + fb.ctl[f].cur_slot) * d.prep_size;
+        for (int e = t; e < 9 * J; e += 256) s_Rw[e] = pp[prep_off_Rw(d) + e];
+        if (t < 3 * J) { s_o[t] = pp[prep_off_o(d) + t]; s_jp[t] = pp[prep_off_Jh(d) + t] + pp[prep_off_off(d) + t % 3]; }
+        if (t < K) s_w[t] = pp[prep_off_w(d) + t];
+        __syncthreads();
     } else {
-        for (int e = t; e < 9 * J; e += 256) {  // R is column-major per joint -> row-major in LDS
-            const int j = e / 9, r = (e % 9) / 3, c = e % 3;
-            s_rot[e] = R_in[(size_t)f * 9 * J + 9 * j + 3 * c + r];
+        const double* xs = nullptr;
+        if (from_state) xs = fb.x + ((size_t)f * 2 + fb.ctl[f].cur_slot) * d.xsize;
+        if (t < K) s_w[t] = from_state ? xs[3 + 4 * J + t] : w_in[(size_t)f * K + t];
+        if (t < 3) s_p[t] = from_state ? xs[t] : p_in[(size_t)f * 3 + t];
+        if (t < J) { s_parent[t] = dm.parent[t]; s_lvl[t] = dm.jlevel[t]; }
+        if (t == 0) s_lvl[J] = d.nlevels - 1;
+        if (from_state) {
+            if (t < J) quat_to_rot(xs + 3 + 4 * t, s_rot + 9 * t);
+        } else {
+            for (int e = t; e < 9 * J; e += 256) {  // R is column-major per joint -> row-major in LDS
+                const int j = e / 9, r = (e % 9) / 3, c = e % 3;
+                s_rot[e] = R_in[(size_t)f * 9 * J + 9 * j + 3 * c + r];
+            }
         }
+        __syncthreads();
+        // jointPos = initialJointPos + jointShapeReg * w   (Avatar.cpp:31-36)
+        if (t < 3 * J) {
+            double s = 0.0;
+            for (int k = 0; k < K; ++k) s += dm.jsr[(size_t)t * K + k] * s_w[k];
+            s_jp[t] = dm.jsr_base[t] + s;
+        }
+        __syncthreads();
+        fk_chain(J, s_parent, s_rot, s_jp, s_p, s_Rw, s_o, s_lvl);
     }
-    __syncthreads();
-    // jointPos = initialJointPos + jointShapeReg * w   (Avatar.cpp:31-36)
-    if (t < 3 * J) {
-        double s = 0.0;
-        for (int k = 0; k < K; ++k) s += dm.jsr[(size_t)t * K + k] * s_w[k];
-        s_jp[t] = dm.jsr_base[t] + s;
-    }
-    __syncthreads();
-    fk_chain(J, s_parent, s_rot, s_jp, s_p, s_Rw, s_o, s_lvl);
     // jointPos_i <- t_i ; t_i -= R_i * jPosInit   (Avatar.cpp:59-64)
     if (t < 3 * J) {
         const int j = t / 3, r = t % 3;
