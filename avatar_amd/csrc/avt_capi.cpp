@@ -108,13 +108,16 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
     // histogram beside the skinning, the scatter beside the visibility pass of the first ICP iteration): two launches fewer on
     // the dependency chain; k_finalize restores the cursors.  (No ICP iteration: the stand-alone launches, cursors cleared.)
     const bool fuse_bucket = o->icp_iters > 0;
+    // Few frames (the latency shape, G >= 64): the trial point of every ICP iteration (trial := current + its skeleton tables)
+    // is set up by a workgroup in the grid of the k_lbs launch in front of it instead of by a k_solve INIT launch behind k_records.
+    const bool fuse_init = c->fb.G >= 64;
     if (!fuse_bucket) { ProfScope ps(c, AVT_K_BUCKET); launch_bucket(c, nf, true); }
-    { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 1, vis_init, fuse_bucket); }   // ava.update() precondition (:1356)
+    { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 1, vis_init, fuse_bucket, fuse_init && o->icp_iters > 0); }   // ava.update() precondition (:1356)
     for (int icp = 0; icp < o->icp_iters; ++icp) {
         { ProfScope ps(c, AVT_K_VISIBILITY); launch_visibility(c, nf, o->enable_occlusion, fuse_bucket && icp == 0); }
         { ProfScope ps(c, AVT_K_NN); launch_nn(c, nf); }
         { ProfScope ps(c, AVT_K_AGGREGATE); launch_finalize(c, nf); launch_records(c, nf); }
-        { ProfScope ps(c, AVT_K_PREPARE); launch_solve(c, nf, SOLVE_INIT); }
+        if (!fuse_init) { ProfScope ps(c, AVT_K_PREPARE); launch_solve(c, nf, SOLVE_INIT); }
         { ProfScope ps(c, AVT_K_EVAL); launch_eval(c, nf, false); }
         { ProfScope ps(c, AVT_K_REDUCE); launch_reduce(c, nf); }
         for (int it = 1; it <= std::max(1, o->max_iters_per_icp); ++it) {
@@ -129,7 +132,7 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
                 launch_reduce(c, nf, true);
             }
         }
-        { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 2, vis_init); }   // :1494-1497 (2: from the skeleton tables of the current point)
+        { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 2, vis_init, false, fuse_init && icp + 1 < o->icp_iters); }   // :1494-1497 (2: from the skeleton tables of the current point)
         c->ran_icp_iters++;
     }
     c->lbs_cleared = false;
@@ -362,7 +365,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         HIP_OK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
     }
     c->cur_stream = c->stream;
-    if (avt_solve_set_attributes() || avt_eval_set_attributes()) { avt_set_error("avt_ctx_create: hipFuncSetAttribute failed"); return 1; }
+    if (avt_solve_set_attributes() || avt_eval_set_attributes() || avt_lbs_set_attributes()) { avt_set_error("avt_ctx_create: hipFuncSetAttribute failed"); return 1; }
     DeviceModel& dm = c->dm;
     dm.d = m->d;
     dm.d.num_parts = num_parts;

@@ -256,7 +256,8 @@ void avt_set_error(const std::string& s);
 enum { SOLVE_INIT = 0, SOLVE_FIRST = 1, SOLVE_NORMAL = 2 };
 void launch_lbs(avt_ctx* c, int nframes, const double* x_state_or_null, const double* w, const double* p, const double* R,
                 int from_state, int vis_init /* -1: leave bookkeeping alone; 0/1: reset it, visibility flags to this value */,
-                bool with_bucket_count = false);
+                bool with_bucket_count = false, bool with_init = false);
+int avt_lbs_set_attributes();
 void launch_visibility(avt_ctx* c, int nframes, int enable, bool with_bucket_scatter = false);
 void launch_bucket(avt_ctx* c, int nframes, bool clear_after);
 void launch_state_reset(avt_ctx* c, int nframes);

@@ -2,6 +2,7 @@
 // linear-blend skinning, back-face visibility, data bucketing by body part, correspondence finalisation.
 // (nearest neighbour: avt_nn.hip; residual/Jacobian/J^T J: avt_eval.hip; reduce + LM solve: avt_lm.hip)
 #include "avt_device.h"
+#include "avt_prep.h"
 
 // =================================================================================================
 // Data bucketing by body-part label (the data-side counterpart of AvatarOptimizer.cpp:1274-1293): a
@@ -101,13 +102,20 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(DeviceModel dm, FrameBuf
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, const double* __restrict__ w_in,
                                              const double* __restrict__ p_in, const double* __restrict__ R_in,
-                                             int from_state, int vis_init, int nlbs) {
+                                             int from_state, int vis_init, int nlbs, int with_init) {
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, V = d.V;
     const int f = blockIdx.y + fb.f0, t = threadIdx.x;
-    // trailing workgroups of the grid (the first launch of optimize() only): the label histogram of the data points - it depends
-    // on nothing this kernel computes, and riding here saves a launch on the dependency chain
-    if ((int)blockIdx.x >= nlbs) { bucket_count_block(dm, fb, f, (int)blockIdx.x - nlbs); return; }
+    // trailing workgroups of the grid: work that depends on nothing this kernel computes and would otherwise be a launch of its
+    // own on the dependency chain - (few frames) the trial point of the ICP iteration that follows (prep_init_block), (first
+    // launch of optimize()) the label histogram of the data points
+    extern __shared__ __attribute__((aligned(16))) char lbs_dyn[];
+    if ((int)blockIdx.x >= nlbs) {
+        const int bx = (int)blockIdx.x - nlbs;
+        if (with_init && bx == 0) prep_init_block(dm, fb, f, lbs_dyn);
+        else bucket_count_block(dm, fb, f, bx - (with_init ? 1 : 0));
+        return;
+    }
     __shared__ double s_rot[AVT_MAX_JOINTS * 9], s_Rw[AVT_MAX_JOINTS * 9], s_o[AVT_MAX_JOINTS * 3], s_jp[AVT_MAX_JOINTS * 3];
     __shared__ double s_T[AVT_MAX_JOINTS * 12];  // jointTrans, column-major 3x4 per joint (Avatar.h:215)
     __shared__ double s_w[AVT_MAX_SHAPE], s_p[3];
@@ -210,12 +218,19 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
     }
 }
 
-// with_bucket_count: also histogram the data labels (first half of launch_bucket) in trailing workgroups
-void launch_lbs(avt_ctx* c, int nframes, const double*, const double* w, const double* p, const double* R, int from_state, int vis_init, bool with_bucket_count) {
+// with_bucket_count: also histogram the data labels (first half of launch_bucket) in trailing workgroups;
+// with_init: also set up the trial point of the next ICP iteration (one trailing workgroup per frame)
+void launch_lbs(avt_ctx* c, int nframes, const double*, const double* w, const double* p, const double* R, int from_state, int vis_init,
+                bool with_bucket_count, bool with_init) {
     const int nlbs = (c->dm.d.V + 255) / 256;
     const int nb = with_bucket_count ? std::max(1, (c->launch_maxN + BUCKET_TILE - 1) / BUCKET_TILE) : 0;
-    dim3 grid(nlbs + nb, nframes);
-    hipLaunchKernelGGL(k_lbs, grid, dim3(256), 0, c->cur_stream, c->dm, c->fb, w, p, R, from_state, vis_init, nlbs);
+    dim3 grid(nlbs + (with_init ? 1 : 0) + nb, nframes);
+    const size_t lds = with_init ? prep_init_lds_bytes(c->dm.d) : 0;
+    hipLaunchKernelGGL(k_lbs, grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, w, p, R, from_state, vis_init, nlbs, with_init ? 1 : 0);
+}
+
+int avt_lbs_set_attributes() {
+    return hipFuncSetAttribute((const void*)k_lbs, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess;
 }
 
 // =================================================================================================

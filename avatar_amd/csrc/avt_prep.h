@@ -1,0 +1,139 @@
+// avt_prep.h - the skeleton pass shared by k_solve (avt_lm.hip) and the initial-point workgroup that rides in k_lbs's grid
+// (avt_kernels.hip).  Device code only.
+#pragma once
+#include "avt_device.h"
+
+// -------------------------------------------------------------------------------------------------
+// Skeleton pass: state x=(p,q,w) -> prep block (PrepareForEvaluation, AvatarOptimizer.cpp:283-325), LDS only.
+//   B      : double scratch laid out by prep_layout(J,K) (avt_internal.h);
+//   items  : host-built work items of the level-parallel pass, two 32-bit words each:
+//            word0 = rp | v << 14 | stride_code << 28,  word1 = add | out << 14   (offsets into B)
+//            B[out] = (B[rp] B[v] + B[rp+1] B[v+st] + B[rp+2] B[v+2st]) + B[add]
+//            which is a world-rotation entry (R(-1,pa) rot_j), a world-origin entry (o_pa + R(-1,pa)(J_j - J_pa)) or a
+//            shape-table entry (H_pa + R(-1,pa) Sp_j) depending on the offsets (:303-324); the root uses the identity.
+// prep_stage_constants() runs at kernel start (its global loads hide behind the LM decision and the factorisation),
+// prep_set_state() installs the state, prep_run() does the pass and writes the prep block.
+// -------------------------------------------------------------------------------------------------
+template <int NTH>
+__device__ __forceinline__ void prep_stage_constants(const DeviceModel& dm, const PrepLayout& L, double* __restrict__ B,
+                                                     int2* __restrict__ items, int* __restrict__ level) {
+    const AvtDims& d = dm.d;
+    const int J = d.J, K = d.K, t = threadIdx.x;
+    for (int e = t; e < 3 * J * K; e += NTH) {
+        B[L.Sp + e] = dm.Sp[e];
+        B[L.S + e] = dm.S[e];
+        B[L.jsr + e] = dm.jsr[e];
+    }
+    if (t < 3 * J) B[L.jsrb + t] = dm.jsr_base[t];
+    if (t < 9) B[L.ident + t] = (t == 0 || t == 4 || t == 8) ? 1.0 : 0.0;
+    if (t < 3) B[L.zero + t] = 0.0;
+    const int2* gi = (const int2*)dm.fk_items;
+    for (int e = t; e < L.nitems; e += NTH) items[e] = gi[e];
+    if (t <= d.nlevels) level[t] = dm.fk_level_off[t];
+    if (t < J) level[AVT_MAX_JOINTS + 2 + t] = dm.parent[t];     // parents follow the level offsets
+}
+
+// local rotations, shape parameters and root position of the state into the scratch (q, w, p: LDS or registers' source)
+__device__ __forceinline__ void prep_set_state(const AvtDims& d, const PrepLayout& L, double* __restrict__ B, const double* q,
+                                               const double* w, const double* p) {
+    const int t = threadIdx.x;
+    if (t < d.J) quat_to_rot(q + 4 * t, B + L.rot + 9 * t);
+    if (t < d.K) B[L.w + t] = w[t];
+    if (t < 3) B[L.dv + t] = p[t];          // the root's "offset from its parent" is the global position
+}
+
+// callers: a barrier separates prep_set_state() from prep_run()
+template <int NTH>
+__device__ void prep_run(const DeviceModel& dm, const PrepLayout& L, double* __restrict__ B, const int2* __restrict__ items,
+                         const int* __restrict__ level, const double* __restrict__ q, double* __restrict__ prep) {
+    const AvtDims d = dm.d;
+    const int J = d.J, K = d.K, t = threadIdx.x;
+    // CalcShape (AvatarOptimizer.cpp:249-281): jointPosInit = base + jointShapeReg*w, and each joint's offset from its
+    // parent (the parent's position is recomputed by the same lane: same operations, same bits, no barrier)
+    auto joint_positions = [&](const int KK) {    // KK: constant for SMPL, so both dot products unroll and their LDS reads are in flight together
+        if (t < 3 * J) {
+            const int j = t / 3, c = t - 3 * j;
+            const int tp = j > 0 ? 3 * level[AVT_MAX_JOINTS + 2 + j] + c : t;
+            double a = 0.0, ap = 0.0;
+            for (int k = 0; k < KK; ++k) {
+                const double wk = B[L.w + k];
+                a += B[L.jsr + t * KK + k] * wk;
+                ap += B[L.jsr + tp * KK + k] * wk;
+            }
+            const double mine = B[L.jsrb + t] + a;
+            B[L.jp + t] = mine;
+            if (j > 0) B[L.dv + t] = mine - (B[L.jsrb + tp] + ap);
+        }
+    };
+    if (K == 10) joint_positions(10); else joint_positions(K);
+    __syncthreads();
+#ifdef AVT_TIMING
+    if (threadIdx.x == 0) prep[d.prep_size - 1] = (double)clock64();
+#endif
+    // one tree level per barrier
+    for (int lv = 0; lv < d.nlevels; ++lv) {
+        const int lo = level[lv], hi = level[lv + 1];
+        for (int idx = lo + t; idx < hi; idx += NTH) {
+            const int2 it = items[idx];
+            const int rp = it.x & 0x3fff, v = (it.x >> 14) & 0x3fff, scode = (unsigned)it.x >> 28;
+            const int st = scode == 3 ? K : (scode == 2 ? 3 : scode);
+            const int add = it.y & 0x3fff, out = (unsigned)it.y >> 14;
+            B[out] = (B[rp] * B[v] + B[rp + 1] * B[v + st] + B[rp + 2] * B[v + 2 * st]) + B[add];
+        }
+        __syncthreads();
+    }
+#ifdef AVT_TIMING
+    if (threadIdx.x == 0) prep[d.prep_size - 2] = (double)clock64();
+#endif
+    const double off0 = B[L.jp], off1 = B[L.jp + 1], off2 = B[L.jp + 2];
+    for (int e = t; e < 9 * J; e += NTH) prep[prep_off_Rw(d) + e] = B[L.Rw + e];
+    for (int e = t; e < 3 * J; e += NTH) {
+        prep[prep_off_o(d) + e] = B[L.o + e];
+        const int c = e % 3;
+        prep[prep_off_Jh(d) + e] = B[L.jp + e] - (c == 0 ? off0 : (c == 1 ? off1 : off2));   // root at origin (:270-272)
+    }
+    // G[j] = H[j] - Rw[j]*S[j]  (shape block of :568-580); the index split divides by K: constant for SMPL
+    auto g_table = [&](const int KK) {
+        for (int e = t; e < 3 * J * KK; e += NTH) {
+            const int j = e / (3 * KK), r = (e / KK) % 3, k = e % KK;
+            const double* Rj = B + L.Rw + 9 * j;
+            const double* S = B + L.S + j * 3 * KK;
+            prep[prep_off_G(d) + e] = B[L.H + e] - (Rj[3 * r] * S[k] + Rj[3 * r + 1] * S[KK + k] + Rj[3 * r + 2] * S[2 * KK + k]);
+        }
+    };
+    if (K == 10) g_table(10); else g_table(K);
+    for (int e = t; e < 4 * J; e += NTH) prep[prep_off_q(d) + e] = q[e];
+    if (t < K) prep[prep_off_w(d) + t] = B[L.w + t];
+    if (t < 3) prep[prep_off_off(d) + t] = (t == 0 ? off0 : (t == 1 ? off1 : off2));
+}
+
+
+// LDS the initial-point workgroup needs behind its 16-byte aligned base: the current state, the skeleton scratch, the work items
+inline size_t prep_init_lds_bytes(const AvtDims& d) {
+    const PrepLayout L = prep_layout(d.J, d.K, d.xsize);
+    return sizeof(double) * (((size_t)d.xsize + 1) & ~(size_t)1) + sizeof(double) * (size_t)L.ndoubles + sizeof(int) * (2 * (size_t)L.nitems + 2 * AVT_MAX_JOINTS + 4) + 64;
+}
+
+// Trial point := current point, with its skeleton tables: what the first evaluation of an ICP iteration runs on
+// (the state part of k_solve<.., SOLVE_INIT>; it depends on the state alone, so for few frames it rides in the grid of the
+// k_lbs launch in front of the ICP iteration instead of being a launch of its own behind k_records).  256 threads.
+__device__ __forceinline__ void prep_init_block(const DeviceModel& dm, const FrameBuffers& fb, int f, char* smem) {
+    const AvtDims& d = dm.d;
+    const int J = d.J, K = d.K, xs = d.xsize, t = threadIdx.x;
+    const PrepLayout L = prep_layout(J, K, xs);
+    double* s_x = (double*)smem;
+    double* B = s_x + ((xs + 1) & ~1);
+    int2* s_items = (int2*)(B + L.ndoubles);
+    int* s_level = (int*)(s_items + L.nitems);
+    AvtFrameCtl& ctl = fb.ctl[f];
+    const int cur = ctl.cur_slot, tr = 1 - cur;
+    double* x0 = fb.x + ((size_t)f * 2) * xs;
+    for (int e = t; e < xs; e += 256) s_x[e] = x0[(size_t)cur * xs + e];
+    prep_stage_constants<256>(dm, L, B, s_items, s_level);
+    __syncthreads();
+    if (t == 0) ctl.try_valid = 1;
+    for (int e = t; e < xs; e += 256) x0[(size_t)tr * xs + e] = s_x[e];
+    prep_set_state(d, L, B, s_x + 3, s_x + 3 + 4 * J, s_x);
+    __syncthreads();
+    prep_run<256>(dm, L, B, s_items, s_level, s_x + 3, fb.prep + ((size_t)f * 2 + tr) * d.prep_size);
+}
