@@ -48,10 +48,10 @@ int dev_upload(avt_ctx* c, T** p, const std::vector<T>& v) {
     return 0;
 }
 
-// frame groups of one optimize(): measured on MI355X, two groups pay off from ~48 frames, more never do
+// frame groups of one optimize(): measured on MI355X, two groups pay off from ~32 frames, more never do
 // (AVT_GROUPS overrides; tuning knob)
 int choose_groups(int nframes) {
-    int n = nframes >= 48 ? 2 : 1;
+    int n = nframes >= 32 ? 2 : 1;      // measured: 24 frames 0.866 (one group) / 0.899 ms (two), 32: 0.964 / 0.954, 40: 1.075 / 1.026
     if (const char* e = getenv("AVT_GROUPS")) n = atoi(e);
     if (getenv("AVT_ONE_GROUP")) n = 1;
     return std::max(1, std::min(std::min(n, AVT_MAX_GROUPS), nframes));

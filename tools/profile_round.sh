@@ -13,7 +13,7 @@ O=$R/gpurun_out
 mkdir -p $O
 COMMON="--no-cpu-baseline --no-throughput-config --no-label-stage --no-render-stage --no-shard --saturation-frames 0 --regions 3"
 for F in ${FRAMES:-1 64}; do
-  nfg=$(python -c "print($F if $F < 48 else ($F + 1) // 2)")     # frames per launch: two frame groups from 48 frames on
+  nfg=$(python -c "print($F if $F < 32 else ($F + 1) // 2)")     # frames per launch: two frame groups from 32 frames on
   steps=$([ $F = 1 ] && echo 25 || echo 5)
   cmd="python $R/bench.py --frames $F --steps $steps --warmup 2 $COMMON"
   rocprofv3 --kernel-trace --stats -d $O/prof_kt_$F -o p -- $cmd > $O/prof_kt_$F.log 2>&1
