@@ -13,6 +13,8 @@
 // load inside any sequential loop.  -DAVT_TIMING adds s_memtime probes (tools/kernel_timing_probe.py).
 #include <algorithm>
 
+#include <type_traits>
+
 #include "avt_device.h"
 
 #ifdef AVT_TIMING
@@ -592,17 +594,33 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     // (six tile slots per wave: slot s <= rA is tile (rA, s), the slots behind are tiles (rB, 0..rB))
     double mraw[TRI ? 1 : 2][TRI ? 1 : 6][4];
     if constexpr (!TRI) {
+        // (one copy per wave role: tile rows and columns are compile-time constants there, an entry's address is one add)
+        const double* Hl = H0 + (size_t)(4 * 0 + mf_g4) * HS + mf_c16;
+        auto load_role = [&](auto role) {
+            constexpr int W = decltype(role)::value, rA = 5 - W, rB = W - 2;
 #pragma unroll
-        for (int ti = 0; ti < 6; ++ti) {
-            const bool first = ti <= mf_rA;
-            const int rb = first ? mf_rA : max(mf_rB, 0), cb = first ? ti : ti - mf_rA - 1;
-            const bool own = first || cb <= mf_rB;
+            for (int ti = 0; ti < 6; ++ti) {
+                constexpr bool hasB = rB >= 0;
+                const bool first = ti <= rA;
+                const int rb = first ? rA : (hasB ? rB : 0), cb = first ? ti : ti - rA - 1;
+                const bool own = first || (hasB && cb <= rB);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int row = min(16 * rb + 4 * v + mf_g4, HS - 1), col = min(16 * cb + mf_c16, HS - 1);
-                mraw[0][ti][v] = own ? H0[(size_t)row * HS + col] : 0.0;
-                mraw[1][ti][v] = own ? H0[(size_t)HS * HS + (size_t)row * HS + col] : 0.0;
+                for (int v = 0; v < 4; ++v) {
+                    // rows / columns past the matrix (tile row 5, tile column 5) are clamped: their values are replaced below
+                    const int row = 16 * rb + 4 * v, col = 16 * cb;
+                    const bool inb = row + 3 < HS && col + 15 < HS;
+                    const size_t off = inb ? (size_t)row * HS + col
+                                           : (size_t)(min(row + mf_g4, HS - 1) - mf_g4) * HS + (min(col + mf_c16, HS - 1) - mf_c16);
+                    mraw[0][ti][v] = own ? Hl[off] : 0.0;
+                    mraw[1][ti][v] = own ? Hl[(size_t)HS * HS + off] : 0.0;
+                }
             }
+        };
+        switch (mf_wv) {
+            case 0: load_role(std::integral_constant<int, 0>{}); break;
+            case 1: load_role(std::integral_constant<int, 1>{}); break;
+            case 2: load_role(std::integral_constant<int, 2>{}); break;
+            default: load_role(std::integral_constant<int, 3>{}); break;
         }
     }
     const double hpp0 = H0[(size_t)P * HS + P], hpp1 = H0[(size_t)HS * HS + (size_t)P * HS + P];
