@@ -26,11 +26,12 @@
 #include "avt_prep.h"
 
 // =================================================================================================
-// k_reduce<Q>.  grid (NPAIR, nframes), block Q x 256 tile elements; Q = 4 quarters when a frame has >= 64 partial
-// tiles per pair (few frames), Q = 1 for frame batches (few partials each, many workgroups).
+// k_reduce<Q, DECIDE>.  grid (NPAIR, nframes), block Q x 256 tile elements.  Q = 1 is the shape of frame batches (few partials
+// per pair, many workgroups); few frames (G >= 64) use k_reduce_strip below (Q = 4, one workgroup of four quarters per pair, was
+// that shape until late round 2 and is kept as the reference form of it).
 //   Hraw[f][try][r][c] = sum_g partial[f][g][pair][e] in a fixed order (deterministic): quarter q sums its
 //   contiguous range of workgroups g in ascending order with up to 32 loads in flight (the kernel is a chain of
-//   L2 round trips, so what counts is how few rounds it takes), the four quarter sums are added in order 0..3.
+//   L2 round trips, so what counts is how few rounds it takes), the quarter sums are added in order 0..Q-1.
 //   The tile is written to both triangles of the dense (HS x HS) symmetric block; row/column P carry J^T r and
 //   sum c|r|^2.  (The GMM pose prior of the trial point is evaluated by extra workgroups of k_eval, avt_prior.h.)
 // =================================================================================================
