@@ -235,3 +235,28 @@ def test_512_frames_per_gpu_rendered_on_the_gpu(smpl, omodel, gmodel):
         d, l = ctx.frame_download(i)
         pa, qa, wa, _ = one.optimize_batch([d], [l], opt, p0[i][None], q0[i][None], w0[i][None])
         assert np.abs(pa[0] - p[i]).max() < 1e-9 and np.abs(qa[0] - q[i]).max() < 1e-9 and np.abs(wa[0] - w[i]).max() < 1e-8
+
+
+@pytest.mark.gpu
+def test_every_launch_shape_gives_the_single_frame_answer(smpl, gmodel):
+    """optimize() picks its launch shape by frame count: the few-frames shape (up to 6 frames: strided batches, k_reduce_strip,
+    the trial point set up in k_lbs's grid), the batch shape on one frame group (7..31) and two frame groups (32 on).  The same
+    frame must come out the same (to summation order) from all of them, and identical frames identically inside a batch."""
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    fr = synth.make_frame(smpl, 21)
+    data, labels = fr["data"][::3], fr["labels"][::3]
+    p0, q0, w0 = _start(fr)
+    opt = Options.demo(max_iters_per_icp=4, icp_iters=2)
+    ctx1 = api.Context(gmodel, 24, pm, len(labels), 1)
+    pr, qr, wr, sr = ctx1.optimize_batch([data], [labels], opt, p0[None], q0[None], w0[None])
+    for frames in (2, 6, 7, 12, 31, 33):
+        ctx = api.Context(gmodel, 24, pm, len(labels), frames)
+        p, q, w, st = ctx.optimize_batch([data] * frames, [labels] * frames, opt, np.repeat(p0[None], frames, 0),
+                                         np.repeat(q0[None], frames, 0), np.repeat(w0[None], frames, 0))
+        groups, nfg, G = ctx.launch_shape()
+        assert (G >= 64) == (frames <= 6) and groups == (2 if frames >= 32 else 1), (frames, groups, nfg, G)
+        assert np.abs(p - pr).max() < 1e-9 and np.abs(q - qr).max() < 1e-9 and np.abs(w - wr).max() < 1e-8, frames
+        assert all(s.gn_iterations == sr[0].gn_iterations and s.accepted_steps == sr[0].accepted_steps for s in st)
+        same_group = range(nfg)          # frames of one group run the same launches: bit-identical results
+        assert all(np.array_equal(p[f], p[0]) and np.array_equal(q[f], q[0]) and np.array_equal(w[f], w[0]) for f in same_group)
