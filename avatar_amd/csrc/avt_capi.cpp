@@ -113,7 +113,7 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
     const bool fuse_bucket = o->icp_iters > 0;
     // Few frames (the latency shape, G >= 64): the trial point of every ICP iteration (trial := current + its skeleton tables)
     // is set up by a workgroup in the grid of the k_lbs launch in front of it instead of by a k_solve INIT launch behind k_records.
-    const bool fuse_init = c->fb.G >= 64;
+    const bool fuse_init = c->fb.G >= 64 && avt_lbs_can_init(c->dm.d);
     if (!fuse_bucket) { ProfScope ps(c, AVT_K_BUCKET); launch_bucket(c, nf, true); }
     { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 1, vis_init, fuse_bucket, fuse_init && o->icp_iters > 0); }   // ava.update() precondition (:1356)
     for (int icp = 0; icp < o->icp_iters; ++icp) {

@@ -258,6 +258,7 @@ void launch_lbs(avt_ctx* c, int nframes, const double* x_state_or_null, const do
                 int from_state, int vis_init /* -1: leave bookkeeping alone; 0/1: reset it, visibility flags to this value */,
                 bool with_bucket_count = false, bool with_init = false);
 int avt_lbs_set_attributes();
+bool avt_lbs_can_init(const AvtDims& d);
 void launch_visibility(avt_ctx* c, int nframes, int enable, bool with_bucket_scatter = false);
 void launch_bucket(avt_ctx* c, int nframes, bool clear_after);
 void launch_state_reset(avt_ctx* c, int nframes);

@@ -229,6 +229,9 @@ void launch_lbs(avt_ctx* c, int nframes, const double*, const double* w, const d
     hipLaunchKernelGGL(k_lbs, grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, w, p, R, from_state, vis_init, nlbs, with_init ? 1 : 0);
 }
 
+// the trial-point workgroup's scratch must fit beside k_lbs's static LDS (large skeletons fall back to the k_solve INIT launch)
+bool avt_lbs_can_init(const AvtDims& d) { return prep_init_lds_bytes(d) <= 96 * 1024; }
+
 int avt_lbs_set_attributes() {
     return hipFuncSetAttribute((const void*)k_lbs, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess;
 }
