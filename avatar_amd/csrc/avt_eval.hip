@@ -314,7 +314,7 @@ __device__ __forceinline__ void mfma_pair(const double* __restrict__ a, const do
 // CJ/CK != 0: dimensions fixed at compile time (SMPL: 24 joints, 10 shape keys); 0: taken from the model.
 // =================================================================================================
 // MT = column tiles the instantiation is sized for (accumulators per wave, zeroing passes): 6 for the SMPL shape, 8 for
-// generic skeletons of up to 128 columns, AVT_MAX_TILES (11) up to 176 columns (SMPL-H)
+// generic skeletons of up to 128 columns, AVT_MAX_TILES (12) up to 192 columns (SMPL-H, SMPL-X)
 // COST: the evaluation behind which no solve follows - residual column and tile pair (res, res) only (see build_rows)
 template <int CJ, int CK, int MT, bool COST>
 __global__ __launch_bounds__(256, (CJ != 0) ? 3 : (MT > 8 ? 1 : 2)) void k_eval(DeviceModel dm, FrameBuffers fb, int nframes) {

@@ -17,8 +17,8 @@
                               // stride makes columns c and c+8 collide (2-way), an odd one is conflict-free (plain ds_read_b64 too)
 #define AVT_EVAL_TILE(ncols) ((((ncols) * AVT_EVAL_RS) + 1) & ~1)   // doubles of a tile of ncols columns, kept even (16-byte alignment of what follows)
 #define AVT_ERANGE 66         // G + 1 entries per frame for G < 64 (FrameBuffers::erange)
-#define AVT_MAX_TILES 11      // ceil((P+1)/16) with P <= 175 (k_solve: one 4x4 block of the bordered system per lane of <= 1024 threads)
-#define AVT_MAX_P 175
+#define AVT_MAX_TILES 12      // ceil((P+1)/16) with P <= 179
+#define AVT_MAX_P 179         // k_solve<1024, true>: the packed factor of the bordered system (45 x 46 / 2 blocks of 144 B) must fit the LDS
 #define AVT_MAX_COMPS 16      // GMM components
 #define AVT_MAX_GROUPS 4      // frame groups of one optimize() running on separate streams
 #define AVT_PRIOR_STRIDE (2 + 3 * AVT_MAX_JOINTS)   // doubles per (frame, component) of prior scratch

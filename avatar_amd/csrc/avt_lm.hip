@@ -501,9 +501,105 @@ __device__ __forceinline__ bool mf_rounds(v4f64 (&accA)[6], v4f64 (&accB)[2], do
 }
 
 
+// -------------------------------------------------------------------------------------------------
+// The same factorisation for the 1024-thread shape (systems of 89..180 columns): a T x T tile grid, T <= 12, 16 waves.  Tile
+// tau = rb (rb + 1) / 2 + cb of the lower triangle belongs to wave tau mod 16, as its accumulator slot tau / 16 (at most
+// MFG_SLOTS = 5); which tiles a slot holds is wave-uniform run-time data, the slots themselves are compile-time registers.
+// Rounds as above: row phase (threads 0 .. 16 T - 1, one matrix row each), matrix phase (one matrix instruction per live
+// slot), publish.  The factor is the packed lower triangle (wblk<true>): blocks above the diagonal do not exist, so fragment
+// rows above the panel read as zero by a select.
+// -------------------------------------------------------------------------------------------------
+#define MFG_SLOTS 5
+#define MFG_PB_DOUBLES (192 * MF_PB_STRIDE)
+struct MfgSlots { int rb[MFG_SLOTS], cb[MFG_SLOTS]; };      // rb = -1: empty slot
+
+__device__ __forceinline__ MfgSlots mfg_slots(int wv, int T) {
+    MfgSlots S;
+#pragma unroll
+    for (int s = 0; s < MFG_SLOTS; ++s) {
+        int tau = wv + 16 * s, rb = 0;
+        if (tau < T * (T + 1) / 2) {
+            while (tau > rb) { tau -= rb + 1; ++rb; }
+            S.rb[s] = rb; S.cb[s] = tau;
+        } else { S.rb[s] = -1; S.cb[s] = -1; }
+    }
+    return S;
+}
+
+__device__ __forceinline__ bool mfg_rounds(v4f64 (&acc)[MFG_SLOTS], const MfgSlots& S, double* __restrict__ PB, double* __restrict__ Lblk,
+                                           double* __restrict__ s_R, int* __restrict__ s_fail, int P, int NB, int T, int t) {
+    const int NR = (P + 3) >> 2;          // rounds: pivots 0..P-1
+    const int ln = t & 63, k = ln >> 4, c16 = ln & 15;
+    // the panel of a round: columns 4 jq .. 4 jq + 3 of the tiles in tile column cbn, rows 16 rb + 4 v + k
+    auto publish = [&](int cbn, int jq) {
+        if ((c16 >> 2) == jq) {
+#pragma unroll
+            for (int s = 0; s < MFG_SLOTS; ++s)
+                if (S.cb[s] == cbn) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) PB[(16 * S.rb[s] + 4 * v + k) * MF_PB_STRIDE + (ln & 3)] = acc[s][v];
+                }
+        }
+    };
+    publish(0, 0);
+#pragma unroll 1
+    for (int kb = 0; kb < NR; ++kb) {
+        const int cb = kb >> 2, jq = kb & 3;
+        const int cbn = jq == 3 ? cb + 1 : cb;               // tile column of the next panel = first tile column still live
+        __syncthreads();                                     // the panel of this round is published
+        if (t < 16 * T) {
+            const d2v* PB2 = (const d2v*)PB;
+            const d2v q0 = PB2[(4 * kb) * 2], q1 = PB2[(4 * kb + 1) * 2], q2a = PB2[(4 * kb + 2) * 2], q2b = PB2[(4 * kb + 2) * 2 + 1];
+            const d2v q3a = PB2[(4 * kb + 3) * 2], q3b = PB2[(4 * kb + 3) * 2 + 1];
+            const d2v s01 = PB2[t * 2], s23 = PB2[t * 2 + 1];
+            const double D00 = q0.x, D10 = q1.x;
+            double D11 = q1.y, D20 = q2a.x, D21 = q2a.y, D22 = q2b.x, D30 = q3a.x, D31 = q3a.y, D32 = q3b.x, D33 = q3b.y;
+            const double r0 = fast_rcp(D00), l10 = D10 * r0, l20 = D20 * r0, l30 = D30 * r0;
+            D11 = fma(-l10, D10, D11); D21 = fma(-l20, D10, D21); D31 = fma(-l30, D10, D31);
+            D22 = fma(-l20, D20, D22); D32 = fma(-l30, D20, D32); D33 = fma(-l30, D30, D33);
+            const double r1 = fast_rcp(D11), l21 = D21 * r1, l31 = D31 * r1;
+            D22 = fma(-l21, D21, D22); D32 = fma(-l31, D21, D32); D33 = fma(-l31, D31, D33);
+            const double r2 = fast_rcp(D22), l32 = D32 * r2;
+            D33 = fma(-l32, D32, D33);
+            const double r3 = fast_rcp(D33);
+            const bool real1 = 4 * kb + 1 < P, real2 = 4 * kb + 2 < P, real3 = 4 * kb + 3 < P;
+            const bool bad = !(D00 > 0.0) | (real1 & !(D11 > 0.0)) | (real2 & !(D22 > 0.0)) | (real3 & !(D33 > 0.0));
+            const double w0 = s01.x, w1 = fma(-w0, l10, s01.y), w2 = fma(-w1, l21, fma(-w0, l20, s23.x));
+            const double w3 = fma(-w2, l32, fma(-w1, l31, fma(-w0, l30, s23.y)));
+            const int rr = t - 4 * kb;     // row inside the trailing part; the diagonal block keeps its strictly lower part
+            if (rr >= 0 && (t >> 2) < NB) {
+                d2v* Wo = (d2v*)(Lblk + (size_t)wblk<true>(kb, t >> 2, NB) * 18 + (t & 3) * 4);
+                Wo[0] = (d2v){rr < 1 ? 0.0 : w0, rr < 2 ? 0.0 : w1};
+                Wo[1] = (d2v){rr < 3 ? 0.0 : w2, rr < 4 ? 0.0 : w3};
+            }
+            if (t == 0) {
+                d2v* Ro = (d2v*)(s_R + 4 * kb);
+                Ro[0] = (d2v){r0, real1 ? r1 : 0.0}; Ro[1] = (d2v){real2 ? r2 : 0.0, real3 ? r3 : 0.0};
+                if (bad) *s_fail = 1;
+            }
+        }
+        __syncthreads();                                     // W rows, reciprocal pivots and the failure flag are visible
+        if (*s_fail) return false;
+        if (kb + 1 >= NR) return true;
+        // fragments: lane (c16, k) holds row 16 b + c16, pivot k of the round; A = W(:,k), B = -W(:,k) / d_k
+        const double nrk = -s_R[4 * kb + k];
+        auto frag = [&](int r) {
+            const int rowblk = 4 * r + (c16 >> 2);
+            const bool there = rowblk >= kb && rowblk < NB;          // (above the panel / past the matrix: zero)
+            return there ? Lblk[(size_t)wblk<true>(kb, there ? rowblk : kb, NB) * 18 + (c16 & 3) * 4 + k] : 0.0;
+        };
+#pragma unroll
+        for (int s = 0; s < MFG_SLOTS; ++s)
+            if (S.cb[s] >= cbn)                                      // wave-uniform; empty slots have cb = -1
+                acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag(S.rb[s]), frag(S.cb[s]) * nrk, acc[s], 0, 0, 0);
+        publish(cbn, (jq + 1) & 3);
+    }
+    return true;
+}
+
 // =================================================================================================
 // k_solve<NTH, TRI>.  grid (nframes), block NTH.  <256, false>: systems of up to 88 columns (SMPL: 86), one 4x4 block per
-// lane of 256 threads, the factor in a square LDS array whose unused blocks read as zeros.  <1024, true>: up to 176 columns
+// lane of 256 threads, the factor in a square LDS array whose unused blocks read as zeros.  <1024, true>: up to 180 columns
 // (SMPL-H: 170): the same algorithm on 16 waves, the factor as a packed lower triangle (990 blocks = 139 KB), the skeleton
 // scratch overlaid on it once the back substitution is done.
 // =================================================================================================
@@ -524,8 +620,8 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     // carries L^-1 rhs
     double* Lblk = (double*)smem;
     const size_t nblk = TRI ? (size_t)NBk * (NBk + 1) / 2 : (size_t)NBk * NBk;
-    double* s_PB = Lblk + nblk * 18;                        // (256-thread shape) [96][4] the four panel columns of a round
-    double* s_W = s_PB + (TRI ? 0 : MF_PB_DOUBLES);         // [max(HS, 4J) + 2]  reciprocal pivots, later the new quaternions
+    double* s_PB = Lblk + nblk * 18;                        // [96 or 192][4] the four panel columns of a round
+    double* s_W = s_PB + (TRI ? MFG_PB_DOUBLES : MF_PB_DOUBLES);         // [max(HS, 4J) + 2]  reciprocal pivots, later the new quaternions
     double* s_delta = s_W + ((max(HS, 4 * J) + 3) & ~1);    // [HS]
     double* s_x = s_delta + HS + 2;                         // [2][xsize] both state slots
     const PrepLayout L = prep_layout(J, K, d.xsize);
@@ -564,30 +660,11 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     }
     TPROBE(0);
     // ---- a. one round trip for everything the LM decision and the system need: the control block, the objective
-    // terms of BOTH state slots and this thread's 4x4 block of BOTH data-term matrices (the slot is chosen below) ----
-    // Thread t owns the 4x4 block (bi >= bj) of the bordered (P+1)x(P+1) matrix [[H + lambda diag H, .],[-g^T, .]]
-    // (row P carries the rhs so D^-1 L^-1 (-g) falls out of the factorisation as row P of the unit-lower factor).
+    // terms of BOTH state slots and (256-thread shape) this lane's entries of BOTH data-term matrices (the slot is chosen
+    // below).  The system is the bordered (P+1)x(P+1) matrix [[H + lambda diag H, .],[-g^T, .]] (row P carries the rhs so
+    // D^-1 L^-1 (-g) falls out of the factorisation as row P of the unit-lower factor).
     const int NB = HS >> 2;
-    int bi = -1, bj = -1;
-    if (t < NB * (NB + 1) / 2) {
-        int r0 = 0, rem = t;
-        while (rem > r0) { rem -= r0 + 1; ++r0; }
-        bi = r0; bj = rem;
-    }
     const double* H0 = fb.Hraw + ((size_t)f * 2) * HS * HS;
-    // my block, and the diagonal block of my block column: of BOTH slots, requested before the decision (SMPL shape) - or of
-    // the chosen slot only, after it (1024-thread shape: 128 registers per lane)
-    constexpr int NSL = TRI ? 1 : 2;
-    d2v hraw[NSL][4][2], hdiag[NSL][4][2];
-    auto load_blocks = [&](int slot, int into) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const d2v* src = (const d2v*)(H0 + (size_t)slot * HS * HS + (size_t)(4 * max(bi, 0) + r) * HS + 4 * max(bj, 0));
-            hraw[into][r][0] = src[0]; hraw[into][r][1] = src[1];
-            const d2v* srd = (const d2v*)(H0 + (size_t)slot * HS * HS + (size_t)(4 * max(bj, 0) + r) * HS + 4 * max(bj, 0));
-            hdiag[into][r][0] = srd[0]; hdiag[into][r][1] = srd[1];
-        }
-    };
     // 256-thread shape: the system goes straight into the MFMA accumulator layout - wave w owns tile row rA = 5 - w (tile
     // slots 0..5) and, for w >= 2, tile row rB = w - 2 (slots 6, 7); lane (g4 = l >> 4, c16 = l & 15) holds rows 4v + g4 of
     // column c16 of a tile.  Raw data-term entries of BOTH slots are requested now (indices clamped, selected later).
@@ -700,84 +777,51 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     const double sc2 = sc * sc;
     const double gs = sc * sbp * 0.7071067811865476;    // J^T r = sc*sbp*sqrt(1/2) * Prec (x - mu)
     const double* Pr = dm.prior_prec + (size_t)(comp >= 0 ? comp : 0) * n * n;
-    // (all loads unconditional on clamped indices, the conditions applied as selects: loads in flight together, no branches)
-    // assemble(rb, h, out): block (rb, bj) of the bordered system from its raw data-term block h[slot][row][half]
-    double gq[4], xq[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int col = 4 * max(bj, 0) + c, pc = min(max(col - 6, 0), max(n - 1, 0)), sk = min(max(col - (3 + 3 * J), 0), max(K - 1, 0));
-        gq[c] = use_pose ? pri[2 + pc] : 0.0;
-        xq[c] = xc[3 + 4 * J + sk];
-    }
-    if constexpr (TRI) load_blocks(cur, 0);
-    auto assemble = [&](int rb, const d2v (&h)[NSL][4][2], double (&out)[4][4]) {
-        double prv[4][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int pc = min(max(4 * max(bj, 0) + c - 6, 0), max(n - 1, 0));
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int pr_ = min(max(4 * max(rb, 0) + r - 6, 0), max(n - 1, 0));
-                prv[r][c] = use_pose ? Pr[(size_t)pr_ * n + pc] : 0.0;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int row = 4 * rb + r, col = 4 * bj + c;
-                const d2v hv = (!TRI && cur) ? h[NSL - 1][r][c >> 1] : h[0][r][c >> 1];
-                double v = (c & 1) ? hv.y : hv.x;
-                const int pc = col - 6, sk = col - (3 + 3 * J), pr_ = row - 6;
-                const bool in_pose_c = use_pose && pc >= 0 && pc < n;
-                const bool shape_c = sbs > 0.0 && sk >= 0 && col < P;
-                // rows < P: H + priors, diagonal damped
-                double vh = v;
-                vh += (in_pose_c && pr_ >= 0 && pr_ < n) ? sc2 * prv[r][c] : 0.0;
-                if (row == col) { vh += shape_c ? sbs * sbs : 0.0; vh += lambda * vh; }
-                // row P: -(J^T r) including the priors
-                double vg = v;
-                vg += in_pose_c ? gs * gq[c] : 0.0;
-                vg += shape_c ? sbs * (xq[c] * sbs) : 0.0;
-                const bool inside = rb >= 0 && row <= P && col < P;
-                out[r][c] = inside ? (row < P ? vh : -vg) : ((row == col) ? 1.0 : 0.0);
-            }
-    };
     bool fail = false;
     double* s_R = s_W;                                      // [HS] reciprocal pivots
+    // ---- b. the damped system of the current point in MFMA accumulator layout: tile (rb, cb), lane (g4, c16) holds rows
+    // 16 rb + 4 v + g4 (v = 0..3) of column 16 cb + c16.  raw(v) = the data-term entry; the priors come from a second, short
+    // round trip (precision entries and gradient of the chosen GMM component, read-only data).  All loads unconditional on
+    // clamped indices, the conditions applied as selects: loads in flight together, no branches.
+    auto sys_tile = [&](int rb, int cb, bool own, const double (&raw)[4]) __attribute__((always_inline)) {
+        const int col = 16 * cb + mf_c16, pc = col - 6, sk = col - (3 + 3 * J);
+        const int pcc = min(max(pc, 0), max(n - 1, 0)), skc = min(max(sk, 0), max(K - 1, 0));
+        const double gqc = use_pose ? pri[2 + pcc] : 0.0, xqc = xc[3 + 4 * J + skc];
+        const bool in_pose_c = use_pose && pc >= 0 && pc < n;
+        const bool shape_c = sbs > 0.0 && sk >= 0 && col < P;
+        v4f64 out;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = 16 * rb + 4 * v + mf_g4, pr_ = row - 6, prc = min(max(pr_, 0), max(n - 1, 0));
+            const double prv = use_pose ? Pr[(size_t)prc * n + pcc] : 0.0;
+            const double v0 = raw[v];
+            // rows < P: H + priors, diagonal damped
+            double vh = v0;
+            vh += (in_pose_c && pr_ >= 0 && pr_ < n) ? sc2 * prv : 0.0;
+            if (row == col) { vh += shape_c ? sbs * sbs : 0.0; vh += lambda * vh; }
+            // row P: -(J^T r) including the priors
+            double vg = v0;
+            vg += in_pose_c ? gs * gqc : 0.0;
+            vg += shape_c ? sbs * (xqc * sbs) : 0.0;
+            const bool inside = row <= P && col < P;
+            const double val = inside ? (row < P ? vh : -vg) : ((row == col) ? 1.0 : 0.0);
+            out[v] = own ? val : 0.0;
+        }
+        return out;
+    };
     if constexpr (!TRI) {
-        // ---- b'. the damped system in the MFMA accumulator layout (same element formula as `assemble` above, same bits) ----
         v4f64 tile[6];
 #pragma unroll
         for (int ti = 0; ti < 6; ++ti) {
             const bool first = ti <= mf_rA;
             const int rb = first ? mf_rA : max(mf_rB, 0), cb = first ? ti : ti - mf_rA - 1;
-            const bool own = first || cb <= mf_rB;
-            const int col = 16 * cb + mf_c16, pc = col - 6, sk = col - (3 + 3 * J);
-            const int pcc = min(max(pc, 0), max(n - 1, 0)), skc = min(max(sk, 0), max(K - 1, 0));
-            const double gqc = use_pose ? pri[2 + pcc] : 0.0, xqc = xc[3 + 4 * J + skc];
-            const bool in_pose_c = use_pose && pc >= 0 && pc < n;
-            const bool shape_c = sbs > 0.0 && sk >= 0 && col < P;
-            v4f64 out;
+            double raw[4];
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int row = 16 * rb + 4 * v + mf_g4, pr_ = row - 6, prc = min(max(pr_, 0), max(n - 1, 0));
-                const double prv = use_pose ? Pr[(size_t)prc * n + pcc] : 0.0;
-                const double v0 = cur ? mraw[TRI ? 0 : 1][TRI ? 0 : ti][v] : mraw[0][TRI ? 0 : ti][v];
-                double vh = v0;
-                vh += (in_pose_c && pr_ >= 0 && pr_ < n) ? sc2 * prv : 0.0;
-                if (row == col) { vh += shape_c ? sbs * sbs : 0.0; vh += lambda * vh; }
-                double vg = v0;
-                vg += in_pose_c ? gs * gqc : 0.0;
-                vg += shape_c ? sbs * (xqc * sbs) : 0.0;
-                const bool inside = row <= P && col < P;
-                const double val = inside ? (row < P ? vh : -vg) : ((row == col) ? 1.0 : 0.0);
-                out[v] = own ? val : 0.0;
-            }
-            tile[ti] = out;
+            for (int v = 0; v < 4; ++v) raw[v] = cur ? mraw[TRI ? 0 : 1][TRI ? 0 : ti][v] : mraw[0][TRI ? 0 : ti][v];
+            tile[ti] = sys_tile(rb, cb, first || cb <= mf_rB, raw);
         }
         TPROBE(2);
-        // ---- c'. LDL^T, four pivots and two barriers per round, the trailing matrix in the accumulators (mf_rounds) ----
+        // ---- c. LDL^T, four pivots and two barriers per round, the trailing matrix in the accumulators (mf_rounds) ----
         if (t == 0) s_failf[0] = 0;
         bool okf;
         const v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
@@ -793,105 +837,23 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         }
         fail = !okf;
     } else {
-        double a4[4][4], dg[4][4];
-        assemble(bi, hraw, a4);
-        assemble(bj, hdiag, dg);    // private copy of the diagonal block of my column (its lower triangle is what is used)
-        TPROBE(2);
-
-        // ---- c. register-blocked LDL^T, four pivots and ONE barrier per round ---------------------------------------------
-        //  (1) the lanes owning the pivot block column (bj == kb) take the factorisation D = Ld diag(d) Ld^T of their PRIVATE
-        //      copy of the diagonal block and publish their own block of W = A Ld^-T; the diagonal lane also publishes 1/d;
-        //  (2) after the barrier every trailing lane (bj > kb) reads W of its row block and of its column block and
-        //      applies the rank-4 update A -= W_i diag(1/d) W_j^T to its block and to its copy of its column's
-        //      diagonal block (same operands, +40 FMAs, no extra LDS traffic) - so nobody ever publishes or reads a
-        //      diagonal block, and the next round's panel can start without a second barrier.
-        // Measured on MI355X (tools/ubench/ldlt.hip), clocks per round: two barriers + published diagonal + W and L
-        // stored 2520; W only 2215; private diagonal copies 2030; with the factorisation hoisted (below) 1900.  The rounds are
-        // bound by LDS traffic and latency, not by the FMAs.
-        // (A look-ahead variant that rebuilt the diagonal block from a published copy measured slower, 2770.)
-        // D = Ld diag(d) Ld^T of my diagonal-block copy.  Every lane factors its copy right after updating it - wasted work
-        // unless its column is the next panel, but it keeps the rcp chain in the same straight-line block as the 64
-        // independent FMAs of the lane's own block update, where its latency hides (2030 -> 1900 clocks per round).
-        double l10, l20, l30, l21, l31, l32, r0, r1, r2, r3, P0, P1, P2, P3;
-#define AVT_FACTOR_DG() do {                                                                                       \
-            const double D00 = dg[0][0], D10 = dg[1][0];                                                                \
-            double D11 = dg[1][1], D20 = dg[2][0], D21 = dg[2][1], D22 = dg[2][2], D30 = dg[3][0], D31 = dg[3][1], D32 = dg[3][2], D33 = dg[3][3]; \
-            P0 = D00; r0 = fast_rcp(D00); l10 = D10 * r0; l20 = D20 * r0; l30 = D30 * r0;                              \
-            D11 = fma(-l10, D10, D11); D21 = fma(-l20, D10, D21); D31 = fma(-l30, D10, D31);                            \
-            D22 = fma(-l20, D20, D22); D32 = fma(-l30, D20, D32); D33 = fma(-l30, D30, D33);                            \
-            P1 = D11; r1 = fast_rcp(D11); l21 = D21 * r1; l31 = D31 * r1;                                               \
-            D22 = fma(-l21, D21, D22); D32 = fma(-l31, D21, D32); D33 = fma(-l31, D31, D33);                            \
-            P2 = D22; r2 = fast_rcp(D22); l32 = D32 * r2; D33 = fma(-l32, D32, D33);                                    \
-            P3 = D33; r3 = fast_rcp(D33);                                                                               \
-        } while (0)
-        AVT_FACTOR_DG();
-        if (t < 2) s_failf[t] = 0;
-        __syncthreads();
-        for (int kb = 0; kb < NB; ++kb) {
-            if (kb > 0 && s_failf[(kb - 1) & 1]) { fail = true; break; }
-            if (bj == kb) {
-                const bool real1 = 4 * kb + 1 < P, real2 = 4 * kb + 2 < P, real3 = 4 * kb + 3 < P;   // 4*kb < P always
-                const int bad = (int)!(P0 > 0.0) | ((int)real1 & (int)!(P1 > 0.0)) | ((int)real2 & (int)!(P2 > 0.0)) | ((int)real3 & (int)!(P3 > 0.0));
-                if (bad) s_failf[kb & 1] = 1;
-                d2v* Wo = (d2v*)(Lblk + (size_t)wblk<TRI>(kb, bi, NB) * 18);
+        // 1024-thread shape: 16 waves on a T x T tile grid, run-time tile slots (mfg_rounds); the entries of the chosen slot only,
+        // requested after the decision (128 registers per lane)
+        const int T = (P + 16) >> 4;
+        const MfgSlots S = mfg_slots(__builtin_amdgcn_readfirstlane(t >> 6), T);
+        const double* Hc = H0 + (size_t)cur * HS * HS;
+        v4f64 acc[MFG_SLOTS];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double w0 = a4[r][0];
-                    const double w1 = fma(-w0, l10, a4[r][1]);
-                    const double w2 = fma(-w1, l21, fma(-w0, l20, a4[r][2]));
-                    const double w3 = fma(-w2, l32, fma(-w1, l31, fma(-w0, l30, a4[r][3])));
-                    // (the diagonal block keeps its strictly lower part only: nobody but the back substitution reads it)
-                    const bool dgb = bi == kb;
-                    Wo[2 * r] = (d2v){(dgb && r < 1) ? 0.0 : w0, (dgb && r < 2) ? 0.0 : w1};
-                    Wo[2 * r + 1] = (d2v){(dgb && r < 3) ? 0.0 : w2, dgb ? 0.0 : w3};
-                }
-                if (bi == kb) {   // reciprocal pivots; 0 for the rhs / padding rows (only the back substitution reads those)
-                    d2v* Ro = (d2v*)(s_R + 4 * kb);
-                    Ro[0] = (d2v){r0, real1 ? r1 : 0.0}; Ro[1] = (d2v){real2 ? r2 : 0.0, real3 ? r3 : 0.0};
-                }
-            }
-            __syncthreads();                                    // W and 1/d of pivot block kb are visible
-            if (bj > kb) {
-                const d2v* Wi = (const d2v*)(Lblk + (size_t)wblk<TRI>(kb, bi, NB) * 18);
-                const d2v* Wj = (const d2v*)(Lblk + (size_t)wblk<TRI>(kb, bj, NB) * 18);
-                const d2v* Rq = (const d2v*)(s_R + 4 * kb);
-                d2v wv[4][2], wj[4][2], lv[4][2];
-                // column-block operands first: the diagonal copy and its factorisation are the critical chain
+        for (int sl = 0; sl < MFG_SLOTS; ++sl) {
+            const int rb = max(S.rb[sl], 0), cb = max(S.cb[sl], 0);
+            double raw[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { wj[r][0] = Wj[2 * r]; wj[r][1] = Wj[2 * r + 1]; }
-                const d2v ra = Rq[0], rb = Rq[1];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { wv[r][0] = Wi[2 * r]; wv[r][1] = Wi[2 * r + 1]; }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { lv[r][0].x = wj[r][0].x * ra.x; lv[r][0].y = wj[r][0].y * ra.y; lv[r][1].x = wj[r][1].x * rb.x; lv[r][1].y = wj[r][1].y * rb.y; }
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int cc = 0; cc <= r; ++cc) {
-                        double v = dg[r][cc];
-                        v = fma(-wj[r][0].x, lv[cc][0].x, v);
-                        v = fma(-wj[r][0].y, lv[cc][0].y, v);
-                        v = fma(-wj[r][1].x, lv[cc][1].x, v);
-                        v = fma(-wj[r][1].y, lv[cc][1].y, v);
-                        dg[r][cc] = v;
-                    }
-                AVT_FACTOR_DG();
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) {
-                        double v = a4[r][cc];
-                        v = fma(-wv[r][0].x, lv[cc][0].x, v);
-                        v = fma(-wv[r][0].y, lv[cc][0].y, v);
-                        v = fma(-wv[r][1].x, lv[cc][1].x, v);
-                        v = fma(-wv[r][1].y, lv[cc][1].y, v);
-                        a4[r][cc] = v;
-                    }
-            }
+            for (int v = 0; v < 4; ++v) raw[v] = Hc[(size_t)min(16 * rb + 4 * v + mf_g4, HS - 1) * HS + min(16 * cb + mf_c16, HS - 1)];
+            acc[sl] = sys_tile(rb, cb, S.rb[sl] >= 0, raw);
         }
-#undef AVT_FACTOR_DG
-        if (!fail && s_failf[(NB - 1) & 1]) fail = true;
-
+        TPROBE(2);
+        if (t == 0) s_failf[0] = 0;
+        fail = !mfg_rounds(acc, S, s_PB, Lblk, s_R, &s_failf[0], P, NB, T, t);
     }
     __syncthreads();
     TPROBE(3);
@@ -965,7 +927,8 @@ static size_t solve_lds_bytes(const AvtDims& d) {
     const size_t prep_bytes = sizeof(double) * (size_t)L.ndoubles + sizeof(int) * (2 * (size_t)L.nitems + 2 * AVT_MAX_JOINTS + 4);
     const size_t fixed = sizeof(double) * (((std::max(HS, 4 * d.J) + 3) & ~1) + HS + 2 + ((2 * d.xsize + 1) & ~1));
     const size_t factor = sizeof(double) * nblk * 18;
-    return (solve_big(d) ? std::max(factor, prep_bytes) + fixed : factor + sizeof(double) * MF_PB_DOUBLES + fixed + prep_bytes) + 64;
+    return (solve_big(d) ? std::max(factor, prep_bytes) + sizeof(double) * MFG_PB_DOUBLES + fixed
+                         : factor + sizeof(double) * MF_PB_DOUBLES + fixed + prep_bytes) + 64;
 }
 
 // decide = the launch behind the LAST evaluation of an ICP iteration: the lane that sums H(P,P) also takes the accept / reject decision

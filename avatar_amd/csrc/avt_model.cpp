@@ -200,8 +200,8 @@ static int avt_model_create_impl(const avt_model_desc* desc, avt_model** out) {
         avt_set_error("avt_model_create: unsupported dimensions (J<=64, K<=16)");
         return 1;
     }
-    if (3 + 3 * J + K > AVT_MAX_P) {  // k_solve maps one 4x4 block of the bordered system per lane: 256 threads up to P = 87, 1024 up to 175
-        avt_set_error("avt_model_create: 3+3J+K must be <= 175 in this build (SMPL: 85, SMPL-H: 169)");
+    if (3 + 3 * J + K > AVT_MAX_P) {  // k_solve: 256 threads up to P = 87, 1024 threads (packed factor in LDS) up to 179
+        avt_set_error("avt_model_create: 3+3J+K must be <= 179 in this build (SMPL: 85, SMPL-H: 169, SMPL-X with 10 shape keys: 178)");
         return 1;
     }
     if (desc->parent[0] != -1) { avt_set_error("avt_model_create: parent[0] must be -1 (AvatarModel.cpp:41)"); return 1; }

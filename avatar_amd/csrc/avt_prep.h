@@ -44,7 +44,7 @@ __device__ __forceinline__ void prep_set_state(const AvtDims& d, const PrepLayou
 
 // callers: a barrier separates prep_set_state() from prep_run()
 template <int NTH>
-__device__ void prep_run(const DeviceModel& dm, const PrepLayout& L, double* __restrict__ B, const int2* __restrict__ items,
+__device__ __forceinline__ void prep_run(const DeviceModel& dm, const PrepLayout& L, double* __restrict__ B, const int2* __restrict__ items,
                          const int* __restrict__ level, const double* __restrict__ q, double* __restrict__ prep) {
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, t = threadIdx.x;

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AVT_MAX_JOINTS 64   /* SMPL: 24, SMPL-H: 52; additionally 3 + 3J + K <= 175 (avt_model_create) */
+#define AVT_MAX_JOINTS 64   /* SMPL: 24, SMPL-H: 52; SMPL-X: 55; additionally 3 + 3J + K <= 179 (avt_model_create) */
 #define AVT_MAX_SHAPE 16    /* SMPL: 10 */
 #define AVT_MAX_ASSIGN 4    /* AvatarOptimizer.cpp:164 MAX_ASSIGN */
 #define AVT_MAX_PARTS 64

@@ -1,7 +1,7 @@
-"""A synthetic 52-joint skeleton (SMPL-H sized: P = 3 + 3*52 + 10 = 169) grown from the 24-joint synthetic model: five
-finger chains (3,3,3,3,2 joints) hang off each hand joint; hand vertices are re-weighted onto one finger segment each
-(<= 4 weights per vertex, <= 16 ancestors per vertex kept), joint regressor rows and the GMM prior are extended to match.
-Test helper only."""
+"""Synthetic skeletons beyond 24 joints, grown from the 24-joint synthetic model: five finger chains hang off each hand joint
+(3,3,3,3,2 joints: 52 joints, SMPL-H sized, P = 3 + 3*52 + 10 = 169; 3,3,3,3,3 plus one jaw-like joint on the head: 55
+joints, SMPL-X sized, P = 178); hand (head) vertices are re-weighted onto one new segment each (<= 4 weights per vertex,
+<= 16 ancestors per vertex kept), joint regressor rows and the GMM prior are extended to match.  Test helper only."""
 import numpy as np
 
 from avatar_amd import synth
@@ -9,7 +9,9 @@ from avatar_amd import synth
 CHAINS = (3, 3, 3, 3, 2)
 
 
-def extend_model(smpl):
+def extend_model(smpl, joints=52):
+    assert joints in (52, 55)
+    chains = CHAINS if joints == 52 else (3, 3, 3, 3, 3)
     J0 = 24
     parent = list(synth.PARENT)
     W0 = np.asarray(smpl["weights"], np.float64)
@@ -24,8 +26,8 @@ def extend_model(smpl):
         # fingers = five contiguous groups along the axis of largest extent; segments by distance from the hand joint
         ax = int(np.argmax(np.ptp(vt[verts], 0)))
         verts = verts[np.argsort(vt[verts, ax], kind="stable")]
-        groups = np.array_split(verts, len(CHAINS))
-        for g, nseg in zip(groups, CHAINS):
+        groups = np.array_split(verts, len(chains))
+        for g, nseg in zip(groups, chains):
             g = g[np.argsort(np.linalg.norm(vt[g] - jpos[hand], axis=1), kind="stable")]
             prev = hand
             for seg in np.array_split(g, nseg):
@@ -35,8 +37,16 @@ def extend_model(smpl):
                 members[j] = seg
                 for v in seg:
                     newW[int(v)] = j
+    if joints == 55:      # a jaw-like joint on the head: the lower third of the head's vertices
+        verts = np.flatnonzero(mj == 15)
+        verts = verts[np.argsort(vt[verts, 1], kind="stable")][: max(8, len(verts) // 3)]
+        j = len(parent)
+        parent.append(15)
+        members[j] = verts
+        for v in verts:
+            newW[int(v)] = j
     J = len(parent)
-    assert J == 52
+    assert J == joints
     W = np.zeros((V, J))
     W[:, :J0] = W0
     for v, j in newW.items():
@@ -68,8 +78,8 @@ def extend_model(smpl):
 
 
 def make_frame(model52, omodel52, smpl24, seed):
-    """Ground truth, rendered depth cloud + labels (52 identity parts) and a perturbed start for the 52-joint model."""
-    J = 52
+    """Ground truth, rendered depth cloud + labels (identity parts) and a perturbed start for the extended model."""
+    J = np.asarray(model52["kintree_table"]).shape[1]
     rng = np.random.default_rng(4242 + seed)
     w, p, R24 = synth.sample_ground_truth(smpl24, seed)
     R = np.tile(np.eye(3), (J, 1, 1)); R[:24] = R24
