@@ -129,13 +129,12 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
             if (it < o->max_iters_per_icp) {
                 { ProfScope ps(c, AVT_K_EVAL); launch_eval(c, nf, false); }
                 { ProfScope ps(c, AVT_K_REDUCE); launch_reduce(c, nf); }
-            } else {   // no solve follows the last trial point: its cost alone, and the accept test inside the reduction
+            } else {   // no solve follows the last trial point: its cost alone; the accept test is taken by the k_lbs launch below
                 ProfScope ps(c, AVT_K_DECIDE);
                 launch_eval(c, nf, true);
-                launch_reduce(c, nf, true);
             }
         }
-        { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 2, vis_init, false, fuse_init && icp + 1 < o->icp_iters); }   // :1494-1497 (2: from the skeleton tables of the current point)
+        { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 2, vis_init, false, fuse_init && icp + 1 < o->icp_iters, o->max_iters_per_icp > 0); }   // :1494-1497 (2: from the skeleton tables of the current point)
         c->ran_icp_iters++;
     }
     c->lbs_cleared = false;
@@ -721,7 +720,7 @@ int avt_get_normal_equations(avt_ctx* c, int frame, double* H, double* g, double
     c->cur_stream = c->stream;
     launch_solve(c, c->nframes, SOLVE_INIT);
     launch_eval(c, c->nframes, false);
-    launch_reduce(c, c->nframes, false);
+    launch_reduce(c, c->nframes);
     c->fb.G = G_keep;
     if (check_launch("avt_get_normal_equations")) return 1;
     HIP_OK(hipStreamSynchronize(c->stream));

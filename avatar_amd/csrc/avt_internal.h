@@ -41,6 +41,7 @@ struct AvtDims {
     int nb_max;              // eval batches a frame can have: ceil(V/16)
     int col_tr, col_shape, col_res;   // storage columns of the evaluation tile: root translation, first shape key, residual (avt_model.cpp)
     int res_tile, res_pair;  // the column tile that holds the residual column and the index of its diagonal tile pair
+    int res_elem;            // element of that pair's 16x16 tile (k_eval's partial-tile layout) that holds sum c|r|^2
     // six-tile evaluation (SMPL shape): which wave contracts which tile pair - pair_deal[wave] (five 5-bit pair indices each; 20 pairs), and the pair
     // whose 12 k-steps are split over the four waves; dealt on the host so that the waves' expected loads are even (avt_model.cpp)
     unsigned pair_deal[4];   // wave w: five 5-bit pair indices, pair i at bits 5i..5i+4; bit 25+i: pair i is diagonal (i = 5: the split pair)
@@ -108,7 +109,11 @@ struct AvtFrameCtl {
     int accepted;
     int comp_cur;             // GMM component chosen at the current point
     int N;                    // data points of this frame
-    int pad[2];
+    // what the accept test of the LAST trial point of an ICP iteration reads: cur_slot, try_valid, cost_cur and lambda as the last
+    // k_solve left them.  Every workgroup of the k_lbs launch that follows takes that decision for itself while one of them
+    // rewrites the fields above, so the inputs live in fields nobody writes during that launch.
+    int dec_cur_slot, dec_try_valid;
+    double dec_cost_cur, dec_lambda;
 };
 
 // the knobs of optimize() the kernels read (avt_options), kept in device memory so that they are not baked into the
@@ -256,7 +261,7 @@ void avt_set_error(const std::string& s);
 enum { SOLVE_INIT = 0, SOLVE_FIRST = 1, SOLVE_NORMAL = 2 };
 void launch_lbs(avt_ctx* c, int nframes, const double* x_state_or_null, const double* w, const double* p, const double* R,
                 int from_state, int vis_init /* -1: leave bookkeeping alone; 0/1: reset it, visibility flags to this value */,
-                bool with_bucket_count = false, bool with_init = false);
+                bool with_bucket_count = false, bool with_init = false, bool decide = false /* from_state 2: accept test of the last trial point first */);
 int avt_lbs_set_attributes();
 bool avt_lbs_can_init(const AvtDims& d);
 void launch_visibility(avt_ctx* c, int nframes, int enable, bool with_bucket_scatter = false);
@@ -266,6 +271,6 @@ void launch_nn(avt_ctx* c, int nframes);
 void launch_finalize(avt_ctx* c, int nframes);
 void launch_eval(avt_ctx* c, int nframes, bool cost_only = false);
 void launch_records(avt_ctx* c, int nframes);
-void launch_reduce(avt_ctx* c, int nframes, bool decide = false);
+void launch_reduce(avt_ctx* c, int nframes);
 void launch_solve(avt_ctx* c, int nframes, int mode);
 void launch_pack_results(avt_ctx* c, int nframes, double* out, int stride);

@@ -3,6 +3,7 @@
 // (nearest neighbour: avt_nn.hip; residual/Jacobian/J^T J: avt_eval.hip; reduce + LM solve: avt_lm.hip)
 #include "avt_device.h"
 #include "avt_prep.h"
+#include "avt_decide.h"
 
 // =================================================================================================
 // Data bucketing by body-part label (the data-side counterpart of AvatarOptimizer.cpp:1274-1293): a
@@ -102,17 +103,21 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(DeviceModel dm, FrameBuf
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, const double* __restrict__ w_in,
                                              const double* __restrict__ p_in, const double* __restrict__ R_in,
-                                             int from_state, int vis_init, int nlbs, int with_init) {
+                                             int from_state, int vis_init, int nlbs, int with_init, int decide) {
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, V = d.V;
     const int f = blockIdx.y + fb.f0, t = threadIdx.x;
+    // decide (from_state == 2 only): the accept test of the last trial point happens here, in every wave (avt_decide.h)
+    // (its requests go out first; the skeleton tables of both slots follow in the same round trip)
+    LastDecisionInputs dec_in;
+    if (decide) dec_in = lm_last_load(dm, fb, f);
     // trailing workgroups of the grid: work that depends on nothing this kernel computes and would otherwise be a launch of its
     // own on the dependency chain - (few frames) the trial point of the ICP iteration that follows (prep_init_block), (first
     // launch of optimize()) the label histogram of the data points
     extern __shared__ __attribute__((aligned(16))) char lbs_dyn[];
     if ((int)blockIdx.x >= nlbs) {
         const int bx = (int)blockIdx.x - nlbs;
-        if (with_init && bx == 0) prep_init_block(dm, fb, f, lbs_dyn);
+        if (with_init && bx == 0) prep_init_block(dm, fb, f, lbs_dyn, decide ? lm_last_decide(dm, fb, f, dec_in, false) : fb.ctl[f].cur_slot);
         else bucket_count_block(dm, fb, f, bx - (with_init ? 1 : 0));
         return;
     }
@@ -124,10 +129,34 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
     if (from_state == 2) {
         // from the skeleton tables k_solve made for the current point (its world rotations, joint origins and rest joints are
         // what the forward kinematics below would recompute): no chain of tree levels on the way to the vertices
-        const double* pp = fb.prep + ((size_t)f * 2 + fb.ctl[f].cur_slot) * d.prep_size;
-        for (int e = t; e < 9 * J; e += 256) s_Rw[e] = pp[prep_off_Rw(d) + e];
-        if (t < 3 * J) { s_o[t] = pp[prep_off_o(d) + t]; s_jp[t] = pp[prep_off_Jh(d) + t] + pp[prep_off_off(d) + t % 3]; }
-        if (t < K) s_w[t] = pp[prep_off_w(d) + t];
+        if (decide) {      // both slots' tables were requested together with the inputs of the decision: one round trip
+            const double* p0 = fb.prep + ((size_t)f * 2) * d.prep_size;
+            const double* p1 = p0 + d.prep_size;
+            constexpr int NR = (9 * AVT_MAX_JOINTS + 255) / 256;
+            double ra[NR], rb[NR], oa = 0.0, ob = 0.0, ja = 0.0, jb = 0.0, ka = 0.0, kb = 0.0, wa = 0.0, wb = 0.0;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int e = min(t + 256 * i, 9 * J - 1);
+                ra[i] = p0[prep_off_Rw(d) + e]; rb[i] = p1[prep_off_Rw(d) + e];
+            }
+            {
+                const int e = min(t, 3 * J - 1), k = min(t, K - 1);
+                oa = p0[prep_off_o(d) + e]; ob = p1[prep_off_o(d) + e];
+                ja = p0[prep_off_Jh(d) + e]; jb = p1[prep_off_Jh(d) + e];
+                ka = p0[prep_off_off(d) + e % 3]; kb = p1[prep_off_off(d) + e % 3];
+                wa = p0[prep_off_w(d) + k]; wb = p1[prep_off_w(d) + k];
+            }
+            const int dec_slot = lm_last_decide(dm, fb, f, dec_in, blockIdx.x == 0 && t == 0);
+#pragma unroll
+            for (int i = 0; i < NR; ++i) if (t + 256 * i < 9 * J) s_Rw[t + 256 * i] = dec_slot ? rb[i] : ra[i];
+            if (t < 3 * J) { s_o[t] = dec_slot ? ob : oa; s_jp[t] = dec_slot ? jb + kb : ja + ka; }
+            if (t < K) s_w[t] = dec_slot ? wb : wa;
+        } else {
+            const double* pp = fb.prep + ((size_t)f * 2 + fb.ctl[f].cur_slot) * d.prep_size;
+            for (int e = t; e < 9 * J; e += 256) s_Rw[e] = pp[prep_off_Rw(d) + e];
+            if (t < 3 * J) { s_o[t] = pp[prep_off_o(d) + t]; s_jp[t] = pp[prep_off_Jh(d) + t] + pp[prep_off_off(d) + t % 3]; }
+            if (t < K) s_w[t] = pp[prep_off_w(d) + t];
+        }
         __syncthreads();
     } else {
         const double* xs = nullptr;
@@ -221,12 +250,13 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
 // with_bucket_count: also histogram the data labels (first half of launch_bucket) in trailing workgroups;
 // with_init: also set up the trial point of the next ICP iteration (one trailing workgroup per frame)
 void launch_lbs(avt_ctx* c, int nframes, const double*, const double* w, const double* p, const double* R, int from_state, int vis_init,
-                bool with_bucket_count, bool with_init) {
+                bool with_bucket_count, bool with_init, bool decide) {
     const int nlbs = (c->dm.d.V + 255) / 256;
     const int nb = with_bucket_count ? std::max(1, (c->launch_maxN + BUCKET_TILE - 1) / BUCKET_TILE) : 0;
     dim3 grid(nlbs + (with_init ? 1 : 0) + nb, nframes);
     const size_t lds = with_init ? prep_init_lds_bytes(c->dm.d) : 0;
-    hipLaunchKernelGGL(k_lbs, grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, w, p, R, from_state, vis_init, nlbs, with_init ? 1 : 0);
+    hipLaunchKernelGGL(k_lbs, grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, w, p, R, from_state, vis_init, nlbs, with_init ? 1 : 0,
+                       decide && from_state == 2 ? 1 : 0);
 }
 
 // the trial-point workgroup's scratch must fit beside k_lbs's static LDS (large skeletons fall back to the k_solve INIT launch)

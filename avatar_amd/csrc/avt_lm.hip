@@ -35,55 +35,13 @@
 //   The tile is written to both triangles of the dense (HS x HS) symmetric block; row/column P carry J^T r and
 //   sum c|r|^2.  (The GMM pose prior of the trial point is evaluated by extra workgroups of k_eval, avt_prior.h.)
 // =================================================================================================
-// Accept / reject of the LAST trial point of an ICP iteration (no further solve follows): run by the one lane of the final
-// k_reduce launch that has just summed H(P,P) = sum c|r|^2 of the trial point - the same rule k_solve applies at the start of
-// every other iteration (AvatarOptimizer.cpp:1486's accept test in the LM form of DESIGN section 4), without a launch of its own.
-__device__ __forceinline__ void lm_decide_last(const DeviceModel& dm, const FrameBuffers& fb, int f, double hpp_try) {
-    const AvtDims& d = dm.d;
-    AvtFrameCtl& ctl = fb.ctl[f];
-    const int J = d.J, K = d.K, xs = d.xsize;
-    const int cur0 = ctl.cur_slot, try0 = 1 - cur0, try_valid = ctl.try_valid;
-    const double sbp = ctl.sbp, sbs = ctl.sbs, cost_cur0 = ctl.cost_cur;
-    double lambda = ctl.lambda;
-    double cost = 0.5 * hpp_try + ctl.cost_const;
-    int comp_try = -1;
-    if (sbp > 0.0 && d.ncomps > 0) {   // strict '<' in ascending component order (GaussianMixture.cpp:103)
-        double best = 1.7976931348623157e308;
-        double pr[AVT_MAX_COMPS];
-#pragma unroll
-        for (int c = 0; c < AVT_MAX_COMPS; ++c)
-            pr[c] = (c < d.ncomps) ? fb.prior[(((size_t)f * 2 + try0) * AVT_MAX_COMPS + c) * AVT_PRIOR_STRIDE] : 0.0;
-#pragma unroll
-        for (int c = 0; c < AVT_MAX_COMPS; ++c)
-            if (c < d.ncomps && pr[c] < best) { best = pr[c]; comp_try = c; }
-        cost += 0.5 * sbp * sbp * best;
-    }
-    if (sbs > 0.0) {
-        const double* xt = fb.x + ((size_t)f * 2 + try0) * xs;
-        double a = 0.0;
-        for (int k = 0; k < K; ++k) { const double r = xt[3 + 4 * J + k] * sbs; a += r * r; }
-        cost += 0.5 * a;
-    }
-    bool accepted = false;
-    if (try_valid) {
-        if (cost < cost_cur0) { accepted = true; lambda = fmax(lambda * fb.params->lm_down, fb.params->lm_min); }
-        else lambda = fmin(lambda * fb.params->lm_up, fb.params->lm_max);
-    }
-    const double cost_cur = accepted ? cost : cost_cur0;
-    if (accepted) { ctl.cur_slot = try0; ctl.cost_cur = cost; ctl.comp_cur = comp_try; ctl.accepted += 1; }
-    const int it = ctl.gn_iterations + 1;
-    ctl.gn_iterations = it;
-    if (it < 40) fb.trace[(size_t)f * 64 + it] = cost_cur;
-    ctl.lambda = lambda;
-}
-
-template <int Q, bool DECIDE>
+template <int Q>
 __global__ __launch_bounds__(256 * Q) void k_reduce(DeviceModel dm, FrameBuffers fb) {
     __builtin_amdgcn_s_setprio(3);
     const AvtDims d = dm.d;
     const int f = blockIdx.y + fb.f0, t = threadIdx.x & 255, q = threadIdx.x >> 8, NPAIR = d.NPAIR, NT = d.NT, P = d.P, HS = d.HS;
     const int G = fb.G, glo = (G * q) / Q, ghi = (G * (q + 1)) / Q;
-    const int pair = DECIDE ? d.res_pair : (int)blockIdx.x;     // DECIDE: grid (1, frames), only the pair that holds H(P,P)
+    const int pair = (int)blockIdx.x;
     const double* part = fb.partial + ((size_t)f * G * NPAIR + pair) * 256 + t;
     const size_t st = (size_t)NPAIR * 256;
     // which of my workgroups g wrote this pair (k_eval skips the tile pairs its batches never touch): lane l asks for
@@ -133,9 +91,7 @@ __global__ __launch_bounds__(256 * Q) void k_reduce(DeviceModel dm, FrameBuffers
         const int tj = ti + p;
         // tile coordinates -> parameter indices (the evaluation tile has its own column order, avt_model.cpp)
         const int r = dm.tile_param[ti * 16 + ((t >> 4) & 3) + 4 * (t >> 6)], c = dm.tile_param[tj * 16 + (t & 15)];
-        if constexpr (DECIDE) {   // nothing reads the system of this trial point: only the accept test
-            if (r == P && c == P) lm_decide_last(dm, fb, f, a);
-        } else if (r >= 0 && c >= 0) {
+        if (r >= 0 && c >= 0) {
             double* H = fb.Hraw + ((size_t)f * 2 + try_slot) * HS * HS;
             H[(size_t)r * HS + c] = a;
             if (ti != tj) H[(size_t)c * HS + r] = a;
@@ -143,19 +99,19 @@ __global__ __launch_bounds__(256 * Q) void k_reduce(DeviceModel dm, FrameBuffers
     }
 }
 
-// k_reduce_strip<DECIDE, NS>: the few-frames shape (G >= 64) of the reduction.  One workgroup per tile pair pulls G x 2 KB =
+// k_reduce_strip<NS>: the few-frames shape (G >= 64) of the reduction.  One workgroup per tile pair pulls G x 2 KB =
 // 256 KB of partial tiles through one CU (k_reduce<4>: 7.3 us per launch on one frame); here a pair is NS workgroups on NS CUs,
 // each reducing a strip of 256 / NS tile elements (contiguous in every partial tile): 1024 threads = EL elements x NSL slices of
 // the G workgroups, <= 8 loads per thread in flight together with the written-masks, the slice sums added in fixed order
-// through LDS.  grid (NS NPAIR, frames) - DECIDE: (NS, frames), only the pair that holds H(P,P).  5.0 us per launch on one frame.
-template <bool DECIDE, int NS>
+// through LDS.  grid (NS NPAIR, frames).  4.7 us per launch on one frame.
+template <int NS>
 __global__ __launch_bounds__(1024) void k_reduce_strip(DeviceModel dm, FrameBuffers fb) {
     __builtin_amdgcn_s_setprio(3);
     constexpr int EL = 256 / NS, NSL = 1024 / EL, NLD = (128 + NSL - 1) / NSL;     // elements per strip, slices, loads per thread (G <= 128)
     const AvtDims d = dm.d;
     const int f = blockIdx.y + fb.f0, el = threadIdx.x % EL, slice = threadIdx.x / EL, strip = blockIdx.x % NS;
     const int NPAIR = d.NPAIR, NT = d.NT, P = d.P, HS = d.HS;
-    const int pair = DECIDE ? d.res_pair : (int)(blockIdx.x / NS);
+    const int pair = (int)(blockIdx.x / NS);
     const int e = strip * EL + el;                       // element of the tile: (row = (e >> 4 & 3) + 4 (e >> 6), col = e & 15)
     const int G = fb.G, glo = (G * slice) / NSL, ghi = (G * (slice + 1)) / NSL;
     const double* part = fb.partial + ((size_t)f * G * NPAIR + pair) * 256 + e;
@@ -182,9 +138,7 @@ __global__ __launch_bounds__(1024) void k_reduce_strip(DeviceModel dm, FrameBuff
     while (p >= NT - ti) { p -= NT - ti; ++ti; }
     const int tj = ti + p;
     const int r = dm.tile_param[ti * 16 + ((e >> 4) & 3) + 4 * (e >> 6)], c = dm.tile_param[tj * 16 + (e & 15)];
-    if constexpr (DECIDE) {
-        if (r == P && c == P) lm_decide_last(dm, fb, f, a);
-    } else if (r >= 0 && c >= 0) {
+    if (r >= 0 && c >= 0) {
         double* H = fb.Hraw + ((size_t)f * 2 + (1 - fb.ctl[f].cur_slot)) * HS * HS;
         H[(size_t)r * HS + c] = a;
         if (ti != tj) H[(size_t)c * HS + r] = a;
@@ -906,7 +860,11 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         prep_set_state(d, L, B, xc + 3, xc + 3 + 4 * J, xc);
         lambda = fmin(lambda * lm_up, lm_max);
     }
-    if (t == 0) { ctl.lambda = lambda; ctl.try_valid = ok ? 1 : 0; }
+    if (t == 0) {
+        ctl.lambda = lambda; ctl.try_valid = ok ? 1 : 0;
+        // what the accept test of the trial point just made reads if no further solve follows (avt_decide.h)
+        ctl.dec_cur_slot = cur; ctl.dec_try_valid = ok ? 1 : 0; ctl.dec_cost_cur = cost_cur; ctl.dec_lambda = lambda;
+    }
     __syncthreads();
     TPROBE(5);
     // ---- d. skeleton tables of the new trial point ----------------------------------------------------
@@ -931,20 +889,15 @@ static size_t solve_lds_bytes(const AvtDims& d) {
                          : factor + sizeof(double) * MF_PB_DOUBLES + fixed + prep_bytes) + 64;
 }
 
-// decide = the launch behind the LAST evaluation of an ICP iteration: the lane that sums H(P,P) also takes the accept / reject decision
-void launch_reduce(avt_ctx* c, int nframes, bool decide) {
+// (the accept test behind the LAST evaluation of an ICP iteration needs no reduction launch: avt_decide.h, inside k_lbs)
+void launch_reduce(avt_ctx* c, int nframes) {
     const AvtDims& d = c->dm.d;
-    const dim3 grid(decide ? 1 : d.NPAIR, nframes);
-    if (c->fb.G >= 64) {      // few frames: four workgroups per pair (k_reduce_strip)
-        const int ns = nframes == 1 ? 8 : 4;     // measured, one frame: 2 / 4 / 8 / 16 strips 0.582 / 0.556 / 0.543 / 0.560 ms per step; eight frames: 0.817 / 0.778 / 0.800 / 0.915
-        const dim3 grid4(decide ? ns : ns * d.NPAIR, nframes);
-#define AVT_RS(NS) do { if (decide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_strip<true, NS>), grid4, dim3(1024), 0, c->cur_stream, c->dm, c->fb); \
-                        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_strip<false, NS>), grid4, dim3(1024), 0, c->cur_stream, c->dm, c->fb); } while (0)
-        if (ns == 8) AVT_RS(8); else AVT_RS(4);
-#undef AVT_RS
+    if (c->fb.G >= 64) {      // few frames: several workgroups per pair (k_reduce_strip)
+        // measured, one frame: 2 / 4 / 8 / 16 strips 0.582 / 0.556 / 0.543 / 0.560 ms per step; eight frames: 0.817 / 0.778 / 0.800 / 0.915
+        if (nframes == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_strip<8>), dim3(8 * d.NPAIR, nframes), dim3(1024), 0, c->cur_stream, c->dm, c->fb);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce_strip<4>), dim3(4 * d.NPAIR, nframes), dim3(1024), 0, c->cur_stream, c->dm, c->fb);
     } else {
-        if (decide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<1, true>), grid, dim3(256), 0, c->cur_stream, c->dm, c->fb);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<1, false>), grid, dim3(256), 0, c->cur_stream, c->dm, c->fb);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reduce<1>), dim3(d.NPAIR, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
     }
 }
 

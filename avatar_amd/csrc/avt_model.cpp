@@ -333,6 +333,8 @@ static int avt_model_create_impl(const avt_model_desc* desc, avt_model** out) {
     for (int tc = 0; tc < 16 * d.NT; ++tc) if (m->tile_param[tc] == d.P) d.res_tile = tc / 16;
     d.res_pair = 0;
     for (int i = 0; i < d.res_tile; ++i) d.res_pair += d.NT - i;
+    d.res_elem = 0;            // element e of a partial tile: row (e >> 4 & 3) + 4 (e >> 6), column e & 15
+    for (int rr = 0; rr < 16; ++rr) if (m->tile_param[d.res_tile * 16 + rr] == d.P) d.res_elem = ((rr >> 2) << 6) | ((rr & 3) << 4) | rr;
     deal_tile_pairs(m);
     m->deal_col.assign(4 * 6 * 2 * 16, d.P + 1);
     if (d.NT == 6)

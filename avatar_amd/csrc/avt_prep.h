@@ -117,7 +117,7 @@ inline size_t prep_init_lds_bytes(const AvtDims& d) {
 // Trial point := current point, with its skeleton tables: what the first evaluation of an ICP iteration runs on
 // (the state part of k_solve<.., SOLVE_INIT>; it depends on the state alone, so for few frames it rides in the grid of the
 // k_lbs launch in front of the ICP iteration instead of being a launch of its own behind k_records).  256 threads.
-__device__ __forceinline__ void prep_init_block(const DeviceModel& dm, const FrameBuffers& fb, int f, char* smem) {
+__device__ __forceinline__ void prep_init_block(const DeviceModel& dm, const FrameBuffers& fb, int f, char* smem, int cur) {
     const AvtDims& d = dm.d;
     const int J = d.J, K = d.K, xs = d.xsize, t = threadIdx.x;
     const PrepLayout L = prep_layout(J, K, xs);
@@ -126,7 +126,7 @@ __device__ __forceinline__ void prep_init_block(const DeviceModel& dm, const Fra
     int2* s_items = (int2*)(B + L.ndoubles);
     int* s_level = (int*)(s_items + L.nitems);
     AvtFrameCtl& ctl = fb.ctl[f];
-    const int cur = ctl.cur_slot, tr = 1 - cur;
+    const int tr = 1 - cur;
     double* x0 = fb.x + ((size_t)f * 2) * xs;
     for (int e = t; e < xs; e += 256) s_x[e] = x0[(size_t)cur * xs + e];
     prep_stage_constants<256>(dm, L, B, s_items, s_level);

@@ -40,7 +40,7 @@ LIMITER = {
     "nn": "fp64 VALU issue (8 flop + one v_min per candidate, candidates through scalar loads)",
     "lbs": "HBM/L2 streaming of the shape planes", "bucket": "LDS + global atomics", "visibility": "launch latency",
     "aggregate": "launch latency / gathers", "prepare": "latency (skeleton pass)",
-    "decide": "cost-only evaluation of the last trial point + accept test inside its reduction",
+    "decide": "cost-only evaluation of the last trial point (its accept test is taken inside the k_lbs launch that follows)",
 }
 
 
