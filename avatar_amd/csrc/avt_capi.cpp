@@ -412,7 +412,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         dev_alloc(c, &fb.dz, FN) || dev_alloc(c, &fb.dorig, FN) || dev_alloc(c, &fb.part_off, (size_t)max_frames * (num_parts + 1)) || dev_alloc(c, &fb.part_cnt, (size_t)max_frames * 2 * (AVT_MAX_PARTS + 1)) ||
         dev_alloc(c, &fb.corr, FN) || dev_alloc(c, &fb.corr_sorted, FN) || dev_alloc(c, &fb.cloud, FV * 3) || dev_alloc(c, &fb.pcx, FV) ||
         dev_alloc(c, &fb.pcy, FV) || dev_alloc(c, &fb.pcz, FV) || dev_alloc(c, &fb.visible, FV) || dev_alloc(c, &fb.vcx, FV) || dev_alloc(c, &fb.vcy, FV) ||
-        dev_alloc(c, &fb.vcz, FV) || dev_alloc(c, &fb.vcid, FV) || dev_alloc(c, &fb.vcount, (size_t)max_frames * num_parts) ||
+        dev_alloc(c, &fb.vcz, FV) || dev_alloc(c, &fb.vcid, FV) || dev_alloc(c, &fb.vcount, (size_t)max_frames * num_parts) || dev_alloc(c, &fb.vis_sorted, FV) ||
         dev_alloc(c, &cntsum, FV * (sizeof(int) + 3 * sizeof(long long)) + 64) || dev_alloc(c, &fb.matched, FV) ||
         dev_alloc(c, &fb.const_part, (size_t)max_frames * fb.const_blocks) ||
         dev_alloc(c, &fb.x, (size_t)max_frames * 2 * d.xsize) || dev_alloc(c, &fb.x_start, (size_t)max_frames * 2 * d.xsize) ||

@@ -186,6 +186,7 @@ struct FrameBuffers {
     double* vcx; double* vcy; double* vcz;   // [max_frames][V] visible model points, compacted per part segment
     int* vcid;                               // [max_frames][V] vertex id of each compacted candidate
     int* vcount;                             // [max_frames][num_parts] visible candidates per part
+    unsigned char* vis_sorted;               // [max_frames][V] the visibility flags in part-sorted order (inside optimize(): k_nn_vis)
     // correspondence aggregation
     int* cnt;             // [max_frames][V]
     long long* fsum;      // [max_frames][3][V] fixed-point centred sums

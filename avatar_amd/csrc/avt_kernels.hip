@@ -241,6 +241,7 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
     }
     if (dm.part_pos) {
         const int pp = dm.part_pos[v];
+        if (vis_init >= 0) fb.vis_sorted[(size_t)f * V + pp] = (unsigned char)vis_init;
         fb.pcx[(size_t)f * V + pp] = cx;
         fb.pcy[(size_t)f * V + pp] = cy;
         fb.pcz[(size_t)f * V + pp] = cz;
@@ -287,6 +288,10 @@ __global__ __launch_bounds__(256) void k_visibility(DeviceModel dm, FrameBuffers
     if (z > 1e-4) {
         unsigned char* vis = fb.visible + (size_t)f * V;
         vis[i1] = 1; vis[i2] = 1; vis[i3] = 1;
+        if (dm.part_pos) {      // the same flags in part-sorted order: what the fused compaction of k_nn_vis reads
+            unsigned char* vs = fb.vis_sorted + (size_t)f * V;
+            vs[dm.part_pos[i1]] = 1; vs[dm.part_pos[i2]] = 1; vs[dm.part_pos[i3]] = 1;
+        }
     }
 }
 

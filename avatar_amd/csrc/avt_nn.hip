@@ -36,9 +36,10 @@ __device__ __forceinline__ long long rint_to_ll(double x) {
 // costs: a scan over runs of at most 8 queries with DPP row shifts instead of LDS permutes measured slower).
 template <int LANES>
 __device__ __forceinline__ void nn_record(const FrameBuffers& fb, const AvtFrameCtl& ctl, int f, int V, size_t base, int s, bool active, int sub,
-                                          int bi, double a0, double a1, double a2) {
+                                          int mv, double a0, double a1, double a2) {
+    // mv: the matched model vertex of this lane's query (-1: none)
     const bool qlane = active && sub == 0;
-    const int m = (qlane && bi != 0x7fffffff) ? fb.vcid[(size_t)f * V + bi] : -1;
+    const int m = qlane ? mv : -1;
     if (qlane) {
         fb.corr_sorted[base + s] = m;
         fb.corr[base + fb.dorig[base + s]] = m;
@@ -184,7 +185,146 @@ __global__ __launch_bounds__(256) void k_nn(DeviceModel dm, FrameBuffers fb) {
         const int oi = __shfl_xor(bi, m, 64);
         if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
-    nn_record<LANES>(fb, ctl, f, V, base, s, active, sub, bi, a0, a1, a2);
+    const int mv = (active && sub == 0 && bi != 0x7fffffff) ? fb.vcid[(size_t)f * V + bi] : -1;
+    nn_record<LANES>(fb, ctl, f, V, base, s, active, sub, mv, a0, a1, a2);
+}
+
+// -------------------------------------------------------------------------------------------------
+// k_nn_vis: k_nn<LANES> with the compaction of the visible model points inside it (few frames, inside optimize()): every
+// workgroup compacts the tile of part-sorted model points it is about to scan - positions, vertex ids and the part-sorted
+// visibility flags k_visibility / k_lbs keep (vis_sorted) - into its LDS instead of reading what a k_compact launch wrote:
+// one launch and one pass through memory less on the dependency chain of a frame.  A tile is NN_TILE consecutive positions of
+// the part-sorted arrays (all points, visible or not); thread t owns positions 4t .. 4t+3, an order-preserving compaction
+// (wave scan of the per-thread counts) keeps ascending vertex order inside every part, s_pre[p] = number of visible points
+// before position p of the tile gives a part's candidate range.  Same scan, same tie rule and the same result as k_compact +
+// k_nn; the member of the winning group is settled at the end of the tile that produced it (the tile then leaves the LDS).
+// -------------------------------------------------------------------------------------------------
+template <int LANES>
+__global__ __launch_bounds__(256) void k_nn_vis(DeviceModel dm, FrameBuffers fb) {
+    constexpr int NN_QPB = 256 / LANES;
+    const int f = blockIdx.y + fb.f0, t = threadIdx.x;
+    const int V = dm.d.V, np = dm.d.num_parts;
+    const AvtFrameCtl& ctl = fb.ctl[f];
+    const int* po = fb.part_off + (size_t)f * (np + 1);
+    const int nvalid = po[np];  // bucketed points with a valid label
+    const int s0 = blockIdx.x * NN_QPB;
+    if (s0 >= nvalid) return;
+    const size_t base = (size_t)f * fb.max_points;
+    const int sub = t % LANES;
+    const int s = s0 + t / LANES;
+    const bool active = s < nvalid;
+
+    __shared__ double c_x[NN_TILE], c_y[NN_TILE], c_z[NN_TILE];
+    __shared__ int c_id[NN_TILE], s_pre[NN_TILE + 4], s_wtot[4];
+    __shared__ int s_qlo, s_qhi;
+    if (t == 0) {
+        int lo = 0, hi = np - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (po[mid] <= s0) lo = mid; else hi = mid - 1; }
+        s_qlo = lo;
+        const int last = min(s0 + NN_QPB - 1, nvalid - 1);
+        lo = 0; hi = np - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (po[mid] <= last) lo = mid; else hi = mid - 1; }
+        s_qhi = lo;
+    }
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (active) { a0 = fb.dx[base + s]; a1 = fb.dy[base + s]; a2 = fb.dz[base + s]; }
+    __syncthreads();
+    const int qlo = s_qlo, qhi = s_qhi;
+    int q = qlo;
+    if (active) while (q < qhi && po[q + 1] <= s) ++q;
+    const int my_b = dm.part_start[q], my_e = dm.part_start[q + 1];        // my part's positions (visible or not)
+    const int ub = dm.part_start[qlo], ue = dm.part_start[qhi + 1];
+    const double* pcx = fb.pcx + (size_t)f * V;
+    const double* pcy = fb.pcy + (size_t)f * V;
+    const double* pcz = fb.pcz + (size_t)f * V;
+    const unsigned char* vs = fb.vis_sorted + (size_t)f * V;
+    double best = 1.7976931348623157e308;  // numeric_limits<double>::max(), KNNResultSet::init
+    constexpr int NN_GROUP = 8;
+    int bkey = 0x7fffffff, bv = -1;         // winner so far: its rank in scan order (tile base + compacted index) and its vertex
+    auto dist2 = [&](double cx, double cy, double cz) {
+        const double d0 = a0 - cx, d1 = a1 - cy, d2 = a2 - cz;
+        double r = d0 * d0;                 // (0 + d0*d0) == d0*d0 exactly
+        r = r + d1 * d1;
+        r = r + d2 * d2;
+        return r;
+    };
+    for (int tb = ub; tb < ue; tb += NN_TILE) {
+        const int tn = min(NN_TILE, ue - tb);
+        // ---- compaction of positions tb .. tb + tn - 1 ----
+        double px[4], py[4], pz[4];
+        int pid[4];
+        bool keep[4];
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = 4 * t + i, pos = tb + min(e, tn - 1);
+            px[i] = pcx[pos]; py[i] = pcy[pos]; pz[i] = pcz[pos]; pid[i] = dm.part_vertices[pos];
+            keep[i] = e < tn && vs[pos] != 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) n += keep[i] ? 1 : 0;
+        int incl = n;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) { const int v = __shfl_up(incl, sft, 64); if (lane_id() >= sft) incl += v; }
+        __syncthreads();                    // the previous tile has been scanned by everybody
+        if (lane_id() == 63) s_wtot[wave_id()] = incl;
+        __syncthreads();
+        int off = incl - n;
+        for (int w = 0; w < wave_id(); ++w) off += s_wtot[w];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = 4 * t + i;
+            if (e <= tn) s_pre[e] = off;
+            if (keep[i]) { c_x[off] = px[i]; c_y[off] = py[i]; c_z[off] = pz[i]; c_id[off] = pid[i]; ++off; }
+        }
+        if (t == 255) s_pre[NN_TILE] = off;              // (tn == NN_TILE: the entry behind the last position)
+        __syncthreads();
+        // ---- scan of my part's visible points in this tile ----
+        if (active) {
+            const int b = s_pre[min(max(my_b - tb, 0), tn)], e = s_pre[min(max(my_e - tb, 0), tn)];
+            int gpos = -1;
+            int c = b + sub;
+            for (; c + (NN_GROUP - 1) * LANES < e; c += NN_GROUP * LANES) {
+                double r[NN_GROUP];
+#pragma unroll
+                for (int u = 0; u < NN_GROUP; ++u) r[u] = dist2(c_x[c + u * LANES], c_y[c + u * LANES], c_z[c + u * LANES]);
+#pragma unroll
+                for (int w = 1; w < NN_GROUP; w <<= 1)
+#pragma unroll
+                    for (int u = 0; u + w < NN_GROUP; u += 2 * w) r[u] = __builtin_fmin(r[u], r[u + w]);
+                gpos = (r[0] < best) ? c : gpos;
+                best = __builtin_fmin(best, r[0]);
+            }
+            for (; c < e; c += LANES) {     // the tail of the range: groups of one
+                const double r = dist2(c_x[c], c_y[c], c_z[c]);
+                gpos = (r < best) ? c : gpos;
+                best = __builtin_fmin(best, r);
+            }
+            if (gpos >= 0) {                // this tile improved the minimum: the first member of the group whose distance IS the minimum
+                double r[NN_GROUP];
+#pragma unroll
+                for (int u = 0; u < NN_GROUP; ++u) {
+                    const int pos = min(gpos + u * LANES, e - 1);
+                    r[u] = dist2(c_x[pos], c_y[pos], c_z[pos]);
+                }
+                int bi = gpos;
+#pragma unroll
+                for (int u = NN_GROUP - 1; u >= 0; --u)
+                    if (gpos + u * LANES < e && r[u] == best) bi = gpos + u * LANES;
+                bkey = tb + bi;
+                bv = c_id[bi];
+            }
+        }
+    }
+    // combine the sub-scans: smallest distance, ties to the earliest candidate in scan order - exactly the winner of one
+    // ascending scan with strict '<'
+#pragma unroll
+    for (int m = 1; m < LANES; m <<= 1) {
+        const double ob = __shfl_xor(best, m, 64);
+        const int ok = __shfl_xor(bkey, m, 64), ov = __shfl_xor(bv, m, 64);
+        if (ob < best || (ob == best && ok < bkey)) { best = ob; bkey = ok; bv = ov; }
+    }
+    nn_record<LANES>(fb, ctl, f, V, base, s, active, sub, bv, a0, a1, a2);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -264,7 +404,8 @@ __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb
         for (int u = NN_GROUP - 1; u >= 0; --u)
             if (gpos + u < pe && r[u] == best) bi = gpos + u;
     }
-    nn_record<1>(fb, ctl, f, V, base, s, active, 0, bi, a0, a1, a2);
+    const int mv = (active && bi != 0x7fffffff) ? fb.vcid[(size_t)f * V + bi] : -1;
+    nn_record<1>(fb, ctl, f, V, base, s, active, 0, mv, a0, a1, a2);
 }
 
 // Visible model points of every part, compacted in ascending vertex order inside the part's segment of the
@@ -311,8 +452,13 @@ void launch_nn(avt_ctx* c, int nframes) {
     }
     const int maxN = c->launch_maxN;
     if (maxN <= 0) return;
-    hipLaunchKernelGGL(k_compact, dim3(c->dm.d.num_parts, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
     // few queries: 4 lanes per query (more workgroups, shorter scans); many: one lane per query, one part per workgroup
-    if ((long long)nframes * maxN <= 400000) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn<4>), dim3((maxN + 63) / 64, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
+    const bool few = (long long)nframes * maxN <= 400000;
+    if (few && c->lbs_cleared) {   // inside optimize() (k_lbs / k_visibility keep the part-sorted visibility flags): compaction fused into the scan
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_vis<4>), dim3((maxN + 63) / 64, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
+        return;
+    }
+    hipLaunchKernelGGL(k_compact, dim3(c->dm.d.num_parts, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
+    if (few) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn<4>), dim3((maxN + 63) / 64, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
     else hipLaunchKernelGGL(k_nn_part, dim3((maxN + 255) / 256 + c->dm.d.num_parts, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
 }
