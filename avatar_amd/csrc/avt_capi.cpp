@@ -115,7 +115,10 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
     // is set up by a workgroup in the grid of the k_lbs launch in front of it instead of by a k_solve INIT launch behind k_records.
     const bool fuse_init = c->fb.G >= 64 && avt_lbs_can_init(c->dm.d);
     if (!fuse_bucket) { ProfScope ps(c, AVT_K_BUCKET); launch_bucket(c, nf, true); }
-    { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 1, vis_init, fuse_bucket, fuse_init && o->icp_iters > 0); }   // ava.update() precondition (:1356)
+    // frame batches: k_compact gathers its candidates from the cloud, so k_lbs does not write the part-sorted copy of it
+    const bool few = avt_nn_few(c, nf);
+    c->nn_from_cloud = !few;
+    { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 1, vis_init, fuse_bucket, fuse_init && o->icp_iters > 0, false, few); }   // ava.update() precondition (:1356)
     for (int icp = 0; icp < o->icp_iters; ++icp) {
         { ProfScope ps(c, AVT_K_VISIBILITY); launch_visibility(c, nf, o->enable_occlusion, fuse_bucket && icp == 0); }
         { ProfScope ps(c, AVT_K_NN); launch_nn(c, nf); }
@@ -134,10 +137,12 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
                 launch_eval(c, nf, true);
             }
         }
-        { ProfScope ps(c, AVT_K_LBS); launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 2, vis_init, false, fuse_init && icp + 1 < o->icp_iters, o->max_iters_per_icp > 0); }   // :1494-1497 (2: from the skeleton tables of the current point)
+        { ProfScope ps(c, AVT_K_LBS); const bool more = icp + 1 < o->icp_iters;      // the last launch of the call skins only: no bookkeeping reset, no part-sorted copy
+          launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 2, more ? vis_init : -1, false, fuse_init && more, o->max_iters_per_icp > 0, few && more); }   // :1494-1497 (2: from the skeleton tables of the current point)
         c->ran_icp_iters++;
     }
     c->lbs_cleared = false;
+    c->nn_from_cloud = false;
     c->fb.f0 = 0;
     c->cur_stream = c->stream;
 }
@@ -356,6 +361,9 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
     c->launch_maxN = 0;
     c->use_graph = getenv("AVT_NO_GRAPH") == nullptr;
     c->lbs_cleared = false;
+    c->scatter_in_compact = false;
+    c->nn_from_cloud = false;
+    c->vis_frame_min = 0;            // set once the model dimensions are known (below)
     c->graph_clock = 0;
     c->params_valid = false;
     c->frames_valid = c->state_valid = false;
@@ -370,6 +378,10 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
     if (avt_solve_set_attributes() || avt_eval_set_attributes() || avt_lbs_set_attributes()) { avt_set_error("avt_ctx_create: hipFuncSetAttribute failed"); return 1; }
     DeviceModel& dm = c->dm;
     dm.d = m->d;
+    {   // visibility as one workgroup per frame when the frame's x, y fit the LDS (AVT_VIS_FRAME_MIN: experiments)
+        const char* e = getenv("AVT_VIS_FRAME_MIN");
+        c->vis_frame_min = avt_visibility_frame_lds(m->d) <= 150 * 1024 ? (e ? atoi(e) : 64) : 0;
+    }
     dm.d.num_parts = num_parts;
     const int V = dm.d.V, J = dm.d.J;
     c->part_map.assign(part_map, part_map + J);   // >= J entries (AvatarOptimizer.cpp:1229)

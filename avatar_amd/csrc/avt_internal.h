@@ -245,6 +245,9 @@ struct avt_ctx {
     int ran_icp_iters, ran_max_iters;
     int launch_maxN;                 // max points per frame of the resident batch, rounded up to 2048 (grid sizing)
     bool lbs_cleared;                // the preceding k_lbs reset visibility / correspondence bookkeeping
+    bool nn_from_cloud;              // inside optimize(), frame batches: k_compact gathers the candidates from the cloud (no pcx/pcy/pcz)
+    bool scatter_in_compact;         // launch_visibility left the scatter pass of the bucketing to the k_compact launch that follows
+    int vis_frame_min;               // frames per launch from which visibility runs as one workgroup per frame (0: never)
     bool use_graph;                  // replay the optimize() launch sequence as a hipGraph (AVT_NO_GRAPH=1 disables)
     struct GraphEntry { std::string key; hipGraphExec_t exec; unsigned long long last_used; };
     std::vector<GraphEntry> graphs;  // small LRU cache keyed on the launch SHAPE only (frames, groups, grids, iteration counts)
@@ -262,9 +265,12 @@ void avt_set_error(const std::string& s);
 enum { SOLVE_INIT = 0, SOLVE_FIRST = 1, SOLVE_NORMAL = 2 };
 void launch_lbs(avt_ctx* c, int nframes, const double* x_state_or_null, const double* w, const double* p, const double* R,
                 int from_state, int vis_init /* -1: leave bookkeeping alone; 0/1: reset it, visibility flags to this value */,
-                bool with_bucket_count = false, bool with_init = false, bool decide = false /* from_state 2: accept test of the last trial point first */);
+                bool with_bucket_count = false, bool with_init = false, bool decide = false /* from_state 2: accept test of the last trial point first */,
+                bool write_pc = true /* also the part-sorted copy of the cloud (pcx/pcy/pcz, vis_sorted) */);
 int avt_lbs_set_attributes();
 bool avt_lbs_can_init(const AvtDims& d);
+size_t avt_visibility_frame_lds(const AvtDims& d);
+bool avt_nn_few(const avt_ctx* c, int nframes);
 void launch_visibility(avt_ctx* c, int nframes, int enable, bool with_bucket_scatter = false);
 void launch_bucket(avt_ctx* c, int nframes, bool clear_after);
 void launch_state_reset(avt_ctx* c, int nframes);

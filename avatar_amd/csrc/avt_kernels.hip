@@ -4,94 +4,9 @@
 #include "avt_device.h"
 #include "avt_prep.h"
 #include "avt_decide.h"
-
-// =================================================================================================
-// Data bucketing by body-part label (the data-side counterpart of AvatarOptimizer.cpp:1274-1293): a
-// two-pass counting sort over many workgroups.  Pass 1 histograms labels (LDS atomics, then one global atomic
-// per (workgroup, part)); pass 2 reserves a range per (workgroup, part) and scatters.  The order of points
-// INSIDE a part bucket is not deterministic, and nothing downstream depends on it: the nearest neighbour of a
-// point does not depend on its neighbours, the correspondence sums are order-independent integer atomics and
-// every floating-point reduction over data points runs in original index order.
-// =================================================================================================
-#define BUCKET_TILE 2048
-
-__device__ __forceinline__ void bucket_count_block(const DeviceModel& dm, const FrameBuffers& fb, int f, int bx) {
-    const int t = threadIdx.x, np = dm.d.num_parts;
-    const int N = fb.ctl[f].N;
-    const int s0 = bx * BUCKET_TILE;
-    if (s0 >= N) return;
-    __shared__ int hist[AVT_MAX_PARTS + 1];
-    if (t <= np) hist[t] = 0;
-    __syncthreads();
-    const int* lab = fb.labels_raw + (size_t)f * fb.max_points;
-#pragma unroll
-    for (int u = 0; u < BUCKET_TILE / 256; ++u) {
-        const int i = s0 + u * 256 + t;
-        if (i < N) {
-            int q = lab[i];
-            if (q < 0 || q >= np) q = np;
-            atomicAdd(&hist[q], 1);
-        }
-    }
-    __syncthreads();
-    if (t <= np && hist[t]) atomicAdd(fb.part_cnt + (size_t)f * 2 * (AVT_MAX_PARTS + 1) + t, hist[t]);
-}
+#include "avt_bucket.h"
 
 __global__ __launch_bounds__(256) void k_bucket_count(DeviceModel dm, FrameBuffers fb) { bucket_count_block(dm, fb, blockIdx.y + fb.f0, blockIdx.x); }
-
-__device__ __forceinline__ void bucket_scatter_block(const DeviceModel& dm, const FrameBuffers& fb, int f, int bx) {
-    const int t = threadIdx.x, np = dm.d.num_parts;
-    AvtFrameCtl& ctl = fb.ctl[f];
-    const int N = ctl.N;
-    const int s0 = bx * BUCKET_TILE;
-    const size_t base = (size_t)f * fb.max_points;
-    __shared__ int hist[AVT_MAX_PARTS + 1], poff[AVT_MAX_PARTS + 2], bbase[AVT_MAX_PARTS + 1];
-    int* pcnt = fb.part_cnt + (size_t)f * 2 * (AVT_MAX_PARTS + 1);
-    int* cursor = pcnt + (AVT_MAX_PARTS + 1);
-    if (t <= np) hist[t] = 0;
-    if (t == 0) {
-        int acc = 0;
-        for (int q = 0; q <= np; ++q) { poff[q] = acc; acc += pcnt[q]; }
-        poff[np + 1] = acc;
-    }
-    __syncthreads();
-    if (bx == 0) {
-        if (t <= np) fb.part_off[(size_t)f * (np + 1) + t] = poff[t];
-        if (t < 3 && N > 0) ctl.centre[t] = fb.data_raw[3 * base + t];
-    }
-    if (s0 >= N) return;
-    const int* lab = fb.labels_raw + base;
-    int qs[BUCKET_TILE / 256];
-#pragma unroll
-    for (int u = 0; u < BUCKET_TILE / 256; ++u) {
-        const int i = s0 + u * 256 + t;
-        int q = -1;
-        if (i < N) {
-            q = lab[i];
-            if (q < 0 || q >= np) q = np;
-            atomicAdd(&hist[q], 1);
-        }
-        qs[u] = q;
-    }
-    __syncthreads();
-    if (t <= np) {
-        bbase[t] = hist[t] ? poff[t] + atomicAdd(cursor + t, hist[t]) : 0;
-        hist[t] = 0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < BUCKET_TILE / 256; ++u) {
-        const int i = s0 + u * 256 + t;
-        const int q = qs[u];
-        if (q < 0) continue;
-        const int pos = bbase[q] + atomicAdd(&hist[q], 1);
-        fb.dx[base + pos] = fb.data_raw[3 * (base + i)];
-        fb.dy[base + pos] = fb.data_raw[3 * (base + i) + 1];
-        fb.dz[base + pos] = fb.data_raw[3 * (base + i) + 2];
-        fb.dorig[base + pos] = i;
-        if (q == np) fb.corr[base + i] = -1;
-    }
-}
 
 __global__ __launch_bounds__(256) void k_bucket_scatter(DeviceModel dm, FrameBuffers fb) { bucket_scatter_block(dm, fb, blockIdx.y + fb.f0, blockIdx.x); }
 
@@ -103,7 +18,7 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(DeviceModel dm, FrameBuf
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, const double* __restrict__ w_in,
                                              const double* __restrict__ p_in, const double* __restrict__ R_in,
-                                             int from_state, int vis_init, int nlbs, int with_init, int decide) {
+                                             int from_state, int vis_init, int nlbs, int with_init, int decide, int write_pc) {
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, V = d.V;
     const int f = blockIdx.y + fb.f0, t = threadIdx.x;
@@ -239,7 +154,7 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
         long long* fs = fb.fsum + (size_t)f * 3 * V;
         fs[v] = 0; fs[(size_t)V + v] = 0; fs[2 * (size_t)V + v] = 0;
     }
-    if (dm.part_pos) {
+    if (dm.part_pos && write_pc) {     // the part-sorted copy k_nn_vis scans (few frames; frame batches gather from the cloud in k_compact)
         const int pp = dm.part_pos[v];
         if (vis_init >= 0) fb.vis_sorted[(size_t)f * V + pp] = (unsigned char)vis_init;
         fb.pcx[(size_t)f * V + pp] = cx;
@@ -251,20 +166,22 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
 // with_bucket_count: also histogram the data labels (first half of launch_bucket) in trailing workgroups;
 // with_init: also set up the trial point of the next ICP iteration (one trailing workgroup per frame)
 void launch_lbs(avt_ctx* c, int nframes, const double*, const double* w, const double* p, const double* R, int from_state, int vis_init,
-                bool with_bucket_count, bool with_init, bool decide) {
+                bool with_bucket_count, bool with_init, bool decide, bool write_pc) {
     const int nlbs = (c->dm.d.V + 255) / 256;
     const int nb = with_bucket_count ? std::max(1, (c->launch_maxN + BUCKET_TILE - 1) / BUCKET_TILE) : 0;
     dim3 grid(nlbs + (with_init ? 1 : 0) + nb, nframes);
     const size_t lds = with_init ? prep_init_lds_bytes(c->dm.d) : 0;
     hipLaunchKernelGGL(k_lbs, grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, w, p, R, from_state, vis_init, nlbs, with_init ? 1 : 0,
-                       decide && from_state == 2 ? 1 : 0);
+                       decide && from_state == 2 ? 1 : 0, write_pc ? 1 : 0);
 }
 
 // the trial-point workgroup's scratch must fit beside k_lbs's static LDS (large skeletons fall back to the k_solve INIT launch)
 bool avt_lbs_can_init(const AvtDims& d) { return prep_init_lds_bytes(d) <= 96 * 1024; }
 
+__global__ void k_visibility_frame(DeviceModel dm, FrameBuffers fb);
 int avt_lbs_set_attributes() {
-    return hipFuncSetAttribute((const void*)k_lbs, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess;
+    return hipFuncSetAttribute((const void*)k_lbs, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_visibility_frame, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess;
 }
 
 // =================================================================================================
@@ -295,12 +212,51 @@ __global__ __launch_bounds__(256) void k_visibility(DeviceModel dm, FrameBuffers
     }
 }
 
+// k_visibility_frame: the same test with ONE workgroup of 1024 threads per frame.  The x, y of the frame's cloud are read once,
+// coalesced, into LDS (16 V bytes: 110 KB for SMPL); the faces gather from there and set byte flags in LDS; the flags leave
+// as two contiguous byte rows (vertex order and part-sorted order).  No scattered global stores, no cleared flags needed
+// beforehand (k_visibility: 6 x 8-byte gathers and up to 6 scattered byte stores per face, 226 us per 256 frames).
+// grid (frames).  Frame batches only (a lone frame is faster spread over 54 workgroups); the scatter pass of the data bucketing,
+// which rides in k_visibility's grid, rides in k_compact's here (a 1024-thread workgroup with 117 KB of LDS is no place for it).
+__global__ __launch_bounds__(1024) void k_visibility_frame(DeviceModel dm, FrameBuffers fb) {
+    const int F = dm.d.F, V = dm.d.V;
+    const int f = blockIdx.x + fb.f0, t = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) char vis_dyn[];
+    double2* s_xy = (double2*)vis_dyn;
+    unsigned char* s_flag = (unsigned char*)(s_xy + V);
+    const double* cl = fb.cloud + (size_t)f * 3 * V;
+    for (int v = t; v < V; v += 1024) s_xy[v] = make_double2(cl[3 * v], cl[3 * v + 1]);
+    for (int w = t; w < (V + 3) / 4; w += 1024) ((unsigned*)s_flag)[w] = 0u;
+    __syncthreads();
+    for (int face = t; face < F; face += 1024) {
+        const int i1 = dm.mesh[face], i2 = dm.mesh[(size_t)F + face], i3 = dm.mesh[2 * (size_t)F + face];
+        const double2 p1 = s_xy[i1], p2 = s_xy[i2], p3 = s_xy[i3];
+        const double ax = p2.x - p1.x, ay = p2.y - p1.y, bx = p1.x - p3.x, by = p1.y - p3.y;
+        const double z = __dsub_rn(__dmul_rn(ax, by), __dmul_rn(ay, bx));  // no FMA: same rounding as the CPU expression
+        if (z > 1e-4) { s_flag[i1] = 1; s_flag[i2] = 1; s_flag[i3] = 1; }
+    }
+    __syncthreads();
+    unsigned char* vis = fb.visible + (size_t)f * V;
+    for (int v = t; v < V; v += 1024) vis[v] = s_flag[v];
+    if (dm.part_vertices) {
+        unsigned char* vs = fb.vis_sorted + (size_t)f * V;
+        for (int pos = t; pos < V; pos += 1024) vs[pos] = s_flag[dm.part_vertices[pos]];
+    }
+}
+
+size_t avt_visibility_frame_lds(const AvtDims& d) { return (size_t)d.V * 16 + (((size_t)d.V + 3) & ~(size_t)3); }
+
 // with_bucket_scatter: also run the scatter pass of the data bucketing (second half of launch_bucket) in trailing workgroups
 void launch_visibility(avt_ctx* c, int nframes, int enable, bool with_bucket_scatter) {
     const int V = c->dm.d.V;
     if (!c->lbs_cleared) (void)hipMemsetAsync(c->fb.visible + (size_t)c->fb.f0 * V, enable ? 0 : 1, (size_t)nframes * V, c->cur_stream);
     const int nb = with_bucket_scatter ? std::max(1, (c->launch_maxN + BUCKET_TILE - 1) / BUCKET_TILE) : 0;
-    if (enable) {
+    c->scatter_in_compact = false;
+    if (enable && c->lbs_cleared && c->vis_frame_min > 0 && nframes >= c->vis_frame_min && !avt_nn_few(c, nframes)) {
+        // inside optimize(), frame batches: one workgroup per frame; k_compact follows and takes the scatter workgroups
+        hipLaunchKernelGGL(k_visibility_frame, dim3(nframes), dim3(1024), avt_visibility_frame_lds(c->dm.d), c->cur_stream, c->dm, c->fb);
+        c->scatter_in_compact = with_bucket_scatter;
+    } else if (enable) {
         const int nvis = (c->dm.d.F + 255) / 256;
         hipLaunchKernelGGL(k_visibility, dim3(nvis + nb, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb, nvis);
     } else if (nb) {

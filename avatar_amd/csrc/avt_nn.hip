@@ -19,6 +19,7 @@
 // (2^40, frame-centred) sum of its data points with integer atomics: order-independent, hence bit-wise
 // reproducible run to run (k_finalize turns them into sqrt(count) and the mean data point).
 #include "avt_device.h"
+#include "avt_bucket.h"
 
 #define NN_TILE 1024
 
@@ -410,8 +411,12 @@ __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb
 
 // Visible model points of every part, compacted in ascending vertex order inside the part's segment of the
 // part-sorted arrays (exactly the per-part clouds findNN builds at AvatarOptimizer.cpp:860-878).  grid (parts, frames).
-__global__ __launch_bounds__(256) void k_compact(DeviceModel dm, FrameBuffers fb) {
+// Workgroups past the parts (first ICP iteration of a frame batch): the scatter pass of the data bucketing (avt_bucket.h).
+// from_cloud: the coordinates come from the cloud through the vertex id (frame batches inside optimize(): k_lbs then skips
+// the part-sorted copy, three scattered stores per vertex) instead of from pcx/pcy/pcz.
+__global__ __launch_bounds__(256) void k_compact(DeviceModel dm, FrameBuffers fb, int from_cloud) {
     const int f = blockIdx.y + fb.f0, q = blockIdx.x, t = threadIdx.x, V = dm.d.V, np = dm.d.num_parts;
+    if (q >= np) { bucket_scatter_block(dm, fb, f, q - np); return; }
     const int b = dm.part_start[q], e = dm.part_start[q + 1];
     __shared__ int s_wcnt[4];
     __shared__ int s_run;
@@ -431,9 +436,14 @@ __global__ __launch_bounds__(256) void k_compact(DeviceModel dm, FrameBuffers fb
         for (int w = 0; w < wave_id(); ++w) off += s_wcnt[w];
         if (keep) {
             const size_t o = (size_t)f * V + b + off + rank;
-            fb.vcx[o] = fb.pcx[(size_t)f * V + pos];
-            fb.vcy[o] = fb.pcy[(size_t)f * V + pos];
-            fb.vcz[o] = fb.pcz[(size_t)f * V + pos];
+            if (from_cloud) {
+                const double* cl = fb.cloud + ((size_t)f * V + v) * 3;
+                fb.vcx[o] = cl[0]; fb.vcy[o] = cl[1]; fb.vcz[o] = cl[2];
+            } else {
+                fb.vcx[o] = fb.pcx[(size_t)f * V + pos];
+                fb.vcy[o] = fb.pcy[(size_t)f * V + pos];
+                fb.vcz[o] = fb.pcz[(size_t)f * V + pos];
+            }
             fb.vcid[o] = v;
         }
         __syncthreads();
@@ -442,6 +452,9 @@ __global__ __launch_bounds__(256) void k_compact(DeviceModel dm, FrameBuffers fb
     }
     if (t == 0) fb.vcount[(size_t)f * np + q] = s_run;
 }
+
+// few queries: the latency shape of the nearest-neighbour stage (4 lanes per query); many: one lane per query, one part per workgroup
+bool avt_nn_few(const avt_ctx* c, int nframes) { return (long long)nframes * c->launch_maxN <= 400000; }
 
 void launch_nn(avt_ctx* c, int nframes) {
     const int V = c->dm.d.V;
@@ -453,12 +466,14 @@ void launch_nn(avt_ctx* c, int nframes) {
     const int maxN = c->launch_maxN;
     if (maxN <= 0) return;
     // few queries: 4 lanes per query (more workgroups, shorter scans); many: one lane per query, one part per workgroup
-    const bool few = (long long)nframes * maxN <= 400000;
+    const bool few = avt_nn_few(c, nframes);
     if (few && c->lbs_cleared) {   // inside optimize() (k_lbs / k_visibility keep the part-sorted visibility flags): compaction fused into the scan
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn_vis<4>), dim3((maxN + 63) / 64, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
         return;
     }
-    hipLaunchKernelGGL(k_compact, dim3(c->dm.d.num_parts, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
+    const int nscat = c->scatter_in_compact ? std::max(1, (maxN + BUCKET_TILE - 1) / BUCKET_TILE) : 0;
+    c->scatter_in_compact = false;
+    hipLaunchKernelGGL(k_compact, dim3(c->dm.d.num_parts + nscat, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb, c->nn_from_cloud ? 1 : 0);
     if (few) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn<4>), dim3((maxN + 63) / 64, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
     else hipLaunchKernelGGL(k_nn_part, dim3((maxN + 255) / 256 + c->dm.d.num_parts, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
 }
