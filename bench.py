@@ -38,7 +38,7 @@ LIMITER = {
     "eval": "LDS pipe and dependent-latency chains of the row builder at three workgroups per CU; fp64 MFMA contraction behind it",
     "reduce": "L2 round trips (partial tiles live in L2/MALL)",
     "nn": "fp64 VALU issue (8 flop + one v_min per candidate, candidates through scalar loads)",
-    "lbs": "HBM/L2 streaming of the shape planes", "bucket": "LDS + global atomics", "visibility": "launch latency",
+    "lbs": "HBM/L2 streaming of the shape planes", "bucket": "LDS + global atomics", "visibility": "launch latency (few frames); one pass over the cloud, faces from LDS (batches)",
     "aggregate": "launch latency / gathers", "prepare": "latency (skeleton pass)",
     "decide": "cost-only evaluation of the last trial point (its accept test is taken inside the k_lbs launch that follows)",
 }
@@ -49,8 +49,8 @@ def algorithmic_bytes_per_gn_iter(N, V, K, P):
     return 24 * N + 4 * N + 24 * V * (K + 1) + 48 * V + 24 * V + 8 * P * (P + 1)
 
 
-# symbol-name fragments (eval: the full evaluation k_eval<.., false>; solve: k_solve<.., SOLVE_NORMAL>; reduce: k_reduce<Q, false>)
-KERNEL_SYMBOL = {"eval": "Lb0EEv11DeviceModel12FrameBuffersi", "solve": "ELi2EEv11DeviceModel", "reduce": "ELb0EEv11DeviceModel12FrameBuffers.kd", "nn": "k_nn", "lbs": "k_lbs"}
+# symbol-name fragments (eval: the full evaluation k_eval<.., false>; solve: k_solve<.., SOLVE_NORMAL>; reduce: k_reduce<1> / k_reduce_strip<NS>)
+KERNEL_SYMBOL = {"eval": "Lb0EEv11DeviceModel12FrameBuffersi", "solve": "ELi2EEv11DeviceModel", "reduce": "k_reduce", "nn": "k_nn", "lbs": "k_lbs"}
 
 
 def pmc_traffic(frames_per_launch, kernel_class):
