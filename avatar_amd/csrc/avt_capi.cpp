@@ -63,7 +63,9 @@ int choose_G(int nframes) {
     // many).  From 128 frames per launch on: 1536, two rounds, so that the hardware's dispatch evens out frames with different
     // numbers of matched points (512 frames: 747 k -> 774 k GN it/s; three rounds: 770 k).
     const int target = nframes >= 128 ? 1536 : 768;
-    int g = std::max(2, std::min(128, target / std::max(1, nframes)));
+    int gcap = 128;
+    if (const char* e = getenv("AVT_GCAP")) gcap = std::max(2, std::min(AVT_G_MAX, atoi(e)));
+    int g = std::max(2, std::min(gcap, target / std::max(1, nframes)));
     // G >= 64 also selects the few-frames launch shapes (strided batches, k_reduce_strip, the trial point set up in k_lbs's
     // grid): they win up to 6 frames (8 frames: 0.762 ms against 0.712 with G = 63; 12: 0.822 / 0.770)
     if (nframes >= 7) g = std::min(g, 63);

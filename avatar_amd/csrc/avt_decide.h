@@ -13,8 +13,8 @@
 // The per-component prior scores and the shape coefficients of BOTH slots are one vector load: lane 16 sl + c holds the score
 // of component c at slot sl, lane 32 + 16 sl + k shape coefficient k of slot sl.
 struct LastDecisionInputs {
-    double v0, v1;                             // this lane's two partial sums of sum c|r|^2 of the trial point ...
-    unsigned long long m0, m1;                 // ... and the written-masks of the workgroups they come from
+    double v[AVT_G_MAX / 64];                  // this lane's partial sums of sum c|r|^2 of the trial point (workgroups lane, lane + 64, ..) ...
+    unsigned long long m[AVT_G_MAX / 64];      // ... and the written-masks of the workgroups they come from
     double pv;                                 // this lane's prior score / shape coefficient (above)
     unsigned cw;                               // lane l < 32: 32-bit word l of the frame's control block; lanes 32..47: of AvtRunParams
 };
@@ -29,9 +29,12 @@ __device__ __forceinline__ LastDecisionInputs lm_last_load(const DeviceModel& dm
     const double* part = fb.partial + ((size_t)f * G * d.NPAIR + pair) * 256 + d.res_elem;
     const size_t st = (size_t)d.NPAIR * 256;
     const unsigned long long* wm = fb.wmask + (size_t)f * G;
-    const int g0 = min(lane, G - 1), g1 = min(lane + 64, G - 1);           // G <= 128 (choose_G)
-    in.v0 = part[(size_t)g0 * st]; in.v1 = part[(size_t)g1 * st];
-    in.m0 = wm[g0]; in.m1 = wm[g1];
+#pragma unroll
+    for (int u = 0; u < AVT_G_MAX / 64; ++u) {                             // G <= AVT_G_MAX (choose_G)
+        const int g = min(lane + 64 * u, G - 1);
+        in.v[u] = part[(size_t)g * st];
+        in.m[u] = wm[g];
+    }
     const int sl = (lane >> 4) & 1, c = lane & 15;
     const bool is_prior = lane < 32, there = is_prior ? c < d.ncomps : c < K;
     const double* src = is_prior ? fb.prior + (((size_t)f * 2 + sl) * AVT_MAX_COMPS + (there ? c : 0)) * AVT_PRIOR_STRIDE
@@ -62,8 +65,12 @@ __device__ __forceinline__ int lm_last_decide(const DeviceModel& dm, const Frame
 #undef AVT_CTL_W
 #undef AVT_PAR_W
     // a workgroup without batches wrote nothing: its tile is stale memory
-    const bool on0 = lane < G && (pair >= 64 || ((in.m0 >> (pair & 63)) & 1ull)), on1 = lane + 64 < G && (pair >= 64 || ((in.m1 >> (pair & 63)) & 1ull));
-    double a = (on0 ? in.v0 : 0.0) + (on1 ? in.v1 : 0.0);
+    double a = 0.0;
+#pragma unroll
+    for (int u = 0; u < AVT_G_MAX / 64; ++u) {
+        const bool on = lane + 64 * u < G && (pair >= 64 || ((in.m[u] >> (pair & 63)) & 1ull));
+        a += on ? in.v[u] : 0.0;
+    }
     const bool there = lane < 32 ? (lane & 15) < d.ncomps : (lane & 15) < d.K;
     const double pv = there ? in.pv : (lane < 32 ? 1.7976931348623157e308 : 0.0);
 #pragma unroll

@@ -20,6 +20,7 @@
 #define AVT_MAX_TILES 12      // ceil((P+1)/16) with P <= 179
 #define AVT_MAX_P 179         // k_solve<1024, true>: the packed factor of the bordered system (45 x 46 / 2 blocks of 144 B) must fit the LDS
 #define AVT_MAX_COMPS 16      // GMM components
+#define AVT_G_MAX 128         // most evaluation workgroups a frame can have (k_reduce_strip, avt_decide.h)
 #define AVT_MAX_GROUPS 4      // frame groups of one optimize() running on separate streams
 #define AVT_PRIOR_STRIDE (2 + 3 * AVT_MAX_JOINTS)   // doubles per (frame, component) of prior scratch
 #define AVT_FIX_SCALE 1099511627776.0  // 2^40 fixed-point scale of the centred correspondence sums

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256 * Q) void k_reduce(DeviceModel dm, FrameBuffers
 template <int NS>
 __global__ __launch_bounds__(1024) void k_reduce_strip(DeviceModel dm, FrameBuffers fb) {
     __builtin_amdgcn_s_setprio(3);
-    constexpr int EL = 256 / NS, NSL = 1024 / EL, NLD = (128 + NSL - 1) / NSL;     // elements per strip, slices, loads per thread (G <= 128)
+    constexpr int EL = 256 / NS, NSL = 1024 / EL, NLD = (AVT_G_MAX + NSL - 1) / NSL;     // elements per strip, slices, loads per thread (G <= AVT_G_MAX)
     const AvtDims d = dm.d;
     const int f = blockIdx.y + fb.f0, el = threadIdx.x % EL, slice = threadIdx.x / EL, strip = blockIdx.x % NS;
     const int NPAIR = d.NPAIR, NT = d.NT, P = d.P, HS = d.HS;
