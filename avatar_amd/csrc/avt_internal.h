@@ -187,6 +187,7 @@ struct FrameBuffers {
     double* vcx; double* vcy; double* vcz;   // [max_frames][V] visible model points, compacted per part segment
     int* vcid;                               // [max_frames][V] vertex id of each compacted candidate
     int* vcount;                             // [max_frames][num_parts] visible candidates per part
+    unsigned* ride_ctr;                      // [max_frames] reduction workgroups of the current k_solve launch that have delivered (zero between launches)
     unsigned char* vis_sorted;               // [max_frames][V] the visibility flags in part-sorted order (inside optimize(): k_nn_vis)
     // correspondence aggregation
     int* cnt;             // [max_frames][V]
@@ -245,6 +246,7 @@ struct avt_ctx {
     std::vector<void*> allocs;
     int ran_icp_iters, ran_max_iters;
     int launch_maxN;                 // max points per frame of the resident batch, rounded up to 2048 (grid sizing)
+    int num_cus;                     // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     bool lbs_cleared;                // the preceding k_lbs reset visibility / correspondence bookkeeping
     bool nn_from_cloud;              // inside optimize(), frame batches: k_compact gathers the candidates from the cloud (no pcx/pcy/pcz)
     bool scatter_in_compact;         // launch_visibility left the scatter pass of the bucketing to the k_compact launch that follows
@@ -280,5 +282,6 @@ void launch_finalize(avt_ctx* c, int nframes);
 void launch_eval(avt_ctx* c, int nframes, bool cost_only = false);
 void launch_records(avt_ctx* c, int nframes);
 void launch_reduce(avt_ctx* c, int nframes);
+bool avt_solve_rides(const avt_ctx* c, int nframes);      // the reduction rides in k_solve's launch: no launch_reduce in front of launch_solve
 void launch_solve(avt_ctx* c, int nframes, int mode);
 void launch_pack_results(avt_ctx* c, int nframes, double* out, int stride);

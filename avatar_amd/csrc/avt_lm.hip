@@ -551,6 +551,63 @@ __device__ __forceinline__ bool mfg_rounds(v4f64 (&acc)[MFG_SLOTS], const MfgSlo
     return true;
 }
 
+// -------------------------------------------------------------------------------------------------
+// Few frames: the reduction rides in k_solve's own launch (RIDE).  Workgroups 1 .. 4 NPAIR of a frame are the reduction - four
+// 256-thread workgroups per tile pair, each a strip of 64 tile elements, its four waves each summing a quarter of the G partial
+// tiles in ascending order (<= 32 loads per lane in flight), the quarter sums added in order through LDS - and hand the system
+// to the frame's solver (workgroup 0) INSIDE the launch: the entries leave as agent-scope write-through stores, the wave waits
+// for its own stores, one agent-scope atomic increment per workgroup; the solver spins (bounded) on the count and reads its
+// entries with agent-scope loads (no cache-wide fence on either side: tools/ubench/hop.hip, 0.8-1.1 us per hand-over against a
+// kernel of its own at >= 4.6 us plus a 1.7 us boundary).  Every kernel of a one-frame chain pays ~4.6 us before its first
+// and after its last instruction whatever it does, so a GN iteration is two launches instead of three.
+// Deadlock-free for the shapes that use it (<= 6 frames): the waiting workgroups are one per frame, the producers wait for nobody.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void st_agent(double* p, double v) {
+    __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+#define AVT_RIDE_STRIPS 4
+
+__device__ __forceinline__ void reduce_ride_block(const DeviceModel& dm, const FrameBuffers& fb, int f, int bx, double* s_q /* 192 doubles of the launch's dynamic LDS */) {
+    const AvtDims& d = dm.d;
+    const int t = threadIdx.x, lane = t & 63, slice = t >> 6;
+    const int NPAIR = d.NPAIR, NT = d.NT, HS = d.HS;
+    const int pair = bx / AVT_RIDE_STRIPS, strip = bx % AVT_RIDE_STRIPS;
+    const int e = strip * 64 + lane;                       // element of the tile: (row = (e >> 4 & 3) + 4 (e >> 6), col = e & 15)
+    const int G = fb.G, glo = (G * slice) / 4, ghi = (G * (slice + 1)) / 4, ng = ghi - glo;       // G <= 128: ng <= 32
+    const double* part = fb.partial + ((size_t)f * G * NPAIR + pair) * 256 + e;
+    const size_t st = (size_t)NPAIR * 256;
+    double v[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) v[u] = __builtin_nontemporal_load(part + (size_t)min(glo + u, G - 1) * st);
+    const unsigned long long wmine = lane < ng ? fb.wmask[(size_t)f * G + glo + lane] : 0ull;
+    const int try_slot = 1 - fb.ctl[f].cur_slot;
+    int p = pair, ti = 0;
+    while (p >= NT - ti) { p -= NT - ti; ++ti; }
+    const int tj = ti + p;
+    const int r = dm.tile_param[ti * 16 + ((e >> 4) & 3) + 4 * (e >> 6)], c = dm.tile_param[tj * 16 + (e & 15)];
+    // a workgroup without batches in this pair wrote nothing: its tile is stale memory
+    const unsigned long long wrote = pair < 64 ? __ballot((int)((wmine >> (pair & 63)) & 1ull)) : ~0ull;
+    double a = 0.0;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) a += (u < ng && ((wrote >> u) & 1ull)) ? v[u] : 0.0;
+    if (slice > 0) s_q[(slice - 1) * 64 + lane] = a;
+    __syncthreads();
+    if (slice == 0) {
+        a += s_q[lane]; a += s_q[64 + lane]; a += s_q[128 + lane];
+        if (r >= 0 && c >= 0) {
+            double* H = fb.Hraw + ((size_t)f * 2 + try_slot) * HS * HS;
+            st_agent(H + (size_t)r * HS + c, a);
+            if (ti != tj) st_agent(H + (size_t)c * HS + r, a);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);                      // my stores have been acknowledged
+        if (t == 0) __hip_atomic_fetch_add(fb.ride_ctr + f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // =================================================================================================
 // k_solve<NTH, TRI>.  grid (nframes), block NTH.  <256, false>: systems of up to 88 columns (SMPL: 86), one 4x4 block per
 // lane of 256 threads, the factor in a square LDS array whose unused blocks read as zeros.  <1024, true>: up to 180 columns
@@ -559,15 +616,19 @@ __device__ __forceinline__ bool mfg_rounds(v4f64 (&acc)[MFG_SLOTS], const MfgSlo
 // =================================================================================================
 // MODE (SOLVE_INIT / FIRST / NORMAL) is a template parameter so that the three roles are three symbols in a kernel trace
 // (their durations differ six-fold) and the short ones do not carry the factorisation's code.
-template <int NTH, bool TRI, int MODE>
+template <int NTH, bool TRI, int MODE, bool RIDE = false>
 __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) {
     constexpr int mode = MODE;
+    static_assert(!RIDE || (NTH == 256 && !TRI && MODE != SOLVE_INIT), "the riding reduction exists for the 256-thread solves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if constexpr (RIDE) {      // grid (frames, 1 + AVT_RIDE_STRIPS NPAIR): y = 0 the solver, the rest the reduction in front of it
+        if (blockIdx.y > 0) { reduce_ride_block(dm, fb, blockIdx.x + fb.f0, (int)blockIdx.y - 1, (double*)smem); return; }
+    }
     __builtin_amdgcn_s_setprio(3);   // one dependency chain per frame: issue ahead of the evaluation waves of another frame group on this CU
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, P = d.P, HS = d.HS;
     const int f = blockIdx.x + fb.f0, t = threadIdx.x;
     AvtFrameCtl& ctl = fb.ctl[f];
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NBk = HS >> 2;                                // 4-row blocks covering rows 0..P (22 for SMPL)
     // W = L diag(d) of the factorisation H = L diag(d) L^T, block layout [pivot block kb][row block bi][18]: a 4x4
     // block is 16 doubles + 2 of padding (144 B), so lanes reading different blocks spread over the LDS banks; row P
@@ -625,6 +686,15 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     const int mf_wv = t >> 6, mf_g4 = (t >> 4) & 3, mf_c16 = t & 15, mf_rA = 5 - mf_wv, mf_rB = mf_wv - 2;
     // (six tile slots per wave: slot s <= rA is tile (rA, s), the slots behind are tiles (rB, 0..rB))
     double mraw[TRI ? 1 : 2][TRI ? 1 : 6][4];
+    if constexpr (RIDE) {      // the reduction workgroups of this launch have all delivered their strips of the trial point's system
+        if (t == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(fb.ride_ctr + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(AVT_RIDE_STRIPS * d.NPAIR) && spins < (1 << 20)) { __builtin_amdgcn_s_sleep(1); ++spins; }
+            __hip_atomic_store(fb.ride_ctr + f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next launch (a kernel boundary lies between)
+        }
+        __syncthreads();
+    }
+    auto hload = [&](const double* q) { if constexpr (RIDE) return ld_agent(q); else return *q; };
     if constexpr (!TRI) {
         // (one copy per wave role: tile rows and columns are compile-time constants there, an entry's address is one add)
         const double* Hl = H0 + (size_t)(4 * 0 + mf_g4) * HS + mf_c16;
@@ -643,8 +713,8 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
                     const bool inb = row + 3 < HS && col + 15 < HS;
                     const size_t off = inb ? (size_t)row * HS + col
                                            : (size_t)(min(row + mf_g4, HS - 1) - mf_g4) * HS + (min(col + mf_c16, HS - 1) - mf_c16);
-                    mraw[0][ti][v] = own ? Hl[off] : 0.0;
-                    mraw[1][ti][v] = own ? Hl[(size_t)HS * HS + off] : 0.0;
+                    mraw[0][ti][v] = own ? hload(Hl + off) : 0.0;
+                    mraw[1][ti][v] = own ? hload(Hl + (size_t)HS * HS + off) : 0.0;
                 }
             }
         };
@@ -655,7 +725,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
             default: load_role(std::integral_constant<int, 3>{}); break;
         }
     }
-    const double hpp0 = H0[(size_t)P * HS + P], hpp1 = H0[(size_t)HS * HS + (size_t)P * HS + P];
+    const double hpp0 = hload(H0 + (size_t)P * HS + P), hpp1 = hload(H0 + (size_t)HS * HS + (size_t)P * HS + P);
     const double lm_up = fb.params->lm_up, lm_down = fb.params->lm_down, lm_min = fb.params->lm_min, lm_max = fb.params->lm_max;   // same round trip
     const int cur0 = ctl.cur_slot, try_valid = ctl.try_valid, comp_cur0 = ctl.comp_cur;
     const double sbp = ctl.sbp, sbs = ctl.sbs, cost_cur0 = ctl.cost_cur;
@@ -910,8 +980,21 @@ static void launch_solve_shape(avt_ctx* c, int nframes, int mode, size_t lds) {
     }
 }
 
+// few frames, 256-thread solves: the reduction of the trial point's system rides in the solve's launch (no launch_reduce in front)
+// (while every workgroup of the launch - 1 + 4 NPAIR per frame, one per CU with the solver's LDS request - is resident at once:
+// three SMPL frames on 256 CUs; six frames in two rounds measured 0.751 against 0.689 ms with the reduction as its own launch)
+bool avt_solve_rides(const avt_ctx* c, int nframes) {
+    return c->fb.G >= 64 && !solve_big(c->dm.d) && nframes * (1 + AVT_RIDE_STRIPS * c->dm.d.NPAIR) <= c->num_cus && getenv("AVT_NO_RIDE") == nullptr;
+}
+
 void launch_solve(avt_ctx* c, int nframes, int mode) {
     const AvtDims& d = c->dm.d;
+    if (mode != SOLVE_INIT && avt_solve_rides(c, nframes)) {
+        const dim3 grid(nframes, 1 + AVT_RIDE_STRIPS * d.NPAIR);
+        if (mode == SOLVE_FIRST) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256, false, SOLVE_FIRST, true>), grid, dim3(256), solve_lds_bytes(d), c->cur_stream, c->dm, c->fb);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256, false, SOLVE_NORMAL, true>), grid, dim3(256), solve_lds_bytes(d), c->cur_stream, c->dm, c->fb);
+        return;
+    }
     if (solve_big(d)) launch_solve_shape<1024, true>(c, nframes, mode, solve_lds_bytes(d));
     else launch_solve_shape<256, false>(c, nframes, mode, solve_lds_bytes(d));
 }
@@ -924,4 +1007,9 @@ static int solve_attr() {
            hipFuncSetAttribute((const void*)k_solve<NTH, TRI, SOLVE_NORMAL>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess;
 }
 
-int avt_solve_set_attributes() { return solve_attr<256, false>() || solve_attr<1024, true>(); }
+int avt_solve_set_attributes() {
+    const int cap = 160 * 1024 - 512;
+    return solve_attr<256, false>() || solve_attr<1024, true>() ||
+           hipFuncSetAttribute((const void*)k_solve<256, false, SOLVE_FIRST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_solve<256, false, SOLVE_NORMAL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess;
+}
