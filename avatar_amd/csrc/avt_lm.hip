@@ -568,35 +568,39 @@ __device__ __forceinline__ void st_agent(double* p, double v) {
 __device__ __forceinline__ double ld_agent(const double* p) {
     return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
-#define AVT_RIDE_STRIPS 4
 
-__device__ __forceinline__ void reduce_ride_block(const DeviceModel& dm, const FrameBuffers& fb, int f, int bx, double* s_q /* 192 doubles of the launch's dynamic LDS */) {
+template <int STRIPS>
+__device__ __forceinline__ void reduce_ride_block(const DeviceModel& dm, const FrameBuffers& fb, int f, int bx, double* s_q /* 256 doubles of the launch's dynamic LDS */) {
+    constexpr int EL = 256 / STRIPS, NSL = 256 / EL, NLD = AVT_G_MAX / NSL;      // elements per strip, slices (of EL lanes), partial tiles per slice
+    static_assert(EL == 64 || EL == 32, "a slice is a wave or half a wave");
     const AvtDims& d = dm.d;
-    const int t = threadIdx.x, lane = t & 63, slice = t >> 6;
+    const int t = threadIdx.x, el = t % EL, slice = t / EL;
     const int NPAIR = d.NPAIR, NT = d.NT, HS = d.HS;
-    const int pair = bx / AVT_RIDE_STRIPS, strip = bx % AVT_RIDE_STRIPS;
-    const int e = strip * 64 + lane;                       // element of the tile: (row = (e >> 4 & 3) + 4 (e >> 6), col = e & 15)
-    const int G = fb.G, glo = (G * slice) / 4, ghi = (G * (slice + 1)) / 4, ng = ghi - glo;       // G <= 128: ng <= 32
+    const int pair = bx / STRIPS, strip = bx % STRIPS;
+    const int e = strip * EL + el;                         // element of the tile: (row = (e >> 4 & 3) + 4 (e >> 6), col = e & 15)
+    const int G = fb.G, glo = (G * slice) / NSL, ghi = (G * (slice + 1)) / NSL, ng = ghi - glo;       // G <= AVT_G_MAX: ng <= NLD
     const double* part = fb.partial + ((size_t)f * G * NPAIR + pair) * 256 + e;
     const size_t st = (size_t)NPAIR * 256;
-    double v[32];
+    double v[NLD];
 #pragma unroll
-    for (int u = 0; u < 32; ++u) v[u] = __builtin_nontemporal_load(part + (size_t)min(glo + u, G - 1) * st);
-    const unsigned long long wmine = lane < ng ? fb.wmask[(size_t)f * G + glo + lane] : 0ull;
+    for (int u = 0; u < NLD; ++u) v[u] = __builtin_nontemporal_load(part + (size_t)min(glo + u, G - 1) * st);
+    const unsigned long long wmine = el < ng ? fb.wmask[(size_t)f * G + glo + el] : 0ull;
     const int try_slot = 1 - fb.ctl[f].cur_slot;
     int p = pair, ti = 0;
     while (p >= NT - ti) { p -= NT - ti; ++ti; }
     const int tj = ti + p;
     const int r = dm.tile_param[ti * 16 + ((e >> 4) & 3) + 4 * (e >> 6)], c = dm.tile_param[tj * 16 + (e & 15)];
     // a workgroup without batches in this pair wrote nothing: its tile is stale memory
-    const unsigned long long wrote = pair < 64 ? __ballot((int)((wmine >> (pair & 63)) & 1ull)) : ~0ull;
+    unsigned long long wrote = pair < 64 ? __ballot((int)((wmine >> (pair & 63)) & 1ull)) : ~0ull;
+    if (EL == 32) wrote >>= 32 * (slice & 1);              // two slices per wave: my half of the ballot
     double a = 0.0;
 #pragma unroll
-    for (int u = 0; u < 32; ++u) a += (u < ng && ((wrote >> u) & 1ull)) ? v[u] : 0.0;
-    if (slice > 0) s_q[(slice - 1) * 64 + lane] = a;
+    for (int u = 0; u < NLD; ++u) a += (u < ng && ((wrote >> u) & 1ull)) ? v[u] : 0.0;
+    if (slice > 0) s_q[(slice - 1) * EL + el] = a;
     __syncthreads();
     if (slice == 0) {
-        a += s_q[lane]; a += s_q[64 + lane]; a += s_q[128 + lane];
+#pragma unroll
+        for (int i = 0; i < NSL - 1; ++i) a += s_q[i * EL + el];
         if (r >= 0 && c >= 0) {
             double* H = fb.Hraw + ((size_t)f * 2 + try_slot) * HS * HS;
             st_agent(H + (size_t)r * HS + c, a);
@@ -616,13 +620,13 @@ __device__ __forceinline__ void reduce_ride_block(const DeviceModel& dm, const F
 // =================================================================================================
 // MODE (SOLVE_INIT / FIRST / NORMAL) is a template parameter so that the three roles are three symbols in a kernel trace
 // (their durations differ six-fold) and the short ones do not carry the factorisation's code.
-template <int NTH, bool TRI, int MODE, bool RIDE = false>
+template <int NTH, bool TRI, int MODE, int RIDE = 0>      // RIDE: 0, or the riding reduction's strips per tile pair
 __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) {
     constexpr int mode = MODE;
     static_assert(!RIDE || (NTH == 256 && !TRI && MODE != SOLVE_INIT), "the riding reduction exists for the 256-thread solves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if constexpr (RIDE) {      // grid (frames, 1 + AVT_RIDE_STRIPS NPAIR): y = 0 the solver, the rest the reduction in front of it
-        if (blockIdx.y > 0) { reduce_ride_block(dm, fb, blockIdx.x + fb.f0, (int)blockIdx.y - 1, (double*)smem); return; }
+    if constexpr (RIDE) {      // grid (frames, 1 + RIDE NPAIR): y = 0 the solver, the rest the reduction in front of it
+        if (blockIdx.y > 0) { reduce_ride_block<RIDE>(dm, fb, blockIdx.x + fb.f0, (int)blockIdx.y - 1, (double*)smem); return; }
     }
     __builtin_amdgcn_s_setprio(3);   // one dependency chain per frame: issue ahead of the evaluation waves of another frame group on this CU
     const AvtDims d = dm.d;
@@ -689,7 +693,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     if constexpr (RIDE) {      // the reduction workgroups of this launch have all delivered their strips of the trial point's system
         if (t == 0) {
             int spins = 0;
-            while (__hip_atomic_load(fb.ride_ctr + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(AVT_RIDE_STRIPS * d.NPAIR) && spins < (1 << 20)) { __builtin_amdgcn_s_sleep(1); ++spins; }
+            while (__hip_atomic_load(fb.ride_ctr + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(RIDE * d.NPAIR) && spins < (1 << 20)) { __builtin_amdgcn_s_sleep(1); ++spins; }
             __hip_atomic_store(fb.ride_ctr + f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next launch (a kernel boundary lies between)
         }
         __syncthreads();
@@ -983,16 +987,24 @@ static void launch_solve_shape(avt_ctx* c, int nframes, int mode, size_t lds) {
 // few frames, 256-thread solves: the reduction of the trial point's system rides in the solve's launch (no launch_reduce in front)
 // (while every workgroup of the launch - 1 + 4 NPAIR per frame, one per CU with the solver's LDS request - is resident at once:
 // three SMPL frames on 256 CUs; six frames in two rounds measured 0.751 against 0.689 ms with the reduction as its own launch)
-bool avt_solve_rides(const avt_ctx* c, int nframes) {
-    return c->fb.G >= 64 && !solve_big(c->dm.d) && nframes * (1 + AVT_RIDE_STRIPS * c->dm.d.NPAIR) <= c->num_cus && getenv("AVT_NO_RIDE") == nullptr;
+static int ride_strips(const avt_ctx* c, int nframes) {      // 8 strips per pair while the whole grid is resident (one SMPL frame), else 4, else none
+    if (c->fb.G < 64 || solve_big(c->dm.d) || getenv("AVT_NO_RIDE")) return 0;
+    int want = 8;
+    if (const char* e = getenv("AVT_RIDE_STRIPS")) want = atoi(e);
+    for (int s = want; s >= 4; s -= 4) if (nframes * (1 + s * c->dm.d.NPAIR) <= c->num_cus) return s;
+    return 0;
 }
+bool avt_solve_rides(const avt_ctx* c, int nframes) { return ride_strips(c, nframes) != 0; }
 
 void launch_solve(avt_ctx* c, int nframes, int mode) {
     const AvtDims& d = c->dm.d;
-    if (mode != SOLVE_INIT && avt_solve_rides(c, nframes)) {
-        const dim3 grid(nframes, 1 + AVT_RIDE_STRIPS * d.NPAIR);
-        if (mode == SOLVE_FIRST) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256, false, SOLVE_FIRST, true>), grid, dim3(256), solve_lds_bytes(d), c->cur_stream, c->dm, c->fb);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256, false, SOLVE_NORMAL, true>), grid, dim3(256), solve_lds_bytes(d), c->cur_stream, c->dm, c->fb);
+    const int rs = mode != SOLVE_INIT ? ride_strips(c, nframes) : 0;
+    if (rs) {
+        const dim3 grid(nframes, 1 + rs * d.NPAIR);
+#define AVT_RIDE(M, S) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256, false, M, S>), grid, dim3(256), solve_lds_bytes(d), c->cur_stream, c->dm, c->fb)
+        if (mode == SOLVE_FIRST) { if (rs == 8) AVT_RIDE(SOLVE_FIRST, 8); else AVT_RIDE(SOLVE_FIRST, 4); }
+        else { if (rs == 8) AVT_RIDE(SOLVE_NORMAL, 8); else AVT_RIDE(SOLVE_NORMAL, 4); }
+#undef AVT_RIDE
         return;
     }
     if (solve_big(d)) launch_solve_shape<1024, true>(c, nframes, mode, solve_lds_bytes(d));
@@ -1010,6 +1022,8 @@ static int solve_attr() {
 int avt_solve_set_attributes() {
     const int cap = 160 * 1024 - 512;
     return solve_attr<256, false>() || solve_attr<1024, true>() ||
-           hipFuncSetAttribute((const void*)k_solve<256, false, SOLVE_FIRST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
-           hipFuncSetAttribute((const void*)k_solve<256, false, SOLVE_NORMAL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess;
+           hipFuncSetAttribute((const void*)k_solve<256, false, SOLVE_FIRST, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_solve<256, false, SOLVE_NORMAL, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_solve<256, false, SOLVE_FIRST, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_solve<256, false, SOLVE_NORMAL, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess;
 }
