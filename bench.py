@@ -50,7 +50,7 @@ def algorithmic_bytes_per_gn_iter(N, V, K, P):
 
 
 # symbol-name fragments (eval: the full evaluation k_eval<.., false>; solve: k_solve<.., SOLVE_NORMAL>; reduce: k_reduce<1> / k_reduce_strip<NS>)
-KERNEL_SYMBOL = {"eval": "Lb0EEv11DeviceModel12FrameBuffersi", "solve": "ELi2EEv11DeviceModel", "reduce": "k_reduce", "nn": "k_nn", "lbs": "k_lbs"}
+KERNEL_SYMBOL = {"eval": "Lb0EEv11DeviceModel12FrameBuffersi", "solve": "k_solveILi256ELb0ELi2", "reduce": "k_reduce", "nn": "k_nn", "lbs": "k_lbs"}
 
 
 def pmc_traffic(frames_per_launch, kernel_class):
