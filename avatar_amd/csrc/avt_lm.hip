@@ -279,21 +279,44 @@ __device__ __forceinline__ void backsub_blocked(const double* __restrict__ Lblk,
     }
 }
 
-// The same back substitution for the packed-triangle storage and up to 192 unknowns (three columns per lane of the wave):
-// plain loop, W(k,l) = 0 for l >= k by a select instead of by stored zeros.
+// The same back substitution for the packed-triangle storage and up to 192 unknowns (three columns per lane of the wave).
+// W(k,l) = 0 for l >= k by a select instead of by stored zeros.  Everything a step reads from the factor - the diagonal block,
+// the reciprocal pivots, this lane's three column blocks - has an address that does not depend on the unknowns, so it is
+// requested one step ahead; a step is then readlanes, the 4-unknown chain and 12 FMAs (61 k -> ... clocks for 43 steps
+// before / after on the 52-joint model, tools/big_model_phase_probe.py).
 __device__ __forceinline__ void backsub_tri(const double* __restrict__ Lblk, const double* __restrict__ s_R, int NB, int P, int t,
                                             double* __restrict__ s_delta) {
     auto blockp = [&](int kb, int bi) { return Lblk + (size_t)wblk<true>(kb, bi, NB) * 18; };
     double wp[3], acc[3] = {0.0, 0.0, 0.0};
+    int cbk[3], li[3];
+    bool live[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { const int l = t + 64 * c; wp[c] = (l < P) ? blockp(l >> 2, P >> 2)[(P & 3) * 4 + (l & 3)] : 0.0; }
-    for (int kb = NB - 1; kb >= 0; --kb) {
-        const int base = 4 * kb;
+    for (int c = 0; c < 3; ++c) {
+        const int l = t + 64 * c;
+        live[c] = l < P; cbk[c] = min(l, P - 1) >> 2; li[c] = l & 3;
+        wp[c] = live[c] ? blockp(l >> 2, P >> 2)[(P & 3) * 4 + (l & 3)] : 0.0;
+    }
+    struct Step { d2v a, bq, cq, e, r01, r23; double bp[3][4]; };
+    auto fetch = [&](int kb) {
+        Step s;
         const d2v* Wd = (const d2v*)blockp(kb, kb);
-        const d2v a = Wd[2], bq = Wd[4], cq = Wd[6], e = Wd[7];
-        const double w10 = a.x, w20 = bq.x, w21 = bq.y, w30 = cq.x, w31 = cq.y, w32 = e.x;
-        const d2v* Rq = (const d2v*)(s_R + base);
-        const double r0 = Rq[0].x, r1 = Rq[0].y, r2 = Rq[1].x, r3 = Rq[1].y;
+        s.a = Wd[2]; s.bq = Wd[4]; s.cq = Wd[6]; s.e = Wd[7];
+        const d2v* Rq = (const d2v*)(s_R + 4 * kb);
+        s.r01 = Rq[0]; s.r23 = Rq[1];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {      // my column l lives in pivot block cb; rows of block kb matter if kb >= cb (kb == cb: strictly lower part)
+            const double* bp = blockp(cbk[c], max(kb, cbk[c])) + li[c];
+            s.bp[c][0] = bp[0]; s.bp[c][1] = bp[4]; s.bp[c][2] = bp[8]; s.bp[c][3] = bp[12];
+        }
+        return s;
+    };
+    Step nx = fetch(NB - 1);
+    for (int kb = NB - 1; kb >= 0; --kb) {
+        const Step cu = nx;
+        if (kb > 0) nx = fetch(kb - 1);
+        const int base = 4 * kb;
+        const double w10 = cu.a.x, w20 = cu.bq.x, w21 = cu.bq.y, w30 = cu.cq.x, w31 = cu.cq.y, w32 = cu.e.x;
+        const double r0 = cu.r01.x, r1 = cu.r01.y, r2 = cu.r23.x, r3 = cu.r23.y;
         const int own = base >> 6;                                  // which of my columns holds unknown `base`
         const double u = (own == 0 ? wp[0] - acc[0] : (own == 1 ? wp[1] - acc[1] : wp[2] - acc[2]));
         const double u0 = readlane_f64(u, base & 63), u1 = readlane_f64(u, (base + 1) & 63);
@@ -304,15 +327,10 @@ __device__ __forceinline__ void backsub_tri(const double* __restrict__ Lblk, con
         const double d0 = r0 * fma(-w10, d1, fma(-w20, d2, fma(-w30, d3, u0)));
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const int l = t + 64 * c, cb = l >> 2;                  // my column l lives in pivot block cb; rows of block kb matter if kb > cb
-            if (l < P && kb > cb) {
-                const double* bp = blockp(cb, kb) + (l & 3);
-                acc[c] += fma(bp[0], d0, bp[4] * d1) + fma(bp[8], d2, bp[12] * d3);
-            } else if (l < P && kb == cb) {                          // inside the diagonal block: strictly lower part only
-                const double* bp = blockp(cb, cb) + (l & 3);
-                const int li = l & 3;
-                acc[c] += (li < 1 ? bp[4] * d1 : 0.0) + (li < 2 ? bp[8] * d2 : 0.0) + (li < 3 ? bp[12] * d3 : 0.0);
-            }
+            const bool below = live[c] && kb > cbk[c], diag = live[c] && kb == cbk[c];
+            const double full = fma(cu.bp[c][0], d0, cu.bp[c][1] * d1) + fma(cu.bp[c][2], d2, cu.bp[c][3] * d3);
+            const double part = (li[c] < 1 ? cu.bp[c][1] * d1 : 0.0) + (li[c] < 2 ? cu.bp[c][2] * d2 : 0.0) + (li[c] < 3 ? cu.bp[c][3] * d3 : 0.0);
+            acc[c] += below ? full : (diag ? part : 0.0);
         }
         if (t == 0) { d2v* o = (d2v*)(s_delta + base); o[0] = (d2v){d0, d1}; o[1] = (d2v){d2, d3}; }
     }
