@@ -260,3 +260,29 @@ def test_every_launch_shape_gives_the_single_frame_answer(smpl, gmodel):
         assert all(s.gn_iterations == sr[0].gn_iterations and s.accepted_steps == sr[0].accepted_steps for s in st)
         same_group = range(nfg)          # frames of one group run the same launches: bit-identical results
         assert all(np.array_equal(p[f], p[0]) and np.array_equal(q[f], q[0]) and np.array_equal(w[f], w[0]) for f in same_group)
+
+
+@pytest.mark.gpu
+def test_in_launch_hand_over_is_reproducible(smpl, gmodel):
+    """Up to three frames the reduced system reaches the solver INSIDE the k_solve launch (agent-scope stores, a counter, a
+    bounded spin): a lost, early or torn hand-over would change bits.  Every repeat of the same call must download the same
+    bytes, and the launch shape with the reduction as its own launch (four frames) must agree to summation order."""
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    frs = [synth.make_frame(smpl, 40 + s) for s in range(4)]
+    opt = Options.demo()
+    res = {}
+    for F in (1, 3, 4):
+        ctx = api.Context(gmodel, 24, pm, 60000, F)
+        ctx.frames_upload([f["data"] for f in frs[:F]], [f["labels"] for f in frs[:F]])
+        ctx.state_upload(np.array([f["start"][1] for f in frs[:F]]), np.array([api.rot_to_quat(f["start"][2]) for f in frs[:F]]),
+                         np.array([f["start"][0] for f in frs[:F]]))
+        ctx.state_reset(); ctx.optimize_resident(opt)
+        ref = ctx.state_download()
+        for _ in range(150):
+            ctx.state_reset(); ctx.optimize_resident(opt)
+            p, q, w, _st = ctx.state_download()
+            assert np.array_equal(p, ref[0]) and np.array_equal(q, ref[1]) and np.array_equal(w, ref[2])
+        res[F] = ref
+    for F in (3, 4):
+        assert np.abs(res[F][0][0] - res[1][0][0]).max() < 1e-9 and np.abs(res[F][1][0] - res[1][1][0]).max() < 1e-9
