@@ -315,16 +315,27 @@ __device__ __forceinline__ void mfma_pair(const double* __restrict__ a, const do
 // =================================================================================================
 // MT = column tiles the instantiation is sized for (accumulators per wave, zeroing passes): 6 for the SMPL shape, 8 for
 // generic skeletons of up to 128 columns, AVT_MAX_TILES (12) up to 192 columns (SMPL-H, SMPL-X)
+// Generic skeletons with more than 8 column tiles (SMPL-H, SMPL-X: 11 / 12): tile pairs are dealt to the waves by tile ROW -
+// rows in ascending order (longest first) to waves 0 1 2 3 3 2 1 0 0 1 .. - so that a wave reads the fragment of every column
+// tile it needs ONCE per k-step (<= NT reads) and uses it as the A operand of its rows and the B operand of their columns,
+// instead of two reads per matrix instruction (the fragment reads, 40 per k-step and wave, bounded the phase: 6.4 k clocks
+// per batch).  NT is a template argument there, so tiles and accumulator slots are compile-time.
+__host__ __device__ constexpr int rd_wave(int r) { return ((r >> 2) & 1) ? 3 - (r & 3) : (r & 3); }
+__host__ __device__ constexpr int rd_slots(int NT, int W) { int n = 0; for (int r = 0; r < NT; ++r) if (rd_wave(r) == W) n += NT - r; return n; }
+__host__ __device__ constexpr int rd_maxslots(int NT) { int m = 0; for (int w = 0; w < 4; ++w) m = rd_slots(NT, w) > m ? rd_slots(NT, w) : m; return m; }
+__host__ __device__ constexpr int rd_pair(int NT, int ti, int tj) { return ti * NT - (ti * (ti - 1)) / 2 + (tj - ti); }
+
 // COST: the evaluation behind which no solve follows - residual column and tile pair (res, res) only (see build_rows)
 template <int CJ, int CK, int MT, bool COST>
 __global__ __launch_bounds__(256, (CJ != 0) ? 3 : (MT > 8 ? 1 : 2)) void k_eval(DeviceModel dm, FrameBuffers fb, int nframes) {
     constexpr bool FIXED = CJ != 0;
     const AvtDims d = dm.d;
     const int J = FIXED ? CJ : d.J, K = FIXED ? CK : d.K, P = 3 + 3 * J + K;
-    const int NT = FIXED ? (3 + 3 * CJ + CK + 16) / 16 : d.NT, NPAIR = NT * (NT + 1) / 2;
+    constexpr bool ROWDEAL = !FIXED && MT > 8;            // NT == MT exactly (launch_eval picks the instantiation)
+    const int NT = FIXED ? (3 + 3 * CJ + CK + 16) / 16 : (ROWDEAL ? MT : d.NT), NPAIR = NT * (NT + 1) / 2;
     static_assert(!FIXED || (3 + 3 * CJ + CK + 16) / 16 == 6, "fixed-shape path is written for 6 column tiles");
     constexpr int RS = AVT_EVAL_RS;
-    constexpr int MAXPW = FIXED ? 6 : (MT * (MT + 1) / 2 + 3) / 4;
+    constexpr int MAXPW = FIXED ? 6 : (ROWDEAL ? rd_maxslots(MT) : (MT * (MT + 1) / 2 + 3) / 4);
     const int G = fb.G, t = threadIdx.x;
     const int id = blockIdx.x;
     if (id >= nframes * G) {   // trailing workgroups: pose prior of the trial point, one (frame, GMM component) each
@@ -414,7 +425,12 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : (MT > 8 ? 1 : 2)) void k_eval(
     // generic shapes: static round-robin deal of whole tile pairs to the waves
     int pr_ti[MAXPW], pr_tj[MAXPW];
     const double *pr_a[MAXPW], *pr_b[MAXPW];
-    if constexpr (!FIXED) {
+    const double* colp[ROWDEAL ? MT : 1];                         // row deal: my lane's fragment address of every column tile
+    if constexpr (ROWDEAL) {
+#pragma unroll
+        for (int tl = 0; tl < MT; ++tl) colp[tl] = s_Jt + (size_t)dm.tile_col[tl * 16 + (ln & 15)] * RS + (ln >> 4);
+    }
+    if constexpr (!FIXED && !ROWDEAL) {
 #pragma unroll
         for (int i = 0; i < MAXPW; ++i) {
             int p = wv + 4 * i, ti = 0;
@@ -474,15 +490,73 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : (MT > 8 ? 1 : 2)) void k_eval(
                 }
             }
             EPROBE(1);
-        } else {
-#pragma unroll 1
-            for (int k0 = 0; k0 < AVT_EVAL_ROWS; k0 += 4) {
+        } else if constexpr (ROWDEAL) {
+            const double* zc = s_Jt + (size_t)NC * RS + (ln >> 4);           // the zero column, rows k0 + (l >> 4): what a dead tile reads
+            const double* cq[MT];
 #pragma unroll
-                for (int i = 0; i < MAXPW; ++i) {
-                    if (pr_ti[i] >= 0 && ((tm >> pr_ti[i]) & (tm >> pr_tj[i]) & 1)) {
-                        acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(pr_a[i][k0], pr_b[i][k0], acc[i], 0, 0, 0);
+            for (int tl = 0; tl < MT; ++tl) cq[tl] = ((tm >> tl) & 1) ? colp[tl] : zc;
+            auto role = [&](auto wc) {
+                constexpr int W = decltype(wc)::value;
+#pragma unroll 1
+                for (int k0 = 0; k0 < AVT_EVAL_ROWS; k0 += 4) {
+                    double fr[MT];
+#pragma unroll
+                    for (int tl = 0; tl < MT; ++tl) fr[tl] = tl >= W ? cq[tl][k0] : 0.0;      // (my smallest row is W)
+                    int slot = 0;
+#pragma unroll
+                    for (int r = 0; r < MT; ++r) {
+                        if (rd_wave(r) != W) continue;
+                        if ((tm >> r) & 1) {                     // wave-uniform: a dead row tile has no live pair
+#pragma unroll
+                            for (int tj = r; tj < MT; ++tj)
+                                acc[slot + tj - r] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[r], fr[tj], acc[slot + tj - r], 0, 0, 0);
+                        }
+                        slot += MT - r;
                     }
                 }
+            };
+            switch (__builtin_amdgcn_readfirstlane(wv)) {
+                case 0: role(std::integral_constant<int, 0>{}); break;
+                case 1: role(std::integral_constant<int, 1>{}); break;
+                case 2: role(std::integral_constant<int, 2>{}); break;
+                default: role(std::integral_constant<int, 3>{}); break;
+            }
+        } else {
+            // generic shapes: the wave's pairs in chunks of CH; a chunk without a live pair is skipped for the whole batch (one
+            // wave-uniform branch), inside a live chunk the dead pairs read the all-zero column, so a k-step is branch-free:
+            // the fragment reads of all live chunks go out together, then the matrix instructions (independent accumulators)
+            // - instead of a branch, two reads and a wait in front of every single matrix instruction (12.6 k -> ... clocks
+            // per batch of the 11-tile shape).
+#ifndef AVT_EVAL_CH
+#define AVT_EVAL_CH 5
+#endif
+            constexpr int CH = AVT_EVAL_CH, NCH = (MAXPW + CH - 1) / CH;
+            const double* zc = s_Jt + (size_t)NC * RS + (ln >> 4);           // the zero column, rows k0 + (l >> 4)
+            const double *qa[MAXPW], *qb[MAXPW];
+            bool chl[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) chl[c] = false;
+#pragma unroll
+            for (int i = 0; i < MAXPW; ++i) {
+                const bool live = pr_ti[i] >= 0 && ((tm >> pr_ti[i]) & (tm >> pr_tj[i]) & 1);       // wave-uniform
+                qa[i] = live ? pr_a[i] : zc; qb[i] = live ? pr_b[i] : zc;
+                chl[i / CH] = chl[i / CH] || live;
+            }
+#pragma unroll 1
+            for (int k0 = 0; k0 < AVT_EVAL_ROWS; k0 += 4) {
+                double fa[MAXPW], fbv[MAXPW];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+                    if (chl[c]) {
+#pragma unroll
+                        for (int i = c * CH; i < (c + 1) * CH && i < MAXPW; ++i) { fa[i] = qa[i][k0]; fbv[i] = qb[i][k0]; }
+                    }
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+                    if (chl[c]) {
+#pragma unroll
+                        for (int i = c * CH; i < (c + 1) * CH && i < MAXPW; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fbv[i], acc[i], 0, 0, 0);
+                    }
             }
         }
     }
@@ -515,8 +589,31 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : (MT > 8 ? 1 : 2)) void k_eval(
     }
     // partial tiles out: element (row = (ln>>4) + 4*reg, col = ln&15) of pair p at [p][reg*64 + ln]
     double* part = fb.partial + (((size_t)f * G + g) * NPAIR) * 256;
+    if constexpr (ROWDEAL) {
+        auto out_role = [&](auto wc) {
+            constexpr int W = decltype(wc)::value;
+            int slot = 0;
 #pragma unroll
-    for (int i = 0; i < MAXPW; ++i) {
+            for (int r = 0; r < MT; ++r) {
+                if (rd_wave(r) != W) continue;
+#pragma unroll
+                for (int tj = r; tj < MT; ++tj) {
+                    const int p = rd_pair(MT, r, tj);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) part[(size_t)p * 256 + q * 64 + ln] = acc[slot + tj - r][q];
+                }
+                slot += MT - r;
+            }
+        };
+        switch (__builtin_amdgcn_readfirstlane(wv)) {
+            case 0: out_role(std::integral_constant<int, 0>{}); break;
+            case 1: out_role(std::integral_constant<int, 1>{}); break;
+            case 2: out_role(std::integral_constant<int, 2>{}); break;
+            default: out_role(std::integral_constant<int, 3>{}); break;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < (ROWDEAL ? 0 : MAXPW); ++i) {
         int p = wv + 4 * i;
         if constexpr (FIXED) p = (i < 5 || wv == 0) ? dp_bit[i] : NPAIR;     // my dealt pairs; wave 0 also writes the split pair
         if (p < NPAIR && (p >= 64 || ((wm >> (p & 63)) & 1))) {   // untouched pairs stay unwritten: k_reduce reads the mask
@@ -542,7 +639,14 @@ void launch_eval(avt_ctx* c, int nframes, bool cost_only) {
 #define AVT_EVAL_LAUNCH(...) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<__VA_ARGS__>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, nframes)
     if (eval_fixed_shape(d)) { if (cost_only) AVT_EVAL_LAUNCH(24, 10, 6, true); else AVT_EVAL_LAUNCH(24, 10, 6, false); }
     else if (d.NT <= 8) { if (cost_only) AVT_EVAL_LAUNCH(0, 0, 8, true); else AVT_EVAL_LAUNCH(0, 0, 8, false); }
-    else { if (cost_only) AVT_EVAL_LAUNCH(0, 0, AVT_MAX_TILES, true); else AVT_EVAL_LAUNCH(0, 0, AVT_MAX_TILES, false); }
+    else {
+        switch (d.NT) {       // row-dealt shapes: NT is a template argument
+            case 9: if (cost_only) AVT_EVAL_LAUNCH(0, 0, 9, true); else AVT_EVAL_LAUNCH(0, 0, 9, false); break;
+            case 10: if (cost_only) AVT_EVAL_LAUNCH(0, 0, 10, true); else AVT_EVAL_LAUNCH(0, 0, 10, false); break;
+            case 11: if (cost_only) AVT_EVAL_LAUNCH(0, 0, 11, true); else AVT_EVAL_LAUNCH(0, 0, 11, false); break;
+            default: if (cost_only) AVT_EVAL_LAUNCH(0, 0, 12, true); else AVT_EVAL_LAUNCH(0, 0, 12, false); break;
+        }
+    }
 #undef AVT_EVAL_LAUNCH
 }
 
@@ -552,11 +656,17 @@ void avt_eval_report_occupancy(const AvtDims& d) {
     fprintf(stderr, "[avt] k_eval<24,10>: dynamic LDS %zu B, occupancy query -> %d blocks/CU (%s)\n", eval_lds_bytes(d), nb, hipGetErrorString(e));
 }
 
+template <int NTX>
+static int eval_big_attr() {
+    static_assert(NTX <= AVT_MAX_TILES, "row-dealt evaluation shapes up to AVT_MAX_TILES column tiles");
+    return hipFuncSetAttribute((const void*)k_eval<0, 0, NTX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_eval<0, 0, NTX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess;
+}
+
 int avt_eval_set_attributes() {
     // the fixed-shape kernel needs < 64 KB of dynamic LDS: leave its attribute alone (raising the cap costs residency);
     // the generic shape may need more.
     return hipFuncSetAttribute((const void*)k_eval<0, 0, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
            hipFuncSetAttribute((const void*)k_eval<0, 0, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
-           hipFuncSetAttribute((const void*)k_eval<0, 0, AVT_MAX_TILES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess ||
-           hipFuncSetAttribute((const void*)k_eval<0, 0, AVT_MAX_TILES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess;
+           eval_big_attr<9>() || eval_big_attr<10>() || eval_big_attr<11>() || eval_big_attr<12>();
 }
