@@ -282,8 +282,8 @@ __device__ __forceinline__ void backsub_blocked(const double* __restrict__ Lblk,
 // The same back substitution for the packed-triangle storage and up to 192 unknowns (three columns per lane of the wave).
 // W(k,l) = 0 for l >= k by a select instead of by stored zeros.  Everything a step reads from the factor - the diagonal block,
 // the reciprocal pivots, this lane's three column blocks - has an address that does not depend on the unknowns, so it is
-// requested one step ahead; a step is then readlanes, the 4-unknown chain and 12 FMAs (61 k -> ... clocks for 43 steps
-// before / after on the 52-joint model, tools/big_model_phase_probe.py).
+// requested one step ahead; a step is then readlanes, the 4-unknown chain and 12 FMAs (61 k -> 40 k clocks for 43 steps
+// on the 52-joint model, tools/big_model_phase_probe.py; what is left is the instruction issue of one wave, ~100 per step).
 __device__ __forceinline__ void backsub_tri(const double* __restrict__ Lblk, const double* __restrict__ s_R, int NB, int P, int t,
                                             double* __restrict__ s_delta) {
     auto blockp = [&](int kb, int bi) { return Lblk + (size_t)wblk<true>(kb, bi, NB) * 18; };
@@ -310,6 +310,8 @@ __device__ __forceinline__ void backsub_tri(const double* __restrict__ Lblk, con
         }
         return s;
     };
+    // (two named buffers swapping roles instead of the copy below cost more than the copy: the kernel runs at 128 registers per lane
+    // and the second buffer spilled - 66 k clocks against 40 k)
     Step nx = fetch(NB - 1);
     for (int kb = NB - 1; kb >= 0; --kb) {
         const Step cu = nx;
@@ -327,10 +329,9 @@ __device__ __forceinline__ void backsub_tri(const double* __restrict__ Lblk, con
         const double d0 = r0 * fma(-w10, d1, fma(-w20, d2, fma(-w30, d3, u0)));
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const bool below = live[c] && kb > cbk[c], diag = live[c] && kb == cbk[c];
+            // (rows of my own pivot block would only change sums whose unknowns this step has just finished; lanes past P are never read)
             const double full = fma(cu.bp[c][0], d0, cu.bp[c][1] * d1) + fma(cu.bp[c][2], d2, cu.bp[c][3] * d3);
-            const double part = (li[c] < 1 ? cu.bp[c][1] * d1 : 0.0) + (li[c] < 2 ? cu.bp[c][2] * d2 : 0.0) + (li[c] < 3 ? cu.bp[c][3] * d3 : 0.0);
-            acc[c] += below ? full : (diag ? part : 0.0);
+            acc[c] += kb > cbk[c] ? full : 0.0;
         }
         if (t == 0) { d2v* o = (d2v*)(s_delta + base); o[0] = (d2v){d0, d1}; o[1] = (d2v){d2, d3}; }
     }
