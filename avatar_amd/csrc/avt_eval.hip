@@ -327,7 +327,7 @@ __host__ __device__ constexpr int rd_pair(int NT, int ti, int tj) { return ti * 
 
 // COST: the evaluation behind which no solve follows - residual column and tile pair (res, res) only (see build_rows)
 template <int CJ, int CK, int MT, bool COST>
-__global__ __launch_bounds__(256, (CJ != 0) ? 3 : (MT > 8 ? 1 : 2)) void k_eval(DeviceModel dm, FrameBuffers fb, int nframes) {
+__global__ __launch_bounds__(256, (CJ != 0) ? 3 : 1) void k_eval(DeviceModel dm, FrameBuffers fb, int nframes) {
     constexpr bool FIXED = CJ != 0;
     const AvtDims d = dm.d;
     const int J = FIXED ? CJ : d.J, K = FIXED ? CK : d.K, P = 3 + 3 * J + K;
