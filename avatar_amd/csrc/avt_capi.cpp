@@ -130,7 +130,7 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
         { ProfScope ps(c, AVT_K_EVAL); launch_eval(c, nf, false); }
         if (!rides) { ProfScope ps(c, AVT_K_REDUCE); launch_reduce(c, nf); }
         for (int it = 1; it <= std::max(1, o->max_iters_per_icp); ++it) {
-            { ProfScope ps(c, AVT_K_SOLVE); launch_solve(c, nf, it == 1 ? SOLVE_FIRST : SOLVE_NORMAL); }
+            { ProfScope ps(c, AVT_K_SOLVE); launch_solve(c, nf, it == 1 ? SOLVE_FIRST : SOLVE_NORMAL, it); }
             if (o->max_iters_per_icp == 0) break;
             if (it < o->max_iters_per_icp) {
                 { ProfScope ps(c, AVT_K_EVAL); launch_eval(c, nf, false); }
@@ -428,7 +428,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         dev_alloc(c, &fb.dz, FN) || dev_alloc(c, &fb.dorig, FN) || dev_alloc(c, &fb.part_off, (size_t)max_frames * (num_parts + 1)) || dev_alloc(c, &fb.part_cnt, (size_t)max_frames * 2 * (AVT_MAX_PARTS + 1)) ||
         dev_alloc(c, &fb.corr, FN) || dev_alloc(c, &fb.corr_sorted, FN) || dev_alloc(c, &fb.cloud, FV * 3) || dev_alloc(c, &fb.pcx, FV) ||
         dev_alloc(c, &fb.pcy, FV) || dev_alloc(c, &fb.pcz, FV) || dev_alloc(c, &fb.visible, FV) || dev_alloc(c, &fb.vcx, FV) || dev_alloc(c, &fb.vcy, FV) ||
-        dev_alloc(c, &fb.vcz, FV) || dev_alloc(c, &fb.vcid, FV) || dev_alloc(c, &fb.vcount, (size_t)max_frames * num_parts) || dev_alloc(c, &fb.vis_sorted, FV) || dev_alloc(c, &fb.ride_ctr, (size_t)max_frames) ||
+        dev_alloc(c, &fb.vcz, FV) || dev_alloc(c, &fb.vcid, FV) || dev_alloc(c, &fb.vcount, (size_t)max_frames * num_parts) || dev_alloc(c, &fb.vis_sorted, FV) || dev_alloc(c, &fb.ride_ctr, (size_t)max_frames) || dev_alloc(c, &fb.spec, (size_t)max_frames) || dev_alloc(c, &fb.x_spec, (size_t)max_frames * AVT_MAX_SPEC * d.xsize) || dev_alloc(c, &fb.prep_spec, (size_t)max_frames * AVT_MAX_SPEC * d.prep_size) ||
         dev_alloc(c, &cntsum, FV * (sizeof(int) + 3 * sizeof(long long)) + 64) || dev_alloc(c, &fb.matched, FV) ||
         dev_alloc(c, &fb.const_part, (size_t)max_frames * fb.const_blocks) ||
         dev_alloc(c, &fb.x, (size_t)max_frames * 2 * d.xsize) || dev_alloc(c, &fb.x_start, (size_t)max_frames * 2 * d.xsize) ||
@@ -448,6 +448,8 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
     HIP_OK(hipMemset(fb.trace, 0, (size_t)max_frames * 64 * sizeof(double)));
     HIP_OK(hipMemset(fb.ctl, 0, (size_t)max_frames * sizeof(AvtFrameCtl)));
     HIP_OK(hipMemset(fb.ride_ctr, 0, (size_t)max_frames * sizeof(unsigned)));
+    HIP_OK(hipMemset(fb.spec, 0, (size_t)max_frames * sizeof(AvtSpecCtl)));
+    fb.nspec = 0; fb.seq = 0;
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemset(fb.part_cnt, 0, (size_t)max_frames * 2 * (AVT_MAX_PARTS + 1) * sizeof(int)));   // invariant of launch_bucket
     if (getenv("AVT_DEBUG")) avt_eval_report_occupancy(dm.d);

@@ -119,6 +119,16 @@ struct AvtFrameCtl {
 
 // the knobs of optimize() the kernels read (avt_options), kept in device memory so that they are not baked into the
 // captured launch sequence: a tracker that varies betaPose / the LM scalars replays the same hipGraph
+// Speculative LM steps (avt_lm.hip): a rejected trial point is followed by a solve of the SAME system with a larger lambda, so
+// the solve launch factors that system for lambda, lambda up, lambda up^2 .. side by side (one workgroup each); after a rejection
+// the next launch installs the step that is already there instead of factoring again.
+#define AVT_MAX_SPEC 4
+struct AvtSpecCtl {
+    int next, n;                   // next speculative step to use, how many the last full solve launch made
+    int valid[AVT_MAX_SPEC];       // its factorisation succeeded
+    double lambda[AVT_MAX_SPEC];   // the damping it was made with (= what the accept test would have set)
+};
+
 struct AvtRunParams {
     double beta_pose, beta_shape, lambda0, lm_up, lm_down, lm_min, lm_max, pad;
 };
@@ -169,6 +179,8 @@ struct DeviceModel {
 struct FrameBuffers {
     int max_frames, max_points;   // per frame
     int G;                        // eval blocks per frame
+    int nspec;                    // speculative solver workgroups per frame in the current k_solve launch (riding shape; 0: none)
+    int seq;                      // which solve of the ICP iteration the current k_solve launch is (1 = FIRST): the riding reduction counts up to seq x its workgroups
     int f0;                       // first frame of the frame group a launch covers (grid frame index is relative to it)
     // raw inputs
     double* data_raw;     // [max_frames*max_points][3]
@@ -187,7 +199,10 @@ struct FrameBuffers {
     double* vcx; double* vcy; double* vcz;   // [max_frames][V] visible model points, compacted per part segment
     int* vcid;                               // [max_frames][V] vertex id of each compacted candidate
     int* vcount;                             // [max_frames][num_parts] visible candidates per part
-    unsigned* ride_ctr;                      // [max_frames] reduction workgroups of the current k_solve launch that have delivered (zero between launches)
+    unsigned* ride_ctr;                      // [max_frames] reduction workgroups that have delivered since k_finalize cleared it (k_solve launch seq waits for seq x its reduction workgroups)
+    AvtSpecCtl* spec;                        // [max_frames] speculative steps of the current system (avt_lm.hip)
+    double* x_spec;                          // [max_frames][AVT_MAX_SPEC][xsize] their trial states ...
+    double* prep_spec;                       // [max_frames][AVT_MAX_SPEC][prep_size] ... and skeleton tables
     unsigned char* vis_sorted;               // [max_frames][V] the visibility flags in part-sorted order (inside optimize(): k_nn_vis)
     // correspondence aggregation
     int* cnt;             // [max_frames][V]
@@ -283,5 +298,5 @@ void launch_eval(avt_ctx* c, int nframes, bool cost_only = false);
 void launch_records(avt_ctx* c, int nframes);
 void launch_reduce(avt_ctx* c, int nframes);
 bool avt_solve_rides(const avt_ctx* c, int nframes);      // the reduction rides in k_solve's launch: no launch_reduce in front of launch_solve
-void launch_solve(avt_ctx* c, int nframes, int mode);
+void launch_solve(avt_ctx* c, int nframes, int mode, int seq = 0 /* which solve of the ICP iteration (riding shape) */);
 void launch_pack_results(avt_ctx* c, int nframes, double* out, int stride);

@@ -18,7 +18,7 @@
 #include "avt_device.h"
 
 #ifdef AVT_TIMING
-#define TPROBE(i) do { if (threadIdx.x == 0) fb.trace[(size_t)(blockIdx.x + fb.f0) * 64 + 40 + (i)] = (double)clock64(); } while (0)
+#define TPROBE(i) do { if (threadIdx.x == 0 && blockIdx.y == 0) fb.trace[(size_t)(blockIdx.x + fb.f0) * 64 + 40 + (i)] = (double)clock64(); } while (0)
 #else
 #define TPROBE(i) do {} while (0)
 #endif
@@ -644,8 +644,11 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     constexpr int mode = MODE;
     static_assert(!RIDE || (NTH == 256 && !TRI && MODE != SOLVE_INIT), "the riding reduction exists for the 256-thread solves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if constexpr (RIDE) {      // grid (frames, 1 + RIDE NPAIR): y = 0 the solver, the rest the reduction in front of it
-        if (blockIdx.y > 0) { reduce_ride_block<RIDE>(dm, fb, blockIdx.x + fb.f0, (int)blockIdx.y - 1, (double*)smem); return; }
+    // RIDE: grid (frames, 1 + nspec + RIDE NPAIR): y = 0 the solver, y = 1 .. nspec the speculative solvers (the same system with
+    // lambda up, lambda up^2 ..: the steps a run of rejected trial points will ask for), the rest the reduction in front of them
+    const int role = RIDE ? (int)blockIdx.y : 0;
+    if constexpr (RIDE) {
+        if (role > fb.nspec) { reduce_ride_block<RIDE>(dm, fb, blockIdx.x + fb.f0, role - 1 - fb.nspec, (double*)smem); return; }
     }
     __builtin_amdgcn_s_setprio(3);   // one dependency chain per frame: issue ahead of the evaluation waves of another frame group on this CU
     const AvtDims d = dm.d;
@@ -712,8 +715,8 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     if constexpr (RIDE) {      // the reduction workgroups of this launch have all delivered their strips of the trial point's system
         if (t == 0) {
             int spins = 0;
-            while (__hip_atomic_load(fb.ride_ctr + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(RIDE * d.NPAIR) && spins < (1 << 20)) { __builtin_amdgcn_s_sleep(1); ++spins; }
-            __hip_atomic_store(fb.ride_ctr + f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next launch (a kernel boundary lies between)
+            // (the count runs on from launch to launch of an ICP iteration - k_finalize clears it -: several workgroups wait on it)
+            while (__hip_atomic_load(fb.ride_ctr + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(fb.seq * RIDE * d.NPAIR) && spins < (1 << 20)) { __builtin_amdgcn_s_sleep(1); ++spins; }
         }
         __syncthreads();
     }
@@ -803,7 +806,18 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     }
     const double cost_cur = accepted ? cost : cost_cur0;
     const int comp = accepted ? comp_try : comp_cur0;
-    if (t == 0) {
+    // Speculative steps (RIDE shapes): a rejected trial point is followed by a solve of the SAME system with lambda up - which
+    // a speculative workgroup of the last full solve launch has already made.  The solver then installs it (trial state and
+    // skeleton tables copied into the trial slot) instead of factoring, and the speculative workgroups of this launch go home.
+    AvtSpecCtl& sp = fb.spec[f];
+    const int sp_next = sp.next, sp_n = sp.n;
+    const bool rejected = mode != SOLVE_FIRST && try_valid && !accepted;
+    const bool use_spec = RIDE && rejected && sp_next < sp_n && sp.valid[min(sp_next, AVT_MAX_SPEC - 1)] != 0;
+    if (RIDE && role > 0 && use_spec) return;
+    if (RIDE && role > 0) {      // my damping: what `role` rejections in a row would make of the solver's
+        for (int i = 0; i < role; ++i) lambda = fmin(lambda * lm_up, lm_max);
+    }
+    if (t == 0 && role == 0) {
         ctl.cur_slot = cur;
         ctl.cost_cur = cost_cur;
         ctl.comp_cur = comp;
@@ -811,6 +825,20 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         if (mode == SOLVE_FIRST) { ctl.cost_initial = cost; ctl.cost_const = cost_const; }
         else { it += 1; ctl.gn_iterations = it; if (accepted) ctl.accepted += 1; }
         if (it < 40) fb.trace[(size_t)f * 64 + it] = cost_cur;
+    }
+    if (RIDE && use_spec) {      // (role 0) the step exists: install it as the new trial point
+        const int k = sp_next, tr = 1 - cur;
+        const double* xsrc = fb.x_spec + ((size_t)f * AVT_MAX_SPEC + k) * xs;
+        const double* psrc = fb.prep_spec + ((size_t)f * AVT_MAX_SPEC + k) * d.prep_size;
+        for (int e = t; e < xs; e += NTH) x0[(size_t)tr * xs + e] = xsrc[e];
+        for (int e = t; e < d.prep_size; e += NTH) prep0[(size_t)tr * d.prep_size + e] = psrc[e];
+        if (t == 0) {
+            const double lam = sp.lambda[k];
+            sp.next = k + 1;
+            ctl.lambda = lam; ctl.try_valid = 1;
+            ctl.dec_cur_slot = cur; ctl.dec_try_valid = 1; ctl.dec_cost_cur = cost_cur; ctl.dec_lambda = lam;
+        }
+        return;
     }
     TPROBE(1);
 
@@ -906,7 +934,9 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     TPROBE(3);
     const bool ok = !fail;
     const int ntry = 1 - cur;
-    double* xn = x0 + (size_t)ntry * xs;
+    // where the new trial point goes: the trial slot, or (speculative solver) its own slot until a rejection asks for it
+    double* xn = role == 0 ? x0 + (size_t)ntry * xs : fb.x_spec + ((size_t)f * AVT_MAX_SPEC + (role - 1)) * xs;
+    double* prep_out = role == 0 ? prep0 + (size_t)ntry * d.prep_size : fb.prep_spec + ((size_t)f * AVT_MAX_SPEC + (role - 1)) * d.prep_size;
     double* s_qnew = s_W;                                   // [4J] quaternions of the new trial point (s_W is free again)
     if (ok) {
         // ---- back substitution by wave 0 (the other waves wait at the barrier)
@@ -953,15 +983,18 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         prep_set_state(d, L, B, xc + 3, xc + 3 + 4 * J, xc);
         lambda = fmin(lambda * lm_up, lm_max);
     }
-    if (t == 0) {
+    if (t == 0 && role == 0) {
         ctl.lambda = lambda; ctl.try_valid = ok ? 1 : 0;
         // what the accept test of the trial point just made reads if no further solve follows (avt_decide.h)
         ctl.dec_cur_slot = cur; ctl.dec_try_valid = ok ? 1 : 0; ctl.dec_cost_cur = cost_cur; ctl.dec_lambda = lambda;
+        if (RIDE) { sp.next = 0; sp.n = fb.nspec; }          // the speculative workgroups of this launch are making steps 0 .. nspec - 1
     }
+    if (RIDE && t == 0 && role > 0) { sp.valid[role - 1] = ok ? 1 : 0; sp.lambda[role - 1] = lambda; }
+    if (RIDE && role > 0 && !ok) return;                     // (a refused speculative factorisation: the slot stays invalid)
     __syncthreads();
     TPROBE(5);
     // ---- d. skeleton tables of the new trial point ----------------------------------------------------
-    prep_run<NTH>(dm, L, B, s_items, s_level, s_qnew, prep0 + (size_t)ntry * d.prep_size);
+    prep_run<NTH>(dm, L, B, s_items, s_level, s_qnew, prep_out);
     TPROBE(6);
 #ifdef AVT_TIMING
     __syncthreads();
@@ -1006,6 +1039,13 @@ static void launch_solve_shape(avt_ctx* c, int nframes, int mode, size_t lds) {
 // few frames, 256-thread solves: the reduction of the trial point's system rides in the solve's launch (no launch_reduce in front)
 // (while every workgroup of the launch - 1 + 4 NPAIR per frame, one per CU with the solver's LDS request - is resident at once:
 // three SMPL frames on 256 CUs; six frames in two rounds measured 0.751 against 0.689 ms with the reduction as its own launch)
+// speculative solver workgroups per frame (AVT_NSPEC, default 2) next to the solver, as many as leave the grid resident
+static int ride_nspec(const avt_ctx* c, int nframes, int strips) {
+    int want = 2;
+    if (const char* e = getenv("AVT_NSPEC")) want = std::max(0, std::min(AVT_MAX_SPEC, atoi(e)));
+    while (want > 0 && nframes * (1 + want + strips * c->dm.d.NPAIR) > c->num_cus) --want;
+    return want;
+}
 static int ride_strips(const avt_ctx* c, int nframes) {      // 8 strips per pair while the whole grid is resident (one SMPL frame), else 4, else none
     if (c->fb.G < 64 || solve_big(c->dm.d) || getenv("AVT_NO_RIDE")) return 0;
     int want = 8;
@@ -1015,11 +1055,13 @@ static int ride_strips(const avt_ctx* c, int nframes) {      // 8 strips per pai
 }
 bool avt_solve_rides(const avt_ctx* c, int nframes) { return ride_strips(c, nframes) != 0; }
 
-void launch_solve(avt_ctx* c, int nframes, int mode) {
+void launch_solve(avt_ctx* c, int nframes, int mode, int seq) {
     const AvtDims& d = c->dm.d;
     const int rs = mode != SOLVE_INIT ? ride_strips(c, nframes) : 0;
+    c->fb.nspec = 0; c->fb.seq = seq;
     if (rs) {
-        const dim3 grid(nframes, 1 + rs * d.NPAIR);
+        c->fb.nspec = ride_nspec(c, nframes, rs);
+        const dim3 grid(nframes, 1 + c->fb.nspec + rs * d.NPAIR);
 #define AVT_RIDE(M, S) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256, false, M, S>), grid, dim3(256), solve_lds_bytes(d), c->cur_stream, c->dm, c->fb)
         if (mode == SOLVE_FIRST) { if (rs == 8) AVT_RIDE(SOLVE_FIRST, 8); else AVT_RIDE(SOLVE_FIRST, 4); }
         else { if (rs == 8) AVT_RIDE(SOLVE_NORMAL, 8); else AVT_RIDE(SOLVE_NORMAL, 4); }
