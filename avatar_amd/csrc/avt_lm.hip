@@ -1041,7 +1041,11 @@ static void launch_solve_shape(avt_ctx* c, int nframes, int mode, size_t lds) {
 // three SMPL frames on 256 CUs; six frames in two rounds measured 0.751 against 0.689 ms with the reduction as its own launch)
 // speculative solver workgroups per frame (AVT_NSPEC, default 2) next to the solver, as many as leave the grid resident
 static int ride_nspec(const avt_ctx* c, int nframes, int strips) {
-    int want = 2;
+    // over twelve frames, one frame each: 0 / 2 / 3 / 4 speculative workgroups 0.5045 / 0.4305 / 0.4217 / 0.4166 ms (rejections come
+    // in runs of up to five).  Frame batches gain nothing from them - a launch lasts as long as its slowest frame, and with four
+    // frames or more some frame always needs a full solve (4 / 8 / 16 / 64 frames: 0.639 / 0.712 / 0.786 / 1.247 ms without,
+    // 0.643 / 0.712 / 0.793 / 1.317 ms with four speculative workgroups per frame) - so only the riding shapes have them.
+    int want = AVT_MAX_SPEC;
     if (const char* e = getenv("AVT_NSPEC")) want = std::max(0, std::min(AVT_MAX_SPEC, atoi(e)));
     while (want > 0 && nframes * (1 + want + strips * c->dm.d.NPAIR) > c->num_cus) --want;
     return want;
