@@ -34,7 +34,7 @@ REGIONS = 15                   # the K-step timed region is repeated this many t
 # what actually limits each kernel class (counters under profiles/): the HBM roofline is the yard-stick
 # SURVEY.md §8(d) prescribes, it is NOT what bounds the latency-bound kernels
 LIMITER = {
-    "solve": "latency: one workgroup per frame walking an 85-pivot LDL^T dependency chain (working set in LDS/L2)",
+    "solve": "latency: one workgroup per frame walking an 85-pivot LDL^T dependency chain (working set in LDS/L2); one or two frames: the steps a run of rejections asks for are factored speculatively beside it, a launch that installs one is ~10 us",
     "eval": "LDS pipe and dependent-latency chains of the row builder at three workgroups per CU; fp64 MFMA contraction behind it",
     "reduce": "L2 round trips (partial tiles live in L2/MALL)",
     "nn": "fp64 VALU issue (8 flop + one v_min per candidate, candidates through scalar loads)",
