@@ -286,3 +286,34 @@ def test_in_launch_hand_over_is_reproducible(smpl, gmodel):
         res[F] = ref
     for F in (3, 4):
         assert np.abs(res[F][0][0] - res[1][0][0]).max() < 1e-9 and np.abs(res[F][1][0] - res[1][1][0]).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_speculative_steps_do_not_change_a_bit(smpl, gmodel):
+    """One and two frames: the solve launch factors the steps a run of rejections will ask for beside the one needed now, and a
+    rejection installs the step that is already there.  With the speculative workgroups switched off
+    (AVT_NSPEC=0, read when the launch is enqueued) every step is factored when it is asked for: same bytes."""
+    import os
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    outs = {}
+    old = os.environ.get("AVT_NSPEC")
+    try:
+        for nspec in ("0", "4", "1"):
+            os.environ["AVT_NSPEC"] = nspec
+            res = []
+            for F, seeds in ((1, (4, 8)), (2, (5, 6))):       # frames with runs of three to five rejections
+                frs = [synth.make_frame(smpl, s) for s in seeds[:F]] if F == 2 else None
+                for s in (seeds if F == 1 else (0,)):
+                    fl = [synth.make_frame(smpl, s)] if F == 1 else frs
+                    ctx = api.Context(gmodel, 24, pm, 60000, F)
+                    p, q, w, st = ctx.optimize_batch([f["data"] for f in fl], [f["labels"] for f in fl], Options.demo(icp_iters=2),
+                                                     np.array([f["start"][1] for f in fl]), np.array([api.rot_to_quat(f["start"][2]) for f in fl]),
+                                                     np.array([f["start"][0] for f in fl]))
+                    res += [p.ravel(), q.ravel(), w.ravel(), np.array([x.final_cost for x in st]), np.array([x.accepted_steps for x in st], float)]
+            outs[nspec] = np.concatenate(res)
+    finally:
+        if old is None: os.environ.pop("AVT_NSPEC", None)
+        else: os.environ["AVT_NSPEC"] = old
+    assert np.array_equal(outs["0"], outs["4"]) and np.array_equal(outs["0"], outs["1"])
+    assert outs["0"].size > 400
