@@ -712,6 +712,21 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     const int mf_wv = t >> 6, mf_g4 = (t >> 4) & 3, mf_c16 = t & 15, mf_rA = 5 - mf_wv, mf_rB = mf_wv - 2;
     // (six tile slots per wave: slot s <= rA is tile (rA, s), the slots behind are tiles (rB, 0..rB))
     double mraw[TRI ? 1 : 2][TRI ? 1 : 6][4];
+    // (solver, RIDE) the speculative step the accept test may ask for in a moment: its 10 KB are requested now, while the reduction
+    // is still on its way, so that a rejection only has to store them
+    // (256-thread shape: 3 + 3J + K <= 87 and K <= 16 bound the prep block by 1496 doubles and the state by 115)
+    constexpr int SPN = RIDE ? (1496 + 120 + NTH - 1) / NTH : 1;
+    double sp_pre[SPN];
+    if constexpr (RIDE) {
+        const int k = min(fb.spec[f].next, AVT_MAX_SPEC - 1), ncopy = xs + d.prep_size;
+        const double* xsrc = fb.x_spec + ((size_t)f * AVT_MAX_SPEC + k) * xs;
+        const double* psrc = fb.prep_spec + ((size_t)f * AVT_MAX_SPEC + k) * d.prep_size;
+#pragma unroll
+        for (int i = 0; i < SPN; ++i) {
+            const int e = t + i * NTH;
+            sp_pre[i] = (role == 0 && e < ncopy) ? (e < xs ? xsrc[e] : psrc[e - xs]) : 0.0;
+        }
+    }
     if constexpr (RIDE) {      // the reduction workgroups of this launch have all delivered their strips of the trial point's system
         if (t == 0) {
             int spins = 0;
@@ -830,8 +845,13 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         const int k = sp_next, tr = 1 - cur;
         const double* xsrc = fb.x_spec + ((size_t)f * AVT_MAX_SPEC + k) * xs;
         const double* psrc = fb.prep_spec + ((size_t)f * AVT_MAX_SPEC + k) * d.prep_size;
-        for (int e = t; e < xs; e += NTH) x0[(size_t)tr * xs + e] = xsrc[e];
-        for (int e = t; e < d.prep_size; e += NTH) prep0[(size_t)tr * d.prep_size + e] = psrc[e];
+        (void)xsrc; (void)psrc;
+#pragma unroll
+        for (int i = 0; i < SPN; ++i) {
+            const int e = t + i * NTH;
+            if (e < xs) x0[(size_t)tr * xs + e] = sp_pre[i];
+            else if (e < xs + d.prep_size) prep0[(size_t)tr * d.prep_size + (e - xs)] = sp_pre[i];
+        }
         if (t == 0) {
             const double lam = sp.lambda[k];
             sp.next = k + 1;
