@@ -57,6 +57,21 @@ int choose_groups(int nframes) {
     return std::max(1, std::min(std::min(n, AVT_MAX_GROUPS), nframes));
 }
 
+// Frame groups of one optimize() call.  Two or three frames: one frame per group when the one-frame launch shape has the speculative
+// solver workgroups - in a shared launch a rejection saves its factorisation only if every frame of the launch
+// rejects, on a stream of its own every frame keeps its own pace (2 frames 0.477 -> 0.457 ms, 3 frames 0.607 -> 0.526; four: 0.637 -> 0.709).
+int choose_G(int nframes);
+int plan_groups(avt_ctx* c, int nf) {
+    int ngroups = choose_groups(nf);
+    if ((nf == 2 || nf == 3) && !getenv("AVT_GROUPS") && !getenv("AVT_ONE_GROUP")) {
+        const int g_keep = c->fb.G;
+        c->fb.G = choose_G(1);
+        if (avt_solve_rides(c, 1)) ngroups = nf;
+        c->fb.G = g_keep;
+    }
+    return ngroups;
+}
+
 int choose_G(int nframes) {
     // k_eval workgroups per frame.  Up to 64 frames per launch: 768 workgroups = one resident round at 3 per CU (more rounds
     // cost more in partial tiles and prologues than they balance: 128 frames per group 645 k against 609 k GN it/s with twice as
@@ -177,7 +192,7 @@ int run_optimize(avt_ctx* c, const avt_options* o) {
     // (k_solve, k_finalize, k_reduce) overlap the throughput kernels (k_eval, k_nn) of the others on separate streams.
     // The instrumented (profiling) path keeps the SAME groups and launch shapes and runs them one after the other on
     // the main stream, so that per-launch timings describe the launches the graph replays.
-    const int ngroups = choose_groups(nf);
+    const int ngroups = plan_groups(c, nf);
     const int nfg = (nf + ngroups - 1) / ngroups;       // frames per group (the last group may be smaller)
     c->fb.G = choose_G(nfg);
     if (!c->use_graph || c->profiling) {
@@ -428,7 +443,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         dev_alloc(c, &fb.dz, FN) || dev_alloc(c, &fb.dorig, FN) || dev_alloc(c, &fb.part_off, (size_t)max_frames * (num_parts + 1)) || dev_alloc(c, &fb.part_cnt, (size_t)max_frames * 2 * (AVT_MAX_PARTS + 1)) ||
         dev_alloc(c, &fb.corr, FN) || dev_alloc(c, &fb.corr_sorted, FN) || dev_alloc(c, &fb.cloud, FV * 3) || dev_alloc(c, &fb.pcx, FV) ||
         dev_alloc(c, &fb.pcy, FV) || dev_alloc(c, &fb.pcz, FV) || dev_alloc(c, &fb.visible, FV) || dev_alloc(c, &fb.vcx, FV) || dev_alloc(c, &fb.vcy, FV) ||
-        dev_alloc(c, &fb.vcz, FV) || dev_alloc(c, &fb.vcid, FV) || dev_alloc(c, &fb.vcount, (size_t)max_frames * num_parts) || dev_alloc(c, &fb.vis_sorted, FV) || dev_alloc(c, &fb.ride_ctr, (size_t)max_frames) || dev_alloc(c, &fb.spec, (size_t)max_frames) || dev_alloc(c, &fb.x_spec, (size_t)max_frames * AVT_MAX_SPEC * d.xsize) || dev_alloc(c, &fb.prep_spec, (size_t)max_frames * AVT_MAX_SPEC * d.prep_size) ||
+        dev_alloc(c, &fb.vcz, FV) || dev_alloc(c, &fb.vcid, FV) || dev_alloc(c, &fb.vcount, (size_t)max_frames * num_parts) || dev_alloc(c, &fb.vis_sorted, FV) || dev_alloc(c, &fb.ride_ctr, (size_t)max_frames) || dev_alloc(c, &fb.spec, (size_t)max_frames) || dev_alloc(c, &fb.snap, (size_t)max_frames) || dev_alloc(c, &fb.x_spec, (size_t)max_frames * AVT_MAX_SPEC * d.xsize) || dev_alloc(c, &fb.prep_spec, (size_t)max_frames * AVT_MAX_SPEC * d.prep_size) ||
         dev_alloc(c, &cntsum, FV * (sizeof(int) + 3 * sizeof(long long)) + 64) || dev_alloc(c, &fb.matched, FV) ||
         dev_alloc(c, &fb.const_part, (size_t)max_frames * fb.const_blocks) ||
         dev_alloc(c, &fb.x, (size_t)max_frames * 2 * d.xsize) || dev_alloc(c, &fb.x_start, (size_t)max_frames * 2 * d.xsize) ||
@@ -766,7 +781,7 @@ int avt_debug_trace(avt_ctx* c, int frame, double* out64) {
 
 int avt_launch_shape(avt_ctx* c, int* groups, int* frames_per_group, int* eval_workgroups_per_frame) {
     if (!c || c->nframes <= 0) { avt_set_error("avt_launch_shape: no frames resident"); return 1; }
-    const int ng = choose_groups(c->nframes), nfg = (c->nframes + ng - 1) / ng;
+    const int ng = plan_groups(c, c->nframes), nfg = (c->nframes + ng - 1) / ng;
     if (groups) *groups = ng;
     if (frames_per_group) *frames_per_group = nfg;
     if (eval_workgroups_per_frame) *eval_workgroups_per_frame = choose_G(nfg);

@@ -129,6 +129,16 @@ struct AvtSpecCtl {
     double lambda[AVT_MAX_SPEC];   // the damping it was made with (= what the accept test would have set)
 };
 
+// What the solver roles of a riding k_solve launch decide on (avt_lm.hip): the control block, the speculative-step queue and the
+// shape coefficients of the trial point as the evaluation launch in front of it saw them.  The solver rewrites the live copies
+// while the launch runs; a speculative workgroup that starts late (another stream's work on its CU) must still see the inputs
+// the solver saw, so every role reads this snapshot, which nobody writes during the launch.
+struct AvtSolveSnap {
+    AvtFrameCtl ctl;
+    AvtSpecCtl sp;
+    double xw[AVT_MAX_SHAPE];
+};
+
 struct AvtRunParams {
     double beta_pose, beta_shape, lambda0, lm_up, lm_down, lm_min, lm_max, pad;
 };
@@ -200,6 +210,7 @@ struct FrameBuffers {
     int* vcid;                               // [max_frames][V] vertex id of each compacted candidate
     int* vcount;                             // [max_frames][num_parts] visible candidates per part
     unsigned* ride_ctr;                      // [max_frames] reduction workgroups that have delivered since k_finalize cleared it (k_solve launch seq waits for seq x its reduction workgroups)
+    AvtSolveSnap* snap;                      // [max_frames] (above) written by k_eval, read by the solver roles of the k_solve launch behind it
     AvtSpecCtl* spec;                        // [max_frames] speculative steps of the current system (avt_lm.hip)
     double* x_spec;                          // [max_frames][AVT_MAX_SPEC][xsize] their trial states ...
     double* prep_spec;                       // [max_frames][AVT_MAX_SPEC][prep_size] ... and skeleton tables

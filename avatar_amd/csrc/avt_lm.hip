@@ -604,7 +604,7 @@ __device__ __forceinline__ void reduce_ride_block(const DeviceModel& dm, const F
 #pragma unroll
     for (int u = 0; u < NLD; ++u) v[u] = __builtin_nontemporal_load(part + (size_t)min(glo + u, G - 1) * st);
     const unsigned long long wmine = el < ng ? fb.wmask[(size_t)f * G + glo + el] : 0ull;
-    const int try_slot = 1 - fb.ctl[f].cur_slot;
+    const int try_slot = 1 - fb.snap[f].ctl.cur_slot;      // (the snapshot: the solver of this launch rewrites the live block)
     int p = pair, ti = 0;
     while (p >= NT - ti) { p -= NT - ti; ++ti; }
     const int tj = ti + p;
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     constexpr int SPN = RIDE ? (1496 + 120 + NTH - 1) / NTH : 1;
     double sp_pre[SPN];
     if constexpr (RIDE) {
-        const int k = min(fb.spec[f].next, AVT_MAX_SPEC - 1), ncopy = xs + d.prep_size;
+        const int k = min(fb.snap[f].sp.next, AVT_MAX_SPEC - 1), ncopy = xs + d.prep_size;
         const double* xsrc = fb.x_spec + ((size_t)f * AVT_MAX_SPEC + k) * xs;
         const double* psrc = fb.prep_spec + ((size_t)f * AVT_MAX_SPEC + k) * d.prep_size;
 #pragma unroll
@@ -768,10 +768,13 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     }
     const double hpp0 = hload(H0 + (size_t)P * HS + P), hpp1 = hload(H0 + (size_t)HS * HS + (size_t)P * HS + P);
     const double lm_up = fb.params->lm_up, lm_down = fb.params->lm_down, lm_min = fb.params->lm_min, lm_max = fb.params->lm_max;   // same round trip
-    const int cur0 = ctl.cur_slot, try_valid = ctl.try_valid, comp_cur0 = ctl.comp_cur;
-    const double sbp = ctl.sbp, sbs = ctl.sbs, cost_cur0 = ctl.cost_cur;
-    double cost_const = ctl.cost_const;
-    double lambda = ctl.lambda;
+    // RIDE: every solver role decides on the snapshot the evaluation launch made (AvtSolveSnap): the solver rewrites the live
+    // control block further down, and a speculative workgroup may start late
+    const AvtFrameCtl& cin = RIDE ? fb.snap[f].ctl : ctl;
+    const int cur0 = cin.cur_slot, try_valid = cin.try_valid, comp_cur0 = cin.comp_cur;
+    const double sbp = cin.sbp, sbs = cin.sbs, cost_cur0 = cin.cost_cur;
+    double cost_const = cin.cost_const;
+    double lambda = cin.lambda;
     __shared__ double s_cc;
     if (mode == SOLVE_FIRST && t < 64) {   // the constant part of the data cost (k_records' trailing workgroups), once per ICP iteration
         double a = 0.0;
@@ -807,7 +810,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     }
     if (sbs > 0.0) {
         double a = 0.0;
-        for (int k = 0; k < K; ++k) { const double r = xt[3 + 4 * J + k] * sbs; a += r * r; }
+        for (int k = 0; k < K; ++k) { const double r = (RIDE ? fb.snap[f].xw[k] : xt[3 + 4 * J + k]) * sbs; a += r * r; }
         cost += 0.5 * a;
     }
     int cur = cur0;
@@ -825,9 +828,10 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     // a speculative workgroup of the last full solve launch has already made.  The solver then installs it (trial state and
     // skeleton tables copied into the trial slot) instead of factoring, and the speculative workgroups of this launch go home.
     AvtSpecCtl& sp = fb.spec[f];
-    const int sp_next = sp.next, sp_n = sp.n;
+    const AvtSpecCtl& spin = fb.snap[f].sp;                 // (RIDE only)
+    const int sp_next = RIDE ? spin.next : 0, sp_n = RIDE ? spin.n : 0;
     const bool rejected = mode != SOLVE_FIRST && try_valid && !accepted;
-    const bool use_spec = RIDE && rejected && sp_next < sp_n && sp.valid[min(sp_next, AVT_MAX_SPEC - 1)] != 0;
+    const bool use_spec = RIDE && rejected && sp_next < sp_n && spin.valid[min(sp_next, AVT_MAX_SPEC - 1)] != 0;
     if (RIDE && role > 0 && use_spec) return;
     if (RIDE && role > 0) {      // my damping: what `role` rejections in a row would make of the solver's
         for (int i = 0; i < role; ++i) lambda = fmin(lambda * lm_up, lm_max);
@@ -853,7 +857,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
             else if (e < xs + d.prep_size) prep0[(size_t)tr * d.prep_size + (e - xs)] = sp_pre[i];
         }
         if (t == 0) {
-            const double lam = sp.lambda[k];
+            const double lam = spin.lambda[k];
             sp.next = k + 1;
             ctl.lambda = lam; ctl.try_valid = 1;
             ctl.dec_cur_slot = cur; ctl.dec_try_valid = 1; ctl.dec_cost_cur = cost_cur; ctl.dec_lambda = lam;
