@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 1) void k_eval(DeviceModel dm,
     if (strided && g < d.nb_max) prefetch(g);
     const int M = ctl.M;
     const int try_slot = 1 - ctl.cur_slot;
-    if (!COST && g == 0 && t < 64) {      // what the solver roles of the k_solve launch behind this one decide on (AvtSolveSnap)
+    if (!COST && g == G - 1 && t < 64) {      // what the solver roles of the k_solve launch behind this one decide on (AvtSolveSnap); the last workgroup of a frame has the fewest batches
         static_assert(sizeof(AvtFrameCtl) == 128 && sizeof(AvtSpecCtl) == 56, "snapshot copy below");
         double* sn = (double*)(fb.snap + f);
         if (t < 16) sn[t] = ((const double*)&ctl)[t];

@@ -712,13 +712,22 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     const int mf_wv = t >> 6, mf_g4 = (t >> 4) & 3, mf_c16 = t & 15, mf_rA = 5 - mf_wv, mf_rB = mf_wv - 2;
     // (six tile slots per wave: slot s <= rA is tile (rA, s), the slots behind are tiles (rB, 0..rB))
     double mraw[TRI ? 1 : 2][TRI ? 1 : 6][4];
+    // RIDE: the snapshot every solver role decides on (AvtSolveSnap) is requested now, before the wait for the reduction
+    AvtFrameCtl snap_ctl;
+    AvtSpecCtl snap_sp;
+    double snap_xw[AVT_MAX_SHAPE];
+    if constexpr (RIDE) {
+        snap_ctl = fb.snap[f].ctl; snap_sp = fb.snap[f].sp;
+#pragma unroll
+        for (int k = 0; k < AVT_MAX_SHAPE; ++k) snap_xw[k] = k < K ? fb.snap[f].xw[k] : 0.0;
+    }
     // (solver, RIDE) the speculative step the accept test may ask for in a moment: its 10 KB are requested now, while the reduction
     // is still on its way, so that a rejection only has to store them
     // (256-thread shape: 3 + 3J + K <= 87 and K <= 16 bound the prep block by 1496 doubles and the state by 115)
     constexpr int SPN = RIDE ? (1496 + 120 + NTH - 1) / NTH : 1;
     double sp_pre[SPN];
     if constexpr (RIDE) {
-        const int k = min(fb.snap[f].sp.next, AVT_MAX_SPEC - 1), ncopy = xs + d.prep_size;
+        const int k = min(snap_sp.next, AVT_MAX_SPEC - 1), ncopy = xs + d.prep_size;
         const double* xsrc = fb.x_spec + ((size_t)f * AVT_MAX_SPEC + k) * xs;
         const double* psrc = fb.prep_spec + ((size_t)f * AVT_MAX_SPEC + k) * d.prep_size;
 #pragma unroll
@@ -770,7 +779,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     const double lm_up = fb.params->lm_up, lm_down = fb.params->lm_down, lm_min = fb.params->lm_min, lm_max = fb.params->lm_max;   // same round trip
     // RIDE: every solver role decides on the snapshot the evaluation launch made (AvtSolveSnap): the solver rewrites the live
     // control block further down, and a speculative workgroup may start late
-    const AvtFrameCtl& cin = RIDE ? fb.snap[f].ctl : ctl;
+    const AvtFrameCtl& cin = RIDE ? snap_ctl : ctl;
     const int cur0 = cin.cur_slot, try_valid = cin.try_valid, comp_cur0 = cin.comp_cur;
     const double sbp = cin.sbp, sbs = cin.sbs, cost_cur0 = cin.cost_cur;
     double cost_const = cin.cost_const;
@@ -810,7 +819,12 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     }
     if (sbs > 0.0) {
         double a = 0.0;
-        for (int k = 0; k < K; ++k) { const double r = (RIDE ? fb.snap[f].xw[k] : xt[3 + 4 * J + k]) * sbs; a += r * r; }
+        if constexpr (RIDE) {
+#pragma unroll
+            for (int k = 0; k < AVT_MAX_SHAPE; ++k) if (k < K) { const double r = snap_xw[k] * sbs; a += r * r; }
+        } else {
+            for (int k = 0; k < K; ++k) { const double r = xt[3 + 4 * J + k] * sbs; a += r * r; }
+        }
         cost += 0.5 * a;
     }
     int cur = cur0;
@@ -828,7 +842,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     // a speculative workgroup of the last full solve launch has already made.  The solver then installs it (trial state and
     // skeleton tables copied into the trial slot) instead of factoring, and the speculative workgroups of this launch go home.
     AvtSpecCtl& sp = fb.spec[f];
-    const AvtSpecCtl& spin = fb.snap[f].sp;                 // (RIDE only)
+    const AvtSpecCtl& spin = snap_sp;                       // (RIDE only)
     const int sp_next = RIDE ? spin.next : 0, sp_n = RIDE ? spin.n : 0;
     const bool rejected = mode != SOLVE_FIRST && try_valid && !accepted;
     const bool use_spec = RIDE && rejected && sp_next < sp_n && spin.valid[min(sp_next, AVT_MAX_SPEC - 1)] != 0;
