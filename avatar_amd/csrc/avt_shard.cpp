@@ -175,7 +175,10 @@ int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* data) {
 RcclApi* rccl_api() {
     static RcclApi api;
     static bool tried = false;
-    if (tried) return api.handle ? &api : nullptr;
+    if (tried) {
+        if (!api.handle) avt_set_error("avt_shard: cannot open librccl (" + api.error + "); set AVT_RCCL_LIB");
+        return api.handle ? &api : nullptr;
+    }
     tried = true;
     // one RCCL per process: if the host program (PyTorch) already mapped a librccl, use that very copy
     std::string loaded;
@@ -187,7 +190,8 @@ RcclApi* rccl_api() {
     for (const std::string& p : cand) {
         api.handle = dlopen(p.c_str(), RTLD_NOW | RTLD_GLOBAL);
         if (api.handle) { api.path = p; break; }
-        api.error = dlerror() ? dlerror() : "dlopen failed";
+        const char* e = dlerror();              // dlerror() clears the message: read it once
+        api.error = p + ": " + (e ? e : "dlopen failed");
     }
     if (!api.handle) { avt_set_error("avt_shard: cannot open librccl (" + api.error + "); set AVT_RCCL_LIB"); return nullptr; }
     bool ok = true;

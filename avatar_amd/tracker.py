@@ -48,7 +48,7 @@ class FrameTracker:
         """One tracked frame.  Returns True if the avatar was fitted, False if tracking was declared lost
         (too few body pixels: the next frame reinitialises, demo.cpp:225,283-285)."""
         data, labels = self.subsample(xyz, part_mask, bbox)
-        if len(labels) < self.reinitCnz // (self.interval * self.interval):
+        if len(labels) == 0 or len(labels) < self.reinitCnz // (self.interval * self.interval):   # an empty frame is never fitted
             self.reinit = True
             return False
         icp_iters = self.frameICPIters

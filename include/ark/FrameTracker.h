@@ -58,7 +58,10 @@ class FrameTracker {
     bool process(const float* xyz, const std::uint8_t* part_mask, int width, int height, const Rect& box) {
         (void)height;
         const size_t cnz = subsample(xyz, part_mask, width, box, dataCloud, dataPartLabels);
-        if (cnz < (size_t)(reinitCnz / (interval * interval))) {        // demo.cpp:225
+        // demo.cpp:225 skips a sparse frame; live-demo.cpp:379-383 also asks for a reinitialisation, which is the policy kept
+        // here (documented deviation from demo.cpp).  An EMPTY frame is never fitted whatever reinitCnz says: the centroid
+        // below divides by cnz.
+        if (cnz == 0 || cnz < (size_t)(reinitCnz / (interval * interval))) {
             reinit = true;
             return false;
         }

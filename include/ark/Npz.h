@@ -70,7 +70,10 @@ inline Array parse_npy(const std::vector<unsigned char>& b) {
     if (!((kind == 'f' && (width == 4 || width == 8)) || ((kind == 'i' || kind == 'u') && (width == 4 || width == 8))))
         throw std::runtime_error("npz: unsupported dtype " + descr);
     size_t n = 1;
-    for (size_t sdim : a.shape) { if (sdim != 0 && n > (size_t)1 << 40) throw std::runtime_error("npz: implausible shape"); n *= sdim; }
+    for (size_t sdim : a.shape) {      // the product must not wrap size_t (a crafted header with two 2^40 dimensions did)
+        if (sdim > ((size_t)1 << 40) || (sdim != 0 && n > ((size_t)1 << 40) / sdim)) throw std::runtime_error("npz: implausible shape");
+        n *= sdim;
+    }
     const unsigned char* d = b.data() + off + hlen;
     if (n > (b.size() - off - hlen) / (size_t)width) throw std::runtime_error("npz: truncated array");
     a.is_int = (kind == 'i' || kind == 'u');
@@ -169,7 +172,8 @@ inline std::map<std::string, Array> load(const std::string& path, const std::vec
         }
         try {
             out[name] = parse_npy(raw);
-        } catch (const std::runtime_error& e) {      // not a numeric array: skipped unless the caller asked for exactly this member
+        } catch (const std::exception& e) {          // not a numeric array (incl. std::stoull / std::stoi logic errors on an odd
+                                                     // header): skipped unless the caller asked for exactly this member
             if (only) throw std::runtime_error(std::string(e.what()) + " (member " + name + ")");
         }
         cd = next_cd;
