@@ -235,9 +235,10 @@ class Context:
         _check(self._lib.avt_frames_upload(self.h, C.c_int(F), dptr(data), iptr(lab), iptr(offs)))
         self._F = F
 
-    def render_frames(self, w, p, R, intrin=None, res_scale=1):
+    def render_frames(self, w, p, R, intrin=None, res_scale=1, painter=False):
         """Synthesise depth frames of posed avatars on the GPU, resident in this context.
-        w (F,K), p (F,3), R (F,J,3,3). Returns the number of points of every frame."""
+        w (F,K), p (F,3), R (F,J,3,3). Returns the number of points of every frame.  painter=True: the reference's
+        painter's-order renderer pixel for pixel (AVT_RENDER_PAINTER) instead of the z-buffer."""
         from . import synth
         k = dict(synth.K4A_INTRIN) if intrin is None else dict(intrin)
         m = self.model
@@ -246,13 +247,23 @@ class Context:
         F = w.shape[0]
         Rcm = np.ascontiguousarray(np.transpose(R, (0, 1, 3, 2)))
         n = np.zeros(F, np.int32)
-        _check(self._lib.avt_synth_render_frames(self.h, C.c_int(F), dptr(w), dptr(p), dptr(Rcm), C.c_double(k["fx"] * res_scale),
-                                                 C.c_double(k["fy"] * res_scale), C.c_double(k["cx"] * res_scale),
-                                                 C.c_double(k["cy"] * res_scale), C.c_int(k["width"] * res_scale),
-                                                 C.c_int(k["height"] * res_scale), iptr(n)))
+        _check(self._lib.avt_synth_render_frames_mode(self.h, C.c_int(F), dptr(w), dptr(p), dptr(Rcm), C.c_double(k["fx"] * res_scale),
+                                                      C.c_double(k["fy"] * res_scale), C.c_double(k["cx"] * res_scale),
+                                                      C.c_double(k["cy"] * res_scale), C.c_int(k["width"] * res_scale),
+                                                      C.c_int(k["height"] * res_scale), C.c_int(1 if painter else 0), iptr(n)))
         self._F = F
         self._N = n
+        self._img_shape = (k["height"] * res_scale, k["width"] * res_scale)
         return n
+
+    def render_images(self, frame):
+        """(depth (H,W) float32, part mask (H,W) uint8) of frame `frame` of the last painter=True render_frames call:
+        what AvatarRenderer::renderDepth / renderPartMask return."""
+        H, W = self._img_shape
+        depth = np.empty((H, W), np.float32); mask = np.empty((H, W), np.uint8)
+        _check(self._lib.avt_synth_render_images(self.h, C.c_int(frame), depth.ctypes.data_as(C.POINTER(C.c_float)),
+                                                 mask.ctypes.data_as(C.POINTER(C.c_ubyte))))
+        return depth, mask
 
     def frame_download(self, frame):
         n = int(self._N[frame])

@@ -174,6 +174,9 @@ def load_library():
                                c_double_p, C.POINTER(Stats)],
         "avt_frames_upload": [vp, C.c_int, c_double_p, c_int_p, c_int_p],
         "avt_synth_render_frames": [vp, C.c_int, c_double_p, c_double_p, c_double_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, c_int_p],
+        "avt_synth_render_frames_mode": [vp, C.c_int, c_double_p, c_double_p, c_double_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                                         C.c_int, c_int_p],
+        "avt_synth_render_images": [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_ubyte)],
         "avt_frames_download": [vp, C.c_int, c_double_p, c_int_p],
         "avt_state_upload": [vp, C.c_int, c_double_p, c_double_p, c_double_p],
         "avt_optimize_resident": [vp, C.POINTER(Options)],
@@ -227,7 +230,7 @@ EXPORTED_SYMBOLS = [
     "avt_last_error", "avt_kernel_name", "avt_options_default", "avt_model_create", "avt_model_destroy",
     "avt_model_dims", "avt_model_main_joint", "avt_model_joint_regression", "avt_model_tile_layout", "avt_ctx_create", "avt_ctx_destroy",
     "avt_sync", "avt_lbs_update", "avt_visibility", "avt_nn", "avt_optimize", "avt_optimize_batch",
-    "avt_frames_upload", "avt_synth_render_frames", "avt_frames_download", "avt_state_upload", "avt_optimize_resident", "avt_state_reset", "avt_state_download",
+    "avt_frames_upload", "avt_synth_render_frames", "avt_synth_render_frames_mode", "avt_synth_render_images", "avt_frames_download", "avt_state_upload", "avt_optimize_resident", "avt_state_reset", "avt_state_download",
     "avt_get_correspondences", "avt_get_cloud", "avt_get_posed", "avt_get_normal_equations", "avt_debug_trace", "avt_launch_shape", "avt_profile_begin", "avt_profile_select", "avt_profile_end",
     # include/avt_shard.h
     "avt_shard_owner", "avt_shard_local_count", "avt_shard_local_index", "avt_shard_global_frame", "avt_model_pack_size", "avt_model_pack",

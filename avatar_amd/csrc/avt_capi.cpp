@@ -20,6 +20,9 @@ int avt_solve_set_attributes();
 int avt_eval_set_attributes();
 int avt_render_enqueue(avt_ctx* c, int nframes, const int* d_vertex_part, unsigned long long* d_zkey, unsigned char* d_label, int* d_block,
                        double fx, double fy, double cx, double cy, int width, int height);
+int avt_paint_enqueue(avt_ctx* c, int nframes, const int* d_vertex_part, unsigned long long* d_dkey, unsigned long long* d_mkey, float* d_fkey,
+                      int* d_frank, unsigned char* d_fedge, float* d_depth, unsigned char* d_label, int* d_block, double fx, double fy, double cx,
+                      double cy, int width, int height);
 void avt_eval_report_occupancy(const AvtDims& d);
 
 #define HIP_OK(expr)                                                                          \
@@ -387,6 +390,9 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
     c->params_valid = false;
     c->frames_valid = c->state_valid = false;
     c->render_zkey = nullptr; c->render_label = nullptr; c->render_block = nullptr; c->render_cap_pix = c->render_cap_blk = 0;
+    c->render_mkey = nullptr; c->render_depth = nullptr; c->render_fkey = nullptr; c->render_frank = nullptr; c->render_fedge = nullptr;
+    c->render_cap_paint_pix = c->render_cap_paint_face = 0;
+    c->render_img_frames = c->render_img_w = c->render_img_h = 0;
     HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < AVT_MAX_GROUPS - 1; ++i) {
@@ -495,6 +501,8 @@ void avt_ctx_destroy(avt_ctx* c) {
     if (c->render_zkey) (void)hipFree(c->render_zkey);
     if (c->render_label) (void)hipFree(c->render_label);
     if (c->render_block) (void)hipFree(c->render_block);
+    for (void* p : {(void*)c->render_mkey, (void*)c->render_depth, (void*)c->render_fkey, (void*)c->render_frank, (void*)c->render_fedge})
+        if (p) (void)hipFree(p);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -584,8 +592,16 @@ int avt_nn(avt_ctx* c, const double* model_cloud, const unsigned char* visible, 
 
 int avt_synth_render_frames(avt_ctx* c, int nframes, const double* w, const double* p, const double* R, double fx, double fy, double cx,
                             double cy, int width, int height, int* points_per_frame) {
+    return avt_synth_render_frames_mode(c, nframes, w, p, R, fx, fy, cx, cy, width, height, AVT_RENDER_ZBUFFER, points_per_frame);
+}
+
+int avt_synth_render_frames_mode(avt_ctx* c, int nframes, const double* w, const double* p, const double* R, double fx, double fy, double cx,
+                                 double cy, int width, int height, int mode, int* points_per_frame) {
     AVT_API_GUARD_BEGIN
     if (!c || !w || !p || !R || width <= 0 || height <= 0) { avt_set_error("avt_synth_render_frames: bad argument"); return 1; }
+    if (mode != AVT_RENDER_ZBUFFER && mode != AVT_RENDER_PAINTER) { avt_set_error("avt_synth_render_frames: unknown mode"); return 1; }
+    const bool painter = mode == AVT_RENDER_PAINTER;
+    c->render_img_frames = 0;
     const AvtDims& d = c->dm.d;
     if (nframes <= 0 || nframes > c->fb.max_frames) { avt_set_error("avt_synth_render_frames: nframes out of range"); return 1; }
     HIP_OK(hipSetDevice(c->device));
@@ -599,7 +615,7 @@ int avt_synth_render_frames(avt_ctx* c, int nframes, const double* w, const doub
     launch_lbs(c, nframes, nullptr, dw, dp, dR, 0, -1);
     // rasterise in chunks of frames (8 bytes of z-buffer key per pixel)
     const size_t npix = (size_t)width * height;
-    const int chunk = std::max(1, std::min(nframes, (int)((256ull << 20) / (npix * 9 + 64))));
+    const int chunk = std::max(1, std::min(nframes, (int)((256ull << 20) / (npix * (painter ? 21 : 9) + 64))));
     const int nb = (int)((npix + 255) / 256);
     // z-buffer keys, labels and block counts live in the context and only grow (no hipMalloc / hipFree per call)
     if (c->render_cap_pix < npix * chunk || c->render_cap_blk < (size_t)nb * chunk) {
@@ -613,10 +629,29 @@ int avt_synth_render_frames(avt_ctx* c, int nframes, const double* w, const doub
         HIP_OK(hipMalloc((void**)&c->render_block, (size_t)nb * chunk * sizeof(int)));
         c->render_cap_pix = npix * chunk; c->render_cap_blk = (size_t)nb * chunk;
     }
+    const size_t nface = (size_t)d.F * chunk;
+    if (painter && (c->render_cap_paint_pix < npix * chunk || c->render_cap_paint_face < nface)) {
+        HIP_OK(hipStreamSynchronize(c->stream));
+        for (void* q : {(void*)c->render_mkey, (void*)c->render_depth, (void*)c->render_fkey, (void*)c->render_frank, (void*)c->render_fedge})
+            if (q) (void)hipFree(q);
+        c->render_mkey = nullptr; c->render_depth = nullptr; c->render_fkey = nullptr; c->render_frank = nullptr; c->render_fedge = nullptr;
+        c->render_cap_paint_pix = c->render_cap_paint_face = 0;
+        HIP_OK(hipMalloc((void**)&c->render_mkey, npix * chunk * sizeof(unsigned long long)));
+        HIP_OK(hipMalloc((void**)&c->render_depth, npix * chunk * sizeof(float)));
+        HIP_OK(hipMalloc((void**)&c->render_fkey, nface * sizeof(float)));
+        HIP_OK(hipMalloc((void**)&c->render_frank, nface * sizeof(int)));
+        HIP_OK(hipMalloc((void**)&c->render_fedge, nface));
+        c->render_cap_paint_pix = npix * chunk; c->render_cap_paint_face = nface;
+    }
     int rc = 0;
     for (int f0 = 0; f0 < nframes && !rc; f0 += chunk) {
         c->fb.f0 = f0;
-        rc = avt_render_enqueue(c, std::min(chunk, nframes - f0), c->dm.part_of_vertex, c->render_zkey, c->render_label, c->render_block, fx, fy, cx, cy, width, height);
+        const int nf = std::min(chunk, nframes - f0);
+        if (painter)
+            rc = avt_paint_enqueue(c, nf, c->dm.part_of_vertex, c->render_zkey, c->render_mkey, c->render_fkey, c->render_frank, c->render_fedge,
+                                   c->render_depth, c->render_label, c->render_block, fx, fy, cx, cy, width, height);
+        else
+            rc = avt_render_enqueue(c, nf, c->dm.part_of_vertex, c->render_zkey, c->render_label, c->render_block, fx, fy, cx, cy, width, height);
     }
     c->fb.f0 = 0;
     if (rc) { avt_set_error("avt_synth_render_frames: render launch failed"); return 1; }
@@ -640,8 +675,26 @@ int avt_synth_render_frames(avt_ctx* c, int nframes, const double* w, const doub
     HIP_OK(hipMemcpy2DAsync(&c->fb.ctl_start->N, sizeof(AvtFrameCtl), c->frame_N.data(), sizeof(int), sizeof(int), (size_t)nframes, hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
     c->frames_valid = true;
+    if (painter && nframes <= chunk) { c->render_img_frames = nframes; c->render_img_w = width; c->render_img_h = height; }
     return 0;
     AVT_API_GUARD_END("avt_synth_render_frames")
+}
+
+int avt_synth_render_images(avt_ctx* c, int frame, float* depth, unsigned char* part_mask) {
+    AVT_API_GUARD_BEGIN
+    if (!c) { avt_set_error("avt_synth_render_images: null context"); return 1; }
+    if (c->render_img_frames == 0) {
+        avt_set_error("avt_synth_render_images: no images retained (needs a preceding AVT_RENDER_PAINTER call whose frames fit one scratch chunk)");
+        return 1;
+    }
+    if (frame < 0 || frame >= c->render_img_frames) { avt_set_error("avt_synth_render_images: frame out of range"); return 1; }
+    HIP_OK(hipSetDevice(c->device));
+    const size_t npix = (size_t)c->render_img_w * c->render_img_h;
+    if (depth) HIP_OK(hipMemcpyAsync(depth, c->render_depth + (size_t)frame * npix, npix * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (part_mask) HIP_OK(hipMemcpyAsync(part_mask, c->render_label + (size_t)frame * npix, npix, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+    AVT_API_GUARD_END("avt_synth_render_images")
 }
 
 int avt_frames_download(avt_ctx* c, int frame, double* data_3xN, int* labels) {

@@ -286,6 +286,10 @@ struct avt_ctx {
     bool frames_valid, state_valid;  // resident frames / start state usable by avt_optimize_resident
     // persistent scratch of avt_synth_render_frames (z-buffer keys, labels, block counts), grown on demand
     unsigned long long* render_zkey; unsigned char* render_label; int* render_block; size_t render_cap_pix; size_t render_cap_blk;
+    // painter's-order mode only: second key image, float depth image, per-face sort key / order position / edge-on flag
+    unsigned long long* render_mkey; float* render_depth; float* render_fkey; int* render_frank; unsigned char* render_fedge;
+    size_t render_cap_paint_pix; size_t render_cap_paint_face;
+    int render_img_frames, render_img_w, render_img_h;   // what render_depth / render_label hold (avt_synth_render_images); 0 = nothing
 };
 
 void avt_set_error(const std::string& s);

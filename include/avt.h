@@ -171,6 +171,22 @@ int avt_state_download(avt_ctx* c, double* p, double* q, double* w, avt_stats* s
  * avt_frames_download copies one resident frame back (data 3 x N doubles, labels N ints). */
 int avt_synth_render_frames(avt_ctx* c, int nframes, const double* w, const double* p, const double* R, double fx, double fy,
                             double cx, double cy, int width, int height, int* points_per_frame);
+/* The same with the visibility rule chosen by the caller:
+ *   AVT_RENDER_ZBUFFER  nearest surface per pixel (the fast generator the benchmarks use; inside-triangle coverage);
+ *   AVT_RENDER_PAINTER  the reference's renderer pixel for pixel: faces painted by decreasing mean depth, later faces
+ *                       overwrite (AvatarRenderer.cpp:39-70), renderDepth's row scanline fill with the floored / ceiled end
+ *                       vertices (AvatarHelpers.cpp:61-139), renderPartMask's column fill and nearest-vertex rule
+ *                       (AvatarHelpers.cpp:153-245), edge-on faces painting 0 / 255 with the end-exclusive fill
+ *                       (AvatarHelpers.cpp:247-303); every pixel with depth > 0 becomes a point (optim.cpp:104-120) labelled by
+ *                       the part mask at that pixel (255 where the two fills disagree about coverage: such points carry a
+ *                       label outside [0, num_parts) and optimize() drops them).  Intrinsics are rounded to float first
+ *                       (Calibration.h:13).  Equal face sort keys are ordered by face id (std::sort leaves them unspecified).
+ * After a PAINTER call whose frames fit one scratch chunk, avt_synth_render_images copies out what renderDepth (H x W float32,
+ * 0 = background) and renderPartMask (H x W uint8, 255 = background) return for frame `frame`; either pointer may be NULL. */
+enum { AVT_RENDER_ZBUFFER = 0, AVT_RENDER_PAINTER = 1 };
+int avt_synth_render_frames_mode(avt_ctx* c, int nframes, const double* w, const double* p, const double* R, double fx, double fy,
+                                 double cx, double cy, int width, int height, int mode, int* points_per_frame);
+int avt_synth_render_images(avt_ctx* c, int frame, float* depth_HxW, unsigned char* part_mask_HxW);
 int avt_frames_download(avt_ctx* c, int frame, double* data_3xN, int* labels);
 
 /* ---- introspection of the last optimize call (tests / diagnostics) */

@@ -16,8 +16,9 @@
 // nearest-vertex distances are computed; the second half of the part fill always starts one column after the middle
 // vertex; later faces simply overwrite earlier ones (no depth test).
 // PARITY STATUS: the reference cannot be built here (OpenCV) and holds no rendered fixtures, so this file is pinned only
-// by hand-computed small cases (tests/test_render_oracle_cpu.py); the product's z-buffer generator is compared with it
-// statistically (it is a different visibility algorithm by design).
+// by hand-computed small cases (tests/test_render_oracle_cpu.py).  The product's generator has two modes: AVT_RENDER_PAINTER must
+// reproduce this file's images bit for bit (tests/test_gpu_render.py), the z-buffer mode is a different visibility algorithm by
+// design and is compared statistically.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -38,21 +39,27 @@ void project_points(int V, const double* cloud, float fx, float fy, float cx, fl
 }
 
 // (mean depth, face) sorted by decreasing depth with std::sort, like the reference
-void ordered_faces(int F, const int* mesh, const double* cloud, std::vector<std::pair<float, int>>& out) {
+void ordered_faces(int F, const int* mesh, const double* cloud, std::vector<std::pair<float, int>>& out, bool stable = false) {
     out.resize(F);
     for (int f = 0; f < F; ++f) {
         const int* m = mesh + 3 * (size_t)f;
         out[f].first = (float)((cloud[3 * (size_t)m[0] + 2] + cloud[3 * (size_t)m[1] + 2] + cloud[3 * (size_t)m[2] + 2]) / 3.f);
         out[f].second = f;
     }
-    std::sort(out.begin(), out.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first > b.first; });
+    auto comp = [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first > b.first; };
+    // the reference calls std::sort, which leaves the order of equal keys unspecified; `stable` orders them by face id (what
+    // the HIP generator does) so that a test can assert a fixture does not depend on it
+    if (stable) std::stable_sort(out.begin(), out.end(), comp); else std::sort(out.begin(), out.end(), comp);
 }
 
 bool edge_on(const double* a, const double* b, const double* c) {
     const double ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, ac[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
     const double n[3] = {ab[1] * ac[2] - ab[2] * ac[1], ab[2] * ac[0] - ab[0] * ac[2], ab[0] * ac[1] - ab[1] * ac[0]};
-    const double nn = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-    return std::fabs(n[2] / nn) < 0.1;        // (a degenerate face gives NaN here and is painted, as in the reference)
+    // Eigen 3.3 MatrixBase::normalized(): z = squaredNorm(); z > 0 ? n / sqrt(z) : n  (a zero vector is returned unchanged, so a
+    // degenerate face counts as edge-on)
+    const double z = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+    const double nz = z > 0.0 ? n[2] / std::sqrt(z) : n[2];
+    return std::fabs(nz) < 0.1;
 }
 
 // AvatarHelpers.cpp:61-139
@@ -154,12 +161,17 @@ extern "C" {
 
 // AvatarRenderer::renderDepth (float32 H x W, 0 = background) and renderPartMask (uint8 H x W, 255 = background) of one
 // posed avatar.  vertex_part[v] = part_map[assignedJoints[v][0].second].  Either output may be NULL.
-int orc_render(int V, int F, const double* cloud, const int* mesh, const int* vertex_part, float fx, float fy, float cx, float cy,
-               int W, int H, float* depth_out, std::uint8_t* mask_out) {
+int orc_render_ex(int V, int F, const double* cloud, const int* mesh, const int* vertex_part, float fx, float fy, float cx, float cy,
+                  int W, int H, float* depth_out, std::uint8_t* mask_out, int stable_sort, int* tied_keys_out) {
     std::vector<P2> pr;
     project_points(V, cloud, fx, fy, cx, cy, pr);
     std::vector<std::pair<float, int>> faces;
-    ordered_faces(F, mesh, cloud, faces);
+    ordered_faces(F, mesh, cloud, faces, stable_sort != 0);
+    if (tied_keys_out) {
+        int t = 0;
+        for (int k = 1; k < F; ++k) t += faces[k].first == faces[k - 1].first;
+        *tied_keys_out = t;
+    }
     std::vector<float> depth;
     std::vector<std::uint8_t> mask;
     if (depth_out) depth.assign((size_t)W * H, 0.f);
@@ -180,6 +192,11 @@ int orc_render(int V, int F, const double* cloud, const int* mesh, const int* ve
     if (depth_out) std::copy(depth.begin(), depth.end(), depth_out);
     if (mask_out) std::copy(mask.begin(), mask.end(), mask_out);
     return 0;
+}
+
+int orc_render(int V, int F, const double* cloud, const int* mesh, const int* vertex_part, float fx, float fy, float cx, float cy,
+               int W, int H, float* depth_out, std::uint8_t* mask_out) {
+    return orc_render_ex(V, F, cloud, mesh, vertex_part, fx, fy, cx, cy, W, H, depth_out, mask_out, 0, nullptr);
 }
 
 // optim.cpp:104-120: every pixel with depth > 0 back-projected by CameraIntrin::to3D (float), y negated; labels from the

@@ -24,16 +24,20 @@ def lib():
     return _lib
 
 
-def render(cloud, mesh, vertex_part, intrin, width, height):
-    """(depth (H,W) float32, part mask (H,W) uint8) of posed vertices `cloud` (V,3): AvatarRenderer::renderDepth / renderPartMask."""
+def render(cloud, mesh, vertex_part, intrin, width, height, stable=False, return_ties=False):
+    """(depth (H,W) float32, part mask (H,W) uint8) of posed vertices `cloud` (V,3): AvatarRenderer::renderDepth / renderPartMask.
+    stable=True orders faces of equal sort key by face id instead of leaving them to std::sort; return_ties adds the number of
+    equal adjacent keys in the sorted order."""
     cloud = np.ascontiguousarray(cloud, np.float64); mesh = np.ascontiguousarray(mesh, np.int32)
     vp = np.ascontiguousarray(vertex_part, np.int32)
     depth = np.empty((height, width), np.float32); mask = np.empty((height, width), np.uint8)
-    lib().orc_render(C.c_int(cloud.shape[0]), C.c_int(mesh.shape[0]), cloud.ctypes.data_as(C.POINTER(C.c_double)),
-                     mesh.ctypes.data_as(C.POINTER(C.c_int)), vp.ctypes.data_as(C.POINTER(C.c_int)),
-                     C.c_float(intrin["fx"]), C.c_float(intrin["fy"]), C.c_float(intrin["cx"]), C.c_float(intrin["cy"]),
-                     C.c_int(width), C.c_int(height), depth.ctypes.data_as(C.POINTER(C.c_float)), mask.ctypes.data_as(C.POINTER(C.c_ubyte)))
-    return depth, mask
+    ties = C.c_int(0)
+    lib().orc_render_ex(C.c_int(cloud.shape[0]), C.c_int(mesh.shape[0]), cloud.ctypes.data_as(C.POINTER(C.c_double)),
+                        mesh.ctypes.data_as(C.POINTER(C.c_int)), vp.ctypes.data_as(C.POINTER(C.c_int)),
+                        C.c_float(intrin["fx"]), C.c_float(intrin["fy"]), C.c_float(intrin["cx"]), C.c_float(intrin["cy"]),
+                        C.c_int(width), C.c_int(height), depth.ctypes.data_as(C.POINTER(C.c_float)), mask.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                        C.c_int(1 if stable else 0), C.byref(ties))
+    return (depth, mask, ties.value) if return_ties else (depth, mask)
 
 
 def backproject(depth, mask, intrin):

@@ -80,3 +80,62 @@ def test_gpu_frames_against_the_painters_order_oracle(smpl, gmodel):
         assert iou > 0.92 and (fg_g & ~fg_p).sum() < 0.01 * fg_g.sum()
         assert np.median(dz) < 1e-3 and np.percentile(dz, 95) < 1e-2
         assert same > 0.97
+
+
+def test_painter_mode_is_the_reference_renderer_pixel_for_pixel(smpl, gmodel):
+    """Row f1, AVT_RENDER_PAINTER: the GPU generator's depth image, part mask and back-projected cloud are array_equal to
+    oracle/render_oracle.cpp (painter's order, scanline fills with floored / ceiled end vertices, end-exclusive single-colour
+    fill, nearest-vertex part rule: AvatarRenderer.cpp:39-101, 174-202, AvatarHelpers.cpp:61-303, optim.cpp:104-120)."""
+    from avatar_amd import api
+    from oracle import render_oracle as ro
+    pm = synth.identity_part_map()
+    k = synth.K4A_INTRIN
+    vp = pm[synth.main_joint(smpl)]
+    seeds = (0, 1, 7, 11)
+    gts = [synth.sample_ground_truth(smpl, s) for s in seeds]
+    W = np.array([g[0] for g in gts]); P = np.array([g[1] for g in gts]); R = np.array([g[2] for g in gts])
+    ctx = api.Context(gmodel, 24, pm, 60000, len(seeds), device=0)
+    cloud, _, _ = ctx.lbs_update(W, P, R)
+    n = ctx.render_frames(W, P, R, painter=True)
+    for f in range(len(seeds)):
+        depth_o, mask_o, ties = ro.render(cloud[f], smpl["f"], vp, k, k["width"], k["height"], return_ties=True)
+        # equal sort keys do occur (float mean depths of 13 776 faces); the fixture must not depend on how std::sort orders them
+        depth_s, mask_s = ro.render(cloud[f], smpl["f"], vp, k, k["width"], k["height"], stable=True)
+        assert np.array_equal(depth_o, depth_s) and np.array_equal(mask_o, mask_s), f"seed {seeds[f]}: {ties} tied keys matter"
+        depth_g, mask_g = ctx.render_images(f)
+        assert depth_g.dtype == np.float32 and mask_g.dtype == np.uint8
+        assert (depth_o > 0).sum() > 15000
+        assert np.array_equal(depth_g, depth_o), f"seed {seeds[f]}: {(depth_g != depth_o).sum()} depth pixels differ"
+        assert np.array_equal(mask_g, mask_o), f"seed {seeds[f]}: {(mask_g != mask_o).sum()} mask pixels differ"
+        data_o, lab_o = ro.backproject(depth_o, mask_o, k)
+        data_g, lab_g = ctx.frame_download(f)
+        assert n[f] == len(lab_o)
+        assert np.array_equal(data_g, data_o) and np.array_equal(lab_g, lab_o)
+
+
+def test_painter_mode_dense_frame_and_optimize(smpl, omodel, gmodel):
+    """The dense 2560x1440 render (configs[4]) in painter's order is the oracle's too, and the frame it leaves resident is
+    fitted like any other (labels 255 - pixels the part fill does not cover - are dropped like out-of-range labels)."""
+    from avatar_amd import api
+    from avatar_amd.capi import Options
+    from oracle import render_oracle as ro
+    pm = synth.identity_part_map()
+    k = {kk: (v * 2 if kk != "name" else v) for kk, v in synth.K4A_INTRIN.items()}
+    vp = pm[synth.main_joint(smpl)]
+    w, p, R = synth.sample_ground_truth(smpl, 3)
+    ctx = api.Context(gmodel, 24, pm, 200000, 1, device=0)
+    cloud, _, _ = ctx.lbs_update(w[None], p[None], R[None])
+    n = ctx.render_frames(w[None], p[None], R[None], res_scale=2, painter=True)
+    depth_o, mask_o = ro.render(cloud[0], smpl["f"], vp, k, k["width"], k["height"])
+    depth_g, mask_g = ctx.render_images(0)
+    assert np.array_equal(depth_g, depth_o) and np.array_equal(mask_g, mask_o)
+    assert n[0] == int((depth_o > 0).sum()) > 100000
+    data, lab = ctx.frame_download(0)
+    w0, p0, R0 = synth.perturb_start(w, p, R, 3)
+    q0 = api.rot_to_quat(R0)
+    opt = Options.demo(max_iters_per_icp=3)
+    ctx.state_upload(p0[None], q0[None], w0[None])
+    ctx.optimize_resident(opt)
+    ref = omodel.optimize(pm, 24, data, lab, opt, p0, q0, w0, aggregate=1)
+    assert np.array_equal(ctx.correspondences(0, len(lab)), ref["corr"])
+    assert np.abs(ctx.cloud(0) - ref["cloud"]).max() < 1e-6
