@@ -24,7 +24,9 @@ class AvtError(RuntimeError):
 
 def _check(rc):
     if rc != 0:
-        raise AvtError(capi.load_library().avt_last_error().decode())
+        e = AvtError(capi.load_library().avt_last_error().decode())
+        e.status = rc            # avt.h: AVT_STATUS_NO_DEVICE 2, AVT_STATUS_DEVICE_FAULT 3
+        raise e
 
 
 # ---- rotation <-> quaternion exactly as optimize() converts (AvatarOptimizer.cpp:1250-1254, :1494-1496):

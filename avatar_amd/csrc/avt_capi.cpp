@@ -198,6 +198,7 @@ int run_optimize(avt_ctx* c, const avt_options* o) {
     const int ngroups = plan_groups(c, nf);
     const int nfg = (nf + ngroups - 1) / ngroups;       // frames per group (the last group may be smaller)
     c->fb.G = choose_G(nfg);
+    c->concurrent_groups = ngroups;
     if (!c->use_graph || c->profiling) {
         for (int gi = 0; gi < ngroups; ++gi) {
             const int f0 = gi * nfg, n = std::min(nfg, nf - f0);
@@ -330,7 +331,20 @@ int download_state(avt_ctx* c, double* p, double* q, double* w, avt_stats* st) {
     std::vector<AvtFrameCtl> ctl(nf);
     HIP_OK(hipMemcpyAsync(xs.data(), c->fb.x, xs.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipMemcpyAsync(ctl.data(), c->fb.ctl, ctl.size() * sizeof(AvtFrameCtl), hipMemcpyDeviceToHost, c->stream));
+    std::vector<unsigned> fault(nf, 0u);
+    HIP_OK(hipMemcpyAsync(fault.data(), c->fb.fault, fault.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
+    int bad = -1, nbad = 0;
+    for (int f = 0; f < nf; ++f) if (fault[f]) { if (bad < 0) bad = f; ++nbad; }
+    if (bad >= 0) {     // reported once, then cleared: the next optimize() starts clean
+        char msg[256];
+        snprintf(msg, sizeof msg, "optimize: %d frame(s) carry a device fault (first: frame %d, bits 0x%x%s); their result is not valid", nbad, bad,
+                 fault[bad], (fault[bad] & AVT_FAULT_RIDE_TIMEOUT) ? ": a solver gave up waiting for the in-launch reduction" : "");
+        HIP_OK(hipMemsetAsync(c->fb.fault, 0, (size_t)nf * sizeof(unsigned), c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        avt_set_error(msg);
+        return AVT_STATUS_DEVICE_FAULT;
+    }
     for (int f = 0; f < nf; ++f) {
         const double* x = &xs[((size_t)f * 2 + ctl[f].cur_slot) * d.xsize];
         if (p) std::copy(x, x + 3, p + 3 * f);
@@ -389,6 +403,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
     c->graph_clock = 0;
     c->params_valid = false;
     c->frames_valid = c->state_valid = false;
+    c->concurrent_groups = 1;
     c->render_zkey = nullptr; c->render_label = nullptr; c->render_block = nullptr; c->render_cap_pix = c->render_cap_blk = 0;
     c->render_mkey = nullptr; c->render_depth = nullptr; c->render_fkey = nullptr; c->render_frank = nullptr; c->render_fedge = nullptr;
     c->render_cap_paint_pix = c->render_cap_paint_face = 0;
@@ -449,7 +464,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         dev_alloc(c, &fb.dz, FN) || dev_alloc(c, &fb.dorig, FN) || dev_alloc(c, &fb.part_off, (size_t)max_frames * (num_parts + 1)) || dev_alloc(c, &fb.part_cnt, (size_t)max_frames * 2 * (AVT_MAX_PARTS + 1)) ||
         dev_alloc(c, &fb.corr, FN) || dev_alloc(c, &fb.corr_sorted, FN) || dev_alloc(c, &fb.cloud, FV * 3) || dev_alloc(c, &fb.pcx, FV) ||
         dev_alloc(c, &fb.pcy, FV) || dev_alloc(c, &fb.pcz, FV) || dev_alloc(c, &fb.visible, FV) || dev_alloc(c, &fb.vcx, FV) || dev_alloc(c, &fb.vcy, FV) ||
-        dev_alloc(c, &fb.vcz, FV) || dev_alloc(c, &fb.vcid, FV) || dev_alloc(c, &fb.vcount, (size_t)max_frames * num_parts) || dev_alloc(c, &fb.vis_sorted, FV) || dev_alloc(c, &fb.ride_ctr, (size_t)max_frames) || dev_alloc(c, &fb.spec, (size_t)max_frames) || dev_alloc(c, &fb.snap, (size_t)max_frames) || dev_alloc(c, &fb.x_spec, (size_t)max_frames * AVT_MAX_SPEC * d.xsize) || dev_alloc(c, &fb.prep_spec, (size_t)max_frames * AVT_MAX_SPEC * d.prep_size) ||
+        dev_alloc(c, &fb.vcz, FV) || dev_alloc(c, &fb.vcid, FV) || dev_alloc(c, &fb.vcount, (size_t)max_frames * num_parts) || dev_alloc(c, &fb.vis_sorted, FV) || dev_alloc(c, &fb.ride_ctr, (size_t)max_frames) || dev_alloc(c, &fb.fault, (size_t)max_frames) || dev_alloc(c, &fb.spec, (size_t)max_frames) || dev_alloc(c, &fb.snap, (size_t)max_frames) || dev_alloc(c, &fb.x_spec, (size_t)max_frames * AVT_MAX_SPEC * d.xsize) || dev_alloc(c, &fb.prep_spec, (size_t)max_frames * AVT_MAX_SPEC * d.prep_size) ||
         dev_alloc(c, &cntsum, FV * (sizeof(int) + 3 * sizeof(long long)) + 64) || dev_alloc(c, &fb.matched, FV) ||
         dev_alloc(c, &fb.const_part, (size_t)max_frames * fb.const_blocks) ||
         dev_alloc(c, &fb.x, (size_t)max_frames * 2 * d.xsize) || dev_alloc(c, &fb.x_start, (size_t)max_frames * 2 * d.xsize) ||
@@ -469,6 +484,12 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
     HIP_OK(hipMemset(fb.trace, 0, (size_t)max_frames * 64 * sizeof(double)));
     HIP_OK(hipMemset(fb.ctl, 0, (size_t)max_frames * sizeof(AvtFrameCtl)));
     HIP_OK(hipMemset(fb.ride_ctr, 0, (size_t)max_frames * sizeof(unsigned)));
+    HIP_OK(hipMemset(fb.fault, 0, (size_t)max_frames * sizeof(unsigned)));
+    {   // wall_clock64() ticks at 100 MHz; default 2 s.  AVT_RIDE_TIMEOUT_US=0 makes every wait that is not already satisfied fail (tests)
+        long long us = 2000000;
+        if (const char* e = getenv("AVT_RIDE_TIMEOUT_US")) us = std::max(0ll, atoll(e));
+        fb.ride_timeout = us * 100;
+    }
     HIP_OK(hipMemset(fb.spec, 0, (size_t)max_frames * sizeof(AvtSpecCtl)));
     fb.nspec = 0; fb.seq = 0;
     HIP_OK(hipDeviceSynchronize());

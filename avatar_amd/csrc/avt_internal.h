@@ -139,6 +139,9 @@ struct AvtSolveSnap {
     double xw[AVT_MAX_SHAPE];
 };
 
+// FrameBuffers::fault bits
+#define AVT_FAULT_RIDE_TIMEOUT 1u   // a solver role of a riding k_solve launch gave up waiting for the reduction workgroups of its launch
+
 struct AvtRunParams {
     double beta_pose, beta_shape, lambda0, lm_up, lm_down, lm_min, lm_max, pad;
 };
@@ -209,6 +212,8 @@ struct FrameBuffers {
     double* vcx; double* vcy; double* vcz;   // [max_frames][V] visible model points, compacted per part segment
     int* vcid;                               // [max_frames][V] vertex id of each compacted candidate
     int* vcount;                             // [max_frames][num_parts] visible candidates per part
+    unsigned* fault;                         // [max_frames] sticky error bits a kernel sets when it cannot vouch for its result (AVT_FAULT_*); the host reports and clears them
+    long long ride_timeout;                  // how long a solver role waits for the riding reduction, in wall_clock64() ticks (100 MHz); AVT_RIDE_TIMEOUT_US
     unsigned* ride_ctr;                      // [max_frames] reduction workgroups that have delivered since k_finalize cleared it (k_solve launch seq waits for seq x its reduction workgroups)
     AvtSolveSnap* snap;                      // [max_frames] (above) written by k_eval, read by the solver roles of the k_solve launch behind it
     AvtSpecCtl* spec;                        // [max_frames] speculative steps of the current system (avt_lm.hip)
@@ -284,6 +289,7 @@ struct avt_ctx {
     AvtRunParams params_host;        // what fb.params currently holds
     bool params_valid;
     bool frames_valid, state_valid;  // resident frames / start state usable by avt_optimize_resident
+    int concurrent_groups;           // frame groups the current optimize() call runs side by side (sizes the riding launch shapes)
     // persistent scratch of avt_synth_render_frames (z-buffer keys, labels, block counts), grown on demand
     unsigned long long* render_zkey; unsigned char* render_label; int* render_block; size_t render_cap_pix; size_t render_cap_blk;
     // painter's-order mode only: second key image, float depth image, per-face sort key / order position / edge-on flag

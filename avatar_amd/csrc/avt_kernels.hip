@@ -379,7 +379,8 @@ __global__ __launch_bounds__(128) void k_pack_results(FrameBuffers fb, double* _
     if (t == 0) {
         double* s = o + xsize;
         s[0] = ctl.cost_initial; s[1] = ctl.cost_cur; s[2] = ctl.lambda; s[3] = (double)ctl.T; s[4] = (double)ctl.M;
-        s[5] = (double)ctl.gn_iterations; s[6] = (double)ctl.accepted; s[7] = (double)ctl.N;
+        s[5] = (double)ctl.gn_iterations; s[6] = (double)ctl.accepted;
+        s[7] = (double)fb.fault[f];      // sticky device fault bits of the frame (0 = its result is valid); avt_shard_gather_download checks them
     }
 }
 

@@ -15,6 +15,7 @@
 
 #include <type_traits>
 
+#include <cstring>
 #include "avt_device.h"
 
 #ifdef AVT_TIMING
@@ -738,9 +739,19 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     }
     if constexpr (RIDE) {      // the reduction workgroups of this launch have all delivered their strips of the trial point's system
         if (t == 0) {
-            int spins = 0;
             // (the count runs on from launch to launch of an ICP iteration - k_finalize clears it -: several workgroups wait on it)
-            while (__hip_atomic_load(fb.ride_ctr + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(fb.seq * RIDE * d.NPAIR) && spins < (1 << 20)) { __builtin_amdgcn_s_sleep(1); ++spins; }
+            // The launch is an ordinary one: its reduction workgroups never wait for anything and at most 1 + AVT_MAX_SPEC workgroups
+            // per frame wait here, so they always get to run - but WHEN is the dispatcher's business (another stream, another
+            // process, a profiler serialising dispatch).  The wait is therefore bounded by wall-clock time (2 s by default), and a
+            // role that gives up says so: the frame's fault word makes the host calls that return its result fail
+            // (download_state, avt_shard_gather_download) instead of handing out a fit made from a half-reduced system.
+            const unsigned want = (unsigned)(fb.seq * RIDE * d.NPAIR);
+            const long long t0 = wall_clock64();
+            bool there;
+            while (!(there = __hip_atomic_load(fb.ride_ctr + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) &&
+                   wall_clock64() - t0 < fb.ride_timeout)
+                __builtin_amdgcn_s_sleep(1);
+            if (!there) atomicOr(fb.fault + f, AVT_FAULT_RIDE_TIMEOUT);
         }
         __syncthreads();
     }
@@ -1078,6 +1089,12 @@ static void launch_solve_shape(avt_ctx* c, int nframes, int mode, size_t lds) {
 // (while every workgroup of the launch - 1 + 4 NPAIR per frame, one per CU with the solver's LDS request - is resident at once:
 // three SMPL frames on 256 CUs; six frames in two rounds measured 0.751 against 0.689 ms with the reduction as its own launch)
 // speculative solver workgroups per frame (AVT_NSPEC, default 2) next to the solver, as many as leave the grid resident
+// Residency is a matter of speed, not of correctness (see the wait in k_solve).  AVT_RIDE_SIZING=groups sizes the shapes by the
+// frame groups that run side by side (two / three frames: one group each) instead of by the one launch.
+static int ride_concurrency(const avt_ctx* c) {
+    static const bool by_groups = [] { const char* e = getenv("AVT_RIDE_SIZING"); return e && !strcmp(e, "groups"); }();
+    return by_groups ? std::max(1, c->concurrent_groups) : 1;
+}
 static int ride_nspec(const avt_ctx* c, int nframes, int strips) {
     // over twelve frames, one frame each: 0 / 2 / 3 / 4 speculative workgroups 0.5045 / 0.4305 / 0.4217 / 0.4166 ms (rejections come
     // in runs of up to five).  Frame batches gain nothing from them - a launch lasts as long as its slowest frame, and with four
@@ -1085,14 +1102,14 @@ static int ride_nspec(const avt_ctx* c, int nframes, int strips) {
     // 0.643 / 0.712 / 0.793 / 1.317 ms with four speculative workgroups per frame) - so only the riding shapes have them.
     int want = AVT_MAX_SPEC;
     if (const char* e = getenv("AVT_NSPEC")) want = std::max(0, std::min(AVT_MAX_SPEC, atoi(e)));
-    while (want > 0 && nframes * (1 + want + strips * c->dm.d.NPAIR) > c->num_cus) --want;
+    while (want > 0 && ride_concurrency(c) * nframes * (1 + want + strips * c->dm.d.NPAIR) > c->num_cus) --want;
     return want;
 }
 static int ride_strips(const avt_ctx* c, int nframes) {      // 8 strips per pair while the whole grid is resident (one SMPL frame), else 4, else none
     if (c->fb.G < 64 || solve_big(c->dm.d) || getenv("AVT_NO_RIDE")) return 0;
     int want = 8;
-    if (const char* e = getenv("AVT_RIDE_STRIPS")) want = atoi(e);
-    for (int s = want; s >= 4; s -= 4) if (nframes * (1 + s * c->dm.d.NPAIR) <= c->num_cus) return s;
+    if (const char* e = getenv("AVT_RIDE_STRIPS")) want = atoi(e) >= 8 ? 8 : 4;     // the two instantiated shapes; anything else would launch a grid its kernel was not built for
+    for (int s = want; s >= 4; s -= 4) if (ride_concurrency(c) * nframes * (1 + s * c->dm.d.NPAIR) <= c->num_cus) return s;
     return 0;
 }
 bool avt_solve_rides(const avt_ctx* c, int nframes) { return ride_strips(c, nframes) != 0; }

@@ -490,8 +490,10 @@ extern "C" int avt_shard_gather_download(avt_shard* s, avt_ctx* c, int B, double
     std::vector<double> host(blk * W);
     HIP_OK(hipMemcpyAsync(host.data(), s->d_recv, host.size() * 8, hipMemcpyDeviceToHost, c->stream));   // behind the all-gather
     HIP_OK(hipStreamSynchronize(c->stream));
+    int bad = -1;
     for (int f = 0; f < B; ++f) {
         const double* x = &host[(size_t)(f % W) * blk + (size_t)(f / W) * stride];
+        if (x[xs + 7] != 0.0 && bad < 0) bad = f;       // the owning rank's device fault bits travelled with the result (k_pack_results)
         if (p) std::copy(x, x + 3, p + 3 * (size_t)f);
         if (q) std::copy(x + 3, x + 3 + 4 * J, q + (size_t)4 * J * f);
         if (w) std::copy(x + 3 + 4 * J, x + xs, w + (size_t)K * f);
@@ -501,6 +503,11 @@ extern "C" int avt_shard_gather_download(avt_shard* s, avt_ctx* c, int B, double
             stats[f].num_correspondences = (int)t[3]; stats[f].matched_model_points = (int)t[4];
             stats[f].gn_iterations = (int)t[5]; stats[f].accepted_steps = (int)t[6];
         }
+    }
+    if (bad >= 0) {
+        (void)hipMemsetAsync(c->fb.fault, 0, (size_t)c->fb.max_frames * sizeof(unsigned), c->stream);   // reported once
+        avt_set_error("avt_shard_gather_download: frame " + std::to_string(bad) + " carries a device fault (rank " + std::to_string(bad % W) + "); its result is not valid");
+        return AVT_STATUS_DEVICE_FAULT;
     }
     return 0;
 } catch (const std::exception& e) { avt_set_error(std::string("avt_shard_gather_download: ") + e.what()); return 1; }

@@ -27,6 +27,13 @@
 extern "C" {
 #endif
 
+/* Status codes (every non-zero return is an error; these two are told apart because a caller may want to): */
+#define AVT_STATUS_NO_DEVICE 2      /* avt_ctx_create: no usable HIP device (there is no CPU fallback) */
+#define AVT_STATUS_DEVICE_FAULT 3   /* a kernel could not vouch for a frame's result - e.g. a solver of the few-frames launch shape gave up
+                                     * waiting for the in-launch reduction (avt_lm.hip) - and said so in the frame's fault word: returned by
+                                     * the calls that hand out results (avt_optimize, avt_optimize_batch, avt_state_download,
+                                     * avt_shard_gather_download); the word is cleared when it is reported */
+
 #define AVT_MAX_JOINTS 64   /* SMPL: 24, SMPL-H: 52; SMPL-X: 55; additionally 3 + 3J + K <= 179 (avt_model_create) */
 #define AVT_MAX_SHAPE 16    /* SMPL: 10 */
 #define AVT_MAX_ASSIGN 4    /* AvatarOptimizer.cpp:164 MAX_ASSIGN */
