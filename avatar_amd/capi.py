@@ -201,6 +201,7 @@ def load_library():
         "avt_model_unpack": [vp, C.c_size_t, C.POINTER(vp)],
         "avt_shard_unique_id": [C.c_char_p],
         "avt_shard_create": [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)],
+        "avt_shard_create_loopback": [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)],
         "avt_shard_destroy": [vp],
         "avt_shard_rank": [vp],
         "avt_shard_world": [vp],
@@ -234,7 +235,7 @@ EXPORTED_SYMBOLS = [
     "avt_get_correspondences", "avt_get_cloud", "avt_get_posed", "avt_get_normal_equations", "avt_debug_trace", "avt_launch_shape", "avt_profile_begin", "avt_profile_select", "avt_profile_end",
     # include/avt_shard.h
     "avt_shard_owner", "avt_shard_local_count", "avt_shard_local_index", "avt_shard_global_frame", "avt_model_pack_size", "avt_model_pack",
-    "avt_model_unpack", "avt_shard_unique_id", "avt_shard_create", "avt_shard_destroy", "avt_shard_rank", "avt_shard_world", "avt_shard_backend",
+    "avt_model_unpack", "avt_shard_unique_id", "avt_shard_create", "avt_shard_create_loopback", "avt_shard_destroy", "avt_shard_rank", "avt_shard_world", "avt_shard_backend",
     "avt_shard_broadcast_model", "avt_shard_scatter_frames", "avt_shard_gather_enqueue", "avt_shard_gather_wait", "avt_shard_gather_download",
     "avt_shard_gather_results", "avt_shard_barrier",
 ]

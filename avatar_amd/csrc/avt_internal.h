@@ -140,6 +140,7 @@ struct AvtSolveSnap {
 };
 
 // FrameBuffers::fault bits
+#define AVT_FAULT_NOT_RESIDENT 2u   // (batch split) the owning rank's context did not hold the frame when the results were gathered
 #define AVT_FAULT_RIDE_TIMEOUT 1u   // a solver role of a riding k_solve launch gave up waiting for the reduction workgroups of its launch
 
 struct AvtRunParams {

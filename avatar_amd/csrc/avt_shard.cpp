@@ -11,7 +11,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -214,6 +218,138 @@ RcclApi* rccl_api() {
     return &api;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Loop-back transport: the same five collectives between the THREADS of one process (one avt_shard per thread, any mix of
+// devices), as device-to-device copies behind host-side rendezvous.  It exists for two reasons: a single-process host that
+// drives several GPUs from threads needs no RCCL, and every line of the multi-peer exchange code below can run with W > 1
+// ranks on a one-GPU box (tests/test_gpu_shard.py) - RCCL refuses two ranks on one GPU.  Semantics are stricter than RCCL's
+// (every call completes before it returns); a rank that never arrives makes its peers fail after a time-out instead of
+// hanging (ncclSystemError), and the group stays broken.
+// ---------------------------------------------------------------------------------------------------------------------
+struct LoopSend { int dst; const void* ptr; size_t bytes; };
+struct LoopGroup {
+    std::string name;
+    int world = 0, joined = 0, refs = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long long generation = 0;
+    bool broken = false;
+    double timeout_s = 20.0;
+    std::vector<const void*> slot;                 // one published pointer per rank (broadcast root / all-gather blocks)
+    std::vector<std::vector<LoopSend>> sends;      // per source rank, in issue order
+};
+struct LoopComm { LoopGroup* g; int rank; };
+struct LoopPending { int depth = 0; std::vector<LoopSend> sends; struct R { int src; void* ptr; size_t bytes; }; std::vector<R> recvs; ncclComm_t comm = nullptr; hipStream_t stream = nullptr; };
+thread_local LoopPending loop_pending;
+
+std::mutex loop_registry_mutex;
+std::map<std::string, LoopGroup*> loop_registry;
+
+size_t nccl_type_bytes(ncclDataType_t t) {
+    switch (t) {
+        case ncclChar: case ncclUint8: return 1;
+        case ncclInt32: case ncclUint32: case ncclFloat: return 4;
+        case ncclInt64: case ncclUint64: case ncclDouble: return 8;
+        default: return 0;
+    }
+}
+
+// all ranks of the group meet here; false = somebody did not come (the group is broken from then on)
+bool loop_barrier(LoopGroup* g) {
+    std::unique_lock<std::mutex> lk(g->m);
+    if (g->broken) return false;
+    const unsigned long long gen = g->generation;
+    if (++g->arrived == g->world) { g->arrived = 0; ++g->generation; g->cv.notify_all(); return true; }
+    const bool ok = g->cv.wait_for(lk, std::chrono::duration<double>(g->timeout_s), [&] { return g->generation != gen || g->broken; });
+    if (!ok || g->broken) { g->broken = true; g->cv.notify_all(); return false; }
+    return true;
+}
+
+ncclResult_t loop_copy(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (bytes && dst != src && hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st) != hipSuccess) return ncclUnhandledCudaError;
+    return hipStreamSynchronize(st) == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
+}
+
+ncclResult_t loop_GetVersion(int* v) { *v = 0; return ncclSuccess; }
+const char* loop_GetErrorString(ncclResult_t r) {
+    return r == ncclSuccess ? "no error" : r == ncclSystemError ? "loop-back transport: a rank did not arrive (time-out); the group is broken" : "loop-back transport: device copy failed";
+}
+ncclResult_t loop_CommDestroy(ncclComm_t c) {
+    LoopComm* lc = (LoopComm*)c;
+    std::lock_guard<std::mutex> lk(loop_registry_mutex);
+    if (--lc->g->refs == 0) { loop_registry.erase(lc->g->name); delete lc->g; }
+    delete lc;
+    return ncclSuccess;
+}
+ncclResult_t loop_Broadcast(const void* send, void* recv, size_t count, ncclDataType_t t, int root, ncclComm_t c, hipStream_t st) {
+    LoopComm* lc = (LoopComm*)c; LoopGroup* g = lc->g;
+    if (hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;       // my buffer is ready
+    if (lc->rank == root) g->slot[root] = send;
+    if (!loop_barrier(g)) return ncclSystemError;
+    const ncclResult_t r = loop_copy(recv, g->slot[root], count * nccl_type_bytes(t), st);
+    if (!loop_barrier(g)) return ncclSystemError;                                    // the root may reuse its buffer
+    return r;
+}
+ncclResult_t loop_AllGather(const void* send, void* recv, size_t count, ncclDataType_t t, ncclComm_t c, hipStream_t st) {
+    LoopComm* lc = (LoopComm*)c; LoopGroup* g = lc->g;
+    const size_t bytes = count * nccl_type_bytes(t);
+    if (hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;
+    g->slot[lc->rank] = send;
+    if (!loop_barrier(g)) return ncclSystemError;
+    ncclResult_t r = ncclSuccess;
+    for (int k = 0; k < g->world && r == ncclSuccess; ++k) r = loop_copy((char*)recv + (size_t)k * bytes, g->slot[k], bytes, st);
+    if (!loop_barrier(g)) return ncclSystemError;
+    return r;
+}
+ncclResult_t loop_flush() {      // the end of a group (or a lone send / receive): every rank publishes its sends, then takes its receives
+    LoopPending& p = loop_pending;
+    if (!p.comm) return ncclSuccess;                 // an empty group: like RCCL, nothing to do and nobody to meet
+    LoopComm* lc = (LoopComm*)p.comm; LoopGroup* g = lc->g;
+    ncclResult_t r = hipStreamSynchronize(p.stream) == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
+    g->sends[lc->rank] = p.sends;
+    if (!loop_barrier(g)) r = ncclSystemError;
+    if (r == ncclSuccess) {
+        std::vector<size_t> taken(g->world, 0);      // receives match a peer's sends to me in issue order
+        for (const auto& rc : p.recvs) {
+            const std::vector<LoopSend>& from = g->sends[rc.src];
+            size_t k = taken[rc.src];
+            while (k < from.size() && from[k].dst != lc->rank) ++k;
+            if (k == from.size() || from[k].bytes != rc.bytes) { r = ncclInvalidUsage; break; }
+            taken[rc.src] = k + 1;
+            if ((r = loop_copy(rc.ptr, from[k].ptr, rc.bytes, p.stream)) != ncclSuccess) break;
+        }
+    }
+    if (!loop_barrier(g) && r == ncclSuccess) r = ncclSystemError;
+    g->sends[lc->rank].clear();
+    p.sends.clear(); p.recvs.clear(); p.comm = nullptr; p.stream = nullptr;
+    return r;
+}
+ncclResult_t loop_GroupStart() { ++loop_pending.depth; return ncclSuccess; }
+ncclResult_t loop_GroupEnd() { return --loop_pending.depth == 0 ? loop_flush() : ncclSuccess; }
+ncclResult_t loop_Send(const void* ptr, size_t count, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t st) {
+    loop_pending.comm = c; loop_pending.stream = st;
+    loop_pending.sends.push_back({peer, ptr, count * nccl_type_bytes(t)});
+    return loop_pending.depth == 0 ? loop_flush() : ncclSuccess;
+}
+ncclResult_t loop_Recv(void* ptr, size_t count, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t st) {
+    loop_pending.comm = c; loop_pending.stream = st;
+    loop_pending.recvs.push_back({peer, ptr, count * nccl_type_bytes(t)});
+    return loop_pending.depth == 0 ? loop_flush() : ncclSuccess;
+}
+
+RcclApi* loop_api() {
+    static RcclApi api = [] {
+        RcclApi a;
+        a.path = "in-process loop-back";
+        a.GetVersion = loop_GetVersion; a.CommDestroy = loop_CommDestroy; a.GetErrorString = loop_GetErrorString;
+        a.Broadcast = loop_Broadcast; a.AllGather = loop_AllGather; a.Send = loop_Send; a.Recv = loop_Recv;
+        a.GroupStart = loop_GroupStart; a.GroupEnd = loop_GroupEnd;
+        return a;
+    }();
+    return &api;
+}
+
 }  // namespace
 
 struct avt_shard {
@@ -295,6 +431,40 @@ extern "C" int avt_shard_create(int device, int rank, int world, const char id[A
     return 0;
 }
 
+extern "C" int avt_shard_create_loopback(int device, int rank, int world, const char* group, avt_shard** out) {
+    if (!group || !out || world <= 0 || rank < 0 || rank >= world) { avt_set_error("avt_shard_create_loopback: bad argument"); return 1; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { avt_set_error("avt_shard_create_loopback: device index out of range"); return 2; }
+    HIP_OK(hipSetDevice(device));
+    LoopGroup* g = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(loop_registry_mutex);
+        auto it = loop_registry.find(group);
+        if (it == loop_registry.end()) {
+            g = new LoopGroup();
+            g->name = group; g->world = world; g->slot.assign(world, nullptr); g->sends.resize(world);
+            if (const char* e = getenv("AVT_SHARD_LOOPBACK_TIMEOUT_S")) g->timeout_s = std::max(0.1, atof(e));
+            loop_registry[group] = g;
+        } else {
+            g = it->second;
+            if (g->world != world || g->joined >= world) { avt_set_error("avt_shard_create_loopback: group exists with another world size, or is full"); return 1; }
+        }
+        ++g->joined; ++g->refs;
+    }
+    avt_shard* s = new avt_shard();
+    s->api = loop_api(); s->device = device; s->rank = rank; s->world = world;
+    s->comm = (ncclComm_t) new LoopComm{g, rank};
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+        avt_set_error("avt_shard_create_loopback: hipStreamCreate failed");
+        s->api->CommDestroy(s->comm);
+        delete s;
+        return 1;
+    }
+    s->backend = std::string("loop-back (threads of one process), group ") + group;
+    *out = s;
+    return 0;
+}
+
 extern "C" void avt_shard_destroy(avt_shard* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
@@ -342,38 +512,64 @@ extern "C" int avt_shard_scatter_frames(avt_shard* s, avt_ctx* c, int root, int 
                                         const int* offs, const double* p, const double* q, const double* w) try {
     if (!s || !c || root < 0 || root >= s->world || B <= 0) { avt_set_error("avt_shard_scatter_frames: bad argument"); return 1; }
     const bool is_root = s->rank == root;
-    if (is_root && (!data || !labels || !offs || !p || !q || !w)) { avt_set_error("avt_shard_scatter_frames: root needs all host arrays"); return 1; }
     const AvtDims& d = c->dm.d;
     const int W = s->world, xs = d.xsize, J = d.J, K = d.K;
     const int nloc = avt_shard_local_count(B, s->rank, W);
-    if (nloc > c->fb.max_frames) { avt_set_error("avt_shard_scatter_frames: this rank's share exceeds the context's max_frames"); return 1; }
     HIP_OK(hipSetDevice(s->device));
     hipStream_t st = c->stream;
+    // A rank that leaves before a collective its peers enter blocks them for ever.  Everything that can be wrong on ONE rank
+    // only - the root's arguments, a context too small for this rank's share - is therefore carried INTO the exchange and all
+    // ranks leave together: the root marks a bad batch in the table it broadcasts, and every rank contributes an ok / not-ok
+    // word to a one-double all-gather before any cloud moves.
+    std::string my_error;
     // ---- 1. frame table and start states: one small broadcast.  block = [B point counts as doubles | B x xsize states]
     const size_t tab_n = (size_t)B * (1 + xs);
     std::vector<double> tab(tab_n, 0.0);
     if (is_root) {
-        for (int f = 0; f < B; ++f) {
+        if (!data || !labels || !offs || !p || !q || !w) my_error = "avt_shard_scatter_frames: root needs all host arrays";
+        for (int f = 0; f < B && my_error.empty(); ++f) {
             const int n = offs[f + 1] - offs[f];
-            if (n < 0) { avt_set_error("avt_shard_scatter_frames: frame_offsets not monotone"); return 1; }
+            if (n < 0) { my_error = "avt_shard_scatter_frames: frame_offsets not monotone"; break; }
             tab[f] = (double)n;
             double* x = &tab[(size_t)B + (size_t)f * xs];
             std::copy(p + 3 * (size_t)f, p + 3 * (size_t)f + 3, x);
             std::copy(q + (size_t)4 * J * f, q + (size_t)4 * J * (f + 1), x + 3);
             std::copy(w + (size_t)K * f, w + (size_t)K * (f + 1), x + 3 + 4 * J);
         }
+        if (!my_error.empty()) tab[0] = -1.0;          // a point count cannot be negative: "the root's batch is unusable"
     }
-    if (grow(&s->d_stage2, &s->stage2_cap, tab_n * 8)) return 1;
+    if (grow(&s->d_stage2, &s->stage2_cap, std::max<size_t>(tab_n, (size_t)W + 1) * 8)) return 1;   // (allocation failure: nothing a peer could wait for has begun)
     if (is_root) HIP_OK(hipMemcpyAsync(s->d_stage2, tab.data(), tab_n * 8, hipMemcpyHostToDevice, st));
     NCCL_OK(s, s->api->Broadcast(s->d_stage2, s->d_stage2, tab_n, ncclDouble, root, s->comm, st));
     HIP_OK(hipMemcpyAsync(tab.data(), s->d_stage2, tab_n * 8, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    std::vector<int> cnt(B);
+    std::vector<int> cnt(B, 0);
     std::vector<long long> rank_pts(W, 0);
-    for (int f = 0; f < B; ++f) {
+    const bool root_bad = tab[0] < 0.0;
+    if (root_bad && my_error.empty()) my_error = "avt_shard_scatter_frames: the root rank rejected the batch";
+    if (my_error.empty() && nloc > c->fb.max_frames) my_error = "avt_shard_scatter_frames: this rank's share exceeds the context's max_frames";
+    for (int f = 0; f < B && !root_bad; ++f) {
         cnt[f] = (int)tab[f];
-        if (cnt[f] < 0 || cnt[f] > c->fb.max_points) { avt_set_error("avt_shard_scatter_frames: a frame has more points than max_points_per_frame"); return 1; }
-        rank_pts[f % W] += cnt[f];
+        // every rank checks ITS frames against ITS context (contexts may differ in size)
+        if (f % W == s->rank && my_error.empty() && (cnt[f] < 0 || cnt[f] > c->fb.max_points))
+            my_error = "avt_shard_scatter_frames: a frame has more points than max_points_per_frame";
+        rank_pts[f % W] += std::max(cnt[f], 0);
+    }
+    {   // agreement: one double per rank (0 = fine), everybody sees everybody's
+        std::vector<double> flags((size_t)W + 1, 0.0);
+        flags[W] = my_error.empty() ? 0.0 : 1.0;
+        double* dflag = (double*)s->d_stage2;
+        HIP_OK(hipMemcpyAsync(dflag + W, &flags[W], 8, hipMemcpyHostToDevice, st));
+        NCCL_OK(s, s->api->AllGather(dflag + W, dflag, 1, ncclDouble, s->comm, st));
+        HIP_OK(hipMemcpyAsync(flags.data(), dflag, (size_t)W * 8, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        int bad_rank = -1;
+        for (int r = 0; r < W; ++r) if (flags[r] != 0.0 && bad_rank < 0) bad_rank = r;
+        if (bad_rank >= 0) {
+            c->nframes = 0; c->frames_valid = c->state_valid = false;
+            avt_set_error(!my_error.empty() ? my_error : "avt_shard_scatter_frames: rank " + std::to_string(bad_rank) + " rejected the batch; nothing was exchanged");
+            return 1;
+        }
     }
     // ---- 2. clouds: the root permutes the batch so that every rank's frames are contiguous (rank-major, then local
     // order), uploads it once and sends each rank its block: [3 n doubles | n ints] -> two sends per peer, one group
@@ -438,7 +634,11 @@ extern "C" int avt_shard_scatter_frames(avt_shard* s, avt_ctx* c, int root, int 
         std::copy(x + 3, x + 3 + 4 * J, &lq[(size_t)i * 4 * J]);
         std::copy(x + 3 + 4 * J, x + xs, &lw[(size_t)i * K]);
     }
-    if (nloc == 0) return 0;
+    if (nloc == 0) {       // a rank without frames (B < W): nothing resident, and a later gather must see exactly that
+        c->nframes = 0; c->frames_valid = c->state_valid = false;
+        HIP_OK(hipStreamSynchronize(st));
+        return 0;
+    }
     if (avt_internal_install_frames(c, nloc, lcnt.data(), my_data, my_lab, 1)) return 1;
     if (avt_state_upload(c, nloc, lp.data(), lq.data(), lw.data())) return 1;
     HIP_OK(hipStreamSynchronize(st));
@@ -449,7 +649,9 @@ extern "C" int avt_shard_gather_enqueue(avt_shard* s, avt_ctx* c, int B) {
     if (!s || !c || B <= 0) { avt_set_error("avt_shard_gather_enqueue: bad argument"); return 1; }
     const int W = s->world, per = (B + W - 1) / W, stride = gather_stride(c);
     const int nloc = avt_shard_local_count(B, s->rank, W);
-    if (nloc != c->nframes) { avt_set_error("avt_shard_gather_enqueue: resident frames differ from this rank's share of the batch"); return 1; }
+    // (a rank whose context does not hold its share still takes part in the all-gather - its peers are on their way into it - with
+    // its rows marked faulty, and reports the error afterwards; every rank's download then fails on those rows)
+    const bool mismatch = nloc != (c->frames_valid ? c->nframes : 0);
     HIP_OK(hipSetDevice(s->device));
     const size_t blk = (size_t)per * stride;
     if (s->gather_cap < blk) {
@@ -467,9 +669,17 @@ extern "C" int avt_shard_gather_enqueue(avt_shard* s, avt_ctx* c, int B) {
     // per step, 0.62 ms): this costs 6 us per step; putting the all-gather on the shard's own stream instead - so that the
     // exchange of step k overlaps step k+1 - costs 25 us, because the event record / cross-stream wait the hand-over needs
     // sit in the context stream's critical path (double-buffering the send block and waiting on the host: 24 us).
-    if (nloc) launch_pack_results(c, nloc, s->d_send, stride);
+    if (mismatch) {
+        std::vector<double> rows(blk, 0.0);
+        for (int i = 0; i < per; ++i) rows[(size_t)i * stride + c->dm.d.xsize + 7] = (double)AVT_FAULT_NOT_RESIDENT;
+        HIP_OK(hipMemcpyAsync(s->d_send, rows.data(), blk * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+    } else if (nloc) {
+        launch_pack_results(c, nloc, s->d_send, stride);
+    }
     NCCL_OK(s, s->api->AllGather(s->d_send, s->d_recv, blk, ncclDouble, s->comm, c->stream));
     s->gather_stream = c->stream;
+    if (mismatch) { avt_set_error("avt_shard_gather_enqueue: resident frames differ from this rank's share of the batch (its rows were gathered as faulty)"); return 1; }
     return 0;
 }
 

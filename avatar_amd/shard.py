@@ -27,7 +27,9 @@ def frames_of_rank(num_frames, rank, world):
 def _check(rc):
     if rc != 0:
         from .api import AvtError
-        raise AvtError(capi.load_library().avt_last_error().decode())
+        e = AvtError(capi.load_library().avt_last_error().decode())
+        e.status = rc
+        raise e
 
 
 def pack_model(arrays: capi.ModelArrays) -> bytes:
@@ -65,10 +67,15 @@ def exchange_unique_id(dist, rank, src=0):
 class Shard:
     """avt_shard: one RCCL communicator rank bound to one GPU."""
 
-    def __init__(self, device, rank, world, unique_id: bytes):
+    def __init__(self, device, rank, world, unique_id: bytes = None, loopback_group: str = None):
+        """unique_id: the RCCL rendezvous bytes.  loopback_group: instead of RCCL, the in-process loop-back transport - the
+        ranks are threads of this process that name the same group (avt_shard_create_loopback)."""
         self._lib = capi.load_library()
         self.h = C.c_void_p()
-        _check(self._lib.avt_shard_create(C.c_int(device), C.c_int(rank), C.c_int(world), unique_id, C.byref(self.h)))
+        if loopback_group is not None:
+            _check(self._lib.avt_shard_create_loopback(C.c_int(device), C.c_int(rank), C.c_int(world), loopback_group.encode(), C.byref(self.h)))
+        else:
+            _check(self._lib.avt_shard_create(C.c_int(device), C.c_int(rank), C.c_int(world), unique_id, C.byref(self.h)))
         self.rank, self.world = rank, world
         self.backend = self._lib.avt_shard_backend(self.h).decode()
 

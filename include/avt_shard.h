@@ -50,6 +50,13 @@ int avt_model_unpack(const void* buf, size_t bytes, avt_model** out);
 /* ---- communicator */
 int avt_shard_unique_id(char id[AVT_SHARD_ID_BYTES]);                                  /* ncclGetUniqueId */
 int avt_shard_create(int device, int rank, int world, const char id[AVT_SHARD_ID_BYTES], avt_shard** out);
+/* The same handle over the in-process LOOP-BACK transport instead of RCCL: the `world` ranks are threads of this process
+ * (one avt_shard and one avt_ctx each, on any devices), ranks that name the same `group` string belong together, and the
+ * exchanges below become device-to-device copies behind host-side rendezvous.  For single-process hosts that drive their GPUs
+ * from threads, and for exercising the multi-rank exchange code on a one-GPU box (RCCL refuses two ranks on one GPU).  Every
+ * exchange is collective: each rank's thread must make the call.  A rank that does not arrive within
+ * AVT_SHARD_LOOPBACK_TIMEOUT_S (default 20 s) makes its peers' calls FAIL instead of hang. */
+int avt_shard_create_loopback(int device, int rank, int world, const char* group, avt_shard** out);
 void avt_shard_destroy(avt_shard* s);
 int avt_shard_rank(const avt_shard* s);
 int avt_shard_world(const avt_shard* s);
@@ -64,7 +71,10 @@ int avt_shard_broadcast_model(avt_shard* s, int root, const avt_model_desc* desc
  * [frame_offsets[f], frame_offsets[f+1]) of data/labels; p/q/w frame-major start states).  Other ranks pass NULL for the
  * five arrays.  On return every rank's context holds ITS frames (in avt_shard_global_frame order) resident exactly as
  * after avt_frames_upload + avt_state_upload, ready for avt_optimize_resident.  num_frames is read on every rank and
- * must agree; local frame count must fit ctx's max_frames. */
+ * must agree; local frame count must fit ctx's max_frames.  Errors are COLLECTIVE: what only one rank can see (the root's
+ * arguments, a context too small for its share) is agreed on before any cloud moves, and then every rank returns non-zero -
+ * no rank is left waiting in an exchange its peer never entered.  A rank that owns no frame (num_frames < world) ends with no
+ * resident frames. */
 int avt_shard_scatter_frames(avt_shard* s, avt_ctx* ctx, int root, int num_frames, const double* data, const int* labels,
                              const int* frame_offsets, const double* p, const double* q, const double* w);
 

@@ -127,3 +127,107 @@ def test_failed_context_creation_releases_everything(gmodel):
     for _ in range(200):
         with pytest.raises(api.AvtError):
             api.Context(gmodel, 24, bad_map, 1 << 20, 64, device=0)
+
+
+# ---- W > 1 ranks on one GPU: the loop-back transport (threads of this process) runs every line of the multi-peer exchange ----
+
+def _run_ranks(W, fn):
+    """fn(rank) on W threads; returns the results, re-raising the first exception after all threads ended."""
+    import threading
+    out, err = [None] * W, [None] * W
+
+    def body(r):
+        try:
+            out[r] = fn(r)
+        except BaseException as e:      # noqa: BLE001 - reported below
+            err[r] = e
+    th = [threading.Thread(target=body, args=(r,)) for r in range(W)]
+    for t in th: t.start()
+    for t in th: t.join(120)
+    assert not any(t.is_alive() for t in th), "a rank hangs in an exchange"
+    return out, err
+
+
+@pytest.mark.parametrize("W,B", [(2, 5), (3, 7), (8, 5), (8, 17)])
+def test_loopback_ranks_scatter_optimize_gather(smpl, gmodel, W, B):
+    """W ranks as W threads (one context + one loop-back shard each, all on this GPU): model broadcast, cloud scatter with
+    W - 1 peers (ragged batches; with W = 8, B = 5 three ranks own NO frame), optimize, all-gather.  Every rank ends up with
+    every frame's result in global frame order, bit-identical to the single-context run; every rank's resident block is
+    frames_of_rank(B, rank, W)."""
+    import uuid
+    from avatar_amd import api, shard
+    pm = synth.identity_part_map()
+    frames = [synth.make_frame(smpl, 60 + f) for f in range(B)]
+    datas = [fr["data"][::7 + (f % 3)] for f, fr in enumerate(frames)]
+    labels = [fr["labels"][::7 + (f % 3)] for f, fr in enumerate(frames)]
+    p0 = np.array([fr["start"][1] for fr in frames]); w0 = np.array([fr["start"][0] for fr in frames])
+    q0 = np.array([api.rot_to_quat(fr["start"][2]) for fr in frames])
+    opt = Options.demo(max_iters_per_icp=3)
+    pa, qa, wa, sta = api.Context(gmodel, 24, pm, 8192, B, device=0).optimize_batch(datas, labels, opt, p0, q0, w0)
+    group = "t-" + uuid.uuid4().hex
+    per = (B + W - 1) // W
+
+    def rank_main(r):
+        sh = shard.Shard(0, r, W, loopback_group=group)
+        assert "loop-back" in sh.backend and sh.world == W
+        h = sh.broadcast_model(gmodel.arrays if r == 0 else None, root=0)
+        model = api.AvatarModel(smpl, handle=h)
+        ctx = api.Context(model, 24, pm, 8192, per, device=0)
+        if r == 0: sh.scatter_frames(ctx, B, datas, labels, p0, q0, w0, root=0)
+        else: sh.scatter_frames(ctx, B, root=0)
+        mine = shard.frames_of_rank(B, r, W)
+        ctx._N = np.array([len(labels[f]) for f in mine], np.int32)
+        for i, f in enumerate(mine):                       # this rank's resident block is exactly its share, in order
+            d, l = ctx.frame_download(i)
+            assert np.array_equal(d, datas[f]) and np.array_equal(l, labels[f])
+        if mine:
+            ctx.optimize_resident(opt)
+        res = sh.gather_results(ctx, B)
+        sh.barrier(ctx)
+        sh.close()
+        return res
+
+    out, err = _run_ranks(W, rank_main)
+    for e in err:
+        if e is not None: raise e
+    for r in range(W):
+        pg, qg, wg, stg = out[r]
+        assert np.array_equal(pg, pa) and np.array_equal(qg, qa) and np.array_equal(wg, wa), f"rank {r} of {W}"
+        assert all(stg[f].final_cost == sta[f].final_cost and stg[f].num_correspondences == sta[f].num_correspondences for f in range(B))
+
+
+def test_loopback_a_bad_rank_fails_everybody_and_nobody_hangs(smpl, gmodel):
+    """one rank's context is too small for its share.  The scatter fails on EVERY rank (agreed before any cloud
+    moves), no rank is left inside an exchange; a gather with one rank not holding its share marks that rank's rows faulty:
+    the offender reports at once, its peers at download."""
+    import uuid
+    from avatar_amd import api, shard
+    pm = synth.identity_part_map()
+    W, B = 3, 6
+    frames = [synth.make_frame(smpl, 70 + f) for f in range(B)]
+    datas = [fr["data"][::9] for fr in frames]; labels = [fr["labels"][::9] for fr in frames]
+    p0 = np.array([fr["start"][1] for fr in frames]); w0 = np.array([fr["start"][0] for fr in frames])
+    q0 = np.array([api.rot_to_quat(fr["start"][2]) for fr in frames])
+    group = "t-" + uuid.uuid4().hex
+
+    def rank_main(r):
+        sh = shard.Shard(0, r, W, loopback_group=group)
+        small = api.Context(gmodel, 24, pm, 8192, 1 if r == 1 else 2, device=0)      # rank 1 cannot hold its two frames
+        with pytest.raises(api.AvtError, match="rejected the batch|exceeds the context"):
+            sh.scatter_frames(small, B, *( (datas, labels, p0, q0, w0) if r == 0 else () ), root=0)
+        # same communicator, now a sound batch; rank 2 then "forgets" its frames before the gather
+        ctx = api.Context(gmodel, 24, pm, 8192, 2, device=0)
+        sh.scatter_frames(ctx, B, *((datas, labels, p0, q0, w0) if r == 0 else ()), root=0)
+        ctx.optimize_resident(Options.demo(max_iters_per_icp=2))
+        if r == 2:
+            w, p, R = synth.sample_ground_truth(smpl, 1)
+            ctx.lbs_update(w[None], p[None], R[None])                                  # invalidates the resident frames
+        with pytest.raises(api.AvtError, match="differ from this rank|device fault"):
+            sh.gather_results(ctx, B)
+        sh.close()
+        return True
+
+    out, err = _run_ranks(W, rank_main)
+    for e in err:
+        if e is not None: raise e
+    assert all(out)

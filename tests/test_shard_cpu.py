@@ -65,3 +65,18 @@ def test_packed_model_rejects_damage(smpl):
     b[off_colptr + 4 * V:off_colptr + 4 * V + 4] = np.int32(7).tobytes()          # weights_colptr[V] != nnz
     with pytest.raises(AvtError):
         shard.unpack_model(bytes(b))
+
+
+def test_a_bogus_rccl_path_does_not_crash_the_loader():
+    """ADVICE r2: dlerror() was called twice and a NULL went into a std::string - any candidate that failed to open crashed
+    the process (rc 139) instead of advancing to the next one.  With AVT_RCCL_LIB pointing nowhere the loader must move on to
+    the system copies, or fail with a message."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from avatar_amd import capi; lib = capi.load_library(); "
+            "buf = ctypes.create_string_buffer(128); rc = lib.avt_shard_unique_id(buf); "
+            "print('rc', rc, lib.avt_last_error().decode() if rc else 'ok')" % ROOT)
+    env = dict(os.environ, AVT_RCCL_LIB="/nonexistent/librccl.so.1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, f"the loader crashed: rc {r.returncode}\n{r.stderr[-400:]}"
+    assert "rc 0 ok" in r.stdout or "librccl" in r.stdout or "nccl" in r.stdout
