@@ -47,7 +47,11 @@ int dev_alloc(avt_ctx* c, T** p, size_t n) {
 template <class T>
 int dev_upload(avt_ctx* c, T** p, const std::vector<T>& v) {
     if (dev_alloc(c, p, v.size())) return 1;
-    if (!v.empty()) HIP_OK(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    // (never the legacy stream: another thread of the host may be capturing a graph, and the legacy stream synchronises with it)
+    if (!v.empty()) {
+        HIP_OK(hipMemcpyAsync(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+    }
     return 0;
 }
 
@@ -481,19 +485,19 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
     }
     fb.fsum = (long long*)cntsum;                                   // 8-byte aligned first
     fb.cnt = (int*)(cntsum + FV * 3 * sizeof(long long));
-    HIP_OK(hipMemset(fb.trace, 0, (size_t)max_frames * 64 * sizeof(double)));
-    HIP_OK(hipMemset(fb.ctl, 0, (size_t)max_frames * sizeof(AvtFrameCtl)));
-    HIP_OK(hipMemset(fb.ride_ctr, 0, (size_t)max_frames * sizeof(unsigned)));
-    HIP_OK(hipMemset(fb.fault, 0, (size_t)max_frames * sizeof(unsigned)));
+    HIP_OK(hipMemsetAsync(fb.trace, 0, (size_t)max_frames * 64 * sizeof(double), c->stream));
+    HIP_OK(hipMemsetAsync(fb.ctl, 0, (size_t)max_frames * sizeof(AvtFrameCtl), c->stream));
+    HIP_OK(hipMemsetAsync(fb.ride_ctr, 0, (size_t)max_frames * sizeof(unsigned), c->stream));
+    HIP_OK(hipMemsetAsync(fb.fault, 0, (size_t)max_frames * sizeof(unsigned), c->stream));
     {   // wall_clock64() ticks at 100 MHz; default 2 s.  AVT_RIDE_TIMEOUT_US=0 makes every wait that is not already satisfied fail (tests)
         long long us = 2000000;
         if (const char* e = getenv("AVT_RIDE_TIMEOUT_US")) us = std::max(0ll, atoll(e));
         fb.ride_timeout = us * 100;
     }
-    HIP_OK(hipMemset(fb.spec, 0, (size_t)max_frames * sizeof(AvtSpecCtl)));
+    HIP_OK(hipMemsetAsync(fb.spec, 0, (size_t)max_frames * sizeof(AvtSpecCtl), c->stream));
     fb.nspec = 0; fb.seq = 0;
-    HIP_OK(hipDeviceSynchronize());
-    HIP_OK(hipMemset(fb.part_cnt, 0, (size_t)max_frames * 2 * (AVT_MAX_PARTS + 1) * sizeof(int)));   // invariant of launch_bucket
+    HIP_OK(hipMemsetAsync(fb.part_cnt, 0, (size_t)max_frames * 2 * (AVT_MAX_PARTS + 1) * sizeof(int), c->stream));   // invariant of launch_bucket
+    HIP_OK(hipStreamSynchronize(c->stream));
     if (getenv("AVT_DEBUG")) avt_eval_report_occupancy(dm.d);
     return 0;
 }
@@ -591,7 +595,8 @@ int avt_nn(avt_ctx* c, const double* model_cloud, const unsigned char* visible, 
     c->frames_valid = c->state_valid = false;    // frame slot 0 is scratch for this call
     // part-sorted SoA copy of the model cloud
     std::vector<int> ppos(V);
-    HIP_OK(hipMemcpy(ppos.data(), c->dm.part_pos, (size_t)V * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpyAsync(ppos.data(), c->dm.part_pos, (size_t)V * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
     std::vector<double> px(V), py(V), pz(V);
     for (int v = 0; v < V; ++v) { px[ppos[v]] = model_cloud[3 * v]; py[ppos[v]] = model_cloud[3 * v + 1]; pz[ppos[v]] = model_cloud[3 * v + 2]; }
     HIP_OK(hipMemcpyAsync(c->fb.pcx, px.data(), V * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -722,8 +727,9 @@ int avt_frames_download(avt_ctx* c, int frame, double* data_3xN, int* labels) {
     if (!c || !c->frames_valid || frame < 0 || frame >= c->nframes) { avt_set_error("avt_frames_download: bad argument"); return 1; }
     HIP_OK(hipSetDevice(c->device));
     const size_t N = c->frame_N[frame];
-    if (data_3xN) HIP_OK(hipMemcpy(data_3xN, c->fb.data_raw + (size_t)frame * c->fb.max_points * 3, N * 3 * sizeof(double), hipMemcpyDeviceToHost));
-    if (labels) HIP_OK(hipMemcpy(labels, c->fb.labels_raw + (size_t)frame * c->fb.max_points, N * sizeof(int), hipMemcpyDeviceToHost));
+    if (data_3xN) HIP_OK(hipMemcpyAsync(data_3xN, c->fb.data_raw + (size_t)frame * c->fb.max_points * 3, N * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (labels) HIP_OK(hipMemcpyAsync(labels, c->fb.labels_raw + (size_t)frame * c->fb.max_points, N * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -833,9 +839,11 @@ int avt_get_normal_equations(avt_ctx* c, int frame, double* H, double* g, double
     if (check_launch("avt_get_normal_equations")) return 1;
     HIP_OK(hipStreamSynchronize(c->stream));
     AvtFrameCtl ctl;
-    HIP_OK(hipMemcpy(&ctl, c->fb.ctl + frame, sizeof(ctl), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpyAsync(&ctl, c->fb.ctl + frame, sizeof(ctl), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
     std::vector<double> buf((size_t)d.HS * d.HS);
-    HIP_OK(hipMemcpy(buf.data(), c->fb.Hraw + ((size_t)frame * 2 + (1 - ctl.cur_slot)) * buf.size(), buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpyAsync(buf.data(), c->fb.Hraw + ((size_t)frame * 2 + (1 - ctl.cur_slot)) * buf.size(), buf.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
     for (int r = 0; r < d.P; ++r) {
         if (H) for (int q = 0; q < d.P; ++q) H[(size_t)r * d.P + q] = buf[(size_t)r * d.HS + q];
         if (g) g[r] = buf[(size_t)d.P * d.HS + r];
@@ -849,7 +857,8 @@ int avt_debug_trace(avt_ctx* c, int frame, double* out64) {
     if (!c || !out64 || frame < 0 || frame >= c->fb.max_frames) { avt_set_error("avt_debug_trace: bad argument"); return 1; }
     HIP_OK(hipSetDevice(c->device));
     HIP_OK(hipStreamSynchronize(c->stream));
-    HIP_OK(hipMemcpy(out64, c->fb.trace + (size_t)frame * 64, 64 * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpyAsync(out64, c->fb.trace + (size_t)frame * 64, 64 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
     return 0;
 }
 

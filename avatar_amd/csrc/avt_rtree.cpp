@@ -60,9 +60,10 @@ int upload_tree(avt_rtree* rt) {
     }
     RT_HIP(hipStreamCreateWithFlags(&rt->stream, hipStreamNonBlocking));
     RT_HIP(hipMalloc((void**)&rt->d_nodes, sizeof(RtNodeDev) * n));
-    RT_HIP(hipMemcpy(rt->d_nodes, dev.data(), sizeof(RtNodeDev) * n, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpyAsync(rt->d_nodes, dev.data(), sizeof(RtNodeDev) * n, hipMemcpyHostToDevice, rt->stream));
     RT_HIP(hipMalloc((void**)&rt->d_leaf, sizeof(float) * std::max<size_t>(1, rt->leaf_data.size())));
-    RT_HIP(hipMemcpy(rt->d_leaf, rt->leaf_data.data(), sizeof(float) * rt->leaf_data.size(), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpyAsync(rt->d_leaf, rt->leaf_data.data(), sizeof(float) * rt->leaf_data.size(), hipMemcpyHostToDevice, rt->stream));
+    RT_HIP(hipStreamSynchronize(rt->stream));     // `dev` goes out of scope; the legacy stream is never used (a host thread may be capturing)
     return 0;
 }
 

@@ -14,6 +14,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -227,6 +228,7 @@ RcclApi* rccl_api() {
 // hanging (ncclSystemError), and the group stays broken.
 // ---------------------------------------------------------------------------------------------------------------------
 struct LoopSend { int dst; const void* ptr; size_t bytes; };
+struct LoopMail { const void* ptr; size_t bytes; int state; };   // 0 posted, 1 taken by the receiver, 2 copied
 struct LoopGroup {
     std::string name;
     int world = 0, joined = 0, refs = 0;
@@ -237,7 +239,8 @@ struct LoopGroup {
     bool broken = false;
     double timeout_s = 20.0;
     std::vector<const void*> slot;                 // one published pointer per rank (broadcast root / all-gather blocks)
-    std::vector<std::vector<LoopSend>> sends;      // per source rank, in issue order
+    std::vector<std::deque<LoopMail>> mail;        // [source * world + destination] posted sends, oldest first
+    std::vector<int> outstanding;                  // per source rank: posted sends not yet copied out by their receivers
 };
 struct LoopComm { LoopGroup* g; int rank; };
 struct LoopPending { int depth = 0; std::vector<LoopSend> sends; struct R { int src; void* ptr; size_t bytes; }; std::vector<R> recvs; ncclComm_t comm = nullptr; hipStream_t stream = nullptr; };
@@ -302,26 +305,52 @@ ncclResult_t loop_AllGather(const void* send, void* recv, size_t count, ncclData
     if (!loop_barrier(g)) return ncclSystemError;
     return r;
 }
-ncclResult_t loop_flush() {      // the end of a group (or a lone send / receive): every rank publishes its sends, then takes its receives
+// The end of a group (or a lone send / receive).  Point-to-point like RCCL's: only the two ends of a transfer meet - a rank with
+// an empty group meets nobody - through a mailbox per (source, destination) pair: the sender posts (pointer, size), the receiver
+// takes the oldest posted entry of its pair, copies device-to-device on its own stream and marks it done; the sender returns
+// when all its entries are done (its buffers are free again).  All posts happen before any wait, so groups cannot deadlock.
+ncclResult_t loop_flush() {
     LoopPending& p = loop_pending;
-    if (!p.comm) return ncclSuccess;                 // an empty group: like RCCL, nothing to do and nobody to meet
+    if (!p.comm) return ncclSuccess;
     LoopComm* lc = (LoopComm*)p.comm; LoopGroup* g = lc->g;
-    ncclResult_t r = hipStreamSynchronize(p.stream) == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
-    g->sends[lc->rank] = p.sends;
-    if (!loop_barrier(g)) r = ncclSystemError;
-    if (r == ncclSuccess) {
-        std::vector<size_t> taken(g->world, 0);      // receives match a peer's sends to me in issue order
-        for (const auto& rc : p.recvs) {
-            const std::vector<LoopSend>& from = g->sends[rc.src];
-            size_t k = taken[rc.src];
-            while (k < from.size() && from[k].dst != lc->rank) ++k;
-            if (k == from.size() || from[k].bytes != rc.bytes) { r = ncclInvalidUsage; break; }
-            taken[rc.src] = k + 1;
-            if ((r = loop_copy(rc.ptr, from[k].ptr, rc.bytes, p.stream)) != ncclSuccess) break;
-        }
+    const int me = lc->rank, W = g->world;
+    ncclResult_t r = hipStreamSynchronize(p.stream) == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;   // what I send is ready
+    const auto limit = std::chrono::duration<double>(g->timeout_s);
+    {
+        std::lock_guard<std::mutex> lk(g->m);
+        for (const LoopSend& sd : p.sends) { g->mail[(size_t)me * W + sd.dst].push_back({sd.ptr, sd.bytes, 0}); ++g->outstanding[me]; }
+        g->cv.notify_all();
     }
-    if (!loop_barrier(g) && r == ncclSuccess) r = ncclSystemError;
-    g->sends[lc->rank].clear();
+    for (const auto& rc : p.recvs) {
+        if (r != ncclSuccess) break;
+        std::deque<LoopMail>& box = g->mail[(size_t)rc.src * W + me];
+        LoopMail* m = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(g->m);
+            const bool ok = g->cv.wait_for(lk, limit, [&] {
+                if (g->broken) return true;
+                for (LoopMail& e : box) if (e.state == 0) { m = &e; return true; }
+                return false;
+            });
+            if (!ok || g->broken || !m) { g->broken = true; g->cv.notify_all(); r = ncclSystemError; break; }
+            if (m->bytes != rc.bytes) { g->broken = true; g->cv.notify_all(); r = ncclInvalidUsage; break; }
+            m->state = 1;                                   // taken (deque references stay valid: only the front is ever popped)
+        }
+        const ncclResult_t cr = loop_copy(rc.ptr, m->ptr, rc.bytes, p.stream);
+        {
+            std::lock_guard<std::mutex> lk(g->m);
+            m->state = 2;
+            while (!box.empty() && box.front().state == 2) box.pop_front();
+            --g->outstanding[rc.src];
+            g->cv.notify_all();
+        }
+        if (cr != ncclSuccess) r = cr;
+    }
+    {
+        std::unique_lock<std::mutex> lk(g->m);
+        const bool ok = g->cv.wait_for(lk, limit, [&] { return g->broken || g->outstanding[me] == 0; });
+        if ((!ok || g->broken) && r == ncclSuccess) { g->broken = true; g->cv.notify_all(); r = ncclSystemError; }
+    }
     p.sends.clear(); p.recvs.clear(); p.comm = nullptr; p.stream = nullptr;
     return r;
 }
@@ -442,7 +471,7 @@ extern "C" int avt_shard_create_loopback(int device, int rank, int world, const 
         auto it = loop_registry.find(group);
         if (it == loop_registry.end()) {
             g = new LoopGroup();
-            g->name = group; g->world = world; g->slot.assign(world, nullptr); g->sends.resize(world);
+            g->name = group; g->world = world; g->slot.assign(world, nullptr); g->mail.resize((size_t)world * world); g->outstanding.assign(world, 0);
             if (const char* e = getenv("AVT_SHARD_LOOPBACK_TIMEOUT_S")) g->timeout_s = std::max(0.1, atof(e));
             loop_registry[group] = g;
         } else {
@@ -662,7 +691,7 @@ extern "C" int avt_shard_gather_enqueue(avt_shard* s, avt_ctx* c, int B) {
         s->d_send = s->d_recv = nullptr; s->gather_cap = 0;
         HIP_OK(hipMalloc((void**)&s->d_send, blk * 8));
         HIP_OK(hipMalloc((void**)&s->d_recv, blk * 8 * W));
-        HIP_OK(hipMemset(s->d_send, 0, blk * 8));
+        HIP_OK(hipMemsetAsync(s->d_send, 0, blk * 8, c->stream));
         s->gather_cap = blk;
     }
     // Packing kernel and all-gather go behind optimize() on the context's stream.  Measured on one MI355X (bench.py, one frame
