@@ -5,7 +5,8 @@ Correction per /opt/skills/guides/MI355X_MICROARCH.md §HBM: the counters are in
 the bytes of wide coalesced reads, so the read side is doubled; WRITE_SIZE is taken as is (uncalibrated).
 For every kernel symbol the entry under "kernels" is its MOST FREQUENT launch shape in the run (the shape optimize()
 replays); all shapes are listed under "by_shape".
-Usage: pmc_summary.py <fetch.db> <write.db> <label> [out.json]"""
+Usage: pmc_summary.py <fetch.db> <write.db> <label> [out.json] [points_per_frame]   (the last one lets bench.py check that a
+record belongs to the workload it is timing)"""
 import json
 import sqlite3
 import sys
@@ -23,6 +24,8 @@ def main():
     fetch, write, label = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), sys.argv[3]
     out = {"label": label, "unit": "bytes per launch", "correction": "FETCH_SIZE KiB x2 (gfx950 half-count), WRITE_SIZE KiB x1",
            "kernels": {}, "by_shape": {}}
+    if len(sys.argv) > 5:
+        out["points_per_frame"] = float(sys.argv[5])
     best = {}
     for key in sorted(set(fetch) | set(write)):
         k, shape = key

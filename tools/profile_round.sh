@@ -6,23 +6,28 @@
 #   the instrumented pass of bench.py uses the same shapes as the graph replay.
 # Output: gpurun_out/prof_<tag>/ and gpurun_out/<round>_*.txt / *.json (copy what is to be judged into profiles/).
 set -u
-RND=${RND:-r02}
+RND=${RND:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
-COMMON="--no-cpu-baseline --no-throughput-config --no-label-stage --no-render-stage --no-shard --saturation-frames 0 --regions 3"
-for F in ${FRAMES:-1 64}; do
+COMMON="--no-cpu-baseline --no-throughput-config --no-label-stage --no-render-stage --no-shard --no-dense-config --no-seed-spread --saturation-frames 0 --regions 3"
+# configurations: "<frames>[d]" (d = dense 150k-point frames)
+for CFG in ${FRAMES:-1 64 1d 64d}; do
+  F=${CFG%d}; DENSE=""; TAG=""; [ "$CFG" != "$F" ] && DENSE="--dense" && TAG="_dense"
   nfg=$(python -c "print($F if $F < 32 else ($F + 1) // 2)")     # frames per launch: two frame groups from 32 frames on
   steps=$([ $F = 1 ] && echo 25 || echo 5)
-  cmd="python $R/bench.py --frames $F --steps $steps --warmup 2 $COMMON"
-  rocprofv3 --kernel-trace --stats -d $O/prof_kt_$F -o p -- $cmd > $O/prof_kt_$F.log 2>&1
-  python $R/tools/rocpd_stats.py $(find $O/prof_kt_$F -name "*.db" | head -1) > $O/${RND}_rocprof_kernel_trace_${F}_frames.txt
+  cmd="python $R/bench.py --frames $F $DENSE --steps $steps --warmup 2 $COMMON"
+  rocprofv3 --kernel-trace --stats -d $O/prof_kt_$CFG -o p -- $cmd > $O/prof_kt_$CFG.log 2>&1
+  python $R/tools/rocpd_stats.py $(find $O/prof_kt_$CFG -name "*.db" | head -1) > $O/${RND}_rocprof_kernel_trace_${F}_frames${TAG}.txt
+  # the workload the records belong to (bench.py only uses a record whose points per frame match what it times)
+  npts=$(grep -h '"points_per_frame"' $O/prof_kt_$CFG.log | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['config']['points_per_frame'])" 2>/dev/null || echo 0)
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $ctr -d $O/prof_pmc_${F}_$ctr -o p -- $cmd > $O/prof_pmc_${F}_$ctr.log 2>&1
+    rocprofv3 --pmc $ctr -d $O/prof_pmc_${CFG}_$ctr -o p -- $cmd > $O/prof_pmc_${CFG}_$ctr.log 2>&1
   done
-  python $R/tools/pmc_summary.py $(find $O/prof_pmc_${F}_FETCH_SIZE -name "*.db" | head -1) $(find $O/prof_pmc_${F}_WRITE_SIZE -name "*.db" | head -1) \
-      "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --frames $F ($nfg frames per launch)" $O/${RND}_pmc_${nfg}_frames_per_launch.json > /dev/null
+  python $R/tools/pmc_summary.py $(find $O/prof_pmc_${CFG}_FETCH_SIZE -name "*.db" | head -1) $(find $O/prof_pmc_${CFG}_WRITE_SIZE -name "*.db" | head -1) \
+      "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --frames $F $DENSE ($nfg frames per launch, $npts points per frame)" \
+      $O/${RND}_pmc_${nfg}_frames_per_launch${TAG}.json $npts > /dev/null
 done
 if [ "${SQ:-1}" = 1 ]; then
   for F in ${SQ_FRAMES:-1 64}; do
