@@ -67,7 +67,7 @@ int choose_groups(int nframes) {
 // Frame groups of one optimize() call.  Two or three frames: one frame per group when the one-frame launch shape has the speculative
 // solver workgroups - in a shared launch a rejection saves its factorisation only if every frame of the launch
 // rejects, on a stream of its own every frame keeps its own pace (2 frames 0.477 -> 0.457 ms, 3 frames 0.607 -> 0.526; four: 0.637 -> 0.709).
-int choose_G(int nframes);
+int choose_G(int nframes, int ngroups = 1);
 int plan_groups(avt_ctx* c, int nf) {
     int ngroups = choose_groups(nf);
     if ((nf == 2 || nf == 3) && !getenv("AVT_GROUPS") && !getenv("AVT_ONE_GROUP")) {
@@ -79,12 +79,16 @@ int plan_groups(avt_ctx* c, int nf) {
     return ngroups;
 }
 
-int choose_G(int nframes) {
+int choose_G(int nframes, int ngroups) {
     // k_eval workgroups per frame.  Up to 64 frames per launch: 768 workgroups = one resident round at 3 per CU (more rounds
     // cost more in partial tiles and prologues than they balance: 128 frames per group 645 k against 609 k GN it/s with twice as
     // many).  From 128 frames per launch on: 1536, two rounds, so that the hardware's dispatch evens out frames with different
     // numbers of matched points (512 frames: 747 k -> 774 k GN it/s; three rounds: 770 k).
-    const int target = nframes >= 128 ? 1536 : 768;
+    // Two frame groups side by side (from 32 frames on): the evaluation of one group shares the chip with the other group's
+    // solves and reductions, and FEWER, longer-lived workgroups per frame win (round 3, tools/g_sweep.sh, ms per step at
+    // 512 / 640 / 768 workgroups per launch: 32 frames 0.934 / 0.928 / 0.966; 48: 1.073 / 1.091 / 1.120; 64: 1.227 / 1.246 / 1.271;
+    // 96: 1.625 / 1.623 / 1.622; 128: 2.080 / 1.954 / 1.982; 256 frames: 3.73 / 3.64 / 3.50, 1536: 3.50).
+    const int target = nframes >= 128 ? 1536 : (ngroups >= 2 ? (nframes <= 40 ? 512 : 640) : 768);
     int gcap = 128;
     if (const char* e = getenv("AVT_GCAP")) gcap = std::max(2, std::min(AVT_G_MAX, atoi(e)));
     int g = std::max(2, std::min(gcap, target / std::max(1, nframes)));
@@ -201,7 +205,7 @@ int run_optimize(avt_ctx* c, const avt_options* o) {
     // the main stream, so that per-launch timings describe the launches the graph replays.
     const int ngroups = plan_groups(c, nf);
     const int nfg = (nf + ngroups - 1) / ngroups;       // frames per group (the last group may be smaller)
-    c->fb.G = choose_G(nfg);
+    c->fb.G = choose_G(nfg, ngroups);
     c->concurrent_groups = ngroups;
     if (!c->use_graph || c->profiling) {
         for (int gi = 0; gi < ngroups; ++gi) {
@@ -462,7 +466,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
     // eval workgroups over all frames, for every way run_optimize may split them into groups
     size_t part_cap = 0;
     for (int nf = 1; nf <= max_frames; ++nf)
-        for (int k = 1; k <= std::min(AVT_MAX_GROUPS, nf); ++k) part_cap = std::max(part_cap, (size_t)nf * choose_G((nf + k - 1) / k));
+        for (int k = 1; k <= std::min(AVT_MAX_GROUPS, nf); ++k) part_cap = std::max(part_cap, (size_t)nf * std::max(choose_G((nf + k - 1) / k, 1), choose_G((nf + k - 1) / k, 2)));
     char* cntsum = nullptr;
     if (dev_alloc(c, &fb.data_raw, FN * 3) || dev_alloc(c, &fb.labels_raw, FN) || dev_alloc(c, &fb.dx, FN) || dev_alloc(c, &fb.dy, FN) ||
         dev_alloc(c, &fb.dz, FN) || dev_alloc(c, &fb.dorig, FN) || dev_alloc(c, &fb.part_off, (size_t)max_frames * (num_parts + 1)) || dev_alloc(c, &fb.part_cnt, (size_t)max_frames * 2 * (AVT_MAX_PARTS + 1)) ||
@@ -867,7 +871,7 @@ int avt_launch_shape(avt_ctx* c, int* groups, int* frames_per_group, int* eval_w
     const int ng = plan_groups(c, c->nframes), nfg = (c->nframes + ng - 1) / ng;
     if (groups) *groups = ng;
     if (frames_per_group) *frames_per_group = nfg;
-    if (eval_workgroups_per_frame) *eval_workgroups_per_frame = choose_G(nfg);
+    if (eval_workgroups_per_frame) *eval_workgroups_per_frame = choose_G(nfg, ng);
     return 0;
 }
 
