@@ -68,6 +68,7 @@ __device__ __forceinline__ void nn_record(const FrameBuffers& fb, const AvtFrame
     }
     const int mnext = __shfl_down(m, LANES, 64);
     const bool tail = (ql == 64 / LANES - 1) || (mnext != m);
+#ifndef AVT_NN_NO_ATOMICS      // (timing experiment only, tools/nn_atomics_probe.sh: what the integer atomics cost; results are wrong without them)
     if (sub == 0 && m >= 0 && tail) {
         atomicAdd(fb.cnt + (size_t)f * V + m, cnt);
         unsigned long long* fs = (unsigned long long*)(fb.fsum + (size_t)f * 3 * V);
@@ -75,6 +76,7 @@ __device__ __forceinline__ void nn_record(const FrameBuffers& fb, const AvtFrame
         atomicAdd(fs + (size_t)V + m, (unsigned long long)s1q);
         atomicAdd(fs + 2 * (size_t)V + m, (unsigned long long)s2q);
     }
+#endif
 }
 
 // LANES lanes cooperate on one query (4: low-latency single-frame shape; 1: throughput shape for large batches)
