@@ -7,8 +7,11 @@
 #include <cstring>
 
 #include <exception>
+#include <mutex>
 
 #include "avt_internal.h"
+
+static std::mutex g_graph_mutex;      // every hipGraph call of the process (see run_optimize)
 
 // No C++ exception may cross the C ABI: every entry point that allocates runs inside this guard.
 #define AVT_API_GUARD_BEGIN try {
@@ -216,6 +219,11 @@ int run_optimize(avt_ctx* c, const avt_options* o) {
         return check_launch("optimize launch sequence");
     }
     // The launch sequence depends only on the launch shape: capture it once, replay it afterwards.
+    // Every graph call of the process goes through one mutex: contexts are per thread, but HIP 7.0's hipGraphLaunch is not safe
+    // against a hipGraphLaunch from another thread (found by the 8-thread loop-back tests: SIGSEGV in hip::Graph::UpdateStreams <-
+    // hip::GraphExec::Run, which rearranges a per-device set of helper streams for graphs with parallel branches).  The calls
+    // only enqueue, so the lock is held for microseconds.
+    std::lock_guard<std::mutex> graph_lock(g_graph_mutex);
     char key[160];
     snprintf(key, sizeof key, "%d|%d|%d|%d|%d|%d|%d", nf, ngroups, c->fb.G, c->launch_maxN, o->icp_iters, o->max_iters_per_icp, o->enable_occlusion);
     avt_ctx::GraphEntry* hit = nullptr;
@@ -461,6 +469,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
     fb.max_points = max_points;
     fb.G = choose_G(max_frames);
     fb.const_blocks = (max_points + 255) / 256;
+    fb.bucket_tiles = (max_points + 2047) / 2048;
     const size_t FN = (size_t)max_frames * max_points, FV = (size_t)max_frames * V;
     const AvtDims& d = dm.d;
     // eval workgroups over all frames, for every way run_optimize may split them into groups
@@ -469,7 +478,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         for (int k = 1; k <= std::min(AVT_MAX_GROUPS, nf); ++k) part_cap = std::max(part_cap, (size_t)nf * std::max(choose_G((nf + k - 1) / k, 1), choose_G((nf + k - 1) / k, 2)));
     char* cntsum = nullptr;
     if (dev_alloc(c, &fb.data_raw, FN * 3) || dev_alloc(c, &fb.labels_raw, FN) || dev_alloc(c, &fb.dx, FN) || dev_alloc(c, &fb.dy, FN) ||
-        dev_alloc(c, &fb.dz, FN) || dev_alloc(c, &fb.dorig, FN) || dev_alloc(c, &fb.part_off, (size_t)max_frames * (num_parts + 1)) || dev_alloc(c, &fb.part_cnt, (size_t)max_frames * 2 * (AVT_MAX_PARTS + 1)) ||
+        dev_alloc(c, &fb.dz, FN) || dev_alloc(c, &fb.dorig, FN) || dev_alloc(c, &fb.part_off, (size_t)max_frames * (num_parts + 1)) || dev_alloc(c, &fb.part_cnt, (size_t)max_frames * 2 * (AVT_MAX_PARTS + 1)) || dev_alloc(c, &fb.tile_hist, (size_t)max_frames * ((max_points + 2047) / 2048) * (AVT_MAX_PARTS + 1)) ||
         dev_alloc(c, &fb.corr, FN) || dev_alloc(c, &fb.corr_sorted, FN) || dev_alloc(c, &fb.cloud, FV * 3) || dev_alloc(c, &fb.pcx, FV) ||
         dev_alloc(c, &fb.pcy, FV) || dev_alloc(c, &fb.pcz, FV) || dev_alloc(c, &fb.visible, FV) || dev_alloc(c, &fb.vcx, FV) || dev_alloc(c, &fb.vcy, FV) ||
         dev_alloc(c, &fb.vcz, FV) || dev_alloc(c, &fb.vcid, FV) || dev_alloc(c, &fb.vcount, (size_t)max_frames * num_parts) || dev_alloc(c, &fb.vis_sorted, FV) || dev_alloc(c, &fb.ride_ctr, (size_t)max_frames) || dev_alloc(c, &fb.fault, (size_t)max_frames) || dev_alloc(c, &fb.spec, (size_t)max_frames) || dev_alloc(c, &fb.snap, (size_t)max_frames) || dev_alloc(c, &fb.x_spec, (size_t)max_frames * AVT_MAX_SPEC * d.xsize) || dev_alloc(c, &fb.prep_spec, (size_t)max_frames * AVT_MAX_SPEC * d.prep_size) ||
@@ -533,7 +542,7 @@ void avt_ctx_destroy(avt_ctx* c) {
     for (void* p : {(void*)c->render_mkey, (void*)c->render_depth, (void*)c->render_fkey, (void*)c->render_frank, (void*)c->render_fedge})
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-    for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
+    { std::lock_guard<std::mutex> graph_lock(g_graph_mutex); for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (int i = 0; i < AVT_MAX_GROUPS - 1; ++i) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);

@@ -203,7 +203,9 @@ struct FrameBuffers {
     double* dx; double* dy; double* dz;
     int* dorig;           // original index of sorted point
     int* part_off;        // [max_frames][num_parts+1] offsets (relative to frame segment)
-    int* part_cnt;        // [max_frames][2][AVT_MAX_PARTS+1] label histogram | scatter cursors
+    int* part_cnt;        // [max_frames][2][AVT_MAX_PARTS+1] label histogram | (unused since the scatter is stable)
+    int* tile_hist;       // [max_frames][bucket_tiles][AVT_MAX_PARTS+1] label histogram of every 2048-point tile (stable scatter, avt_bucket.h)
+    int bucket_tiles;     // ceil(max_points / 2048)
     int* corr;            // [max_frames*max_points] model idx per ORIGINAL data index (-1 none)
     int* corr_sorted;     // per sorted position
     // model-side per frame

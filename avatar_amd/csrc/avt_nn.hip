@@ -22,6 +22,11 @@
 #include "avt_bucket.h"
 
 #define NN_TILE 1024
+#define NN_SORTED_FLAG 0x40000000      // in FrameBuffers::vcount: the part's compacted candidates are sorted by (y, vertex id)
+#define NN_SORT_CAP 1024               // largest part k_compact sorts (bitonic sort in LDS)
+#ifndef NN_SLAB_CHUNK
+#define NN_SLAB_CHUNK 32                // candidates per side and round of the slab scan (a multiple of the group size)
+#endif
 
 
 // round-to-nearest-even of x (|x| < 2^51) as an integer: the low mantissa bits of x + 1.5*2^52 (what __double2ll_rn
@@ -330,6 +335,27 @@ __global__ __launch_bounds__(256) void k_nn_vis(DeviceModel dm, FrameBuffers fb)
     nn_record<LANES>(fb, ctl, f, V, base, s, active, sub, bv, a0, a1, a2);
 }
 
+// max over the wave of NON-NEGATIVE doubles, identical in every lane's return value: row_shr scans inside the rows of 16 lanes
+// (lanes shifted in from outside a row read 0.0), then the four row maxima through v_readlane - no LDS permutes
+template <int SH>
+__device__ __forceinline__ double nn_row_shr0(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + SH, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + SH, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double nn_wave_max_nonneg(double v) {
+    v = __builtin_fmax(v, nn_row_shr0<1>(v));
+    v = __builtin_fmax(v, nn_row_shr0<2>(v));
+    v = __builtin_fmax(v, nn_row_shr0<4>(v));
+    v = __builtin_fmax(v, nn_row_shr0<8>(v));         // lane 15 of every row: the row's maximum
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double m = __hiloint2double(__builtin_amdgcn_readlane(hi, 15), __builtin_amdgcn_readlane(lo, 15));
+    m = __builtin_fmax(m, __hiloint2double(__builtin_amdgcn_readlane(hi, 31), __builtin_amdgcn_readlane(lo, 31)));
+    m = __builtin_fmax(m, __hiloint2double(__builtin_amdgcn_readlane(hi, 47), __builtin_amdgcn_readlane(lo, 47)));
+    m = __builtin_fmax(m, __hiloint2double(__builtin_amdgcn_readlane(hi, 63), __builtin_amdgcn_readlane(lo, 63)));
+    return m;
+}
+
 // -------------------------------------------------------------------------------------------------
 // k_nn_part: the throughput shape (frame batches).  A workgroup owns up to 256 consecutive bucketed data points of ONE part
 // (one per lane), so every lane scans the same candidates: the part's visible model points are read with SCALAR loads
@@ -362,7 +388,9 @@ __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     if (active) { a0 = fb.dx[base + s]; a1 = fb.dy[base + s]; a2 = fb.dz[base + s]; }
     const int pb = __builtin_amdgcn_readfirstlane(dm.part_start[q]);
-    const int pe = pb + __builtin_amdgcn_readfirstlane(fb.vcount[(size_t)f * np + q]);   // visible candidates of the part
+    const int vc = __builtin_amdgcn_readfirstlane(fb.vcount[(size_t)f * np + q]);
+    const bool sorted = (vc & NN_SORTED_FLAG) != 0;                    // k_compact sorted them by (y, vertex id): slab scan below
+    const int pe = pb + (vc & ~NN_SORTED_FLAG);                         // visible candidates of the part
     const nn_cptr cx = (nn_cptr)(uintptr_t)(fb.vcx + (size_t)f * V), cy = (nn_cptr)(uintptr_t)(fb.vcy + (size_t)f * V),
                   cz = (nn_cptr)(uintptr_t)(fb.vcz + (size_t)f * V);
     auto dist2 = [&](double px, double py, double pz) {
@@ -375,37 +403,100 @@ __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb
     constexpr int NN_GROUP = 4;
     double best = 1.7976931348623157e308;
     int gpos = -1;
-    int c = pb;
-    for (; c + NN_GROUP <= pe; c += NN_GROUP) {
-        double r[NN_GROUP];
+    bool tie = false;             // (slab scan only) two candidates at exactly the minimum distance: settled by vertex id below
+    // one group of (up to) NN_GROUP consecutive candidates starting at c (a multiple of NN_GROUP past pb; members clipped by hi)
+    auto scan_groups = [&](int lo, int hi, bool watch_ties) {
+        int c = lo;
+        for (; c + NN_GROUP <= hi; c += NN_GROUP) {
+            double r[NN_GROUP];
 #pragma unroll
-        for (int u = 0; u < NN_GROUP; ++u) r[u] = dist2(cx[c + u], cy[c + u], cz[c + u]);
+            for (int u = 0; u < NN_GROUP; ++u) r[u] = dist2(cx[c + u], cy[c + u], cz[c + u]);
 #pragma unroll
-        for (int w = 1; w < NN_GROUP; w <<= 1)
+            for (int w = 1; w < NN_GROUP; w <<= 1)
 #pragma unroll
-            for (int u = 0; u + w < NN_GROUP; u += 2 * w) r[u] = __builtin_fmin(r[u], r[u + w]);
-        gpos = (r[0] < best) ? c : gpos;
-        best = __builtin_fmin(best, r[0]);
-    }
-    for (; c < pe; ++c) {
-        const double r = dist2(cx[c], cy[c], cz[c]);
-        gpos = (r < best) ? c : gpos;
-        best = __builtin_fmin(best, r);
+                for (int u = 0; u + w < NN_GROUP; u += 2 * w) r[u] = __builtin_fmin(r[u], r[u + w]);
+            if (watch_ties) tie = tie || (r[0] == best);
+            gpos = (r[0] < best) ? c : gpos;
+            best = __builtin_fmin(best, r[0]);
+        }
+        for (; c < hi; ++c) {
+            const double r = dist2(cx[c], cy[c], cz[c]);
+            if (watch_ties) tie = tie || (r == best);
+            gpos = (r < best) ? c : gpos;
+            best = __builtin_fmin(best, r);
+        }
+    };
+    if (!sorted) {
+        scan_groups(pb, pe, false);      // ascending vertex order: strict '<' alone implements the tie rule
+    } else {
+        // ---- slab scan.  k_compact sorted this part's visible candidates by (y, vertex id).  A wave's 64 queries are consecutive
+        // pixels of one part - one to three image rows, i.e. a thin slab in y - so the scan starts at the candidate nearest to the
+        // slab and walks outwards on both sides, NN_SLAB_CHUNK candidates a side per round, until on each side the next candidate is further
+        // from the slab IN Y ALONE than the worst current best distance of the wave: every candidate beyond it has
+        // (y_c - y_q)^2 >= (y_edge - y_slab)^2 > max_q best_q, so its rounded distance exceeds every lane's best (margin 1e-12 >>
+        // the 5 ulp the rounding of the two expressions can differ by) and it can neither win nor tie.  Exact: same distance
+        // expression, same winner as the full ascending scan - ties (equal distances, measure zero) are detected and settled by
+        // vertex id in a full rescan.  On the synthetic frames 41-45 % of the candidates are evaluated (tools/nn_slab_sim.py).
+        double ylo = active ? a1 : 1.7976931348623157e308, yhi = active ? a1 : -1.7976931348623157e308;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { ylo = __builtin_fmin(ylo, __shfl_xor(ylo, m, 64)); yhi = __builtin_fmax(yhi, __shfl_xor(yhi, m, 64)); }
+        const int n = pe - pb;
+        bool rdone = true, ldone = true;
+        int R = pb, L = pb;
+        if (__ballot(active) != 0ull && n > 0) {
+            const double ymid = 0.5 * (ylo + yhi);
+            const int step = (n + 63) >> 6;                                  // 64 samples of the sorted y's locate the slab
+            const int si = lane * step;
+            const double ys = fb.vcy[(size_t)f * V + pb + min(si, n - 1)];
+            const int below = __popcll(__ballot(si < n && ys < ymid));
+            const int st = pb + ((min(max(below - 1, 0) * step, n - 1)) & ~(NN_GROUP - 1));   // groups stay aligned to pb + 4k
+            R = L = __builtin_amdgcn_readfirstlane(st);
+            rdone = R >= pe; ldone = L <= pb;
+        }
+        while (!(rdone && ldone)) {                                          // wave-uniform
+            if (!rdone) { const int e = min(R + NN_SLAB_CHUNK, pe); scan_groups(R, e, true); R = e; }
+            if (!ldone) { const int b = max(L - NN_SLAB_CHUNK, pb); scan_groups(b, L, true); L = b; }
+            const double dmax = nn_wave_max_nonneg(active ? best : 0.0);
+            const double bound = dmax * (1.0 + 1e-12);
+            if (!rdone) {
+                bool done = R >= pe;
+                if (!done) { const double gap = cy[R] - yhi; done = gap > 0.0 && gap * gap > bound; }
+                rdone = __builtin_amdgcn_readfirstlane((int)done) != 0;
+            }
+            if (!ldone) {
+                bool done = L <= pb;
+                if (!done) { const double gap = ylo - cy[L - 1]; done = gap > 0.0 && gap * gap > bound; }
+                ldone = __builtin_amdgcn_readfirstlane((int)done) != 0;
+            }
+        }
     }
     int bi = 0x7fffffff;
+    const double* pcx = fb.vcx + (size_t)f * V;
+    const double* pcy = fb.vcy + (size_t)f * V;
+    const double* pcz = fb.vcz + (size_t)f * V;
     if (gpos >= 0) {      // the first member of the winning group whose distance is the minimum
-        const double* pcx = fb.vcx + (size_t)f * V;
-        const double* pcy = fb.vcy + (size_t)f * V;
-        const double* pcz = fb.vcz + (size_t)f * V;
         double r[NN_GROUP];
 #pragma unroll
         for (int u = 0; u < NN_GROUP; ++u) {
             const int pos = min(gpos + u, pe - 1);
             r[u] = dist2(pcx[pos], pcy[pos], pcz[pos]);
         }
+        int hits = 0;
 #pragma unroll
         for (int u = NN_GROUP - 1; u >= 0; --u)
-            if (gpos + u < pe && r[u] == best) bi = gpos + u;
+            if (gpos + u < pe && r[u] == best) { bi = gpos + u; ++hits; }
+        if (sorted && hits > 1) tie = true;
+    }
+    if (sorted && __ballot(tie) != 0ull) {      // exact ties: the candidate with the smallest vertex id among those at the minimum distance
+        const int* ids = fb.vcid + (size_t)f * V;
+        double tb = 1.7976931348623157e308;
+        int tid = 0x7fffffff, tpos = 0x7fffffff;
+        for (int c = pb; c < pe; ++c) {
+            const double r = dist2(cx[c], cy[c], cz[c]);
+            const int id = ids[c];
+            if (r < tb || (r == tb && id < tid)) { tb = r; tid = id; tpos = c; }
+        }
+        if (tie) bi = tpos;
     }
     const int mv = (active && bi != 0x7fffffff) ? fb.vcid[(size_t)f * V + bi] : -1;
     nn_record<1>(fb, ctl, f, V, base, s, active, 0, mv, a0, a1, a2);
@@ -416,47 +507,110 @@ __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb
 // Workgroups past the parts (first ICP iteration of a frame batch): the scatter pass of the data bucketing (avt_bucket.h).
 // from_cloud: the coordinates come from the cloud through the vertex id (frame batches inside optimize(): k_lbs then skips
 // the part-sorted copy, three scattered stores per vertex) instead of from pcx/pcy/pcz.
-__global__ __launch_bounds__(256) void k_compact(DeviceModel dm, FrameBuffers fb, int from_cloud) {
+__global__ __launch_bounds__(256) void k_compact(DeviceModel dm, FrameBuffers fb, int from_cloud, int sort_y) {
     const int f = blockIdx.y + fb.f0, q = blockIdx.x, t = threadIdx.x, V = dm.d.V, np = dm.d.num_parts;
     if (q >= np) { bucket_scatter_block(dm, fb, f, q - np); return; }
     const int b = dm.part_start[q], e = dm.part_start[q + 1];
     __shared__ int s_wcnt[4];
     __shared__ int s_run;
+    struct __attribute__((aligned(16))) Ent { double y; int vid; int pos; };
+    __shared__ Ent s_ent[NN_SORT_CAP];            // sort_y: the part's visible candidates (y, vertex id, part-sorted position)
     if (t == 0) s_run = 0;
     __syncthreads();
     const unsigned char* vis = fb.visible + (size_t)f * V;
-    for (int c0 = b; c0 < e; c0 += 256) {
-        const int pos = c0 + t;
-        int v = -1;
-        bool keep = false;
-        if (pos < e) { v = dm.part_vertices[pos]; keep = vis[v] != 0; }
-        const unsigned long long bal = __ballot(keep);
-        const int rank = __popcll(bal & ((1ull << lane_id()) - 1ull));
-        if (lane_id() == 0) s_wcnt[wave_id()] = __popcll(bal);
-        __syncthreads();
-        int off = s_run;
-        for (int w = 0; w < wave_id(); ++w) off += s_wcnt[w];
-        if (keep) {
-            const size_t o = (size_t)f * V + b + off + rank;
-            if (from_cloud) {
-                const double* cl = fb.cloud + ((size_t)f * V + v) * 3;
-                fb.vcx[o] = cl[0]; fb.vcy[o] = cl[1]; fb.vcz[o] = cl[2];
-            } else {
-                fb.vcx[o] = fb.pcx[(size_t)f * V + pos];
-                fb.vcy[o] = fb.pcy[(size_t)f * V + pos];
-                fb.vcz[o] = fb.pcz[(size_t)f * V + pos];
-            }
-            fb.vcid[o] = v;
+    // pass 0 writes the compacted candidates in ascending vertex order to LDS (sort_y) or straight to memory; if a part turns out
+    // to be larger than the sort's capacity, pass 1 writes it to memory unsorted
+    for (int pass = sort_y ? 0 : 1; pass < 2; ++pass) {
+        if (pass == 1 && sort_y) {
+            if (s_run <= NN_SORT_CAP) break;
+            __syncthreads();
+            if (t == 0) s_run = 0;
+            __syncthreads();
         }
-        __syncthreads();
-        if (t == 0) s_run += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-        __syncthreads();
+        for (int c0 = b; c0 < e; c0 += 256) {
+            const int pos = c0 + t;
+            int v = -1;
+            bool keep = false;
+            if (pos < e) { v = dm.part_vertices[pos]; keep = vis[v] != 0; }
+            const unsigned long long bal = __ballot(keep);
+            const int rank = __popcll(bal & ((1ull << lane_id()) - 1ull));
+            if (lane_id() == 0) s_wcnt[wave_id()] = __popcll(bal);
+            __syncthreads();
+            int off = s_run;
+            for (int w = 0; w < wave_id(); ++w) off += s_wcnt[w];
+            if (keep) {
+                if (pass == 0) {
+                    if (off + rank < NN_SORT_CAP) {
+                        const double y = from_cloud ? fb.cloud[((size_t)f * V + v) * 3 + 1] : fb.pcy[(size_t)f * V + pos];
+                        s_ent[off + rank] = Ent{y, v, pos};
+                    }
+                } else {
+                    const size_t o = (size_t)f * V + b + off + rank;
+                    if (from_cloud) {
+                        const double* cl = fb.cloud + ((size_t)f * V + v) * 3;
+                        fb.vcx[o] = cl[0]; fb.vcy[o] = cl[1]; fb.vcz[o] = cl[2];
+                    } else {
+                        fb.vcx[o] = fb.pcx[(size_t)f * V + pos];
+                        fb.vcy[o] = fb.pcy[(size_t)f * V + pos];
+                        fb.vcz[o] = fb.pcz[(size_t)f * V + pos];
+                    }
+                    fb.vcid[o] = v;
+                }
+            }
+            __syncthreads();
+            if (t == 0) s_run += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+            __syncthreads();
+        }
     }
-    if (t == 0) fb.vcount[(size_t)f * np + q] = s_run;
+    const int n = s_run;
+    const bool sorted = sort_y && n <= NN_SORT_CAP;
+    if (sorted) {
+        // bitonic sort by (y, vertex id) in LDS, padded to a power of two with +inf keys (a rank sort - every element counting
+        // the elements in front of it - is simpler but quadratic: 62 us against 8 for the 32-frame launch with parts of 900)
+        int P2 = 64;
+        while (P2 < n) P2 <<= 1;
+        for (int i = n + t; i < P2; i += 256) s_ent[i] = Ent{1.7976931348623157e308, 0x7fffffff, 0};
+        // pair pi of a stage with distance j: elements i = pi with a zero bit inserted at bit log2(j), and i | j.  With j <= 64 both
+        // lie in the 128-element block pi >> 6, and thread t only ever takes pair indices t + 256 m, i.e. blocks of its own wave: runs
+        // of stages with j <= 64 need no workgroup barrier (LDS operations of one wave execute in order), only the stages with
+        // j >= 128 and their neighbours do - five barriers instead of forty-five for 512 elements.
+        bool prev_big = true;
+        for (int k = 2; k <= P2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const bool big = j >= 128;
+                if (big || prev_big) __syncthreads();
+                else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+                prev_big = big;
+                for (int pi = t; pi < (P2 >> 1); pi += 256) {
+                    const int i = ((pi & ~(j - 1)) << 1) | (pi & (j - 1)), p = i | j;
+                    const Ent a = s_ent[i], c = s_ent[p];
+                    const bool a_after_c = c.y < a.y || (c.y == a.y && c.vid < a.vid);
+                    if (a_after_c == ((i & k) == 0)) { s_ent[i] = c; s_ent[p] = a; }
+                }
+            }
+        __syncthreads();
+        for (int i = t; i < n; i += 256) {
+            const Ent me = s_ent[i];
+            const size_t o = (size_t)f * V + b + i;
+            if (from_cloud) {
+                const double* cl = fb.cloud + ((size_t)f * V + me.vid) * 3;
+                fb.vcx[o] = cl[0]; fb.vcy[o] = me.y; fb.vcz[o] = cl[2];
+            } else {
+                fb.vcx[o] = fb.pcx[(size_t)f * V + me.pos];
+                fb.vcy[o] = me.y;
+                fb.vcz[o] = fb.pcz[(size_t)f * V + me.pos];
+            }
+            fb.vcid[o] = me.vid;
+        }
+    }
+    if (t == 0) fb.vcount[(size_t)f * np + q] = n | (sorted ? NN_SORTED_FLAG : 0);
 }
 
 // few queries: the latency shape of the nearest-neighbour stage (4 lanes per query); many: one lane per query, one part per workgroup
-bool avt_nn_few(const avt_ctx* c, int nframes) { return (long long)nframes * c->launch_maxN <= 400000; }
+bool avt_nn_few(const avt_ctx* c, int nframes) {
+    const bool force_part = getenv("AVT_NN_FORCE_PART") != nullptr;      // tests: the throughput shape on small inputs too
+    return !force_part && (long long)nframes * c->launch_maxN <= 400000;
+}
 
 void launch_nn(avt_ctx* c, int nframes) {
     const int V = c->dm.d.V;
@@ -475,7 +629,10 @@ void launch_nn(avt_ctx* c, int nframes) {
     }
     const int nscat = c->scatter_in_compact ? std::max(1, (maxN + BUCKET_TILE - 1) / BUCKET_TILE) : 0;
     c->scatter_in_compact = false;
-    hipLaunchKernelGGL(k_compact, dim3(c->dm.d.num_parts + nscat, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb, c->nn_from_cloud ? 1 : 0);
+    // (the throughput scan walks y-sorted candidates outwards from the wave's slab of queries; the latency shape keeps ascending vertex order)
+    const bool no_slab = getenv("AVT_NN_NO_SLAB") != nullptr;          // (read per enqueue: a launch-shape knob like AVT_G)
+    hipLaunchKernelGGL(k_compact, dim3(c->dm.d.num_parts + nscat, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb, c->nn_from_cloud ? 1 : 0,
+                       (!few && !no_slab) ? 1 : 0);
     if (few) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn<4>), dim3((maxN + 63) / 64, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
     else hipLaunchKernelGGL(k_nn_part, dim3((maxN + 255) / 256 + c->dm.d.num_parts, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
 }

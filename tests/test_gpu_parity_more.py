@@ -318,3 +318,79 @@ def test_speculative_steps_do_not_change_a_bit(smpl, gmodel):
         else: os.environ["AVT_NSPEC"] = old
     assert np.array_equal(outs["0"], outs["4"]) and np.array_equal(outs["0"], outs["1"])
     assert outs["0"].size > 400
+
+
+def _with_env(name, value):
+    import contextlib
+    import os
+
+    @contextlib.contextmanager
+    def cm():
+        old = os.environ.get(name)
+        os.environ[name] = value
+        try:
+            yield
+        finally:
+            if old is None: os.environ.pop(name, None)
+            else: os.environ[name] = old
+    return cm()
+
+
+def test_slab_scan_against_nanoflann_goldens(smpl, omodel, gmodel):
+    """The throughput shape of the nearest neighbour (k_compact sorting each part's visible candidates by (y, vertex id), k_nn_part
+    walking outwards from the wave's slab of queries until the y gap alone exceeds the worst best distance) on the reference's own
+    nanoflann outputs: the four small cases, 38 k and 125 k queries, and the coarse 6-part map whose parts are larger than the
+    sort's capacity (they take the unsorted full scan).  AVT_NN_FORCE_PART routes the stand-alone avt_nn through that shape.
+    Bit-exact, and identical with the slab switched off (AVT_NN_NO_SLAB)."""
+    import os
+    import sys
+    from avatar_amd import api
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_nn_golden_full as mk
+    zf = np.load(os.path.join(here, "golden", "nn_golden_full.npz"))
+    zs = np.load(os.path.join(here, "golden", "nn_golden.npz"))
+    with _with_env("AVT_NN_FORCE_PART", "1"):
+        for k in range(int(zs["ncase"])):
+            pm = zs[f"part_map_{k}"]; npart = int(zs[f"num_parts_{k}"])
+            ctx = api.Context(gmodel, npart, pm, 60000, 1)
+            got = ctx.nn(zs[f"cloud_{k}"], zs[f"vis_{k}"], zs[f"data_{k}"], zs[f"labels_{k}"])
+            assert np.array_equal(got, zs[f"idx_{k}"]), f"small case {k}"
+        for k, c in enumerate(mk.CASES):
+            pm, npart, cloud, vis, data, labels = mk.case_inputs(smpl, omodel, c)
+            ctx = api.Context(gmodel, npart, pm, len(labels), 1, device=0)
+            got = ctx.nn(cloud, vis, data, labels)
+            assert np.array_equal(got, zf[f"idx_{k}"]), (k, int((got != zf[f"idx_{k}"]).sum()))
+            with _with_env("AVT_NN_NO_SLAB", "1"):
+                assert np.array_equal(ctx.nn(cloud, vis, data, labels), got)
+
+
+def test_slab_scan_settles_exact_ties_by_vertex_id(smpl, omodel, gmodel):
+    """Model points that coincide exactly (distances tie bit for bit): the winner is the smallest vertex id, as in an ascending
+    scan with strict '<' (nanoflann.hpp:175-199 semantics of the oracle's ordered brute force), although the slab scan meets
+    the candidates in y order.  Every vertex of a part is given a twin with a different id."""
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    fr = synth.make_frame(smpl, 2)
+    w0, p0, R0 = fr["start"]
+    c0, _, _ = omodel.update(w0, p0, R0)
+    vis = omodel.visibility(c0, True)
+    part = np.asarray(pm)[synth.main_joint(smpl)]
+    cloud = c0.copy()
+    rng = np.random.default_rng(5)
+    for q in range(24):                       # within every part: random pairs (a, b) of visible vertices, b moved onto a
+        ids = np.nonzero((part == q) & (vis != 0))[0]
+        ids = rng.permutation(ids)
+        half = len(ids) // 2
+        cloud[ids[half:2 * half]] = cloud[ids[:half]]
+    sel = slice(0, None, 3)
+    data, labels = fr["data"][sel], fr["labels"][sel]
+    ref = omodel.nn(pm, 24, cloud, vis, data, labels)
+    with _with_env("AVT_NN_FORCE_PART", "1"):
+        ctx = api.Context(gmodel, 24, pm, 60000, 1)
+        got = ctx.nn(cloud, vis, data, labels)
+    assert np.array_equal(got, ref), int((got != ref).sum())
+    # the ties were real: most matched vertices have a twin at the same position with another id
+    m = ref[ref >= 0]
+    d = np.abs(cloud[:, None, :] - cloud[None, m[:200], :]).max(-1) == 0
+    assert (d.sum(0) >= 2).mean() > 0.5
