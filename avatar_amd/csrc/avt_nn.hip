@@ -57,6 +57,16 @@ __device__ __forceinline__ void nn_record(const FrameBuffers& fb, const AvtFrame
         s1q = rint_to_ll((a1 - ctl.centre[1]) * AVT_FIX_SCALE);
         s2q = rint_to_ll((a2 - ctl.centre[2]) * AVT_FIX_SCALE);
     }
+#ifdef AVT_NN_NO_MERGE       // (timing experiment: every query lane issues its own atomics, no in-wave merge)
+    if (sub == 0 && m >= 0) {
+        atomicAdd(fb.cnt + (size_t)f * V + m, cnt);
+        unsigned long long* fs = (unsigned long long*)(fb.fsum + (size_t)f * 3 * V);
+        atomicAdd(fs + m, (unsigned long long)s0q);
+        atomicAdd(fs + (size_t)V + m, (unsigned long long)s1q);
+        atomicAdd(fs + 2 * (size_t)V + m, (unsigned long long)s2q);
+    }
+    return;
+#endif
     const int ql = lane_id() / LANES;                     // index of my query among the wave's 64/LANES queries
     const int mprev = __shfl_up(m, LANES, 64);
     bool head = (ql == 0) || (mprev != m);
