@@ -42,6 +42,9 @@ __device__ __forceinline__ void bucket_count_block(const DeviceModel& dm, const 
     }
 }
 
+// STABLE: pixel order inside a part (frame batches: the slab scan of k_nn_part wants it); otherwise slots come from atomics (few frames:
+// k_nn_vis scans every candidate anyway, and the scatter rides in k_visibility on the frame's dependency chain: 8.2 against 12.9 us)
+template <bool STABLE>
 __device__ __forceinline__ void bucket_scatter_block(const DeviceModel& dm, const FrameBuffers& fb, int f, int bx) {
     const int t = threadIdx.x, np = dm.d.num_parts;
     AvtFrameCtl& ctl = fb.ctl[f];
@@ -63,20 +66,64 @@ __device__ __forceinline__ void bucket_scatter_block(const DeviceModel& dm, cons
         if (t < 3 && N > 0) ctl.centre[t] = fb.data_raw[3 * base + t];
     }
     if (s0 >= N) return;
-    const int* lab = fb.labels_raw + base;
-    // ranks inside the tile: slot (pass u, wave w) counts its points per part; a point's rank = points of its part in earlier
-    // slots + lanes of its part below it in its own wave (one ballot per distinct label of the wave: neighbouring pixels share labels)
-    __shared__ int slot_cnt[(BUCKET_TILE / 64) * (AVT_MAX_PARTS + 1)];
-    for (int e = t; e < (BUCKET_TILE / 64) * (np + 1); e += 256) slot_cnt[e] = 0;
-    if (t <= np) {       // points of the part in the tiles in front of this one (pass 1 wrote the tile histograms)
-        int acc = poff[t];
-        const int* th = fb.tile_hist + (size_t)f * fb.bucket_tiles * (AVT_MAX_PARTS + 1) + t;
-        for (int b = 0; b < bx; ++b) acc += th[(size_t)b * (AVT_MAX_PARTS + 1)];
-        bbase[t] = acc;
+    if constexpr (STABLE) {
+        const int* lab = fb.labels_raw + base;
+        // ranks inside the tile: slot (pass u, wave w) counts its points per part; a point's rank = points of its part in earlier
+        // slots + lanes of its part below it in its own wave (one ballot per distinct label of the wave: neighbouring pixels share labels)
+        __shared__ int slot_cnt[(BUCKET_TILE / 64) * (AVT_MAX_PARTS + 1)];
+        for (int e = t; e < (BUCKET_TILE / 64) * (np + 1); e += 256) slot_cnt[e] = 0;
+        if (t <= np) {       // points of the part in the tiles in front of this one (pass 1 wrote the tile histograms)
+            int acc = poff[t];
+            const int* th = fb.tile_hist + (size_t)f * fb.bucket_tiles * (AVT_MAX_PARTS + 1) + t;
+            for (int b = 0; b < bx; ++b) acc += th[(size_t)b * (AVT_MAX_PARTS + 1)];
+            bbase[t] = acc;
+        }
+        __syncthreads();
+        int qs[BUCKET_TILE / 256], rk[BUCKET_TILE / 256];
+        const int w = t >> 6, lane = t & 63;
+    #pragma unroll
+        for (int u = 0; u < BUCKET_TILE / 256; ++u) {
+            const int i = s0 + u * 256 + t;
+            int q = -1;
+            if (i < N) {
+                q = lab[i];
+                if (q < 0 || q >= np) q = np;
+            }
+            qs[u] = q;
+            int rank = 0;
+            unsigned long long todo = __ballot(q >= 0);
+            while (todo) {                                   // wave-uniform: one round per distinct label present in the wave
+                const int src = __ffsll((long long)todo) - 1;
+                const int qq = __shfl(q, src, 64);
+                const unsigned long long m = __ballot(q == qq);
+                if (q == qq) rank = __popcll(m & ((1ull << lane) - 1ull));
+                if (lane == src) slot_cnt[(u * 4 + w) * (np + 1) + qq] = __popcll(m);
+                todo &= ~m;
+            }
+            rk[u] = rank;
+        }
+        __syncthreads();
+        if (t <= np) {       // exclusive prefix over the 32 slots, in (pass, wave) = index order
+            int run = 0;
+            for (int sl = 0; sl < BUCKET_TILE / 64; ++sl) { const int c = slot_cnt[sl * (np + 1) + t]; slot_cnt[sl * (np + 1) + t] = run; run += c; }
+        }
+        __syncthreads();
+    #pragma unroll
+        for (int u = 0; u < BUCKET_TILE / 256; ++u) {
+            const int i = s0 + u * 256 + t;
+            const int q = qs[u];
+            if (q < 0) continue;
+            const int pos = bbase[q] + slot_cnt[(u * 4 + w) * (np + 1) + q] + rk[u];
+            fb.dx[base + pos] = fb.data_raw[3 * (base + i)];
+            fb.dy[base + pos] = fb.data_raw[3 * (base + i) + 1];
+            fb.dz[base + pos] = fb.data_raw[3 * (base + i) + 2];
+            fb.dorig[base + pos] = i;
+            if (q == np) fb.corr[base + i] = -1;
+        }
+        return;
     }
-    __syncthreads();
-    int qs[BUCKET_TILE / 256], rk[BUCKET_TILE / 256];
-    const int w = t >> 6, lane = t & 63;
+    const int* lab = fb.labels_raw + base;
+    int qs[BUCKET_TILE / 256];
 #pragma unroll
     for (int u = 0; u < BUCKET_TILE / 256; ++u) {
         const int i = s0 + u * 256 + t;
@@ -84,24 +131,14 @@ __device__ __forceinline__ void bucket_scatter_block(const DeviceModel& dm, cons
         if (i < N) {
             q = lab[i];
             if (q < 0 || q >= np) q = np;
+            atomicAdd(&hist[q], 1);
         }
         qs[u] = q;
-        int rank = 0;
-        unsigned long long todo = __ballot(q >= 0);
-        while (todo) {                                   // wave-uniform: one round per distinct label present in the wave
-            const int src = __ffsll((long long)todo) - 1;
-            const int qq = __shfl(q, src, 64);
-            const unsigned long long m = __ballot(q == qq);
-            if (q == qq) rank = __popcll(m & ((1ull << lane) - 1ull));
-            if (lane == src) slot_cnt[(u * 4 + w) * (np + 1) + qq] = __popcll(m);
-            todo &= ~m;
-        }
-        rk[u] = rank;
     }
     __syncthreads();
-    if (t <= np) {       // exclusive prefix over the 32 slots, in (pass, wave) = index order
-        int run = 0;
-        for (int sl = 0; sl < BUCKET_TILE / 64; ++sl) { const int c = slot_cnt[sl * (np + 1) + t]; slot_cnt[sl * (np + 1) + t] = run; run += c; }
+    if (t <= np) {
+        bbase[t] = hist[t] ? poff[t] + atomicAdd(cursor + t, hist[t]) : 0;
+        hist[t] = 0;
     }
     __syncthreads();
 #pragma unroll
@@ -109,7 +146,7 @@ __device__ __forceinline__ void bucket_scatter_block(const DeviceModel& dm, cons
         const int i = s0 + u * 256 + t;
         const int q = qs[u];
         if (q < 0) continue;
-        const int pos = bbase[q] + slot_cnt[(u * 4 + w) * (np + 1) + q] + rk[u];
+        const int pos = bbase[q] + atomicAdd(&hist[q], 1);
         fb.dx[base + pos] = fb.data_raw[3 * (base + i)];
         fb.dy[base + pos] = fb.data_raw[3 * (base + i) + 1];
         fb.dz[base + pos] = fb.data_raw[3 * (base + i) + 2];

@@ -8,7 +8,7 @@
 
 __global__ __launch_bounds__(256) void k_bucket_count(DeviceModel dm, FrameBuffers fb) { bucket_count_block(dm, fb, blockIdx.y + fb.f0, blockIdx.x); }
 
-__global__ __launch_bounds__(256) void k_bucket_scatter(DeviceModel dm, FrameBuffers fb) { bucket_scatter_block(dm, fb, blockIdx.y + fb.f0, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_bucket_scatter(DeviceModel dm, FrameBuffers fb) { bucket_scatter_block<true>(dm, fb, blockIdx.y + fb.f0, blockIdx.x); }
 
 // =================================================================================================
 // Avatar::update()  (Avatar.cpp:22-75)
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_visibility(DeviceModel dm, FrameBuffers
     const int F = dm.d.F, V = dm.d.V;
     const int f = blockIdx.y + fb.f0;
     // trailing workgroups (first ICP iteration only): the scatter pass of the data bucketing (its histogram rode in k_lbs)
-    if ((int)blockIdx.x >= nvis) { bucket_scatter_block(dm, fb, f, (int)blockIdx.x - nvis); return; }
+    if ((int)blockIdx.x >= nvis) { bucket_scatter_block<false>(dm, fb, f, (int)blockIdx.x - nvis); return; }   // few frames: the fast unordered scatter
     const int face = blockIdx.x * 256 + threadIdx.x;
     if (face >= F) return;
     const int i1 = dm.mesh[face], i2 = dm.mesh[(size_t)F + face], i3 = dm.mesh[2 * (size_t)F + face];

@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb
 // the part-sorted copy, three scattered stores per vertex) instead of from pcx/pcy/pcz.
 __global__ __launch_bounds__(256) void k_compact(DeviceModel dm, FrameBuffers fb, int from_cloud, int sort_y) {
     const int f = blockIdx.y + fb.f0, q = blockIdx.x, t = threadIdx.x, V = dm.d.V, np = dm.d.num_parts;
-    if (q >= np) { bucket_scatter_block(dm, fb, f, q - np); return; }
+    if (q >= np) { bucket_scatter_block<true>(dm, fb, f, q - np); return; }
     const int b = dm.part_start[q], e = dm.part_start[q + 1];
     __shared__ int s_wcnt[4];
     __shared__ int s_run;
