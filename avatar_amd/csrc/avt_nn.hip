@@ -523,8 +523,9 @@ __global__ __launch_bounds__(256) void k_compact(DeviceModel dm, FrameBuffers fb
     const int b = dm.part_start[q], e = dm.part_start[q + 1];
     __shared__ int s_wcnt[4];
     __shared__ int s_run;
-    struct __attribute__((aligned(16))) Ent { double y; int vid; int pos; };
-    __shared__ Ent s_ent[NN_SORT_CAP];            // sort_y: the part's visible candidates (y, vertex id, part-sorted position)
+    struct __attribute__((aligned(16))) Ent { double y; int vid; int slot; };
+    __shared__ Ent s_ent[NN_SORT_CAP];            // sort_y: the part's visible candidates (y, vertex id, slot of its x and z below)
+    __shared__ double s_xz[2 * NN_SORT_CAP];      // x and z of the candidates in compaction order (gathered once, in pass 0)
     if (t == 0) s_run = 0;
     __syncthreads();
     const unsigned char* vis = fb.visible + (size_t)f * V;
@@ -550,10 +551,9 @@ __global__ __launch_bounds__(256) void k_compact(DeviceModel dm, FrameBuffers fb
             for (int w = 0; w < wave_id(); ++w) off += s_wcnt[w];
             if (keep) {
                 if (pass == 0) {
-                    if (off + rank < NN_SORT_CAP) {
-                        const double y = from_cloud ? fb.cloud[((size_t)f * V + v) * 3 + 1] : fb.pcy[(size_t)f * V + pos];
-                        s_ent[off + rank] = Ent{y, v, pos};
-                    }
+                    // (ids only: the coordinates are gathered after the loop, all at once - inside it every iteration would wait for
+                    // its own dependent gather in front of the barrier)
+                    if (off + rank < NN_SORT_CAP) s_ent[off + rank] = Ent{0.0, v, pos};
                 } else {
                     const size_t o = (size_t)f * V + b + off + rank;
                     if (from_cloud) {
@@ -575,6 +575,14 @@ __global__ __launch_bounds__(256) void k_compact(DeviceModel dm, FrameBuffers fb
     const int n = s_run;
     const bool sorted = sort_y && n <= NN_SORT_CAP;
     if (sorted) {
+        for (int i = t; i < n; i += 256) {           // coordinates of the compacted candidates: independent gathers, one exposed latency
+            const int v = s_ent[i].vid, pos = s_ent[i].slot;
+            double x, y, z;
+            if (from_cloud) { const double* cl = fb.cloud + ((size_t)f * V + v) * 3; x = cl[0]; y = cl[1]; z = cl[2]; }
+            else { x = fb.pcx[(size_t)f * V + pos]; y = fb.pcy[(size_t)f * V + pos]; z = fb.pcz[(size_t)f * V + pos]; }
+            s_ent[i] = Ent{y, v, i};
+            s_xz[2 * i] = x; s_xz[2 * i + 1] = z;
+        }
         // bitonic sort by (y, vertex id) in LDS, padded to a power of two with +inf keys (a rank sort - every element counting
         // the elements in front of it - is simpler but quadratic: 62 us against 8 for the 32-frame launch with parts of 900)
         int P2 = 64;
@@ -602,14 +610,7 @@ __global__ __launch_bounds__(256) void k_compact(DeviceModel dm, FrameBuffers fb
         for (int i = t; i < n; i += 256) {
             const Ent me = s_ent[i];
             const size_t o = (size_t)f * V + b + i;
-            if (from_cloud) {
-                const double* cl = fb.cloud + ((size_t)f * V + me.vid) * 3;
-                fb.vcx[o] = cl[0]; fb.vcy[o] = me.y; fb.vcz[o] = cl[2];
-            } else {
-                fb.vcx[o] = fb.pcx[(size_t)f * V + me.pos];
-                fb.vcy[o] = me.y;
-                fb.vcz[o] = fb.pcz[(size_t)f * V + me.pos];
-            }
+            fb.vcx[o] = s_xz[2 * me.slot]; fb.vcy[o] = me.y; fb.vcz[o] = s_xz[2 * me.slot + 1];
             fb.vcid[o] = me.vid;
         }
     }
