@@ -139,3 +139,30 @@ def test_ark_npz_reads_what_the_references_cnpy_reads(smpl, tmp_path, ark_lib, v
     # members that are not numeric arrays: the reference's reader carries their bytes along, ark::npz skips them; neither fails
     for key in set(arrs) - set(FLOAT_KEYS) - set(UINT_KEYS):
         assert key in r and key not in a
+
+
+def _npy_bytes(descr, fortran, shape_text, payload=b""):
+    hdr = ("{'descr': '%s', 'fortran_order': %s, 'shape': (%s), }" % (descr, "True" if fortran else "False", shape_text)).encode()
+    pad = 64 - (10 + len(hdr) + 1) % 64
+    hdr += b" " * (pad % 64) + b"\n"
+    return b"\x93NUMPY\x01\x00" + len(hdr).to_bytes(2, "little") + hdr + payload
+
+
+def test_ark_npz_rejects_shapes_whose_product_wraps_and_skips_odd_headers(tmp_path, ark_lib):
+    """two dimensions of 2^40 wrapped size_t (n = 0 passed the truncation check while shape said 2^80 elements); a
+    member whose header makes std::stoull throw std::out_of_range aborted the whole load instead of being skipped."""
+    import zipfile
+    good = np.arange(12, dtype=np.float64).reshape(3, 4)
+    path = str(tmp_path / "crafted.npz")
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_STORED) as z:
+        import io
+        b = io.BytesIO(); np.save(b, good); z.writestr("v_template.npy", b.getvalue())
+        z.writestr("wraps.npy", _npy_bytes("<f8", False, "1099511627776, 1099511627776"))            # 2^40 x 2^40
+        z.writestr("huge_dim.npy", _npy_bytes("<f8", False, "99999999999999999999999999, 2"))        # stoull: out_of_range
+        z.writestr("odd_descr.npy", _npy_bytes("<f999999999999", False, "2, 2"))                     # stoi: out_of_range
+    a = _load_ark(ark_lib, path)
+    assert set(a) == {"v_template"}                       # the crafted members are skipped, the sound one is read
+    assert np.array_equal(a["v_template"][2].reshape(3, 4), good)
+    h = ark_lib.arknpz_open(path.encode())
+    assert ark_lib.arknpz_error(h) == b""
+    ark_lib.arknpz_close(h)
