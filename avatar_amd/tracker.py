@@ -15,7 +15,7 @@ from . import api
 
 class FrameTracker:
     def __init__(self, ava_opt: "api.AvatarOptimizer", interval=12, frame_icp_iters=3, reinit_icp_iters=6, reinit_cnz=1000,
-                 num_threads=4, rtree=None, rtree_interval=2, dist_to_pre_weight=0.001):
+                 num_threads=4, rtree=None, rtree_interval=2, dist_to_pre_weight=0.001, initial_per_part_cnz=0, initial_icp_iters=None):
         self.opt = ava_opt
         self.ava = ava_opt.ava
         self.interval = interval                      # demo.cpp:58  --data-interval
@@ -23,6 +23,9 @@ class FrameTracker:
         self.reinitICPIters = reinit_icp_iters        # demo.cpp:66  --reinit-icp-iters
         self.reinitCnz = reinit_cnz                   # demo.cpp:71  --min-points
         self.num_threads = num_threads
+        self.initialPerPartCnz = initial_per_part_cnz # live-demo.cpp:89-90 --initial-per-part-thresh (80 there); 0 = demo.cpp: no per-part check
+        self.initialICPIters = reinit_icp_iters if initial_icp_iters is None else initial_icp_iters   # live-demo.cpp:80
+        self.firstTime = True                         # live-demo.cpp:256
         self.reinit = True                            # demo.cpp:151
         self.rtree = rtree                            # avatar_amd.rtree.RTree or None (labels supplied by the caller)
         self.rtreeInterval = rtree_interval           # demo.cpp:198 (predictBest / postProcess interval)
@@ -48,7 +51,11 @@ class FrameTracker:
         """One tracked frame.  Returns True if the avatar was fitted, False if tracking was declared lost
         (too few body pixels: the next frame reinitialises, demo.cpp:225,283-285)."""
         data, labels = self.subsample(xyz, part_mask, bbox)
-        if len(labels) == 0 or len(labels) < self.reinitCnz // (self.interval * self.interval):   # an empty frame is never fitted
+        part_missing = False                          # live-demo.cpp:376-380: the first fit wants every body part seen
+        if self.firstTime and self.initialPerPartCnz > 0:
+            part_cnz = np.bincount(labels, minlength=self.opt.numParts)
+            part_missing = part_cnz.min() < max(1, self.initialPerPartCnz // (self.interval * self.interval))
+        if len(labels) == 0 or part_missing or len(labels) < self.reinitCnz // (self.interval * self.interval):   # an empty frame is never fitted
             self.reinit = True
             return False
         icp_iters = self.frameICPIters
@@ -60,7 +67,8 @@ class FrameTracker:
             ava.r[0] = np.array([[-1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, -1.0]])   # AngleAxis(pi, y)
             self.reinit = False
             ava.update()
-            icp_iters = self.reinitICPIters
+            icp_iters = self.initialICPIters if self.firstTime else self.reinitICPIters     # live-demo.cpp:417-418
+            self.firstTime = False
         self.opt.optimize(data, labels, icp_iters, self.num_threads)
         return True
 

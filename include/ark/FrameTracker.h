@@ -61,7 +61,16 @@ class FrameTracker {
         // demo.cpp:225 skips a sparse frame; live-demo.cpp:379-383 also asks for a reinitialisation, which is the policy kept
         // here (documented deviation from demo.cpp).  An EMPTY frame is never fitted whatever reinitCnz says: the centroid
         // below divides by cnz.
-        if (cnz == 0 || cnz < (size_t)(reinitCnz / (interval * interval))) {
+        bool part_missing = false;       // live-demo.cpp:376-380: the FIRST fit wants every body part seen (initialPerPartCnz pixels at interval 1)
+        if (firstTime && initialPerPartCnz > 0) {
+            std::vector<size_t> partCnz((size_t)avaOpt.numParts, 0);
+            for (size_t i = 0; i < cnz; ++i) ++partCnz[(size_t)dataPartLabels[i]];
+            size_t mn = partCnz.empty() ? 0 : partCnz[0];
+            for (size_t v : partCnz) mn = v < mn ? v : mn;
+            const int need = initialPerPartCnz / (interval * interval);
+            part_missing = mn < (size_t)(need > 1 ? need : 1);
+        }
+        if (cnz == 0 || part_missing || cnz < (size_t)(reinitCnz / (interval * interval))) {
             reinit = true;
             return false;
         }
@@ -91,6 +100,7 @@ class FrameTracker {
     int reinitICPIters = 6;       // demo.cpp:66   --reinit-icp-iters
     int initialICPIters = 6;      // live-demo.cpp:80 (demo.cpp has one budget for both)
     int reinitCnz = 1000;         // demo.cpp:71   --min-points
+    int initialPerPartCnz = 0;    // live-demo.cpp:89-90 --initial-per-part-thresh (80 there); 0 = demo.cpp, which has no per-part check
     int numThreads = 4;
     bool reinit = true;           // demo.cpp:151
     bool firstTime = true;        // live-demo.cpp:256

@@ -78,6 +78,26 @@ def test_tracker_sequence_matches_oracle(smpl, omodel, gmodel):
     assert not tr.process(frames[0][0], empty, (0, 0, 719, 1279)) and tr.reinit
 
 
+@pytest.mark.gpu
+def test_first_fit_wants_every_body_part(smpl, gmodel):
+    """live-demo.cpp:376-383: before the FIRST fit every body part must be seen (initialPerPartCnz pixels at interval 1); a frame
+    with a part missing is skipped and asks for a reinitialisation, later frames are not held to it.  Off (0) = demo.cpp."""
+    from avatar_amd import api
+    from avatar_amd.tracker import FrameTracker
+    xyz, mask, _ = _sequence(smpl, 1)[0]
+    pm = synth.identity_part_map()
+    ava = api.Avatar(gmodel)
+    opt = api.AvatarOptimizer(ava, None, (1280, 720), 24, pm, max_points=4096)
+    tr = FrameTracker(opt, interval=6, frame_icp_iters=1, reinit_icp_iters=1, reinit_cnz=500, initial_per_part_cnz=36)
+    ys, xs = np.nonzero(mask != 255)
+    bbox = (ys.min(), xs.min(), ys.max(), xs.max())
+    part = int(np.bincount(mask[mask != 255]).argmax())
+    holed = mask.copy(); holed[mask == part] = 255            # one body part not seen at all
+    assert not tr.process(xyz, holed, bbox) and tr.reinit and tr.firstTime
+    assert tr.process(xyz, mask, bbox) and not tr.firstTime
+    assert tr.process(xyz, holed, bbox)                        # after the first fit the per-part rule no longer applies
+
+
 def write_sequence(path, frames, interval, frame_icp, reinit_icp, reinit_cnz):
     """sequence.bin of tests/cpp/tracker_demo.cpp: header, then per frame bbox + XYZ map (float32) + part mask (uint8)."""
     import struct
