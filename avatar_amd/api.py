@@ -99,14 +99,15 @@ class AvatarModel:
     holding `model.npz` (+ optional `pose_prior.txt`), the reference's model_dir convention (AvatarModel.cpp:18-23)."""
 
     def __init__(self, model=None, limit_one_joint_per_point=False, handle=None):
-        if limit_one_joint_per_point:
-            raise NotImplementedError("limit_one_joint_per_point is a legacy-format option (AvatarModel.cpp:128-288)")
+        """limit_one_joint_per_point (Avatar.h:76-77): the optimiser's forward model binds every point to its largest-weight joint
+        only (AvatarModel.cpp:190-196 - the reference honours it in the legacy text format; here it is a property of the model
+        description, whatever the source); Avatar::update() keeps all weights."""
         if isinstance(model, (str, os.PathLike)):
             model = load_model_dir(model)
         if model is None:
             raise AvtError("AvatarModel: no model data (the reference's data/avatar-model download is not bundled)")
         self.smpl = model
-        self.arrays = ModelArrays(model)
+        self.arrays = ModelArrays(model, limit_one_joint_per_point)
         self._desc = self.arrays.desc()
         self._lib = capi.load_library()
         if handle is not None:      # an avt_model* built elsewhere (avt_model_unpack / avt_shard_broadcast_model): adopt it
@@ -149,10 +150,78 @@ class AvatarModel:
             pass
 
 
+def _load_pcd_ascii(path):
+    """loadPCDToPointVectorFast (AvatarHelpers.cpp:13-52): WIDTH gives the point count, DATA must be ascii, then 3 numbers per point."""
+    tok = open(path).read().split("\n")
+    n, body = -1, None
+    for i, line in enumerate(tok):
+        parts = line.split()
+        if not parts:
+            continue
+        if parts[0] == "WIDTH":
+            n = int(parts[1])
+        elif parts[0] == "DATA":
+            if n < 0:
+                raise AvtError(f"invalid PCD file at {path}: no WIDTH field before data")
+            if len(parts) < 2 or parts[1] != "ascii":
+                raise AvtError(f"non-ascii PCD not supported: {path}")
+            body = " ".join(tok[i + 1:]).split()
+            break
+    if body is None or len(body) < 3 * n:
+        raise AvtError(f"invalid PCD file at {path}: unexpected EOF")
+    return np.array(body[:3 * n], dtype=np.float64)
+
+
+def load_legacy_model_dir(path):
+    """The reference's deprecated ad-hoc model format (AvatarModel.cpp:128-288): skeleton.txt (joints with parents and rest
+    positions, then every point's (joint, weight) list), model.pcd (base cloud), shapekey/*.pcd (one key cloud each; the reference
+    takes them in directory order, which is unspecified - here sorted by file name), joint_shape_regressor.txt or
+    joint_regressor.txt, mesh.txt.  Returns the same dict layout as model.npz."""
+    tok = iter(open(os.path.join(path, "skeleton.txt")).read().split())
+    J, V = int(next(tok)), int(next(tok))
+    parent = np.zeros(J, np.int64)
+    for i in range(J):
+        jid = int(next(tok)); parent[jid] = int(next(tok)); next(tok); [next(tok) for _ in range(3)]      # name and rest position: not needed
+    parent[0] = -1
+    W = np.zeros((V, J))
+    for v in range(V):
+        for _ in range(int(next(tok))):
+            j = int(next(tok)); W[v, j] = float(next(tok))
+    m = {"v_template": _load_pcd_ascii(os.path.join(path, "model.pcd")).reshape(V, 3), "weights": W,
+         "kintree_table": np.stack([parent, np.arange(J)])}
+    kdir = os.path.join(path, "shapekey")
+    keys = [_load_pcd_ascii(os.path.join(kdir, f)) for f in sorted(os.listdir(kdir))] if os.path.isdir(kdir) else []
+    K = len(keys)
+    m["shapedirs"] = np.stack(keys, 1).reshape(V, 3, K) if K else np.zeros((V, 3, 0))
+    jsr_path, jr_path = os.path.join(path, "joint_shape_regressor.txt"), os.path.join(path, "joint_regressor.txt")
+    m["J_regressor"] = np.zeros((J, V))
+    if os.path.exists(jsr_path):
+        t = open(jsr_path).read().split()
+        nk = int(t[0]); vals = np.array(t[1:], dtype=np.float64)
+        m["joint_shape_reg_base"] = vals[:3 * J]
+        m["joint_shape_reg"] = vals[3 * J:3 * J + 3 * J * nk].reshape(3 * J, nk)       # row by row in the file (AvatarModel.cpp:238-242)
+    elif os.path.exists(jr_path):
+        t = iter(open(jr_path).read().split())
+        for j in range(int(next(t))):
+            for _ in range(int(next(t))):
+                v = int(next(t)); m["J_regressor"][j, v] = float(next(t))
+    mesh_path = os.path.join(path, "mesh.txt")
+    if os.path.exists(mesh_path):
+        t = open(mesh_path).read().split()
+        m["f"] = np.array(t[1:1 + 3 * int(t[0])], dtype=np.int64).reshape(-1, 3)
+    else:
+        m["f"] = np.zeros((0, 3), np.int64)
+    return m
+
+
 def load_model_dir(path):
-    """model.npz in SMPL layout (AvatarModel.cpp:26-104) + pose_prior.txt (GaussianMixture.cpp:12-58)."""
-    with np.load(os.path.join(path, "model.npz")) as z:
-        m = {k: z[k] for k in z.files}
+    """model.npz in SMPL layout (AvatarModel.cpp:26-104) + pose_prior.txt (GaussianMixture.cpp:12-58); without a model.npz the
+    reference's legacy text format (AvatarModel.cpp:128-288)."""
+    if os.path.exists(os.path.join(path, "model.npz")):
+        with np.load(os.path.join(path, "model.npz")) as z:
+            m = {k: z[k] for k in z.files}
+    else:
+        m = load_legacy_model_dir(path)
     pp = os.path.join(path, "pose_prior.txt")
     if os.path.exists(pp) and "prior_weight" not in m:
         tok = open(pp).read().split()

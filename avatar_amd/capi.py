@@ -30,6 +30,9 @@ class ModelDesc(C.Structure):
         ("jreg_colptr", c_int_p), ("jreg_row", c_int_p), ("jreg_val", c_double_p),
         ("prior_ncomps", C.c_int), ("prior_ndims", C.c_int),
         ("prior_weight", c_double_p), ("prior_mean", c_double_p), ("prior_cov", c_double_p),
+        # the reference's legacy model format only (zero / NULL for model.npz): include/avt.h
+        ("limit_one_joint_per_point", C.c_int), ("reserved1", C.c_int),
+        ("joint_shape_reg_base", c_double_p), ("joint_shape_reg", c_double_p),
     ]
 
 
@@ -88,7 +91,10 @@ class ModelArrays:
     (AvatarModel.cpp:26-104: v_template (V,3), f (F,3), kintree_table (2,J), J_regressor (J,V),
     weights (V,J), shapedirs (V,3,K)) plus the GMM (prior_weight, prior_mean, prior_cov)."""
 
-    def __init__(self, smpl: dict):
+    def __init__(self, smpl: dict, limit_one_joint_per_point=False):
+        """Optional keys of the reference's legacy model format (AvatarModel.cpp:128-288): "joint_shape_reg_base" (3J) and
+        "joint_shape_reg" (3J, K) - joint_shape_regressor.txt, taken as given instead of being derived from J_regressor."""
+        self.limit_one_joint_per_point = bool(limit_one_joint_per_point)
         v = np.ascontiguousarray(smpl["v_template"], dtype=np.float64)
         self.V = V = v.shape[0]
         self.J = J = int(np.asarray(smpl["kintree_table"]).shape[1])
@@ -118,6 +124,11 @@ class ModelArrays:
         else:
             self.prior_weight = self.prior_mean = self.prior_cov = None
             self.ncomps, self.ndims = 0, 0
+        if smpl.get("joint_shape_reg") is not None:
+            self.jsr_base = np.ascontiguousarray(smpl["joint_shape_reg_base"], dtype=np.float64).reshape(3 * J)
+            self.jsr = np.asfortranarray(np.asarray(smpl["joint_shape_reg"], dtype=np.float64).reshape(3 * J, K))   # column-major 3J x K
+        else:
+            self.jsr_base = self.jsr = None
 
     def desc(self) -> ModelDesc:
         d = ModelDesc()
@@ -130,6 +141,10 @@ class ModelArrays:
         if self.ncomps > 0:
             d.prior_weight = dptr(self.prior_weight); d.prior_mean = dptr(self.prior_mean)
             d.prior_cov = dptr(self.prior_cov)
+        d.limit_one_joint_per_point = 1 if self.limit_one_joint_per_point else 0
+        if self.jsr is not None:
+            d.joint_shape_reg_base = dptr(self.jsr_base)
+            d.joint_shape_reg = self.jsr.ctypes.data_as(c_double_p)
         return d
 
 

@@ -280,6 +280,7 @@ static int avt_model_create_impl(const avt_model_desc* desc, avt_model** out) {
         }
         std::sort(assigned[v].begin(), assigned[v].end(), std::greater<std::pair<double, int>>());
         if (assigned[v].empty()) { avt_set_error("avt_model_create: vertex without skinning weights"); return 1; }
+        if (desc->limit_one_joint_per_point) { assigned[v].resize(1); assigned[v][0].first = 1.0; }      // AvatarModel.cpp:190-196
         for (size_t a = 0; a < assigned[v].size(); ++a) {
             m->asg_w[a * V + v] = assigned[v][a].first;
             m->asg_j[a * V + v] = assigned[v][a].second;
@@ -299,6 +300,16 @@ static int avt_model_create_impl(const avt_model_desc* desc, avt_model** out) {
                 for (int c = 0; c < 3; ++c)
                     m->jsr[(size_t)(3 * j + c) * K + k] += desc->key_clouds[(size_t)k * 3 * V + 3 * v + c] * wt;
         }
+    if ((desc->joint_shape_reg_base != nullptr) != (desc->joint_shape_reg != nullptr)) {
+        avt_set_error("avt_model_create: joint_shape_reg_base and joint_shape_reg come together");
+        return 1;
+    }
+    if (desc->joint_shape_reg) {       // joint_shape_regressor.txt of the legacy format (AvatarModel.cpp:231-243): taken as given
+        for (int i = 0; i < 3 * J; ++i) {
+            m->jsr_base[i] = desc->joint_shape_reg_base[i];
+            for (int k = 0; k < K; ++k) m->jsr[(size_t)i * K + k] = desc->joint_shape_reg[(size_t)k * 3 * J + i];
+        }
+    }
     // S, Sp (AvatarOptimizer.cpp:215-245)
     m->S.assign((size_t)J * 3 * K, 0.0); m->Sp.assign((size_t)J * 3 * K, 0.0);
     for (int j = 0; j < J; ++j)

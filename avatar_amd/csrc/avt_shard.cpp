@@ -58,9 +58,10 @@ struct PackHeader {
 };
 
 struct PackLayout {
-    size_t off[13], len[13];       // byte offset / byte length of every array
+    size_t off[15], len[15];       // byte offset / byte length of every array (13, 14: the legacy format's joint shape regressor)
     size_t total;
 };
+enum { PACK_LIMIT_ONE_JOINT = 1, PACK_HAS_JSR = 2 };      // PackHeader::pad carries these flags (0 in blocks packed before they existed)
 
 size_t align8(size_t x) { return (x + 7) & ~(size_t)7; }
 
@@ -72,8 +73,11 @@ bool pack_layout(const PackHeader& h, PackLayout& L) {
                              (J + 1) * 4, (size_t)h.nnz_r * 4, (size_t)h.nnz_r * 8, C * 8, C * n * 8, C * n * n * 8};
     size_t o = align8(sizeof(PackHeader));
     for (int i = 0; i < 13; ++i) { L.off[i] = o; L.len[i] = lens[i]; o = align8(o + lens[i]); }
+    const bool jsr = (h.pad & PACK_HAS_JSR) != 0;
+    const size_t extra[2] = {jsr ? 3 * J * 8 : 0, jsr ? 3 * J * K * 8 : 0};
+    for (int i = 0; i < 2; ++i) { L.off[13 + i] = o; L.len[13 + i] = extra[i]; o = align8(o + extra[i]); }
     L.total = o;
-    return true;
+    return (h.pad & ~(PACK_LIMIT_ONE_JOINT | PACK_HAS_JSR)) == 0;
 }
 
 bool header_of(const avt_model_desc* d, PackHeader& h) {
@@ -86,6 +90,7 @@ bool header_of(const avt_model_desc* d, PackHeader& h) {
     h.nnz_r = d->jreg_colptr[d->num_joints];
     h.ncomps = d->prior_ncomps > 0 ? d->prior_ncomps : 0;
     h.ndims = h.ncomps ? d->prior_ndims : 0;
+    h.pad = (d->limit_one_joint_per_point ? PACK_LIMIT_ONE_JOINT : 0) | ((d->joint_shape_reg_base && d->joint_shape_reg) ? PACK_HAS_JSR : 0);
     return true;
 }
 
@@ -106,9 +111,10 @@ extern "C" int avt_model_pack(const avt_model_desc* d, void* buf, size_t bytes) 
     char* b = (char*)buf;
     std::memset(b, 0, L.total);
     std::memcpy(b, &h, sizeof h);
-    const void* src[13] = {d->base_cloud, d->key_clouds, d->parent, d->mesh, d->weights_colptr, d->weights_row, d->weights_val,
-                           d->jreg_colptr, d->jreg_row, d->jreg_val, d->prior_weight, d->prior_mean, d->prior_cov};
-    for (int i = 0; i < 13; ++i) {
+    const void* src[15] = {d->base_cloud, d->key_clouds, d->parent, d->mesh, d->weights_colptr, d->weights_row, d->weights_val,
+                           d->jreg_colptr, d->jreg_row, d->jreg_val, d->prior_weight, d->prior_mean, d->prior_cov,
+                           d->joint_shape_reg_base, d->joint_shape_reg};
+    for (int i = 0; i < 15; ++i) {
         if (L.len[i] == 0) continue;
         if (!src[i]) { avt_set_error("avt_model_pack: a required array of the model description is NULL"); return 1; }
         std::memcpy(b + L.off[i], src[i], L.len[i]);
@@ -135,6 +141,8 @@ extern "C" int avt_model_unpack(const void* buf, size_t bytes, avt_model** out) 
     d.jreg_colptr = (const int*)(b + L.off[7]); d.jreg_row = (const int*)(b + L.off[8]); d.jreg_val = (const double*)(b + L.off[9]);
     d.prior_ncomps = h.ncomps; d.prior_ndims = h.ndims;
     if (h.ncomps) { d.prior_weight = (const double*)(b + L.off[10]); d.prior_mean = (const double*)(b + L.off[11]); d.prior_cov = (const double*)(b + L.off[12]); }
+    d.limit_one_joint_per_point = (h.pad & PACK_LIMIT_ONE_JOINT) ? 1 : 0;
+    if (h.pad & PACK_HAS_JSR) { d.joint_shape_reg_base = (const double*)(b + L.off[13]); d.joint_shape_reg = (const double*)(b + L.off[14]); }
     // the column pointers index the arrays that follow them: check before avt_model_create walks them
     if (d.weights_colptr[0] != 0 || d.weights_colptr[h.V] != h.nnz_w || d.jreg_colptr[0] != 0 || d.jreg_colptr[h.J] != h.nnz_r) {
         avt_set_error("avt_model_unpack: sparse column pointers do not match the block");

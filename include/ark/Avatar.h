@@ -2,6 +2,9 @@
 // (include/avt.h).  Same class names, member names, defaults and call protocol; containers from ark/Types.h stand in
 // for Eigen.  All numerical work happens in libavatar_hip.so (hand-written HIP, gfx950).
 #pragma once
+#include <dirent.h>
+
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -41,11 +44,15 @@ struct GaussianMixture {  // GaussianMixture.h: data only; residual/Jacobian liv
 };
 
 struct AvatarModel {
-    /** @param model_dir directory holding model.npz (SMPL layout, AvatarModel.cpp:26-104) and optionally
-     *  pose_prior.txt; `limit_one_joint_per_point` only exists for the legacy text format and is rejected. */
-    explicit AvatarModel(const std::string& model_dir = "", bool limit_one_joint_per_point = false) : MODEL_DIR(model_dir) {
-        if (limit_one_joint_per_point) { std::fprintf(stderr, "avatar (MI355X): limit_one_joint_per_point is not supported\n"); std::exit(1); }
+    /** @param model_dir directory holding model.npz (SMPL layout, AvatarModel.cpp:26-104) and optionally pose_prior.txt; without a
+     *  model.npz the reference's deprecated ad-hoc text format is read (AvatarModel.cpp:128-288: skeleton.txt, model.pcd,
+     *  shapekey/ *.pcd, joint_shape_regressor.txt or joint_regressor.txt, mesh.txt).
+     *  @param limit_one_joint_per_point the optimiser's forward model binds every point to its largest-weight joint only
+     *  (AvatarModel.cpp:190-196; the reference honours it in the legacy format, here it applies to either); update() keeps all weights. */
+    explicit AvatarModel(const std::string& model_dir = "", bool limit_one_joint_per_point = false)
+        : MODEL_DIR(model_dir), limitOneJointPerPoint(limit_one_joint_per_point) {
         if (model_dir.empty()) { std::fprintf(stderr, "avatar (MI355X): no model directory given (the reference's data download is not bundled)\n"); std::exit(1); }
+        if (!std::ifstream(model_dir + "/model.npz")) { loadLegacy(model_dir); return; }
         std::map<std::string, npz::Array> z;
         try { z = npz::load(model_dir + "/model.npz"); }
         catch (const std::exception& e) { std::fprintf(stderr, "avatar (MI355X): %s\n", e.what()); std::exit(1); }
@@ -106,6 +113,7 @@ struct AvatarModel {
     VectorXd jointShapeReg;    // 3J x K column-major
     bool useJointShapeRegressor = true;
     const std::string MODEL_DIR;
+    const bool limitOneJointPerPoint = false;
 
     avt_model* handle = nullptr;   // C-ABI handle
 
@@ -113,6 +121,132 @@ struct AvatarModel {
     int nV = 0, nJ = 0, nK = 0, nF = 0;
     VectorXi w_colptr, w_row, r_colptr, r_row;
     VectorXd w_val, r_val;
+    VectorXd legacyJsrBase, legacyJsr;      // joint_shape_regressor.txt of the legacy format (3J; 3J x K column-major), else empty
+
+    [[noreturn]] static void legacyFail(const std::string& what) { std::fprintf(stderr, "ERROR: %s\n", what.c_str()); std::exit(1); }
+
+    /** loadPCDToPointVectorFast (AvatarHelpers.cpp:13-52): WIDTH = point count, DATA must be ascii, then 3 numbers per point. */
+    static VectorXd loadPCD(const std::string& path) {
+        std::ifstream pcd(path);
+        int nPoints = -1;
+        std::string label, rest;
+        while (pcd >> label) {
+            if (label == "DATA") {
+                if (nPoints < 0) legacyFail("invalid PCD file at " + path + ": no WIDTH field before data");
+                pcd >> label;
+                if (label != "ascii") legacyFail("non-ascii PCD not supported! File " + path);
+                break;
+            } else if (label == "WIDTH") { pcd >> nPoints; std::getline(pcd, rest); }
+            else std::getline(pcd, rest);
+        }
+        if (!pcd || nPoints < 0) legacyFail("invalid PCD file at " + path + ": unexpected EOF");
+        VectorXd out((size_t)nPoints * 3);
+        for (auto& v : out) pcd >> v;
+        if (!pcd) legacyFail("invalid PCD file at " + path + ": unexpected EOF");
+        return out;
+    }
+
+    /** The reference's old ad-hoc format (AvatarModel.cpp:128-288). */
+    void loadLegacy(const std::string& dir) {
+        std::fprintf(stderr, "WARNING: Using deprecated ad-hoc SMPL model format; please use the SMPL .npz model (model.npz)\n");
+        baseCloud = loadPCD(dir + "/model.pcd");
+        std::ifstream skel(dir + "/skeleton.txt");
+        if (!skel) legacyFail("Avatar model is invalid, skeleton file not found");
+        int J = 0, V = 0;
+        skel >> J >> V;
+        if (!skel || J <= 0 || V <= 0 || (size_t)V * 3 != baseCloud.size()) legacyFail("Invalid avatar skeleton file (joint / point counts)");
+        parent.assign(J, -1);
+        for (int i = 0; i < J; ++i) {                     // joints in topologically sorted order
+            int id = 0, par = 0; std::string name; double x, y, z;
+            skel >> id >> par >> name >> x >> y >> z;
+            if (!skel || id < 0 || id >= J) legacyFail("Invalid avatar skeleton file: joint table");
+            parent[id] = par;
+        }
+        parent[0] = -1;
+        w_colptr.assign(V + 1, 0);
+        for (int v = 0; v < V; ++v) {
+            int n = 0;
+            skel >> n;
+            std::vector<std::pair<int, double>> ent((size_t)(n > 0 ? n : 0));
+            for (auto& e : ent) skel >> e.first >> e.second;
+            if (!skel) legacyFail("Invalid avatar skeleton file: joint assignments are not present");
+            std::sort(ent.begin(), ent.end());            // compressed-column order: joints ascending within a point
+            for (auto& e : ent) { w_row.push_back(e.first); w_val.push_back(e.second); }
+            w_colptr[v + 1] = (int)w_row.size();
+        }
+        // shape keys: one PCD per key; the reference takes them in directory order (unspecified) - here sorted by file name
+        std::vector<std::string> keyFiles = listDir(dir + "/shapekey");
+        std::sort(keyFiles.begin(), keyFiles.end());
+        const int K = (int)keyFiles.size();
+        if (K == 0) std::fprintf(stderr, "WARNING: no shape key directory found for avatar\n");
+        keyClouds.resize((size_t)3 * V * K);
+        for (int k = 0; k < K; ++k) {
+            const VectorXd kc = loadPCD(dir + "/shapekey/" + keyFiles[k]);
+            if (kc.size() != (size_t)3 * V) legacyFail("shape key " + keyFiles[k] + " has another point count than the model");
+            std::copy(kc.begin(), kc.end(), keyClouds.begin() + (size_t)k * 3 * V);
+        }
+        r_colptr.assign(J + 1, 0);
+        std::ifstream jsr(dir + "/joint_shape_regressor.txt");
+        if (jsr) {                                        // AvatarModel.cpp:231-243: base (3J), then the 3J x K matrix row by row
+            int nk = 0;
+            jsr >> nk;
+            if (nk != K) legacyFail("joint_shape_regressor.txt and the shape key directory disagree on the number of keys");
+            legacyJsrBase.resize((size_t)3 * J); legacyJsr.resize((size_t)3 * J * K);
+            for (auto& v : legacyJsrBase) jsr >> v;
+            for (int i = 0; i < 3 * J; ++i)
+                for (int k = 0; k < K; ++k) jsr >> legacyJsr[(size_t)k * 3 * J + i];
+            if (!jsr) legacyFail("joint_shape_regressor.txt: unexpected EOF");
+            useJointShapeRegressor = true;
+        } else {
+            std::ifstream jr(dir + "/joint_regressor.txt");
+            if (jr) {                                     // AvatarModel.cpp:246-262: per joint a list of (point, value)
+                int nj = 0;
+                jr >> nj;
+                if (nj != J) legacyFail("joint_regressor.txt: joint count differs from the skeleton");
+                for (int j = 0; j < J; ++j) {
+                    int n = 0;
+                    jr >> n;
+                    std::vector<std::pair<int, double>> ent((size_t)(n > 0 ? n : 0));
+                    for (auto& e : ent) jr >> e.first >> e.second;
+                    std::sort(ent.begin(), ent.end());
+                    for (auto& e : ent) { r_row.push_back(e.first); r_val.push_back(e.second); }
+                    r_colptr[j + 1] = (int)r_row.size();
+                }
+                if (!jr) legacyFail("joint_regressor.txt: unexpected EOF");
+            } else {
+                std::fprintf(stderr, "WARNING: neither joint regressor nor joint shape regressor found, model may be inaccurate with nonzero shapekey weights\n");
+            }
+            // (the reference then runs update() through shaped * jointRegressor and leaves jointShapeReg unset for the optimiser; here the
+            // regressor is folded into jointShapeRegBase / jointShapeReg like the npz branch does - the same joints, and the optimiser works)
+            useJointShapeRegressor = false;
+        }
+        std::ifstream meshFile(dir + "/mesh.txt");
+        int F = 0;
+        if (meshFile) {
+            meshFile >> F;
+            mesh.a.resize((size_t)3 * (F > 0 ? F : 0));
+            for (auto& v : mesh.a) meshFile >> v;
+            if (!meshFile) legacyFail("mesh.txt: unexpected EOF");
+        } else {
+            std::fprintf(stderr, "WARNING: mesh not found, maybe you are using an older version of avatar data files? Some functions will not work.\n");
+        }
+        posePrior.load(dir + "/pose_prior.txt");
+        nV = V; nJ = J; nK = K; nF = F > 0 ? F : 0;
+        createHandle();
+    }
+
+    static std::vector<std::string> listDir(const std::string& path) {
+        std::vector<std::string> out;
+        if (DIR* d = opendir(path.c_str())) {
+            while (dirent* e = readdir(d)) {
+                const std::string n = e->d_name;
+                if (n != "." && n != "..") out.push_back(n);
+            }
+            closedir(d);
+        }
+        return out;
+    }
+
     void createHandle() {
         avt_model_desc d{};
         d.num_points = nV; d.num_joints = nJ; d.num_shape_keys = nK; d.num_faces = nF;
@@ -121,6 +255,8 @@ struct AvatarModel {
         d.jreg_colptr = r_colptr.data(); d.jreg_row = r_row.data(); d.jreg_val = r_val.data();
         d.prior_ncomps = posePrior.nComps > 0 ? posePrior.nComps : 0; d.prior_ndims = posePrior.nDims;
         d.prior_weight = posePrior.weight.data(); d.prior_mean = posePrior.mean.data(); d.prior_cov = posePrior.cov.data();
+        d.limit_one_joint_per_point = limitOneJointPerPoint ? 1 : 0;
+        if (!legacyJsr.empty()) { d.joint_shape_reg_base = legacyJsrBase.data(); d.joint_shape_reg = legacyJsr.data(); }
         ARK_AVT_CHECK(avt_model_create(&d, &handle));
         mainJoint.resize(nV);
         ARK_AVT_CHECK(avt_model_main_joint(handle, mainJoint.data()));

@@ -67,6 +67,13 @@ typedef struct avt_model_desc {
     const double* prior_weight; /* ncomps */
     const double* prior_mean;   /* ncomps x ndims row-major */
     const double* prior_cov;    /* ncomps x ndims x ndims, each matrix row-major as in the text file */
+    /* ---- the reference's legacy ("ad-hoc") model format only (AvatarModel.cpp:128-288); zero / NULL for model.npz ---- */
+    int limit_one_joint_per_point;      /* AvatarModel(dir, limit_one_joint_per_point = true) (Avatar.h:76-77, AvatarModel.cpp:190-196):
+                                         * assignedJoints[v] keeps its largest weight only, set to 1 - what the OPTIMISER's forward model
+                                         * and Jacobians use; `weights`, i.e. Avatar::update(), keeps every entry */
+    int reserved1;
+    const double* joint_shape_reg_base; /* 3J: jointShapeRegBase read from joint_shape_regressor.txt (AvatarModel.cpp:231-243) instead of */
+    const double* joint_shape_reg;      /* 3J x K column-major: jointShapeReg   being derived from the joint regressor (:112-127); both or neither */
 } avt_model_desc;
 
 /* Knobs: the public data members of AvatarOptimizer (AvatarOptimizer.h:25-39) and the arguments of

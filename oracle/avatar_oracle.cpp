@@ -269,6 +269,7 @@ void build_model_derived(orc_model& m, const avt_model_desc& d) {
             if (m.wval[e] > 1e-12) m.assigned[c].push_back({m.wval[e], m.wrow[e]});
         }
         std::sort(m.assigned[c].begin(), m.assigned[c].end(), std::greater<std::pair<double, int>>());
+        if (d.limit_one_joint_per_point && !m.assigned[c].empty()) { m.assigned[c].resize(1); m.assigned[c][0].first = 1.0; }   // AvatarModel.cpp:190-196
     }
     // initialJointPos = baseCloud(3xV) * jointRegressor ; jointShapeReg col k = keyCloud_k * jointRegressor
     m.initialJointPos.assign(3 * J, 0.0);
@@ -282,6 +283,10 @@ void build_model_derived(orc_model& m, const avt_model_desc& d) {
                 for (int c = 0; c < 3; ++c)
                     m.jointShapeReg[(size_t)k * 3 * J + 3 * j + c] += m.keys[(size_t)k * 3 * V + 3 * v + c] * wt;
         }
+    }
+    if (d.joint_shape_reg_base && d.joint_shape_reg) {       // legacy format: joint_shape_regressor.txt taken as given (AvatarModel.cpp:231-243)
+        m.initialJointPos.assign(d.joint_shape_reg_base, d.joint_shape_reg_base + 3 * J);
+        m.jointShapeReg.assign(d.joint_shape_reg, d.joint_shape_reg + (size_t)3 * J * K);
     }
     // ancestors (AvatarOptimizer.cpp:187-213)
     m.ancestor.assign(V, {});

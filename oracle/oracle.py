@@ -61,8 +61,8 @@ def reference_nn(model_part, model_cloud, visible, data, labels, num_parts):
 
 
 class OracleModel:
-    def __init__(self, smpl: dict):
-        self.arrays = ModelArrays(smpl)
+    def __init__(self, smpl: dict, limit_one_joint_per_point=False):
+        self.arrays = ModelArrays(smpl, limit_one_joint_per_point)
         self._desc = self.arrays.desc()
         self.h = C.c_void_p(lib().orc_model_create(C.byref(self._desc)))
         self.V, self.J, self.K, self.F, self.P = (self.arrays.V, self.arrays.J, self.arrays.K, self.arrays.F,

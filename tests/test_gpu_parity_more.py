@@ -394,3 +394,33 @@ def test_slab_scan_settles_exact_ties_by_vertex_id(smpl, omodel, gmodel):
     m = ref[ref >= 0]
     d = np.abs(cloud[:, None, :] - cloud[None, m[:200], :]).max(-1) == 0
     assert (d.sum(0) >= 2).mean() > 0.5
+
+
+def test_limit_one_joint_per_point_matches_oracle(smpl, frame0):
+    """AvatarModel(dir, limit_one_joint_per_point = true) (Avatar.h:76-77, AvatarModel.cpp:190-196): the optimiser's forward model
+    and Jacobians bind every point to its largest-weight joint (weight 1), Avatar::update() keeps all weights.  GPU against the
+    oracle built from the same model description: update() identical to the unrestricted model, the fit identical to the oracle's."""
+    from avatar_amd import api
+    from oracle import oracle as orc
+    pm = synth.identity_part_map()
+    g1 = api.AvatarModel(smpl, limit_one_joint_per_point=True)
+    g0 = api.AvatarModel(smpl)
+    o1 = orc.OracleModel(smpl, limit_one_joint_per_point=True)
+    w0, p0, R0 = frame0["start"]
+    c1 = g1.default_ctx().lbs_update(w0[None], p0[None], R0[None])[0]
+    c0 = g0.default_ctx().lbs_update(w0[None], p0[None], R0[None])[0]
+    assert np.array_equal(c1, c0)                                 # `weights` (all entries) drive update()
+    sel = slice(0, None, 4)
+    data, labels = frame0["data"][sel], frame0["labels"][sel]
+    q0 = api.rot_to_quat(R0)
+    opt = Options.demo(icp_iters=2, max_iters_per_icp=5)
+    ref = o1.optimize(pm, 24, data, labels, opt, p0, q0, w0, aggregate=1)
+    ctx = api.Context(g1, 24, pm, 16384, 1)
+    p, q, w, st = ctx.optimize_batch([data], [labels], opt, p0[None], q0[None], w0[None])
+    assert np.array_equal(ctx.correspondences(0, len(labels)), ref["corr"])
+    assert st[0].accepted_steps == ref["stats"].accepted_steps
+    assert abs(st[0].final_cost - ref["stats"].final_cost) <= 1e-9 * abs(ref["stats"].final_cost)
+    assert np.abs(ctx.cloud(0) - ref["cloud"]).max() < 1e-6 and np.abs(p[0] - ref["p"]).max() < 1e-7
+    # and it is a different fit from the blended model's (the flag does something)
+    ref0 = orc.OracleModel(smpl).optimize(pm, 24, data, labels, opt, p0, q0, w0, aggregate=1)
+    assert abs(ref0["stats"].final_cost - ref["stats"].final_cost) > 1e-6 * abs(ref["stats"].final_cost)
