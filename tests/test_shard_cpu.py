@@ -80,3 +80,22 @@ def test_a_bogus_rccl_path_does_not_crash_the_loader():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, f"the loader crashed: rc {r.returncode}\n{r.stderr[-400:]}"
     assert "rc 0 ok" in r.stdout or "librccl" in r.stdout or "nccl" in r.stdout
+
+
+def test_packed_model_carries_the_legacy_format_fields(smpl):
+    """limit_one_joint_per_point and a joint shape regressor given directly (joint_shape_regressor.txt of the legacy format) travel in
+    the packed block the model broadcast ships."""
+    lib = capi.load_library()
+    m = dict(smpl)
+    J, K = m["weights"].shape[1], m["shapedirs"].shape[2]
+    rng = np.random.default_rng(2)
+    m["joint_shape_reg_base"] = rng.standard_normal(3 * J)
+    m["joint_shape_reg"] = rng.standard_normal((3 * J, K))
+    arr = capi.ModelArrays(m, limit_one_joint_per_point=True)
+    h = shard.unpack_model(shard.pack_model(arr))
+    ijp = np.empty(3 * J); jsr = np.empty(3 * J * K)
+    assert lib.avt_model_joint_regression(h, ijp.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), jsr.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) == 0
+    assert np.array_equal(ijp, m["joint_shape_reg_base"]) and np.array_equal(jsr.reshape(K, 3 * J).T, m["joint_shape_reg"])
+    lib.avt_model_destroy(h)
+    plain = shard.pack_model(capi.ModelArrays(smpl))
+    assert len(shard.pack_model(arr)) > len(plain)            # the two extra arrays are there only when given
