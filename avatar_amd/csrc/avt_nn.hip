@@ -366,6 +366,28 @@ __device__ __forceinline__ double nn_wave_max_nonneg(double v) {
     return m;
 }
 
+// min (MAX = false) / max over the wave, identical in every lane's return value, without LDS permutes: row_shr scans that keep a lane's
+// own value where the shift leaves its row (update_dpp with old = the value itself, bound_ctrl off), then the four rows through v_readlane
+template <bool MAX, int SH>
+__device__ __forceinline__ double nn_row_step(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x110 + SH, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x110 + SH, 0xf, 0xf, false);
+    const double o = __hiloint2double(hi, lo);
+    return MAX ? __builtin_fmax(v, o) : __builtin_fmin(v, o);
+}
+template <bool MAX>
+__device__ __forceinline__ double nn_wave_reduce(double v) {
+    v = nn_row_step<MAX, 1>(v); v = nn_row_step<MAX, 2>(v); v = nn_row_step<MAX, 4>(v); v = nn_row_step<MAX, 8>(v);   // lane 15 of every row
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double m = __hiloint2double(__builtin_amdgcn_readlane(hi, 15), __builtin_amdgcn_readlane(lo, 15));
+#pragma unroll
+    for (int l = 31; l < 64; l += 16) {
+        const double o = __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l));
+        m = MAX ? __builtin_fmax(m, o) : __builtin_fmin(m, o);
+    }
+    return m;
+}
+
 // -------------------------------------------------------------------------------------------------
 // k_nn_part: the throughput shape (frame batches).  A workgroup owns up to 256 consecutive bucketed data points of ONE part
 // (one per lane), so every lane scans the same candidates: the part's visible model points are read with SCALAR loads
@@ -400,7 +422,11 @@ __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb
     const int pb = __builtin_amdgcn_readfirstlane(dm.part_start[q]);
     const int vc = __builtin_amdgcn_readfirstlane(fb.vcount[(size_t)f * np + q]);
     const bool sorted = (vc & NN_SORTED_FLAG) != 0;                    // k_compact sorted them by (y, vertex id): slab scan below
+#ifdef AVT_NN_NO_SCAN          // (timing experiment: no candidate is looked at - what remains is the kernel's per-wave fixed work)
+    const int pe = pb;
+#else
     const int pe = pb + (vc & ~NN_SORTED_FLAG);                         // visible candidates of the part
+#endif
     const nn_cptr cx = (nn_cptr)(uintptr_t)(fb.vcx + (size_t)f * V), cy = (nn_cptr)(uintptr_t)(fb.vcy + (size_t)f * V),
                   cz = (nn_cptr)(uintptr_t)(fb.vcz + (size_t)f * V);
     auto dist2 = [&](double px, double py, double pz) {
@@ -447,9 +473,7 @@ __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb
         // the 5 ulp the rounding of the two expressions can differ by) and it can neither win nor tie.  Exact: same distance
         // expression, same winner as the full ascending scan - ties (equal distances, measure zero) are detected and settled by
         // vertex id in a full rescan.  On the synthetic frames 41-45 % of the candidates are evaluated (tools/nn_slab_sim.py).
-        double ylo = active ? a1 : 1.7976931348623157e308, yhi = active ? a1 : -1.7976931348623157e308;
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) { ylo = __builtin_fmin(ylo, __shfl_xor(ylo, m, 64)); yhi = __builtin_fmax(yhi, __shfl_xor(yhi, m, 64)); }
+        const double ylo = nn_wave_reduce<false>(active ? a1 : 1.7976931348623157e308), yhi = nn_wave_reduce<true>(active ? a1 : -1.7976931348623157e308);
         const int n = pe - pb;
         bool rdone = true, ldone = true;
         int R = pb, L = pb;
@@ -464,19 +488,20 @@ __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb
             rdone = R >= pe; ldone = L <= pb;
         }
         while (!(rdone && ldone)) {                                          // wave-uniform
-            if (!rdone) { const int e = min(R + NN_SLAB_CHUNK, pe); scan_groups(R, e, true); R = e; }
-            if (!ldone) { const int b = max(L - NN_SLAB_CHUNK, pb); scan_groups(b, L, true); L = b; }
+            // the candidates just outside this round's chunks decide whether there is a next round: requested with the chunks
+            const int e = min(R + NN_SLAB_CHUNK, pe), b = max(L - NN_SLAB_CHUNK, pb);
+            const double edge_r = cy[min(e, pe - 1)], edge_l = cy[max(b - 1, pb)];
+            if (!rdone) { scan_groups(R, e, true); R = e; }
+            if (!ldone) { scan_groups(b, L, true); L = b; }
             const double dmax = nn_wave_max_nonneg(active ? best : 0.0);
             const double bound = dmax * (1.0 + 1e-12);
             if (!rdone) {
-                bool done = R >= pe;
-                if (!done) { const double gap = cy[R] - yhi; done = gap > 0.0 && gap * gap > bound; }
-                rdone = __builtin_amdgcn_readfirstlane((int)done) != 0;
+                const double gap = edge_r - yhi;
+                rdone = R >= pe || __builtin_amdgcn_readfirstlane((int)(gap > 0.0 && gap * gap > bound)) != 0;
             }
             if (!ldone) {
-                bool done = L <= pb;
-                if (!done) { const double gap = ylo - cy[L - 1]; done = gap > 0.0 && gap * gap > bound; }
-                ldone = __builtin_amdgcn_readfirstlane((int)done) != 0;
+                const double gap = ylo - edge_l;
+                ldone = L <= pb || __builtin_amdgcn_readfirstlane((int)(gap > 0.0 && gap * gap > bound)) != 0;
             }
         }
     }
