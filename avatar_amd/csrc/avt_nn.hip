@@ -487,10 +487,16 @@ __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb
             R = L = __builtin_amdgcn_readfirstlane(st);
             rdone = R >= pe; ldone = L <= pb;
         }
+#ifdef AVT_NN_COUNT
+        int cnt_eval = 0, cnt_rounds = 0;
+#endif
         while (!(rdone && ldone)) {                                          // wave-uniform
             // the candidates just outside this round's chunks decide whether there is a next round: requested with the chunks
             const int e = min(R + NN_SLAB_CHUNK, pe), b = max(L - NN_SLAB_CHUNK, pb);
             const double edge_r = cy[min(e, pe - 1)], edge_l = cy[max(b - 1, pb)];
+#ifdef AVT_NN_COUNT
+            ++cnt_rounds; cnt_eval += (rdone ? 0 : e - R) + (ldone ? 0 : L - b);
+#endif
             if (!rdone) { scan_groups(R, e, true); R = e; }
             if (!ldone) { scan_groups(b, L, true); L = b; }
             const double dmax = nn_wave_max_nonneg(active ? best : 0.0);
@@ -504,6 +510,12 @@ __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb
                 ldone = L <= pb || __builtin_amdgcn_readfirstlane((int)(gap > 0.0 && gap * gap > bound)) != 0;
             }
         }
+#ifdef AVT_NN_COUNT   // tools/nn_count_probe.py (make libavatar_hip_nn_count.so): waves, candidates evaluated / available, rounds, slab width
+        if (lane == 0 && __ballot(active) != 0ull) {
+            double* tr = fb.trace + (size_t)f * 64;
+            atomicAdd(tr + 58, 1.0); atomicAdd(tr + 60, (double)cnt_eval); atomicAdd(tr + 61, (double)n); atomicAdd(tr + 62, (double)cnt_rounds); atomicAdd(tr + 63, yhi - ylo);
+        }
+#endif
     }
     int bi = 0x7fffffff;
     const double* pcx = fb.vcx + (size_t)f * V;
@@ -522,6 +534,9 @@ __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb
             if (gpos + u < pe && r[u] == best) { bi = gpos + u; ++hits; }
         if (sorted && hits > 1) tie = true;
     }
+#ifdef AVT_NN_COUNT
+    if (sorted && __ballot(tie) != 0ull && lane == 0) atomicAdd(fb.trace + (size_t)f * 64 + 59, 1.0);
+#endif
     if (sorted && __ballot(tie) != 0ull) {      // exact ties: the candidate with the smallest vertex id among those at the minimum distance
         const int* ids = fb.vcid + (size_t)f * V;
         double tb = 1.7976931348623157e308;

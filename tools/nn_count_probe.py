@@ -1,3 +1,5 @@
+"""What the slab scan of k_nn_part does on the synthetic frames (counting build: make -C avatar_amd/csrc libavatar_hip_nn_count.so;
+AVT_LIB=avatar_amd/csrc/libavatar_hip_nn_count.so AVT_ONE_GROUP=1 python tools/nn_count_probe.py)."""
 import sys
 import numpy as np
 sys.path.insert(0, '/root/repo')
@@ -18,4 +20,6 @@ for f in range(F):
     out = np.zeros(64)
     lib.avt_debug_trace(ctx.h, C.c_int(f), out.ctypes.data_as(C.POINTER(C.c_double)))
     tot += out[58:64]
-print("waves", tot[0], "waves in the tie path", tot[1]); tot = tot[2:]; print("evaluated fraction", tot[0] / tot[1], "rounds per wave", tot[2] / (tot[1] / (tot[1]/tot[2]) ) if False else "", "mean candidates per wave", tot[1], tot[0], "rounds", tot[2], "sum slab width", tot[3])
+waves, tie_waves, ev, avail, rounds, width = tot
+print(f"{int(waves)} waves of k_nn_part's slab scan over {F} frames: {ev / avail:.3f} of the candidates evaluated, {rounds / waves:.2f} rounds and "
+      f"{avail / waves:.0f} candidates available per wave, mean slab width {100 * width / waves:.2f} cm, {int(tie_waves)} waves in the tie path")
