@@ -24,6 +24,7 @@
 #define NN_TILE 1024
 #define NN_SORTED_FLAG 0x40000000      // in FrameBuffers::vcount: the part's compacted candidates are sorted by (y, vertex id)
 #define NN_SORT_CAP 1024               // largest part k_compact sorts (bitonic sort in LDS)
+#define NN_ACC_CAP 512                // candidates of a part whose match counts / sums k_nn_part accumulates in LDS (14 KB)
 #ifndef NN_SLAB_CHUNK
 #define NN_SLAB_CHUNK 32                // candidates per side and round of the slab scan (a multiple of the group size)
 #endif
@@ -549,7 +550,42 @@ __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb
         if (tie) bi = tpos;
     }
     const int mv = (active && bi != 0x7fffffff) ? fb.vcid[(size_t)f * V + bi] : -1;
-    nn_record<1>(fb, ctl, f, V, base, s, active, 0, mv, a0, a1, a2);
+    if (pe - pb > NN_ACC_CAP) {        // a part with more candidates than the accumulators below hold: per-match atomics, merged in-wave
+        nn_record<1>(fb, ctl, f, V, base, s, active, 0, mv, a0, a1, a2);
+        return;
+    }
+    // ---- bookkeeping.  The workgroup's 256 queries belong to ONE part, so their matches are among that part's candidates: counts
+    // and fixed-point sums are accumulated per candidate POSITION in LDS (integer atomics: order-independent) and every matched
+    // candidate is flushed to the per-vertex arrays once per workgroup - a vertex's matches are neighbouring pixels, mostly of one
+    // workgroup, so the global atomics fall from one per run of equal matches in a wave (~12 k x 4 per frame) to ~1.3 per matched
+    // vertex (~2 k x 4), and with them the count / sum lines written back more than once.
+    __shared__ int s_acnt[NN_ACC_CAP];
+    __shared__ unsigned long long s_asum[3][NN_ACC_CAP];
+    const int nacc = pe - pb;
+    for (int i = t; i < nacc; i += 256) { s_acnt[i] = 0; s_asum[0][i] = 0ull; s_asum[1][i] = 0ull; s_asum[2][i] = 0ull; }
+    __syncthreads();
+    if (active) {
+        fb.corr_sorted[base + s] = mv;
+        fb.corr[base + fb.dorig[base + s]] = mv;
+        if (mv >= 0) {
+            const int i = bi - pb;
+            atomicAdd(&s_acnt[i], 1);
+            atomicAdd(&s_asum[0][i], (unsigned long long)rint_to_ll((a0 - ctl.centre[0]) * AVT_FIX_SCALE));
+            atomicAdd(&s_asum[1][i], (unsigned long long)rint_to_ll((a1 - ctl.centre[1]) * AVT_FIX_SCALE));
+            atomicAdd(&s_asum[2][i], (unsigned long long)rint_to_ll((a2 - ctl.centre[2]) * AVT_FIX_SCALE));
+        }
+    }
+    __syncthreads();
+    unsigned long long* fs = (unsigned long long*)(fb.fsum + (size_t)f * 3 * V);
+    for (int i = t; i < nacc; i += 256) {
+        const int c = s_acnt[i];
+        if (c == 0) continue;
+        const int v = fb.vcid[(size_t)f * V + pb + i];
+        atomicAdd(fb.cnt + (size_t)f * V + v, c);
+        atomicAdd(fs + v, s_asum[0][i]);
+        atomicAdd(fs + (size_t)V + v, s_asum[1][i]);
+        atomicAdd(fs + 2 * (size_t)V + v, s_asum[2][i]);
+    }
 }
 
 // Visible model points of every part, compacted in ascending vertex order inside the part's segment of the
