@@ -13,7 +13,7 @@ O=$R/gpurun_out
 mkdir -p $O
 COMMON="--no-cpu-baseline --no-throughput-config --no-label-stage --no-render-stage --no-shard --no-dense-config --no-seed-spread --saturation-frames 0 --regions 3"
 # configurations: "<frames>[d]" (d = dense 150k-point frames)
-for CFG in ${FRAMES:-1 64 1d 64d}; do
+for CFG in ${FRAMES:-1 64 512 1d 16d 64d}; do
   F=${CFG%d}; DENSE=""; TAG=""; [ "$CFG" != "$F" ] && DENSE="--dense" && TAG="_dense"
   nfg=$(python -c "print($F if $F < 32 else ($F + 1) // 2)")     # frames per launch: two frame groups from 32 frames on
   steps=$([ $F = 1 ] && echo 25 || echo 5)
