@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_MFMA_PEAK_TFLOPS = 78.6   # public MI355X spec, fp64 matrix (not listed in the guide's MFMA table)
 FP64_VALU_PEAK_TFLOPS = 78.6   # public MI355X spec, fp64 vector
-ROUND = "r03"
+ROUND = "r04"
 REGIONS = 15                   # the K-step timed region is repeated this many times; value = median region
 
 # what actually limits each kernel class (counters under profiles/): the HBM roofline is the yard-stick
@@ -234,6 +234,7 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
     res["matched_model_points"] = int(M)
     res["final_cost_frame0"] = st[0].final_cost
     res["accepted_steps_frame0"] = st[0].accepted_steps
+    res["accepted_fraction"] = float(sum(s.accepted_steps for s in st)) / max(1, sum(s.gn_iterations for s in st))
     res["frames0"] = {"data": d0, "labels": l0}
     res["opt"] = opt
     res["start0"] = (p0[0], q0[0], w0[0])
@@ -552,6 +553,96 @@ def cpu_baselines(synth, smpl, r, opt, budget, F_batch):
     return out
 
 
+COMPACT_LIMIT = 4096           # the driver parses the LAST stdout line; it must stay small
+
+
+def _r(x, n=4):
+    return None if x is None else round(float(x), n)
+
+
+def _roof(ro):
+    """The contract's roofline object, short form (notes live in bench_detail.json)."""
+    if not ro:
+        return None
+    out = {"kernel": ro.get("kernel"), "bound": ro.get("bound"), "achieved": _r(ro.get("achieved"), 3), "peak": ro.get("peak"),
+           "unit": ro.get("unit"), "frac": _r(ro.get("frac"), 6), "traffic": ro.get("traffic"), "avg_launch_us": _r(ro.get("avg_launch_us"), 3),
+           "algorithmic_bytes_per_launch": ro.get("algorithmic_bytes_per_launch")}
+    if "launch_shape" in ro:
+        out["frames_per_launch"] = ro["launch_shape"].get("frames_per_launch")
+    if ro.get("limiter"):
+        out["limiter"] = str(ro["limiter"])[:80]
+    return out
+
+
+def _triple(c):
+    """value / roofline.frac / roofline_nn.frac of a secondary configuration."""
+    if not c:
+        return None
+    return {"value": _r(c.get("value"), 1), "ms_per_step": _r(c.get("ms_per_step"), 4), "roofline_kernel": (c.get("roofline") or {}).get("kernel"),
+            "roofline_frac": _r((c.get("roofline") or {}).get("frac"), 5), "roofline_nn_frac": _r((c.get("roofline_nn") or {}).get("frac"), 5)}
+
+
+def compact_line(out):
+    """The ONE line the driver parses: the contract keys, `roofline`, `cpu_baseline`, and one scalar triple per secondary
+    configuration.  Everything else (`out` in full) goes to bench_detail.json and stderr.  Always shorter than COMPACT_LIMIT."""
+    keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: out.get(k) for k in keys}
+    cfg = out.get("config", {})
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:160], "frames_per_gpu": cfg.get("frames_per_gpu"),
+                      "points_per_frame": cfg.get("points_per_frame"), "parallelism": str(cfg.get("parallelism", ""))[:120]}
+    line["roofline"] = _roof(out.get("roofline"))
+    if out.get("roofline_nn"):
+        line["roofline_nn"] = _roof(out["roofline_nn"])
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "host_cores": cb.get("host_cores"),
+                                "kind": cb.get("kind"), "port_1_thread": cb.get("port_1_thread"),
+                                "reference_structure_all_cores": cb.get("reference_structure_all_cores_spawn_join"),
+                                "batch_all_cores": (cb.get("batch_all_cores") or {}).get("value"), "sample": str(cb.get("sample", ""))[:200]}
+        line["speedup_vs_cpu"] = out.get("speedup_vs_cpu_port")
+    for k in ("accepted_gn_iterations_per_s", "accepted_fraction", "frames_per_s", "final_cost_frame0"):
+        if k in out:
+            line[k] = out[k]
+    sec = {}
+    for name, key in (("64_frames", "throughput_config"), ("512_frames", "saturation_config"), ("dense_1", "dense_config")):
+        if out.get(key):
+            sec[name] = _triple(out[key])
+    if out.get("dense_batch_config"):
+        sec["dense_64"] = _triple(out["dense_batch_config"].get("64_frames"))
+    if sec:
+        line["configs"] = sec
+    bs = out.get("batch_split") or {}
+    line["batch_split"] = {"enabled": bs.get("enabled"), "world": bs.get("world"), "backend": str(bs.get("backend", ""))[:24],
+                           "ok": bool((bs.get("run") or {}).get("gathered_equals_local", False))}
+    if out.get("tuning"):
+        line["tuning_non_default"] = out["tuning"].get("non_default", [])
+    line["detail"] = "bench_detail.json"
+    s = json.dumps(line, separators=(",", ":"))
+    if len(s) >= COMPACT_LIMIT:         # never let the contract line outgrow the driver's parser: drop the optional parts
+        for k in ("configs", "roofline_nn", "batch_split", "tuning_non_default"):
+            line.pop(k, None)
+            s = json.dumps(line, separators=(",", ":"))
+            if len(s) < COMPACT_LIMIT:
+                break
+    return s
+
+
+def spawn_plan(gpus, env, visible_devices, share_gpu0=False):
+    """`bench.py --gpus N` starts its N ranks itself when nobody else did.  Returns None when this process
+    is already a rank (WORLD_SIZE set) or N == 1; raises when fewer than N devices are visible; otherwise the argv prefix of
+    the launcher (one rank per GPU over RCCL, rendezvous on 127.0.0.1)."""
+    if gpus <= 1 or env.get("WORLD_SIZE"):
+        return None
+    if visible_devices < gpus and not share_gpu0:
+        raise SystemExit(f"bench.py --gpus {gpus}: only {visible_devices} GPU(s) visible; refusing to report a {gpus}-GPU number from fewer devices")
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port)]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -571,7 +662,20 @@ def main():
     ap.add_argument("--no-seed-spread", action="store_true", help="skip the single-frame spread over 12 seeds")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
+    ap.add_argument("--scale-only", action="store_true", help="headline + 64 frames/GPU only (the default for --gpus N > 1: what a scaling record needs)")
+    ap.add_argument("--detail-file", default=os.path.join(ROOT, "bench_detail.json"), help="where the full result object goes (the stdout line is the compact one)")
     args = ap.parse_args()
+
+    share0 = bool(os.environ.get("AVT_BENCH_SHARE_GPU0"))
+    if args.gpus > 1 and not os.environ.get("WORLD_SIZE"):
+        # nobody launched the ranks: do it here, one rank per GPU (the driver's own N>1 launch sets WORLD_SIZE and skips this)
+        import subprocess
+        import torch as _t
+        plan = spawn_plan(args.gpus, os.environ, _t.cuda.device_count(), share0)
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.stdout.flush()
+        raise SystemExit(subprocess.call(plan + [os.path.abspath(__file__)] + sys.argv[1:], env=env))
 
     # ONE JSON line on stdout: libraries that write to fd 1 (RCCL prints a version banner at communicator creation) are
     # sent to stderr for the whole run; the line goes to the saved descriptor at the end
@@ -582,10 +686,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly one rank per GPU")
+    if world > 1:
+        args.scale_only = True
+        args.no_cpu_baseline = True     # the CPU baseline is a rank-0, N = 1 leg (it would time a host busy with N ranks)
     import torch
     import torch.distributed as dist
-    if os.environ.get("AVT_BENCH_SHARE_GPU0"):      # dry run of the N>1 code path on a single-GPU box
+    if share0:      # dry run of the N>1 code path on a single-GPU box
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but only {torch.cuda.device_count()} device(s) are visible")
     torch.cuda.set_device(local_rank)
     if world > 1:
         if args.backend == "nccl":
@@ -634,16 +745,17 @@ def main():
     r2 = r3 = None
     if F == 1 and not args.dense and not args.no_throughput_config:
         r2 = measure(api, synth, Options, torch, dist, smpl, gm, args, 64, max(10, args.steps // 2), 3, rank, world, local_rank, False, shard, args.regions)
-        if args.saturation_frames > 0:
+        if args.saturation_frames > 0 and not args.scale_only:
             r3 = measure(api, synth, Options, torch, dist, smpl, gm, args, args.saturation_frames, 5, 2, rank, world, local_rank, False, shard,
                          max(3, args.regions // 3))
     rd = rd16 = rd64 = None
-    if F == 1 and not args.dense and not args.no_dense_config:      # configs[4]: the dense stress frame, alone and in batches
+    if F == 1 and not args.dense and not args.no_dense_config and not args.scale_only:      # configs[4]: the dense stress frame, alone and in batches
         rd = measure(api, synth, Options, torch, dist, smpl, gm, args, 1, max(10, args.steps // 2), 3, rank, world, local_rank, True, shard, max(3, args.regions // 3))
         rd16 = measure(api, synth, Options, torch, dist, smpl, gm, args, 16, 5, 2, rank, world, local_rank, True, shard, 3)
         rd64 = measure(api, synth, Options, torch, dist, smpl, gm, args, 64, 5, 2, rank, world, local_rank, True, shard, 3)
     chk = None
     if shard is not None:
+        assert shard_info.get("world") == args.gpus, "batch_split.world != n_gpus"
         try:
             os.environ.setdefault("AVT_SHARD_SELF_SENDRECV", "1")     # the root's own block also travels through ncclSend/ncclRecv
             chk = shard_check(api, synth, Options, shard, dist, smpl, gm, rank, world, local_rank)
@@ -664,7 +776,7 @@ def main():
             return {"workload": label, "value": round(rr["value"], 2), "unit": "GN iterations/s", "steps": rr["steps"], "regions": rr["regions"],
                     "ms_per_step": round(rr["elapsed"] / rr["steps"] * 1e3, 4),
                     "ms_per_step_min_max": [round(rr["elapsed_min"] / rr["steps"] * 1e3, 4), round(rr["elapsed_max"] / rr["steps"] * 1e3, 4)],
-                    "frames_per_gpu": rr["F"], "points_per_frame": rr["points_per_frame"], "roofline": rr["roofline"],
+                    "frames_per_gpu": rr["F"], "points_per_frame": rr["points_per_frame"], "accepted_fraction": round(rr["accepted_fraction"], 4), "roofline": rr["roofline"],
                     **({"roofline_nn": rr["roofline_nn"]} if "roofline_nn" in rr else {}), "eval_kernel": rr["eval_kernel"], "kernels": rr["kernels"],
                     **({"shard": rr["shard"]} if "shard" in rr else {})}
 
@@ -692,10 +804,14 @@ def main():
             out["dense_config"] = cfg(rd, "BASELINE configs[4]: ONE dense frame (2560x1440 render, ~150k points), same optimize()")
             out["dense_batch_config"] = {"16_frames": cfg(rd16, "16 dense frames per GPU (one frame group)"),
                                          "64_frames": cfg(rd64, "64 dense frames per GPU (two frame groups of 32): the dense workload as an HBM stress")}
-        if F == 1 and not args.dense and not args.no_seed_spread:
+        if F == 1 and not args.dense and not args.no_seed_spread and not args.scale_only:
             out["single_frame_spread"] = seed_spread(api, synth, Options, smpl, gm, args, local_rank)
         out["frames_per_s"] = round(F * world * args.steps / r["elapsed"], 2)
+        out["accepted_fraction"] = round(r["accepted_fraction"], 4)
+        out["accepted_gn_iterations_per_s"] = round(r["value"] * r["accepted_fraction"], 2)
         out["icp_iterations_per_s"] = round(F * world * opt.icp_iters * args.steps / r["elapsed"], 2)
+        if args.scale_only:
+            args.no_render_stage = args.no_label_stage = True
         if F == 1 and not args.dense and not args.no_render_stage:
             out["render_stage"] = render_stage(api, synth, smpl, gm, not args.no_cpu_baseline, local_rank)
         if F == 1 and not args.dense and not args.no_label_stage:
@@ -714,7 +830,14 @@ def main():
                     out[key]["speedup_vs_cpu_batch_all_cores"] = round(rr["value"] / cb["batch_all_cores"]["value"], 1)
                     out[key]["speedup_vs_cpu_fastest_single_frame"] = round(rr["value"] / cb["value"], 1)
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        try:
+            with open(args.detail_file, "w") as fh:
+                json.dump(out, fh, indent=1)
+        except OSError as e:
+            print(f"bench.py: could not write {args.detail_file}: {e}", file=sys.stderr)
+        print("bench detail: " + json.dumps(out), file=sys.stderr)
+        sys.stderr.flush()
+        os.write(json_fd, (compact_line(out) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -1,0 +1,55 @@
+"""bench.py's contract line: the line the driver parses stays small and carries `roofline` and
+`cpu_baseline`; `--gpus N` decides by itself whether it must start the N ranks."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def canned():
+    # a full result object of the round-3 run (25 KB as one line: what the driver could no longer parse)
+    return json.load(open(os.path.join(ROOT, "profiles", "r03_bench_default.json")))
+
+
+def test_compact_line_is_small_and_complete():
+    out = canned()
+    assert len(json.dumps(out)) > 20000
+    line = bench.compact_line(out)
+    assert "\n" not in line and len(line) < bench.COMPACT_LIMIT
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert d[k] == out[k], k
+    assert d["config"]["workload"] and "model" not in d["config"]
+    ro = d["roofline"]
+    assert ro["frac"] == pytest.approx(ro["achieved"] / ro["peak"], rel=1e-3)
+    assert ro["bound"] in ("hbm", "mfma") and ro["unit"] in ("GB/s", "TFLOP/s") and "traffic" in ro
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("port", "reference") and cb["sample"]
+    assert set(d["configs"]) == {"64_frames", "512_frames", "dense_1", "dense_64"}
+    for c in d["configs"].values():
+        assert c["value"] > 0 and c["roofline_frac"] > 0
+
+
+def test_compact_line_survives_oversized_fields():
+    out = canned()
+    out["config"]["workload"] = "x" * 5000
+    out["cpu_baseline"]["sample"] = "y" * 5000
+    out["roofline"]["limiter"] = "z" * 5000
+    line = bench.compact_line(out)
+    assert len(line) < bench.COMPACT_LIMIT
+    assert json.loads(line)["roofline"]["frac"] > 0
+
+
+def test_spawn_decision():
+    assert bench.spawn_plan(1, {}, 8) is None                          # one GPU: run in place
+    assert bench.spawn_plan(4, {"WORLD_SIZE": "4"}, 8) is None         # already a rank of somebody's launch
+    plan = bench.spawn_plan(4, {}, 8)
+    assert plan[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in plan and "127.0.0.1" in plan
+    with pytest.raises(SystemExit):
+        bench.spawn_plan(8, {}, 1)                                     # fewer devices than ranks: refuse, loudly
+    assert bench.spawn_plan(2, {}, 1, share_gpu0=True) is not None     # the explicit single-GPU dry run
