@@ -388,6 +388,15 @@ class Context:
         _check(self._lib.avt_get_normal_equations(self.h, C.c_int(frame), dptr(H), dptr(g), C.byref(cost)))
         return H, g, cost.value
 
+    DATA_TERM_ROWS, DATA_TERM_MOMENTS = 0, 1
+
+    def set_data_term(self, form):
+        """How the ICP data term of a GN iteration is evaluated (include/avt.h: AVT_DATA_TERM_ROWS / AVT_DATA_TERM_MOMENTS)."""
+        _check(self._lib.avt_set_data_term(self.h, C.c_int(int(form))))
+
+    def data_term(self):
+        return int(self._lib.avt_get_data_term(self.h))
+
     def launch_shape(self):
         """(groups, frames per group, k_eval workgroups per frame) of optimize() over the resident frames."""
         g, n, G = C.c_int(), C.c_int(), C.c_int()

@@ -153,6 +153,24 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
     for (int icp = 0; icp < o->icp_iters; ++icp) {
         { ProfScope ps(c, AVT_K_VISIBILITY); launch_visibility(c, nf, o->enable_occlusion, fuse_bucket && icp == 0); }
         { ProfScope ps(c, AVT_K_NN); launch_nn(c, nf); }
+        if (c->fb.use_moments) {
+            // Moment form (avt_moments.hip): the correspondences' sufficient statistics once per ICP iteration, then every GN iteration
+            // assembles its normal equations from them - no Jacobian rows, no partial tiles, no reduction.
+            { ProfScope ps(c, AVT_K_AGGREGATE); launch_finalize(c, nf); launch_moments(c, nf); }
+            if (!fuse_init) { ProfScope ps(c, AVT_K_PREPARE); launch_solve(c, nf, SOLVE_INIT); }
+            { ProfScope ps(c, AVT_K_EVAL); launch_assemble(c, nf); }
+            for (int it = 1; it <= std::max(1, o->max_iters_per_icp); ++it) {
+                { ProfScope ps(c, AVT_K_SOLVE); launch_solve(c, nf, it == 1 ? SOLVE_FIRST : SOLVE_NORMAL, it); }
+                if (o->max_iters_per_icp == 0) break;
+                { ProfScope ps(c, AVT_K_EVAL); launch_assemble(c, nf); }
+            }
+            // the accept test of the last trial point: one more pass of the solve kernel (the step it also makes is never used)
+            if (o->max_iters_per_icp > 0) { ProfScope ps(c, AVT_K_DECIDE); launch_solve(c, nf, SOLVE_NORMAL, o->max_iters_per_icp + 1); }
+            { ProfScope ps(c, AVT_K_LBS); const bool more = icp + 1 < o->icp_iters;
+              launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 2, more ? vis_init : -1, false, fuse_init && more, false, few && more); }
+            c->ran_icp_iters++;
+            continue;
+        }
         { ProfScope ps(c, AVT_K_AGGREGATE); launch_finalize(c, nf); launch_records(c, nf); }
         if (!fuse_init) { ProfScope ps(c, AVT_K_PREPARE); launch_solve(c, nf, SOLVE_INIT); }
         const bool rides = avt_solve_rides(c, nf);        // few frames: the reduction is part of the solve's launch
@@ -202,6 +220,7 @@ int run_optimize(avt_ctx* c, const avt_options* o) {
     if (o->max_iters_per_icp < 0 || o->max_iters_per_icp > 62 || o->icp_iters < 0) { avt_set_error("avt_optimize: bad iteration counts"); return 1; }
     if (sync_params(c, o)) return 1;
     c->ran_max_iters = o->max_iters_per_icp;
+    c->ran_moments_only = false;
     // Large batches run as several frame groups: the latency-bound single-workgroup-per-frame kernels of one group
     // (k_solve, k_finalize, k_reduce) overlap the throughput kernels (k_eval, k_nn) of the others on separate streams.
     // The instrumented (profiling) path keeps the SAME groups and launch shapes and runs them one after the other on
@@ -225,7 +244,7 @@ int run_optimize(avt_ctx* c, const avt_options* o) {
     // only enqueue, so the lock is held for microseconds.
     std::lock_guard<std::mutex> graph_lock(g_graph_mutex);
     char key[160];
-    snprintf(key, sizeof key, "%d|%d|%d|%d|%d|%d|%d", nf, ngroups, c->fb.G, c->launch_maxN, o->icp_iters, o->max_iters_per_icp, o->enable_occlusion);
+    snprintf(key, sizeof key, "%d|%d|%d|%d|%d|%d|%d|%d", nf, ngroups, c->fb.G, c->launch_maxN, o->icp_iters, o->max_iters_per_icp, o->enable_occlusion, c->fb.use_moments);
     avt_ctx::GraphEntry* hit = nullptr;
     for (auto& e : c->graphs) if (e.key == key) { hit = &e; break; }
     if (!hit) {
@@ -419,6 +438,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
     c->graph_clock = 0;
     c->params_valid = false;
     c->frames_valid = c->state_valid = false;
+    c->ran_moments_only = false;
     c->concurrent_groups = 1;
     c->render_zkey = nullptr; c->render_label = nullptr; c->render_block = nullptr; c->render_cap_pix = c->render_cap_blk = 0;
     c->render_mkey = nullptr; c->render_depth = nullptr; c->render_fkey = nullptr; c->render_frank = nullptr; c->render_fedge = nullptr;
@@ -431,7 +451,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         HIP_OK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
     }
     c->cur_stream = c->stream;
-    if (avt_solve_set_attributes() || avt_eval_set_attributes() || avt_lbs_set_attributes()) { avt_set_error("avt_ctx_create: hipFuncSetAttribute failed"); return 1; }
+    if (avt_solve_set_attributes() || avt_eval_set_attributes() || avt_lbs_set_attributes() || avt_moments_set_attributes()) { avt_set_error("avt_ctx_create: hipFuncSetAttribute failed"); return 1; }
     DeviceModel& dm = c->dm;
     dm.d = m->d;
     {   // visibility as one workgroup per frame when the frame's x, y fit the LDS (AVT_VIS_FRAME_MIN: experiments)
@@ -461,7 +481,11 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         dev_upload(c, &dm.jsr_base, m->jsr_base) || dev_upload(c, &dm.jsr, m->jsr) || dev_upload(c, &dm.S, m->S) ||
         dev_upload(c, &dm.Sp, m->Sp) || dev_upload(c, &dm.prior_mean, m->prior_mean) || dev_upload(c, &dm.prior_prec, m->prior_prec) ||
         dev_upload(c, &dm.prior_clog, m->prior_clog) || dev_upload(c, &dm.part_of_vertex, pov) ||
-        dev_upload(c, &dm.part_start, pstart) || dev_upload(c, &dm.part_vertices, pverts) || dev_upload(c, &dm.part_pos, ppos))
+        dev_upload(c, &dm.part_start, pstart) || dev_upload(c, &dm.part_vertices, pverts) || dev_upload(c, &dm.part_pos, ppos) ||
+        dev_upload(c, &dm.mom_pair, m->mom_pair) || dev_upload(c, &dm.mom_lstart, m->mom_lstart) || dev_upload(c, &dm.mom_lv, m->mom_lv) || dev_upload(c, &dm.mom_lw, m->mom_lw) ||
+        dev_upload(c, &dm.mom_psi, m->mom_psi) || dev_upload(c, &dm.mom_opk_start, m->mom_opk_start) || dev_upload(c, &dm.mom_opk, m->mom_opk) ||
+        dev_upload(c, &dm.mom_sub_start, m->mom_sub_start) || dev_upload(c, &dm.mom_sub, m->mom_sub) || dev_upload(c, &dm.mom_m1_start, m->mom_m1_start) ||
+        dev_upload(c, &dm.mom_m1, m->mom_m1) || dev_upload(c, &dm.mom_s2_start, m->mom_s2_start) || dev_upload(c, &dm.mom_s2, m->mom_s2) || dev_upload(c, &dm.mom_s2_jj, m->mom_s2_jj))
         return 1;
     FrameBuffers& fb = c->fb;
     std::memset(&fb, 0, sizeof(fb));
@@ -491,6 +515,15 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         dev_alloc(c, &fb.jointpos, (size_t)max_frames * 3 * J) || dev_alloc(c, &fb.jointtrans, (size_t)max_frames * 12 * J) ||
         dev_alloc(c, &fb.trace, (size_t)max_frames * 64))
         return 1;
+    fb.use_moments = 0;
+    if (d.mom_ok) {      // moment form of the data term (avt_moments.hip): T per (frame, joint pair), D per (frame, joint), scratch of the assembly
+        if (dev_alloc(c, &fb.mom_T, (size_t)max_frames * d.mom_np * d.mom_npsi * d.mom_npsi) || dev_alloc(c, &fb.mom_D, (size_t)max_frames * J * d.mom_npsi * 3) ||
+            dev_alloc(c, &fb.mom_E, (size_t)max_frames * 2) || dev_alloc(c, &fb.mom_rec, (size_t)max_frames * 2 * d.mom_np * std::max(1, d.K) * 6))
+            return 1;
+        HIP_OK(hipMemsetAsync(fb.mom_D, 0, (size_t)max_frames * J * d.mom_npsi * 3 * sizeof(double), c->stream));      // joints no vertex is assigned to keep zeros
+        fb.use_moments = 1;
+        if (const char* e = getenv("AVT_DATA_TERM")) fb.use_moments = strcmp(e, "rows") != 0;
+    }
     {
         AvtRunParams* pr = nullptr;
         if (dev_alloc(c, &pr, 1)) return 1;
@@ -846,8 +879,13 @@ int avt_get_normal_equations(avt_ctx* c, int frame, double* H, double* g, double
     c->fb.f0 = 0;
     c->cur_stream = c->stream;
     launch_solve(c, c->nframes, SOLVE_INIT);
-    launch_eval(c, c->nframes, false);
-    launch_reduce(c, c->nframes);
+    if (c->fb.use_moments) {      // (the moments of the last ICP iteration's correspondences are still resident)
+        launch_assemble(c, c->nframes);
+    } else {
+        if (c->ran_moments_only) { launch_records(c, c->nframes); c->ran_moments_only = false; }      // the last optimize() made moments, not records
+        launch_eval(c, c->nframes, false);
+        launch_reduce(c, c->nframes);
+    }
     c->fb.G = G_keep;
     if (check_launch("avt_get_normal_equations")) return 1;
     HIP_OK(hipStreamSynchronize(c->stream));
@@ -865,6 +903,26 @@ int avt_get_normal_equations(avt_ctx* c, int frame, double* H, double* g, double
     return 0;
     AVT_API_GUARD_END("avt_get_normal_equations")
 }
+
+int avt_set_data_term(avt_ctx* c, int form) {
+    if (!c || (form != AVT_DATA_TERM_ROWS && form != AVT_DATA_TERM_MOMENTS)) { avt_set_error("avt_set_data_term: bad argument"); return 1; }
+    if (form == AVT_DATA_TERM_MOMENTS && !c->dm.d.mom_ok) { avt_set_error("avt_set_data_term: this model has no moment form (K + 1 <= 16 and 3 + 3J + K <= 87 required)"); return 1; }
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    if (form == AVT_DATA_TERM_ROWS && c->fb.use_moments && c->ran_icp_iters > 0) c->ran_moments_only = true;
+    if (form == AVT_DATA_TERM_MOMENTS && !c->fb.use_moments && c->ran_icp_iters > 0 && c->frames_valid && c->state_valid) {
+        // the resident correspondences have no moments yet: make them now, so that avt_get_normal_equations can compare the two forms
+        c->fb.f0 = 0; c->cur_stream = c->stream;
+        c->fb.const_used = (c->launch_maxN + 255) / 256;
+        launch_moments(c, c->nframes);
+        if (check_launch("avt_set_data_term")) return 1;
+        HIP_OK(hipStreamSynchronize(c->stream));
+    }
+    c->fb.use_moments = form == AVT_DATA_TERM_MOMENTS;
+    return 0;
+}
+
+int avt_get_data_term(avt_ctx* c) { return c ? c->fb.use_moments : -1; }
 
 int avt_debug_trace(avt_ctx* c, int frame, double* out64) {
     if (!c || !out64 || frame < 0 || frame >= c->fb.max_frames) { avt_set_error("avt_debug_trace: bad argument"); return 1; }

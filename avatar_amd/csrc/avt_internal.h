@@ -48,6 +48,14 @@ struct AvtDims {
     unsigned pair_deal[4];   // wave w: five 5-bit pair indices, pair i at bits 5i..5i+4; bit 25+i: pair i is diagonal (i = 5: the split pair)
     int pair_split;
     unsigned long long tile_zpass[AVT_MAX_TILES];   // per tile: the 5-column zeroing passes of build_rows that overlap its storage columns (bit = pass)
+    // moment form of the data term (avt_moments.hip; build_moment_tables, avt_model.cpp)
+    int mom_ok;              // the model can run it (K + 1 <= 16 lanes of a pair group, 256-thread solve)
+    int mom_np;              // unordered co-assigned joint pairs (k <= k')
+    int mom_npsi;            // 3 (K + 1) + 1: entries of psi_m = [base | keys | 1], index (K+1) i + s
+    int mom_ntp;             // ceil(mom_npsi / 16): 16-row tiles of psi
+    int mom_nm1;             // non-empty (k, j') entries of the rot-rot stage 1
+    int mom_nb2;             // (j <= j') blocks of the rot-rot stage 2
+    int mom_lmax;            // longest per-pair vertex list
 };
 
 // prep block layout (doubles), one per frame per slot: what an evaluation needs about the skeleton state
@@ -188,6 +196,21 @@ struct DeviceModel {
     int* part_start;      // [num_parts+1] into part_vertices
     int* part_vertices;   // [V] vertex ids grouped by part, ascending inside a part
     int* part_pos;        // [V] inverse of part_vertices
+    // moment form (avt_moments.hip)
+    int* mom_pair;        // [2 np] (k, k') of every unordered pair
+    int* mom_lstart;      // [np + 1] per-pair vertex lists: the vertices both joints are assigned to, ascending id ...
+    int* mom_lv;          // ... vertex ids
+    double* mom_lw;       // ... [2] the two skinning weights (a_k, a_k')
+    double* mom_psi;      // [V][16 ntp] psi_m, zero padded
+    int* mom_opk_start;   // [J + 1] ordered pairs (op = 2 p: k -> k', 2 p + 1: k' -> k) whose lever joint is k ...
+    int* mom_opk;         // ... op ids
+    int* mom_sub_start;   // [J + 1] subtree of every joint (itself included) ...
+    int* mom_sub;         // ... joint ids, ascending
+    int* mom_m1_start;    // [nm1 + 1] stage 1 of the rot-rot block: entry (k, j') sums the ordered pairs (k, k'), k' under j' ...
+    int* mom_m1;          // ... op ids
+    int* mom_s2_start;    // [2 nb2 + 1] stage 2: block (j <= j') sums the stage-1 entries (k, j'), k under j (list 2b) and (k, j), k under j' (list 2b + 1) ...
+    int* mom_s2;          // ... stage-1 entry ids
+    int* mom_s2_jj;       // [nb2] j | j' << 8
 };
 
 struct FrameBuffers {
@@ -247,6 +270,12 @@ struct FrameBuffers {
     double* jointtrans;   // [max_frames][12J]
     double* trace;        // [max_frames][64] cost trace (debug)
     const AvtRunParams* params;   // one block per context
+    // moment form of the data term (avt_moments.hip): accumulated once per ICP iteration by k_moments
+    double* mom_T;        // [max_frames][np][npsi][npsi] T_kk' = sum_m c_m a_mk a_mk' psi_m psi_m^T (full square)
+    double* mom_D;        // [max_frames][J][npsi][3] D_k = sum_m a_mk psi_m (sum_i (d_i - centre))^T
+    double* mom_E;        // [max_frames][2] sum_m |fsum_m|^2 / c_m
+    double* mom_rec;      // [max_frames][2 np][K][6] scratch of the assembly: per (ordered pair, shape key) axial(Y), U
+    int use_moments;      // the GN iterations take their normal equations from the moments (k_assemble) instead of k_eval + k_reduce
 };
 
 struct avt_model {
@@ -258,6 +287,9 @@ struct avt_model {
     std::vector<unsigned char> anc_n;
     std::vector<unsigned short> anc, vmask;
     std::vector<double> prior_mean, prior_prec, prior_L, prior_clog;
+    // moment form (build_moment_tables)
+    std::vector<int> mom_pair, mom_lstart, mom_lv, mom_opk_start, mom_opk, mom_sub_start, mom_sub, mom_m1_start, mom_m1, mom_s2_start, mom_s2, mom_s2_jj;
+    std::vector<double> mom_lw, mom_psi;
 };
 
 struct avt_ctx {
@@ -292,6 +324,7 @@ struct avt_ctx {
     AvtRunParams params_host;        // what fb.params currently holds
     bool params_valid;
     bool frames_valid, state_valid;  // resident frames / start state usable by avt_optimize_resident
+    bool ran_moments_only;           // the last optimize() ran the moment form: no matched-point records exist for its correspondences
     int concurrent_groups;           // frame groups the current optimize() call runs side by side (sizes the riding launch shapes)
     // persistent scratch of avt_synth_render_frames (z-buffer keys, labels, block counts), grown on demand
     unsigned long long* render_zkey; unsigned char* render_label; int* render_block; size_t render_cap_pix; size_t render_cap_blk;
@@ -324,3 +357,7 @@ void launch_reduce(avt_ctx* c, int nframes);
 bool avt_solve_rides(const avt_ctx* c, int nframes);      // the reduction rides in k_solve's launch: no launch_reduce in front of launch_solve
 void launch_solve(avt_ctx* c, int nframes, int mode, int seq = 0 /* which solve of the ICP iteration (riding shape) */);
 void launch_pack_results(avt_ctx* c, int nframes, double* out, int stride);
+// avt_moments.hip
+void launch_moments(avt_ctx* c, int nframes);             // once per ICP iteration, behind k_finalize (carries the cost-constant workgroups)
+void launch_assemble(avt_ctx* c, int nframes);            // normal equations of the trial point from the moments (+ the pose-prior workgroups)
+int avt_moments_set_attributes();

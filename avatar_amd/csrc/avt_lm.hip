@@ -1106,7 +1106,7 @@ static int ride_nspec(const avt_ctx* c, int nframes, int strips) {
     return want;
 }
 static int ride_strips(const avt_ctx* c, int nframes) {      // 8 strips per pair while the whole grid is resident (one SMPL frame), else 4, else none
-    if (c->fb.G < 64 || solve_big(c->dm.d) || getenv("AVT_NO_RIDE")) return 0;
+    if (c->fb.G < 64 || solve_big(c->dm.d) || getenv("AVT_NO_RIDE") || c->fb.use_moments) return 0;      // (moment form: k_assemble writes the system, nothing to reduce)
     int want = 8;
     if (const char* e = getenv("AVT_RIDE_STRIPS")) want = atoi(e) >= 8 ? 8 : 4;     // the two instantiated shapes; anything else would launch a grid its kernel was not built for
     for (int s = want; s >= 4; s -= 4) if (ride_concurrency(c) * nframes * (1 + s * c->dm.d.NPAIR) <= c->num_cus) return s;

@@ -193,6 +193,100 @@ static void deal_tile_pairs(avt_model* m) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Static tables of the moment form of the data term (avt_moments.hip; tools/moment_proto2.py is the executable specification).
+// Every row of [J | r] of a model point m is linear in psi_m = [base_m | keys_m | 1] with coefficients that depend on the state
+// alone (AvatarOptimizer.cpp:507-582), so J^T J, J^T r and the cost are contractions of
+//   T_kk' = sum_m c_m a_mk a_mk' psi_m psi_m^T     per unordered pair (k <= k') of joints assigned to a common vertex,
+// accumulated once per ICP iteration.  Here: the pairs, per pair the vertices that carry both joints, psi, and the index lists of the
+// tree sums the assembly runs (lever joints k under rotation joints j).
+// -------------------------------------------------------------------------------------------------
+static void build_moment_tables(avt_model* m) {
+    AvtDims& d = m->d;
+    const int V = d.V, J = d.J, K = d.K, S1 = K + 1;
+    d.mom_npsi = 3 * S1 + 1;
+    d.mom_ntp = (d.mom_npsi + 15) / 16;
+    d.mom_ok = (S1 <= 16 && d.HS / 4 <= 22) ? 1 : 0;
+    // psi
+    const int PW = 16 * d.mom_ntp;
+    m->mom_psi.assign((size_t)V * PW, 0.0);
+    for (int v = 0; v < V; ++v) {
+        double* ps = &m->mom_psi[(size_t)v * PW];
+        for (int i = 0; i < 3; ++i) {
+            ps[S1 * i] = m->shape_planes[((size_t)K * 3 + i) * V + v];                                   // s = 0: the base cloud
+            for (int s = 0; s < K; ++s) ps[S1 * i + 1 + s] = m->shape_planes[((size_t)s * 3 + i) * V + v];
+        }
+        ps[3 * S1] = 1.0;
+    }
+    // pairs and their vertex lists
+    std::vector<int> pid((size_t)J * J, -1);
+    for (int v = 0; v < V; ++v)
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) {
+                if (!(m->asg_w[(size_t)a * V + v] > 0.0) || !(m->asg_w[(size_t)b * V + v] > 0.0)) continue;
+                const int ja = m->asg_j[(size_t)a * V + v], jb = m->asg_j[(size_t)b * V + v];
+                if (ja <= jb) pid[(size_t)ja * J + jb] = 0;
+            }
+    m->mom_pair.clear();
+    for (int a = 0; a < J; ++a)
+        for (int b = a; b < J; ++b)
+            if (pid[(size_t)a * J + b] == 0) { pid[(size_t)a * J + b] = (int)m->mom_pair.size() / 2; m->mom_pair.push_back(a); m->mom_pair.push_back(b); }
+    const int NP = (int)m->mom_pair.size() / 2;
+    d.mom_np = NP;
+    std::vector<std::vector<int>> lv(NP);
+    std::vector<std::vector<double>> lw(NP);
+    for (int v = 0; v < V; ++v)
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) {
+                const double wa = m->asg_w[(size_t)a * V + v], wb = m->asg_w[(size_t)b * V + v];
+                if (!(wa > 0.0) || !(wb > 0.0)) continue;
+                const int ja = m->asg_j[(size_t)a * V + v], jb = m->asg_j[(size_t)b * V + v];
+                if (ja > jb || (ja == jb && a != b)) continue;
+                const int p = pid[(size_t)ja * J + jb];
+                lv[p].push_back(v); lw[p].push_back(wa); lw[p].push_back(wb);
+            }
+    m->mom_lstart.assign(NP + 1, 0); m->mom_lv.clear(); m->mom_lw.clear();
+    d.mom_lmax = 0;
+    for (int p = 0; p < NP; ++p) {
+        m->mom_lv.insert(m->mom_lv.end(), lv[p].begin(), lv[p].end());
+        m->mom_lw.insert(m->mom_lw.end(), lw[p].begin(), lw[p].end());
+        m->mom_lstart[p + 1] = (int)m->mom_lv.size();
+        d.mom_lmax = std::max(d.mom_lmax, (int)lv[p].size());
+    }
+    // tree lists
+    auto under = [&](int k, int j) { for (; k >= 0; k = m->parent[k]) if (k == j) return true; return false; };
+    auto first = [&](int op) { return m->mom_pair[2 * (op >> 1) + (op & 1)]; };
+    auto second = [&](int op) { return m->mom_pair[2 * (op >> 1) + 1 - (op & 1)]; };
+    auto exists = [&](int op) { return !(op & 1) || m->mom_pair[2 * (op >> 1)] != m->mom_pair[2 * (op >> 1) + 1]; };
+    m->mom_opk_start.assign(J + 1, 0); m->mom_opk.clear();
+    m->mom_sub_start.assign(J + 1, 0); m->mom_sub.clear();
+    for (int k = 0; k < J; ++k) {
+        for (int op = 0; op < 2 * NP; ++op) if (exists(op) && first(op) == k) m->mom_opk.push_back(op);
+        m->mom_opk_start[k + 1] = (int)m->mom_opk.size();
+        for (int c = 0; c < J; ++c) if (under(c, k)) m->mom_sub.push_back(c);
+        m->mom_sub_start[k + 1] = (int)m->mom_sub.size();
+    }
+    std::vector<int> m1_of((size_t)J * J, -1);
+    m->mom_m1_start.assign(1, 0); m->mom_m1.clear();
+    for (int k = 0; k < J; ++k)
+        for (int jp = 0; jp < J; ++jp) {
+            const size_t before = m->mom_m1.size();
+            for (int e = m->mom_opk_start[k]; e < m->mom_opk_start[k + 1]; ++e) if (under(second(m->mom_opk[e]), jp)) m->mom_m1.push_back(m->mom_opk[e]);
+            if (m->mom_m1.size() > before) { m1_of[(size_t)k * J + jp] = (int)m->mom_m1_start.size() - 1; m->mom_m1_start.push_back((int)m->mom_m1.size()); }
+        }
+    d.mom_nm1 = (int)m->mom_m1_start.size() - 1;
+    m->mom_s2_start.assign(1, 0); m->mom_s2.clear(); m->mom_s2_jj.clear();
+    for (int j = 0; j < J; ++j)
+        for (int jp = j; jp < J; ++jp) {
+            for (int e = m->mom_sub_start[j]; e < m->mom_sub_start[j + 1]; ++e) { const int id = m1_of[(size_t)m->mom_sub[e] * J + jp]; if (id >= 0) m->mom_s2.push_back(id); }
+            m->mom_s2_start.push_back((int)m->mom_s2.size());
+            for (int e = m->mom_sub_start[jp]; e < m->mom_sub_start[jp + 1]; ++e) { const int id = m1_of[(size_t)m->mom_sub[e] * J + j]; if (id >= 0) m->mom_s2.push_back(id); }
+            m->mom_s2_start.push_back((int)m->mom_s2.size());
+            m->mom_s2_jj.push_back(j | (jp << 8));
+        }
+    d.mom_nb2 = (int)m->mom_s2_jj.size();
+}
+
 static int avt_model_create_impl(const avt_model_desc* desc, avt_model** out) {
     if (!desc || !out) { avt_set_error("avt_model_create: null argument"); return 1; }
     const int V = desc->num_points, J = desc->num_joints, K = desc->num_shape_keys, F = desc->num_faces;
@@ -450,6 +544,7 @@ static int avt_model_create_impl(const avt_model_desc* desc, avt_model** out) {
                 }
         }
     }
+    build_moment_tables(m);
     *out = holder.release();
     return 0;
 }

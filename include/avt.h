@@ -215,6 +215,16 @@ int avt_get_posed(avt_ctx* c, int frame, double* cloud_3xV, double* joint_pos_3x
  * iteration, for all resident frames; the fit, its cost and the LM state are not changed. */
 int avt_get_normal_equations(avt_ctx* c, int frame, double* H /* P x P */, double* g /* P */, double* cost);
 
+/* How the ICP data term of a Gauss-Newton iteration is evaluated (same objective, same normal equations up to rounding):
+ *   AVT_DATA_TERM_ROWS     the residual / Jacobian rows of every matched model point are rebuilt and contracted on the matrix cores
+ *                          every iteration (AvatarCostFunctorCache::updateData + the ICP cost functor, AvatarOptimizer.cpp:505-644);
+ *   AVT_DATA_TERM_MOMENTS  the correspondences' sufficient statistics are accumulated once per ICP iteration and every iteration
+ *                          contracts them with the state (avt_moments.hip).  The default where the model allows it.
+ * Takes effect for the following calls; avt_get_normal_equations evaluates with the form selected here (tests compare the two). */
+enum { AVT_DATA_TERM_ROWS = 0, AVT_DATA_TERM_MOMENTS = 1 };
+int avt_set_data_term(avt_ctx* c, int form);
+int avt_get_data_term(avt_ctx* c);
+
 /* diagnostics: 64 doubles per frame (objective after every GN iteration; with -DAVT_TIMING builds also in-kernel
  * s_memtime probes, see tools/kernel_timing_probe.py) */
 int avt_debug_trace(avt_ctx* c, int frame, double* out64);

@@ -1,0 +1,89 @@
+"""GPU: the moment form of the ICP data term (avatar_amd/csrc/avt_moments.hip, include/avt.h AVT_DATA_TERM_MOMENTS) against the
+row form (k_eval: the residual / Jacobian rows rebuilt every iteration) and against the oracle's literal per-block formulas
+(AvatarOptimizer.cpp:505-582, :609-644), through the C ABI."""
+import numpy as np
+import pytest
+
+from avatar_amd import synth
+from avatar_amd.capi import Options
+
+pytestmark = pytest.mark.gpu
+
+
+def _start(fr):
+    from avatar_amd import api
+    w0, p0, R0 = fr["start"]
+    return p0, api.rot_to_quat(R0), w0
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(1e-300, np.abs(b).max())
+
+
+@pytest.mark.parametrize("seed,dense", [(19, False), (3, False), (0, True)])
+def test_moment_normal_equations_equal_the_row_form_and_the_oracle(smpl, omodel, gmodel, seed, dense):
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    fr = synth.make_frame(smpl, seed, dense=dense)
+    p0, q0, w0 = _start(fr)
+    n = len(fr["labels"])
+    opt = Options.demo(max_iters_per_icp=4)
+    for frames in (1, 5):
+        ctx = api.Context(gmodel, 24, pm, n, frames)
+        ctx.set_data_term(ctx.DATA_TERM_ROWS)
+        p, q, w, st = ctx.optimize_batch([fr["data"]] * frames, [fr["labels"]] * frames, opt, np.repeat(p0[None], frames, 0),
+                                         np.repeat(q0[None], frames, 0), np.repeat(w0[None], frames, 0))
+        f = frames - 1
+        Hr, gr, cr = ctx.normal_equations(f)
+        ctx.set_data_term(ctx.DATA_TERM_MOMENTS)          # makes the moments of the resident correspondences
+        Hm, gm, cm = ctx.normal_equations(f)
+        corr = ctx.correspondences(f, n)
+        oc, og, oH, _ = omodel.evaluate(p[f], q[f], w[f], corr, fr["data"], 0.0, 0.0, aggregate=1)
+        for name, H, g in (("rows", Hr, gr), ("moments", Hm, gm)):
+            assert _rel(H, oH) < 1e-10, (name, _rel(H, oH))
+            assert _rel(g, og) < 1e-9, (name, _rel(g, og))
+            assert np.abs(H - H.T).max() == 0.0, name
+        assert _rel(Hm, Hr) < 1e-11 and _rel(gm, gr) < 1e-9
+        # structural zeros: a left-leg joint and a right-arm joint never share a model point
+        assert np.all(Hm[3 + 3 * 4: 6 + 3 * 4, 3 + 3 * 19: 6 + 3 * 19] == 0.0)
+
+
+def test_fit_with_moments_equals_fit_with_rows_and_oracle(smpl, omodel, gmodel):
+    """Ten GN iterations with either form of the data term: same accept / reject sequence, same fit to 1e-7 (the parity bar is 1e-4)."""
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    for seed in (0, 7):
+        fr = synth.make_frame(smpl, seed)
+        p0, q0, w0 = _start(fr)
+        n = len(fr["labels"])
+        opt = Options.demo(icp_iters=2)
+        res = {}
+        for form in (0, 1):
+            ctx = api.Context(gmodel, 24, pm, n, 1)
+            ctx.set_data_term(form)
+            assert ctx.data_term() == form
+            res[form] = ctx.optimize_batch([fr["data"]], [fr["labels"]], opt, p0[None], q0[None], w0[None])
+        ref = omodel.optimize(pm, 24, fr["data"], fr["labels"], opt, p0, q0, w0, aggregate=1)
+        for form in (0, 1):
+            p, q, w, st = res[form]
+            assert st[0].accepted_steps == ref["stats"].accepted_steps and st[0].gn_iterations == ref["stats"].gn_iterations
+            assert np.abs(p[0] - ref["p"]).max() < 1e-7 and np.abs(q[0] - ref["q"]).max() < 1e-7 and np.abs(w[0] - ref["w"]).max() < 1e-6
+            assert abs(st[0].final_cost - ref["stats"].final_cost) < 1e-8 * ref["stats"].final_cost
+        assert np.abs(res[0][0] - res[1][0]).max() < 1e-9 and np.abs(res[0][1] - res[1][1]).max() < 1e-9
+
+
+def test_moments_batch_matches_single(smpl, gmodel):
+    """A batch of different frames through the moment form equals the same frames one at a time, bit for bit."""
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    frs = [synth.make_frame(smpl, s) for s in (21, 22, 23, 24, 25, 26, 27)]
+    starts = [_start(fr) for fr in frs]
+    opt = Options.demo(max_iters_per_icp=6)
+    ctx = api.Context(gmodel, 24, pm, 60000, len(frs))
+    assert ctx.data_term() == 1
+    P, Q, W, st = ctx.optimize_batch([fr["data"] for fr in frs], [fr["labels"] for fr in frs], opt, np.array([s[0] for s in starts]),
+                                     np.array([s[1] for s in starts]), np.array([s[2] for s in starts]))
+    one = api.Context(gmodel, 24, pm, 60000, 1)
+    for i, fr in enumerate(frs):
+        p, q, w, s1 = one.optimize_batch([fr["data"]], [fr["labels"]], opt, starts[i][0][None], starts[i][1][None], starts[i][2][None])
+        assert np.array_equal(p[0], P[i]) and np.array_equal(q[0], Q[i]) and np.array_equal(w[0], W[i])
