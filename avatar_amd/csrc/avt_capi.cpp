@@ -156,7 +156,7 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
         if (c->fb.use_moments) {
             // Moment form (avt_moments.hip): the correspondences' sufficient statistics once per ICP iteration, then every GN iteration
             // assembles its normal equations from them - no Jacobian rows, no partial tiles, no reduction.
-            { ProfScope ps(c, AVT_K_AGGREGATE); launch_finalize(c, nf); launch_moments(c, nf); }
+            { ProfScope ps(c, AVT_K_AGGREGATE); launch_finalize(c, nf); c->fb.const_used = (c->launch_maxN + 2047) / 2048; launch_moments(c, nf); }
             if (!fuse_init) { ProfScope ps(c, AVT_K_PREPARE); launch_solve(c, nf, SOLVE_INIT); }
             { ProfScope ps(c, AVT_K_EVAL); launch_assemble(c, nf); }
             for (int it = 1; it <= std::max(1, o->max_iters_per_icp); ++it) {
@@ -485,7 +485,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         dev_upload(c, &dm.mom_pair, m->mom_pair) || dev_upload(c, &dm.mom_lstart, m->mom_lstart) || dev_upload(c, &dm.mom_lv, m->mom_lv) || dev_upload(c, &dm.mom_lw, m->mom_lw) ||
         dev_upload(c, &dm.mom_psi, m->mom_psi) || dev_upload(c, &dm.mom_opk_start, m->mom_opk_start) || dev_upload(c, &dm.mom_opk, m->mom_opk) ||
         dev_upload(c, &dm.mom_sub_start, m->mom_sub_start) || dev_upload(c, &dm.mom_sub, m->mom_sub) || dev_upload(c, &dm.mom_m1_start, m->mom_m1_start) ||
-        dev_upload(c, &dm.mom_m1, m->mom_m1) || dev_upload(c, &dm.mom_s2_start, m->mom_s2_start) || dev_upload(c, &dm.mom_s2, m->mom_s2) || dev_upload(c, &dm.mom_s2_jj, m->mom_s2_jj))
+        dev_upload(c, &dm.mom_m1, m->mom_m1) || dev_upload(c, &dm.mom_s2_start, m->mom_s2_start) || dev_upload(c, &dm.mom_s2, m->mom_s2) || dev_upload(c, &dm.mom_s2_jj, m->mom_s2_jj) || dev_upload(c, &dm.mom_z2_jj, m->mom_z2_jj))
         return 1;
     FrameBuffers& fb = c->fb;
     std::memset(&fb, 0, sizeof(fb));
@@ -517,8 +517,8 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         return 1;
     fb.use_moments = 0;
     if (d.mom_ok) {      // moment form of the data term (avt_moments.hip): T per (frame, joint pair), D per (frame, joint), scratch of the assembly
-        if (dev_alloc(c, &fb.mom_T, (size_t)max_frames * d.mom_np * d.mom_npsi * d.mom_npsi) || dev_alloc(c, &fb.mom_D, (size_t)max_frames * J * d.mom_npsi * 3) ||
-            dev_alloc(c, &fb.mom_E, (size_t)max_frames * 2) || dev_alloc(c, &fb.mom_rec, (size_t)max_frames * 2 * d.mom_np * std::max(1, d.K) * 6))
+        if (dev_alloc(c, &fb.mom_T, (size_t)max_frames * avt_moments_T_doubles(d)) || dev_alloc(c, &fb.mom_D, (size_t)max_frames * J * d.mom_npsi * 3) ||
+            dev_alloc(c, &fb.mom_E, (size_t)max_frames * 2) || dev_alloc(c, &fb.mom_rec, (size_t)max_frames * avt_moments_frame_scratch(d)))
             return 1;
         HIP_OK(hipMemsetAsync(fb.mom_D, 0, (size_t)max_frames * J * d.mom_npsi * 3 * sizeof(double), c->stream));      // joints no vertex is assigned to keep zeros
         fb.use_moments = 1;
@@ -913,7 +913,7 @@ int avt_set_data_term(avt_ctx* c, int form) {
     if (form == AVT_DATA_TERM_MOMENTS && !c->fb.use_moments && c->ran_icp_iters > 0 && c->frames_valid && c->state_valid) {
         // the resident correspondences have no moments yet: make them now, so that avt_get_normal_equations can compare the two forms
         c->fb.f0 = 0; c->cur_stream = c->stream;
-        c->fb.const_used = (c->launch_maxN + 255) / 256;
+        c->fb.const_used = (c->launch_maxN + 2047) / 2048;
         launch_moments(c, c->nframes);
         if (check_launch("avt_set_data_term")) return 1;
         HIP_OK(hipStreamSynchronize(c->stream));

@@ -54,8 +54,9 @@ struct AvtDims {
     int mom_npsi;            // 3 (K + 1) + 1: entries of psi_m = [base | keys | 1], index (K+1) i + s
     int mom_ntp;             // ceil(mom_npsi / 16): 16-row tiles of psi
     int mom_nm1;             // non-empty (k, j') entries of the rot-rot stage 1
-    int mom_nb2;             // (j <= j') blocks of the rot-rot stage 2
+    int mom_nb2, mom_nz2;    // (j <= j') rot-rot blocks with / without ordered pairs under them
     int mom_lmax;            // longest per-pair vertex list
+    int mom_nopk, mom_nsub, mom_nm1l, mom_ns2l;   // lengths of the index lists mom_opk, mom_sub, mom_m1, mom_s2
 };
 
 // prep block layout (doubles), one per frame per slot: what an evaluation needs about the skeleton state
@@ -211,6 +212,7 @@ struct DeviceModel {
     int* mom_s2_start;    // [2 nb2 + 1] stage 2: block (j <= j') sums the stage-1 entries (k, j'), k under j (list 2b) and (k, j), k under j' (list 2b + 1) ...
     int* mom_s2;          // ... stage-1 entry ids
     int* mom_s2_jj;       // [nb2] j | j' << 8
+    int* mom_z2_jj;       // [nz2] the blocks that are structural zeros
 };
 
 struct FrameBuffers {
@@ -271,10 +273,10 @@ struct FrameBuffers {
     double* trace;        // [max_frames][64] cost trace (debug)
     const AvtRunParams* params;   // one block per context
     // moment form of the data term (avt_moments.hip): accumulated once per ICP iteration by k_moments
-    double* mom_T;        // [max_frames][np][npsi][npsi] T_kk' = sum_m c_m a_mk a_mk' psi_m psi_m^T (full square)
+    double* mom_T;        // [max_frames][np][npsi (npsi + 1) / 2] T_kk' = sum_m c_m a_mk a_mk' psi_m psi_m^T, packed upper triangle
     double* mom_D;        // [max_frames][J][npsi][3] D_k = sum_m a_mk psi_m (sum_i (d_i - centre))^T
     double* mom_E;        // [max_frames][2] sum_m |fsum_m|^2 / c_m
-    double* mom_rec;      // [max_frames][2 np][K][6] scratch of the assembly: per (ordered pair, shape key) axial(Y), U
+    double* mom_rec;      // [max_frames][avt_moments_frame_scratch] what k_pairpass hands to k_assemble (avt_moments.hip)
     int use_moments;      // the GN iterations take their normal equations from the moments (k_assemble) instead of k_eval + k_reduce
 };
 
@@ -288,7 +290,7 @@ struct avt_model {
     std::vector<unsigned short> anc, vmask;
     std::vector<double> prior_mean, prior_prec, prior_L, prior_clog;
     // moment form (build_moment_tables)
-    std::vector<int> mom_pair, mom_lstart, mom_lv, mom_opk_start, mom_opk, mom_sub_start, mom_sub, mom_m1_start, mom_m1, mom_s2_start, mom_s2, mom_s2_jj;
+    std::vector<int> mom_pair, mom_lstart, mom_lv, mom_opk_start, mom_opk, mom_sub_start, mom_sub, mom_m1_start, mom_m1, mom_s2_start, mom_s2, mom_s2_jj, mom_z2_jj;
     std::vector<double> mom_lw, mom_psi;
 };
 
@@ -361,3 +363,5 @@ void launch_pack_results(avt_ctx* c, int nframes, double* out, int stride);
 void launch_moments(avt_ctx* c, int nframes);             // once per ICP iteration, behind k_finalize (carries the cost-constant workgroups)
 void launch_assemble(avt_ctx* c, int nframes);            // normal equations of the trial point from the moments (+ the pose-prior workgroups)
 int avt_moments_set_attributes();
+size_t avt_moments_frame_scratch(const AvtDims& d);   // doubles per frame of FrameBuffers::mom_rec
+size_t avt_moments_T_doubles(const AvtDims& d);       // doubles per frame of FrameBuffers::mom_T

@@ -266,25 +266,34 @@ static void build_moment_tables(avt_model* m) {
         for (int c = 0; c < J; ++c) if (under(c, k)) m->mom_sub.push_back(c);
         m->mom_sub_start[k + 1] = (int)m->mom_sub.size();
     }
-    std::vector<int> m1_of((size_t)J * J, -1);
-    m->mom_m1_start.assign(1, 0); m->mom_m1.clear();
-    for (int k = 0; k < J; ++k)
-        for (int jp = 0; jp < J; ++jp) {
-            const size_t before = m->mom_m1.size();
-            for (int e = m->mom_opk_start[k]; e < m->mom_opk_start[k + 1]; ++e) if (under(second(m->mom_opk[e]), jp)) m->mom_m1.push_back(m->mom_opk[e]);
-            if (m->mom_m1.size() > before) { m1_of[(size_t)k * J + jp] = (int)m->mom_m1_start.size() - 1; m->mom_m1_start.push_back((int)m->mom_m1.size()); }
+    // subtree lists padded to a multiple of four with J (an all-zero row of the per-joint arrays): the assembly walks them four at a time
+    {
+        std::vector<int> st(J + 1, 0), li;
+        for (int k = 0; k < J; ++k) {
+            for (int e = m->mom_sub_start[k]; e < m->mom_sub_start[k + 1]; ++e) li.push_back(m->mom_sub[e]);
+            while (li.size() % 4) li.push_back(J);
+            st[k + 1] = (int)li.size();
         }
-    d.mom_nm1 = (int)m->mom_m1_start.size() - 1;
-    m->mom_s2_start.assign(1, 0); m->mom_s2.clear(); m->mom_s2_jj.clear();
+        m->mom_sub_start = st; m->mom_sub = li;
+    }
+    // rot-rot: block (j <= j') sums the ordered pairs (k, k') with k under j and k' under j'; lists padded with 2 np (an all-zero X16 row)
+    m->mom_s2_start.assign(1, 0); m->mom_s2.clear(); m->mom_s2_jj.clear(); m->mom_z2_jj.clear();
     for (int j = 0; j < J; ++j)
         for (int jp = j; jp < J; ++jp) {
-            for (int e = m->mom_sub_start[j]; e < m->mom_sub_start[j + 1]; ++e) { const int id = m1_of[(size_t)m->mom_sub[e] * J + jp]; if (id >= 0) m->mom_s2.push_back(id); }
-            m->mom_s2_start.push_back((int)m->mom_s2.size());
-            for (int e = m->mom_sub_start[jp]; e < m->mom_sub_start[jp + 1]; ++e) { const int id = m1_of[(size_t)m->mom_sub[e] * J + j]; if (id >= 0) m->mom_s2.push_back(id); }
+            const size_t before = m->mom_s2.size();
+            for (int op = 0; op < 2 * NP; ++op) if (exists(op) && under(first(op), j) && under(second(op), jp)) m->mom_s2.push_back(op);
+            if (m->mom_s2.size() == before) { m->mom_z2_jj.push_back(j | (jp << 8)); continue; }      // a structural zero block
+            while (m->mom_s2.size() % 4) m->mom_s2.push_back(2 * NP);
             m->mom_s2_start.push_back((int)m->mom_s2.size());
             m->mom_s2_jj.push_back(j | (jp << 8));
         }
+    d.mom_nz2 = (int)m->mom_z2_jj.size();
+    if ((int)m->mom_s2_jj.size() * 16 > 2 * (J + 1) * K * 6) d.mom_ok = 0;      // the block sums reuse the records' LDS area (k_assemble)
     d.mom_nb2 = (int)m->mom_s2_jj.size();
+    d.mom_nm1 = 0;
+    m->mom_m1_start.assign(1, 0); m->mom_m1.clear();
+    d.mom_nopk = (int)m->mom_opk.size(); d.mom_nsub = (int)m->mom_sub.size(); d.mom_nm1l = 0; d.mom_ns2l = (int)m->mom_s2.size();
+    if ((int)m->mom_s2.size() > 65535) d.mom_ok = 0;      // 16-bit index lists
 }
 
 static int avt_model_create_impl(const avt_model_desc* desc, avt_model** out) {

@@ -12,80 +12,185 @@
 //     T_kk' = sum_m c_m a_mk a_mk' psi_m psi_m^T      one symmetric matrix per pair (k <= k') of joints assigned to a common vertex
 //     D_k   = sum_m a_mk psi_m (sum_i (d_i - centre))^T
 // which change only with the correspondences: k_moments accumulates them ONCE per ICP iteration (the only dense contraction left,
-// on the fp64 matrix cores), and a Gauss-Newton iteration contracts them with the state (mom_assemble: ~0.45 M multiply-adds
-// against ~20 M for rebuilding and contracting the Jacobian rows; tools/moment_proto2.py is the executable specification and
-// checks it against the oracle's literal per-block formulas: H 4e-15, g 4e-13, cost 1e-12 relative).
+// on the fp64 matrix cores), and a Gauss-Newton iteration contracts them with the state (~0.45 M multiply-adds against ~20 M for
+// rebuilding and contracting the Jacobian rows; tools/moment_proto2.py is the executable specification and checks it against
+// the oracle's literal per-block formulas: H 4e-15, g 4e-13, cost 1e-12 relative).
 //
-//   k_moments   grid (np + 1 + cost-constant blocks, frames): workgroup p < np accumulates T_p (and D_k for a diagonal pair);
-//   k_assemble  grid (1 + GMM components, frames): workgroup 0 builds the dense system of the trial point into Hraw (the layout
-//               k_reduce used to produce: full symmetric, row / column P = J^T r, [P][P] = sum c |r|^2), the others the pose prior.
+//   k_moments    grid (np + cost-constant blocks, frames): workgroup p < np accumulates T_p (packed upper triangle) and, for a
+//                diagonal pair, D_k; the others sum |d_i - centre|^2 over the matched data points;
+//   k_pairpass   grid (ceil(np / 16) + GMM components, frames): one 16-lane group per joint pair contracts its T with the trial state
+//                (phase A); the trailing workgroups evaluate the pose prior there, one component each;
+//   k_assemble   grid (1, frames): turns the pair results into the dense system of the trial point in Hraw (the layout k_reduce
+//                produces: full symmetric, row / column P = J^T r, [P][P] = sum c |r|^2).
 #include <algorithm>
+#include <type_traits>
 
 #include "avt_device.h"
 #include "avt_prior.h"
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ double mld(const double* p) {      // scratch written earlier in the same kernel by another wave: past the L1
-    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void mst(double* p, double v) {
-    __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+#ifdef AVT_TIMING      // in-kernel phase probes of the assembly (tools/moment_phase_probe.py): shader clocks into the frame's debug trace
+#define MPROBE(i) do { if (threadIdx.x == 0) fb.trace[(size_t)f * 64 + 40 + (i)] = (double)clock64(); } while (0)
+#else
+#define MPROBE(i) do {} while (0)
+#endif
+
+// packed upper triangle (row-major, diagonal included) of a symmetric n x n matrix: element (a <= b) at tri_off(a, n) + b - a
+__host__ __device__ inline int tri_off(int a, int n) { return a * n - (a * (a - 1)) / 2; }
+__host__ __device__ inline int tri_size(int n) { return n * (n + 1) / 2; }
 
 // =================================================================================================
 // k_moments<NTP>.  One 256-thread workgroup per (frame, unordered pair).  The pair's static vertex list is compacted to the matched
 // vertices (order kept), four of them per matrix instruction: lane (r = l & 15, v = l >> 4) holds psi_v[16 t + r] for the NTP
 // 16-row tiles of psi - straight from the psi table, no LDS staging -; A = weight x psi, B = psi, one accumulator tile per upper
-// tile pair.  The four waves split the list's rounds and their tiles are added in wave order (deterministic).
+// tile pair, plus NTP tiles for D_k of a diagonal pair.  The accumulator tiles are DEALT to the four waves (tile g to wave g mod 4)
+// and every wave walks all rounds: no cross-wave sum, no barrier behind the compaction, a third of the registers - the kernel's
+// speed is how many workgroups a CU holds (16 accumulator registers per tile; all nine in every wave: 176 registers, two waves per
+// SIMD).  MOM_UN rounds' fragments are requested together: a round is an L2 round trip.
 // =================================================================================================
+#ifdef AVT_TIMING
+#define KPROBE(i) do { if (threadIdx.x == 0 && bx == 20) fb.trace[(size_t)f * 64 + 50 + (i)] = (double)clock64(); } while (0)
+#else
+#define KPROBE(i) do {} while (0)
+#endif
 #define MOM_SEG 1024          // static list entries compacted per pass (4 per thread)
+#define MOM_UN 4              // rounds whose fragments a wave requests together
+
+// the rounds of one compacted list segment for wave WV: its tiles are g = WV, WV + 4, .. of [upper tile pairs | D tiles]
+template <int NTP, int WV>
+__device__ __forceinline__ void moments_rounds(const DeviceModel& dm, const long long* __restrict__ fs, int V, const int* __restrict__ s_v,
+                                               const double* __restrict__ s_w, const double* __restrict__ s_a, int mseg, bool diag, int ln,
+                                               v4f64 (&acc)[(NTP * (NTP + 1) / 2 + NTP + 3) / 4]) {
+    constexpr int NTPAIR = NTP * (NTP + 1) / 2, NSLOT = (NTPAIR + NTP + 3) / 4, PW = 16 * NTP;
+    constexpr int firstD = ((NTPAIR - WV + 3) / 4) * 4 + WV;                    // the wave's first tile index >= NTPAIR
+    constexpr bool hasD = firstD < NTPAIR + NTP;
+    const int r16 = ln & 15, kk = ln >> 4;
+    const int nr = (mseg + 3) >> 2;
+    for (int r0 = 0; r0 < nr; r0 += MOM_UN) {
+        double fr[MOM_UN][NTP], wgt[MOM_UN], bd[MOM_UN];
+        bool on[MOM_UN];
+#pragma unroll
+        for (int u = 0; u < MOM_UN; ++u) {
+            const int idx = 4 * (r0 + u) + kk;
+            on[u] = idx < mseg;
+            const int v = on[u] ? s_v[idx] : 0;
+            wgt[u] = on[u] ? s_w[idx] : 0.0;
+            const double* ps = dm.mom_psi + (size_t)v * PW + r16;
+#pragma unroll
+            for (int q = 0; q < NTP; ++q) fr[u][q] = ps[16 * q];
+            bd[u] = 0.0;
+            if (hasD && diag && on[u] && r16 < 3) bd[u] = s_a[idx] * ((double)fs[(size_t)r16 * V + v] / AVT_FIX_SCALE);      // B = a_mk (sum_i d_i - c centre), columns 0..2
+        }
+#pragma unroll
+        for (int u = 0; u < MOM_UN; ++u) {
+            if (r0 + u < nr) {      // wave-uniform
+#pragma unroll
+                for (int q = 0; q < NTP; ++q) fr[u][q] = on[u] ? fr[u][q] : 0.0;
+#pragma unroll
+                for (int sl = 0; sl < NSLOT; ++sl) {
+                    const int g = WV + 4 * sl;          // compile-time after unrolling
+                    if (g < NTPAIR) {
+                        int ti = 0, pp = g;
+#pragma unroll
+                        for (int i = 0; i < NTP; ++i) if (pp >= NTP - ti && ti == i) { pp -= NTP - ti; ++ti; }
+                        const int tj = ti + pp;
+                        acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[u][ti] * wgt[u], fr[u][tj], acc[sl], 0, 0, 0);
+                    } else if (g < NTPAIR + NTP) {
+                        if (diag) acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[u][g - NTPAIR], bd[u], acc[sl], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NTP, int WV>
+__device__ __forceinline__ void moments_store(const FrameBuffers& fb, const AvtDims& d, int f, int p, int k, bool diag, int ln,
+                                              const v4f64 (&acc)[(NTP * (NTP + 1) / 2 + NTP + 3) / 4]) {
+    constexpr int NTPAIR = NTP * (NTP + 1) / 2, NSLOT = (NTPAIR + NTP + 3) / 4;
+    const int NPSI = d.mom_npsi, r16 = ln & 15, kk = ln >> 4;
+    // accumulator element v of lane (c16 = l & 15, g4 = l >> 4): row 4 v + g4, column c16 of the tile; the upper triangle is kept
+    double* T = fb.mom_T + ((size_t)f * d.mom_np + p) * tri_size(NPSI);
+    double* D = fb.mom_D + ((size_t)f * d.J + k) * NPSI * 3;
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl) {
+        const int g = WV + 4 * sl;
+        if (g < NTPAIR) {
+            int ti = 0, pp = g;
+#pragma unroll
+            for (int i = 0; i < NTP; ++i) if (pp >= NTP - ti && ti == i) { pp -= NTP - ti; ++ti; }
+            const int tj = ti + pp;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int a = 16 * ti + 4 * v + kk, b = 16 * tj + r16;
+                if (a <= b && b < NPSI) T[tri_off(a, NPSI) + b - a] = acc[sl][v];
+            }
+        } else if (g < NTPAIR + NTP) {
+            if (diag) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int a = 16 * (g - NTPAIR) + 4 * v + kk;
+                    if (a < NPSI && r16 < 3) D[(size_t)a * 3 + r16] = acc[sl][v];
+                }
+            }
+        }
+    }
+}
 
 template <int NTP>
 __global__ __launch_bounds__(256) void k_moments(DeviceModel dm, FrameBuffers fb) {
     const AvtDims& d = dm.d;
-    const int f = blockIdx.y + fb.f0, t = threadIdx.x, V = d.V, NP = d.mom_np, NPSI = d.mom_npsi;
+    const int f = blockIdx.y + fb.f0, t = threadIdx.x, V = d.V, NP = d.mom_np;
     const int bx = blockIdx.x;
-    if (bx > NP) { cost_const_block(dm, fb, f, bx - NP - 1); return; }
     __shared__ int s_v[MOM_SEG];
     __shared__ double s_w[MOM_SEG], s_a[MOM_SEG];
     __shared__ int s_wcnt[4];
     __shared__ double s_red[4];
     const int* cnt = fb.cnt + (size_t)f * V;
     const long long* fs = fb.fsum + (size_t)f * 3 * V;
-    if (bx == NP) {      // sum_m |fsum_m|^2 / c_m over the matched vertices, fixed order
-        const int M = fb.ctl[f].M;
+    if (bx >= NP) {
+        // sum over the matched data points of |d_i - centre|^2, 2048 points per workgroup in data order (fixed order): with
+        //   sum_i |x_m - d_i|^2 = c_m |x_m|^2 - 2 x_m . sum_i d_i + sum_i |d_i|^2       (all relative to the frame centre)
+        // it is the part of the data cost that does not depend on the state; k_solve FIRST adds the workgroups' parts up
+        const int blk = bx - NP, N = fb.ctl[f].N;
+        const size_t base = (size_t)f * fb.max_points;
+        const double c0 = fb.ctl[f].centre[0], c1 = fb.ctl[f].centre[1], c2 = fb.ctl[f].centre[2];
         double a = 0.0;
-        for (int e = t; e < M; e += 256) {
-            const int m = fb.matched[(size_t)f * V + e];
-            const double x = (double)fs[m] / AVT_FIX_SCALE, y = (double)fs[(size_t)V + m] / AVT_FIX_SCALE, z = (double)fs[2 * (size_t)V + m] / AVT_FIX_SCALE;
-            a += (x * x + y * y + z * z) / (double)cnt[m];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = blk * 2048 + u * 256 + t;
+            if (i < N && fb.corr[base + i] >= 0) {
+                const double* dp = fb.data_raw + 3 * (base + i);
+                const double ex = dp[0] - c0, ey = dp[1] - c1, ez = dp[2] - c2;
+                a += ex * ex + ey * ey + ez * ez;
+            }
         }
         a = wave_sum(a);
         if ((t & 63) == 0) s_red[t >> 6] = a;
         __syncthreads();
-        if (t == 0) fb.mom_E[(size_t)f * 2] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        if (t == 0) fb.const_part[(size_t)f * fb.const_blocks + blk] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
         return;
     }
+    KPROBE(0);
     const int p = bx, k = dm.mom_pair[2 * p], k2 = dm.mom_pair[2 * p + 1];
     const bool diag = k == k2;
     const int lo = dm.mom_lstart[p], n = dm.mom_lstart[p + 1] - lo;
-    constexpr int NTPAIR = NTP * (NTP + 1) / 2;
-    constexpr int PW = 16 * NTP;
-    v4f64 acc[NTPAIR], accD[NTP];
+    constexpr int NSLOT = (NTP * (NTP + 1) / 2 + NTP + 3) / 4;
+    v4f64 acc[NSLOT];
     const v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < NTPAIR; ++i) acc[i] = z4;
-#pragma unroll
-    for (int i = 0; i < NTP; ++i) accD[i] = z4;
-    const int wv = t >> 6, ln = t & 63, r16 = ln & 15, kk = ln >> 4;
+    for (int i = 0; i < NSLOT; ++i) acc[i] = z4;
+    const int wv = t >> 6, ln = t & 63;
     for (int base = 0; base < n; base += MOM_SEG) {
         // ---- compaction of entries base + 4 t .. base + 4 t + 3 (order kept)
         int vv[4], cc[4], mine = 0;
+        double wa[4], wb[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int e = base + 4 * t + u;
-            vv[u] = e < n ? dm.mom_lv[lo + e] : 0;
+            const int e = min(base + 4 * t + u, n - 1);
+            vv[u] = dm.mom_lv[lo + e];
+            wa[u] = dm.mom_lw[2 * (size_t)(lo + e)]; wb[u] = dm.mom_lw[2 * (size_t)(lo + e) + 1];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -93,6 +198,7 @@ __global__ __launch_bounds__(256) void k_moments(DeviceModel dm, FrameBuffers fb
             cc[u] = e < n ? cnt[vv[u]] : 0;
             mine += cc[u] > 0;
         }
+        KPROBE(1);
         const int incl = wave_incl_scan(mine);
         if (ln == 63) s_wcnt[wv] = incl;
         __syncthreads();
@@ -101,104 +207,31 @@ __global__ __launch_bounds__(256) void k_moments(DeviceModel dm, FrameBuffers fb
         for (int w = 0; w < 4; ++w) { if (w < wv) pos += s_wcnt[w]; mseg += s_wcnt[w]; }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (cc[u] > 0) {
-                const int e = base + 4 * t + u;
-                const double wa = dm.mom_lw[2 * (size_t)(lo + e)], wb = dm.mom_lw[2 * (size_t)(lo + e) + 1];
-                s_v[pos] = vv[u]; s_w[pos] = (double)cc[u] * wa * wb; s_a[pos] = wa;
-                ++pos;
-            }
+            if (cc[u] > 0) { s_v[pos] = vv[u]; s_w[pos] = (double)cc[u] * wa[u] * wb[u]; s_a[pos] = wa[u]; ++pos; }
         __syncthreads();
-        // ---- rounds of four matched vertices: wave w takes rounds w, w + 4, ..
-        const int nr = (mseg + 3) >> 2;
-#pragma unroll 2
-        for (int r = wv; r < nr; r += 4) {
-            const int idx = 4 * r + kk;
-            const bool on = idx < mseg;
-            const int v = on ? s_v[idx] : 0;
-            const double wgt = on ? s_w[idx] : 0.0;
-            const double* ps = dm.mom_psi + (size_t)v * PW + r16;
-            double fr[NTP], fw[NTP];
-#pragma unroll
-            for (int q = 0; q < NTP; ++q) fr[q] = ps[16 * q];
-#pragma unroll
-            for (int q = 0; q < NTP; ++q) { fr[q] = on ? fr[q] : 0.0; fw[q] = fr[q] * wgt; }
-            int pi = 0;
-#pragma unroll
-            for (int ti = 0; ti < NTP; ++ti)
-#pragma unroll
-                for (int tj = ti; tj < NTP; ++tj) { acc[pi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fw[ti], fr[tj], acc[pi], 0, 0, 0); ++pi; }
-            if (diag) {      // D_k: B = a_mk (sum_i d_i - c centre) in columns 0..2
-                double bd = 0.0;
-                if (on && r16 < 3) bd = s_a[idx] * ((double)fs[(size_t)r16 * V + v] / AVT_FIX_SCALE);
-#pragma unroll
-                for (int q = 0; q < NTP; ++q) accD[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[q], bd, accD[q], 0, 0, 0);
-            }
+        KPROBE(2);
+        switch (wv) {
+            case 0: moments_rounds<NTP, 0>(dm, fs, V, s_v, s_w, s_a, mseg, diag, ln, acc); break;
+            case 1: moments_rounds<NTP, 1>(dm, fs, V, s_v, s_w, s_a, mseg, diag, ln, acc); break;
+            case 2: moments_rounds<NTP, 2>(dm, fs, V, s_v, s_w, s_a, mseg, diag, ln, acc); break;
+            default: moments_rounds<NTP, 3>(dm, fs, V, s_v, s_w, s_a, mseg, diag, ln, acc); break;
         }
-        __syncthreads();      // the list is rewritten by the next pass
+        KPROBE(3);
+        if (base + MOM_SEG < n) __syncthreads();      // the list is rewritten by the next pass
     }
-    // ---- the four waves' tiles, added in wave order through one buffer
-    __shared__ double s_buf[(NTPAIR + NTP) * 256];
-    for (int w = 1; w < 4; ++w) {
-        if (wv == w) {
-#pragma unroll
-            for (int i = 0; i < NTPAIR; ++i)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) s_buf[(i * 4 + v) * 64 + ln] = acc[i][v];
-            if (diag) {
-#pragma unroll
-                for (int i = 0; i < NTP; ++i)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) s_buf[((NTPAIR + i) * 4 + v) * 64 + ln] = accD[i][v];
-            }
-        }
-        __syncthreads();
-        if (wv == 0) {
-#pragma unroll
-            for (int i = 0; i < NTPAIR; ++i)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) acc[i][v] += s_buf[(i * 4 + v) * 64 + ln];
-            if (diag) {
-#pragma unroll
-                for (int i = 0; i < NTP; ++i)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) accD[i][v] += s_buf[((NTPAIR + i) * 4 + v) * 64 + ln];
-            }
-        }
-        __syncthreads();
+    KPROBE(4);
+    switch (wv) {
+        case 0: moments_store<NTP, 0>(fb, d, f, p, k, diag, ln, acc); break;
+        case 1: moments_store<NTP, 1>(fb, d, f, p, k, diag, ln, acc); break;
+        case 2: moments_store<NTP, 2>(fb, d, f, p, k, diag, ln, acc); break;
+        default: moments_store<NTP, 3>(fb, d, f, p, k, diag, ln, acc); break;
     }
-    if (wv != 0) return;
-    // accumulator element v of lane (c16 = l & 15, g4 = l >> 4): row 4 v + g4, column c16 of the tile
-    double* T = fb.mom_T + ((size_t)f * NP + p) * NPSI * NPSI;
-    int pi = 0;
-#pragma unroll
-    for (int ti = 0; ti < NTP; ++ti)
-#pragma unroll
-        for (int tj = ti; tj < NTP; ++tj) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int a = 16 * ti + 4 * v + kk, b = 16 * tj + r16;
-                if (a < NPSI && b < NPSI) {
-                    T[(size_t)a * NPSI + b] = acc[pi][v];
-                    if (ti != tj) T[(size_t)b * NPSI + a] = acc[pi][v];
-                }
-            }
-            ++pi;
-        }
-    if (diag) {
-        double* D = fb.mom_D + ((size_t)f * d.J + k) * NPSI * 3;
-#pragma unroll
-        for (int q = 0; q < NTP; ++q)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int a = 16 * q + 4 * v + kk;
-                if (a < NPSI && r16 < 3) D[(size_t)a * 3 + r16] = accD[q][v];
-            }
-    }
+    KPROBE(6);
 }
 
 void launch_moments(avt_ctx* c, int nframes) {
     const AvtDims& d = c->dm.d;
-    const dim3 grid(d.mom_np + 1 + c->fb.const_used, nframes);
+    const dim3 grid(d.mom_np + c->fb.const_used, nframes);
     switch (d.mom_ntp) {
         case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_moments<1>), grid, dim3(256), 0, c->cur_stream, c->dm, c->fb); break;
         case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_moments<2>), grid, dim3(256), 0, c->cur_stream, c->dm, c->fb); break;
@@ -208,16 +241,7 @@ void launch_moments(avt_ctx* c, int nframes) {
 }
 
 // =================================================================================================
-// mom_assemble<NTH>: the dense system of one state from the moments.  Called by every thread of a workgroup (barriers inside).
-//   sk : the skeleton tables of the state in LDS (MomSkel below);
-//   scr: LDS scratch, mom_scratch_doubles(d) doubles;
-//   Hout: HS x HS block, full symmetric; row / column P = J^T r; [P][P] = sum_m c_m |x_m - dbar_m|^2.
-// Phases (tools/moment_proto2.py::assemble, same names):
-//   A   one 16-lane group per unordered pair, lane = s' (0 .. K): 9 (K + 1) + 4 loads of T, Q = omega-contraction, zz = G-contraction,
-//       group butterfly for P2 / p1; lane 0 writes X16 of both orders, lanes 1 .. K the per-(ordered pair, shape key) records;
-//       the shape-shape columns and sum tr(Y) stay in registers across the group's pairs;
-//   A'  per joint: XD_k, Dl_k, and YF;
-//   B0  per-joint partner sums, B1 subtree sums, B2 every block but rot-rot; rot-rot in three stages (M1, S2, blocks).
+// Skeleton tables of the assembly (what every coefficient above is made of), in LDS, from a prep block (avt_internal.h).
 // =================================================================================================
 struct MomSkel {
     const double* Rw;     // [J][9] world rotations, row-major
@@ -227,284 +251,449 @@ struct MomSkel {
     const double* om;     // [K + 1] omega = [1; w]
     const int* parent;    // [J]
 };
+__host__ __device__ inline int mom_skel_doubles(const AvtDims& d) { return ((15 * d.J + 3 * d.J * d.K + d.K + 1) + 1) & ~1; }
 
-__host__ __device__ inline int mom_scratch_doubles(const AvtDims& d, int nth) {
-    const int J = d.J, K = d.K, NG = nth / 16;
-    return 2 * d.mom_np * 16 + d.mom_nm1 * 16 + 2 * J * 16 + 2 * J * K * 6 + J * 9 + NG * (K * K + K) + 2 * K + 8;
+template <int NTH>
+__device__ __forceinline__ void mom_skel_from_prep(const AvtDims& d, const double* __restrict__ prep, const double* centre, double* __restrict__ sk_mem,
+                                                   int* __restrict__ s_parent, const int* __restrict__ parent_g, MomSkel& sk) {
+    const int J = d.J, K = d.K, t = threadIdx.x;
+    double* Rw = sk_mem;                 // [9 J]
+    double* oc = Rw + 9 * J;             // [3 J]
+    double* tau = oc + 3 * J;            // [3 J]
+    double* eta = tau + 3 * J;           // [3 J K]
+    double* om = eta + 3 * J * K;        // [K + 1]
+    for (int e = t; e < 9 * J; e += NTH) Rw[e] = prep[prep_off_Rw(d) + e];
+    for (int e = t; e < 3 * J * K; e += NTH) eta[e] = prep[prep_off_G(d) + e];
+    for (int e = t; e < 3 * J; e += NTH) {
+        const int j = e / 3, r = e - 3 * j;
+        const double* Rj = prep + prep_off_Rw(d) + 9 * j;
+        const double* Jh = prep + prep_off_Jh(d) + 3 * j;
+        const double* off = prep + prep_off_off(d);
+        const double o = prep[prep_off_o(d) + e] - centre[r];
+        oc[e] = o;
+        tau[e] = o - (Rj[3 * r] * (Jh[0] + off[0]) + Rj[3 * r + 1] * (Jh[1] + off[1]) + Rj[3 * r + 2] * (Jh[2] + off[2]));
+    }
+    if (t <= K) om[t] = t == 0 ? 1.0 : prep[prep_off_w(d) + t - 1];
+    if (t < J) s_parent[t] = parent_g[t];
+    sk.Rw = Rw; sk.oc = oc; sk.tau = tau; sk.eta = eta; sk.om = om; sk.parent = s_parent;
 }
 
-template <int NTH, int KC /* K if known at compile time, else 0 */>
-__device__ __forceinline__ void mom_assemble(const DeviceModel& dm, const FrameBuffers& fb, int f, const MomSkel& sk, double* __restrict__ scr,
-                                             double* __restrict__ Hout) {
-    const AvtDims& d = dm.d;
-    const int J = d.J, K = KC ? KC : d.K, S1 = K + 1, NP = d.mom_np, NPSI = d.mom_npsi, P = d.P, HS = d.HS, t = threadIdx.x;
-    constexpr int NG = NTH / 16;
-    double* X16 = scr;                          // [2 NP][16]  W (9, row-major), Va, Vb, t0
-    double* M1 = X16 + 2 * NP * 16;             // [nm1][16]
-    double* PK = M1 + d.mom_nm1 * 16;           // [J][16]  axial(sum W), sum Va, sum Vb, sum t0, axial(XD), Dl
-    double* TK = PK + J * 16;                   // [J][16]  subtree sums of PK
-    double* PR = TK + J * 16;                   // [J][K][6]
-    double* TR = PR + J * K * 6;                // [J][K][6]
-    double* XDt = TR + J * K * 6;               // [J][9]  (only the trace is needed beyond the axial vector: stored whole, small)
-    double* ZR = XDt + J * 9;                   // [NG][K*K + K] the groups' shape-shape columns and sum tr(Y)
-    double* YFs = ZR + NG * (K * K + K);        // [K]
-    double* YXs = YFs + K;                      // [K]
-    double* misc = YXs + K;                     // [8]
-    double* REC = fb.mom_rec + (size_t)f * 2 * NP * K * 6;      // global scratch: [2 NP][K][6]
-    const double* Tf = fb.mom_T + (size_t)f * NP * NPSI * NPSI;
-    const double* Df = fb.mom_D + (size_t)f * J * NPSI * 3;
+// per-frame scratch between k_pairpass and k_assemble (FrameBuffers::mom_rec), in doubles:
+//   X16 [2 np + 1][16]   per ordered pair (op = 2 p: k -> k', 2 p + 1: k' -> k): W (9, row-major), Va, Vb, t0; the last row stays zero
+//   REC [2 np][K][6]     per (ordered pair, shape key): axial(Y), U
+//   Z   [nwg][K K + K]   per pair-pass workgroup: its pairs' shape-shape columns and sum tr(Y)
+__host__ __device__ inline int mom_nwg(const AvtDims& d) { return (d.mom_np + 15) / 16; }
+__host__ __device__ inline size_t mom_off_rec(const AvtDims& d) { return (size_t)(2 * d.mom_np + 1) * 16; }
+__host__ __device__ inline size_t mom_off_z(const AvtDims& d) { return mom_off_rec(d) + (size_t)2 * d.mom_np * d.K * 6; }
+__host__ __device__ inline size_t mom_frame_scratch(const AvtDims& d) { return (mom_off_z(d) + (size_t)mom_nwg(d) * (d.K * d.K + d.K) + 7) & ~(size_t)7; }
 
-    // ---------------- phase A
+// =================================================================================================
+// k_pairpass<KC>.  grid (ceil(np / 16), frames), block 256 = sixteen 16-lane groups, one unordered pair (k <= k') each; lane = s'
+// (0 .. K).  tools/moment_proto2.py::assemble "phase A":
+//   Q[i][i'] = sum_s om_s T[(i,s),(i',s')],  zz[s] = sum_ii' (R_k^T R_k')[i][i'] T[(i,s),(i',s')]   - 9 (K + 1) + 4 loads of the packed T,
+//   P2, p1 by a butterfly over the group; lane 0 writes X16 of both orders, lanes 1 .. K the per-(ordered pair, shape key) records;
+//   the lanes' shape-shape columns and sum tr(Y) are added over the workgroup's pairs in group order through LDS.
+// =================================================================================================
+template <int KC>
+__global__ __launch_bounds__(256) void k_pairpass(DeviceModel dm, FrameBuffers fb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const AvtDims& d = dm.d;
+    const int f = blockIdx.y + fb.f0, t = threadIdx.x;
+    const int J = d.J, K = KC ? KC : d.K, S1 = K + 1, NP = d.mom_np, NPSI = KC ? 3 * (KC + 1) + 1 : d.mom_npsi;
+    const int try_slot = 1 - fb.ctl[f].cur_slot;
+    if ((int)blockIdx.x >= mom_nwg(d)) { prior_component(dm, fb, f, blockIdx.x - mom_nwg(d), try_slot, (double*)smem); return; }      // trailing workgroups: the GMM pose prior, one component each (avt_prior.h)
+    double* skm = (double*)smem;
+    double* ZR = skm + mom_skel_doubles(d);                     // [16][K K + K]
+    int* s_parent = (int*)(ZR + 16 * (K * K + K));
+    MomSkel sk;
+    mom_skel_from_prep<256>(d, fb.prep + ((size_t)f * 2 + try_slot) * d.prep_size, fb.ctl[f].centre, skm, s_parent, dm.parent, sk);
+    double* scr = fb.mom_rec + (size_t)f * mom_frame_scratch(d);
+    double* X16 = scr;
+    double* REC = scr + mom_off_rec(d);
+    const int gid = t >> 4, sl = t & 15;
+    const int p = blockIdx.x * 16 + gid;
+    const bool pair_on = p < NP, lane_on = sl < S1;
+    const int pc = pair_on ? p : 0;
+    const int k = dm.mom_pair[2 * pc], k2 = dm.mom_pair[2 * pc + 1];
+    const double* Tp = fb.mom_T + ((size_t)f * NP + pc) * tri_size(NPSI);
+    const int col = lane_on ? sl : 0;
+    // my three columns c = S1 i' + col of the packed triangle: element (r, c) at (r <= c ? rowoff(r) + c : coloff[i'] + r)
+    int coloff[3], cidx[3];
+#pragma unroll
+    for (int i2 = 0; i2 < 3; ++i2) { cidx[i2] = S1 * i2 + col; coloff[i2] = tri_off(cidx[i2], NPSI) - cidx[i2]; }
+    auto tload = [&](int r, int i2) { return Tp[r <= cidx[i2] ? tri_off(r, NPSI) - r + cidx[i2] : coloff[i2] + r]; };
+    // all loads of T that do not need the skeleton are requested before the barrier
+    double v0[9], tph[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int i2 = 0; i2 < 3; ++i2) v0[3 * i + i2] = tload(S1 * i, i2);
+#pragma unroll
+    for (int i2 = 0; i2 < 3; ++i2) tph[i2] = Tp[coloff[i2] + NPSI - 1];
+    const double t0 = Tp[tri_size(NPSI) - 1];
+    __syncthreads();
+    double zc[KC ? KC : AVT_MAX_SHAPE], yx = 0.0;
+#pragma unroll
+    for (int s = 0; s < (KC ? KC : AVT_MAX_SHAPE); ++s) zc[s] = 0.0;
+    const double om_l = lane_on ? sk.om[sl] : 0.0;
+    const double nu = k == k2 ? 0.5 : 1.0;
+    double Q[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Q[e] = v0[e];        // s = 0 (base): omega_0 = 1
     {
-        const int gid = t >> 4, sl = t & 15;
-        const bool lane_on = sl < S1;
-        const double om_l = lane_on ? sk.om[sl] : 0.0;
-        double zc[KC ? KC : AVT_MAX_SHAPE], yx = 0.0;
+        double G[9];
+        {   // R_k^T R_k' (the rotations themselves are fetched again behind the loop: they would only occupy registers in it)
+            double A[9], B[9];
 #pragma unroll
-        for (int s = 0; s < (KC ? KC : AVT_MAX_SHAPE); ++s) zc[s] = 0.0;
-        for (int p = gid; p < NP; p += NG) {
-            const int k = dm.mom_pair[2 * p], k2 = dm.mom_pair[2 * p + 1];
-            const double* Tp = Tf + (size_t)p * NPSI * NPSI;
-            const double nu = k == k2 ? 0.5 : 1.0;
-            double Ra[9], Rb[9], G[9], ta[3], tb[3];
-#pragma unroll
-            for (int e = 0; e < 9; ++e) { Ra[e] = sk.Rw[9 * k + e]; Rb[e] = sk.Rw[9 * k2 + e]; }
-#pragma unroll
-            for (int e = 0; e < 3; ++e) { ta[e] = sk.tau[3 * k + e]; tb[e] = sk.tau[3 * k2 + e]; }
+            for (int e = 0; e < 9; ++e) { A[e] = sk.Rw[9 * k + e]; B[e] = sk.Rw[9 * k2 + e]; }
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int i2 = 0; i2 < 3; ++i2) G[3 * i + i2] = Ra[i] * Rb[i2] + Ra[3 + i] * Rb[3 + i2] + Ra[6 + i] * Rb[6 + i2];     // R_k^T R_k'
-            const int col = lane_on ? sl : 0;
-            double Q[9];
+                for (int i2 = 0; i2 < 3; ++i2) G[3 * i + i2] = A[i] * B[i2] + A[3 + i] * B[3 + i2] + A[6 + i] * B[6 + i2];
+        }
+        auto use = [&](int s, const double (&v)[9], double& zout) {
+            const double oms = sk.om[s];
+            double zz = 0.0;
 #pragma unroll
-            for (int e = 0; e < 9; ++e) Q[e] = 0.0;
-            // s = 0 (base): only Q
-            {
-                double v[9];
+            for (int e = 0; e < 9; ++e) { Q[e] = fma(oms, v[e], Q[e]); zz = fma(G[e], v[e], zz); }
+            zout = nu * zz;
+        };
+        if (KC) {
+            // the kernel is L2 latency: the 9 K loads go out in three batches, each requested as a whole before its first use
+            constexpr int KK = KC ? KC : 3, B1 = (KK + 2) / 3, B2 = (KK - B1 + 1) / 2, B3 = KK - B1 - B2;
+            auto batch = [&](auto nb, int first) {
+                constexpr int NB = decltype(nb)::value;
+                double vv[NB > 0 ? NB : 1][9];
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int i2 = 0; i2 < 3; ++i2) v[3 * i + i2] = Tp[(size_t)(S1 * i) * NPSI + S1 * i2 + col];
-#pragma unroll
-                for (int e = 0; e < 9; ++e) Q[e] += v[e];        // omega_0 = 1
-            }
-#pragma unroll
-            for (int s = 1; s < (KC ? KC + 1 : 1); ++s) {
-                double v[9];
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int i2 = 0; i2 < 3; ++i2) v[3 * i + i2] = Tp[(size_t)(S1 * i + s) * NPSI + S1 * i2 + col];
-                const double oms = sk.om[s];
-                double zz = 0.0;
-#pragma unroll
-                for (int e = 0; e < 9; ++e) { Q[e] = fma(oms, v[e], Q[e]); zz = fma(G[e], v[e], zz); }
-                zc[s - 1] = fma(nu, zz, zc[s - 1]);
-            }
-            if (!KC) {
-                for (int s = 1; s < S1; ++s) {
-                    double v[9];
+                for (int u = 0; u < NB; ++u)
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
 #pragma unroll
-                        for (int i2 = 0; i2 < 3; ++i2) v[3 * i + i2] = Tp[(size_t)(S1 * i + s) * NPSI + S1 * i2 + col];
-                    const double oms = sk.om[s];
-                    double zz = 0.0;
+                        for (int i2 = 0; i2 < 3; ++i2) vv[u][3 * i + i2] = tload(S1 * i + first + u, i2);
 #pragma unroll
-                    for (int e = 0; e < 9; ++e) { Q[e] = fma(oms, v[e], Q[e]); zz = fma(G[e], v[e], zz); }
+                for (int u = 0; u < NB; ++u) {
 #pragma unroll
-                    for (int q = 0; q < AVT_MAX_SHAPE; ++q) if (q == s - 1) zc[q] = fma(nu, zz, zc[q]);
+                    for (int q = 0; q < KK; ++q) if (q == first + u - 1) use(first + u, vv[u], zc[q]);
                 }
-            }
-            double tph[3];
+            };
+            batch(std::integral_constant<int, B1>{}, 1);
+            batch(std::integral_constant<int, B2>{}, 1 + B1);
+            batch(std::integral_constant<int, B3>{}, 1 + B1 + B2);
+        } else {
+            for (int s = 1; s < S1; ++s) {
+                double v[9], z;
 #pragma unroll
-            for (int i2 = 0; i2 < 3; ++i2) tph[i2] = Tp[(size_t)(NPSI - 1) * NPSI + S1 * i2 + col];
-            const double t0 = Tp[(size_t)NPSI * NPSI - 1];
-            // group sums over the lanes (fixed butterfly: every lane of the group ends with the same bits)
-            double P2[9], p1[3];
+                for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int e = 0; e < 9; ++e) P2[e] = om_l * Q[e];
+                    for (int i2 = 0; i2 < 3; ++i2) v[3 * i + i2] = tload(S1 * i + s, i2);
+                use(s, v, z);
 #pragma unroll
-            for (int e = 0; e < 3; ++e) p1[e] = om_l * tph[e];
-#pragma unroll
-            for (int sft = 8; sft >= 1; sft >>= 1) {
-#pragma unroll
-                for (int e = 0; e < 9; ++e) P2[e] += __shfl_xor(P2[e], sft, 64);
-#pragma unroll
-                for (int e = 0; e < 3; ++e) p1[e] += __shfl_xor(p1[e], sft, 64);
-            }
-            double Rap1[3], Rbp1[3], Va[3], Vb[3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                Rap1[r] = Ra[3 * r] * p1[0] + Ra[3 * r + 1] * p1[1] + Ra[3 * r + 2] * p1[2];
-                Rbp1[r] = Rb[3 * r] * p1[0] + Rb[3 * r + 1] * p1[1] + Rb[3 * r + 2] * p1[2];
-                Va[r] = fma(t0, ta[r], Rap1[r]);
-                Vb[r] = fma(t0, tb[r], Rbp1[r]);
-            }
-            if (sl == 0) {
-                // W_kk' = R_k P2 R_k'^T + Va tau_k'^T + tau_k (R_k' p1)^T;  W_k'k = W_kk'^T
-                double RaP[9], W[9];
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) RaP[3 * r + c] = Ra[3 * r] * P2[c] + Ra[3 * r + 1] * P2[3 + c] + Ra[3 * r + 2] * P2[6 + c];
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        W[3 * r + c] = (RaP[3 * r] * Rb[3 * c] + RaP[3 * r + 1] * Rb[3 * c + 1] + RaP[3 * r + 2] * Rb[3 * c + 2]) + Va[r] * tb[c] + ta[r] * Rbp1[c];
-                double* x0 = X16 + (size_t)(2 * p) * 16;
-#pragma unroll
-                for (int e = 0; e < 9; ++e) x0[e] = W[e];
-#pragma unroll
-                for (int e = 0; e < 3; ++e) { x0[9 + e] = Va[e]; x0[12 + e] = Vb[e]; }
-                x0[15] = t0;
-                double* x1 = x0 + 16;
-                if (k != k2) {
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) x1[3 * r + c] = W[3 * c + r];
-#pragma unroll
-                    for (int e = 0; e < 3; ++e) { x1[9 + e] = Vb[e]; x1[12 + e] = Va[e]; }
-                    x1[15] = t0;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) x1[e] = 0.0;
-                }
-            } else if (lane_on) {
-                const int s = sl - 1;
-                const double* ea = sk.eta + (size_t)k * 3 * K;       // eta_k[r][s]
-                const double* eb = sk.eta + (size_t)k2 * 3 * K;
-                double ya[3], yb[3];                                 // R_k tphi, R_k' tphi
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    ya[r] = Ra[3 * r] * tph[0] + Ra[3 * r + 1] * tph[1] + Ra[3 * r + 2] * tph[2];
-                    yb[r] = Rb[3 * r] * tph[0] + Rb[3 * r + 1] * tph[1] + Rb[3 * r + 2] * tph[2];
-                }
-                const double eas[3] = {ea[s], ea[K + s], ea[2 * K + s]}, ebs[3] = {eb[s], eb[K + s], eb[2 * K + s]};
-                auto record = [&](const double (&RA)[9], const double (&RB)[9], const double (&VA)[3], const double (&TA)[3], const double (&ylin)[3],
-                                  const double (&eB)[3], int op) {
-                    // Y = R_a Qs R_b^T + V_a eta_b,s^T + tau_a ylin^T,  U = ylin + t0 eta_b,s
-                    double RQ[9], Y[9];
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) RQ[3 * r + c] = RA[3 * r] * Q[c] + RA[3 * r + 1] * Q[3 + c] + RA[3 * r + 2] * Q[6 + c];
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c)
-                            Y[3 * r + c] = (RQ[3 * r] * RB[3 * c] + RQ[3 * r + 1] * RB[3 * c + 1] + RQ[3 * r + 2] * RB[3 * c + 2]) + VA[r] * eB[c] + TA[r] * ylin[c];
-                    double* rc = REC + ((size_t)op * K + s) * 6;
-                    mst(rc + 0, Y[5] - Y[7]); mst(rc + 1, Y[6] - Y[2]); mst(rc + 2, Y[1] - Y[3]);
-                    mst(rc + 3, fma(t0, eB[0], ylin[0])); mst(rc + 4, fma(t0, eB[1], ylin[1])); mst(rc + 5, fma(t0, eB[2], ylin[2]));
-                    yx += (Y[0] + Y[4]) + Y[8];
-                };
-                record(Ra, Rb, Va, ta, yb, ebs, 2 * p);
-                if (k != k2) record(Rb, Ra, Vb, tb, ya, eas, 2 * p + 1);
-                // column t = s of Z~': nu (zz + eta_k,s2 . yb + eta_k',s2 . ya + t0 eta_k,s2 . eta_k',t)   (zz is already in zc)
-                const double ebt[3] = {ebs[0], ebs[1], ebs[2]};
-#pragma unroll
-                for (int s2 = 0; s2 < (KC ? KC : AVT_MAX_SHAPE); ++s2) {
-                    if (s2 < K) {
-                        const double e0 = ea[s2], e1 = ea[K + s2], e2 = ea[2 * K + s2];
-                        const double f0 = eb[s2], f1 = eb[K + s2], f2 = eb[2 * K + s2];
-                        const double add = (e0 * yb[0] + e1 * yb[1] + e2 * yb[2]) + (f0 * ya[0] + f1 * ya[1] + f2 * ya[2]) + t0 * (e0 * ebt[0] + e1 * ebt[1] + e2 * ebt[2]);
-                        zc[s2] = fma(nu, add, zc[s2]);
-                    }
-                }
+                for (int q = 0; q < AVT_MAX_SHAPE; ++q) if (q == s - 1) zc[q] = z;
             }
         }
-        if (sl >= 1 && lane_on) {
-            double* zr = ZR + (size_t)gid * (K * K + K);
+    }
+    double Ra[9], Rb[9], ta[3], tb[3];
 #pragma unroll
-            for (int s2 = 0; s2 < (KC ? KC : AVT_MAX_SHAPE); ++s2) if (s2 < K) zr[s2 * K + (sl - 1)] = zc[s2];
-            zr[K * K + (sl - 1)] = yx;
-        }
+    for (int e = 0; e < 9; ++e) { Ra[e] = sk.Rw[9 * k + e]; Rb[e] = sk.Rw[9 * k2 + e]; }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) { ta[e] = sk.tau[3 * k + e]; tb[e] = sk.tau[3 * k2 + e]; }
+    // group sums over the lanes (fixed butterfly: every lane of the group ends with the same bits)
+    double P2[9], p1[3];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) P2[e] = om_l * Q[e];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) p1[e] = om_l * tph[e];
+#pragma unroll
+    for (int sft = 8; sft >= 1; sft >>= 1) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) P2[e] += __shfl_xor(P2[e], sft, 64);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) p1[e] += __shfl_xor(p1[e], sft, 64);
     }
-    // ---------------- phase A': data-side moments per joint
-    for (int e = t; e < J * 3; e += NTH) {      // (k, c): column c of XD_k = R_k (sum_s om_s Dphi_k[.][s][c]) + tau_k Dl_k[c]
-        const int k = e / 3, c = e - 3 * k;
-        const double* Dk = Df + (size_t)k * NPSI * 3;
-        double u[3] = {0.0, 0.0, 0.0};
-        for (int i = 0; i < 3; ++i)
-            for (int s = 0; s < S1; ++s) u[i] = fma(sk.om[s], Dk[(size_t)(S1 * i + s) * 3 + c], u[i]);
-        const double dl = Dk[(size_t)(NPSI - 1) * 3 + c];
-        const double* Rk = sk.Rw + 9 * k;
-        for (int r = 0; r < 3; ++r) XDt[9 * k + 3 * r + c] = (Rk[3 * r] * u[0] + Rk[3 * r + 1] * u[1] + Rk[3 * r + 2] * u[2]) + sk.tau[3 * k + r] * dl;
-        PK[16 * k + 13 + c] = dl;
+    double Rap1[3], Rbp1[3], Va[3], Vb[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        Rap1[r] = Ra[3 * r] * p1[0] + Ra[3 * r + 1] * p1[1] + Ra[3 * r + 2] * p1[2];
+        Rbp1[r] = Rb[3 * r] * p1[0] + Rb[3 * r + 1] * p1[1] + Rb[3 * r + 2] * p1[2];
+        Va[r] = fma(t0, ta[r], Rap1[r]);
+        Vb[r] = fma(t0, tb[r], Rbp1[r]);
     }
-    if (t < K) {      // YF[s] = sum_k tr(R_k Dphi_k[s]) + eta_k,s . Dl_k
-        const int s = t;
-        double a = 0.0;
-        for (int k = 0; k < J; ++k) {
-            const double* Dk = Df + (size_t)k * NPSI * 3;
-            const double* Rk = sk.Rw + 9 * k;
-            double q = 0.0;
+    if (pair_on && sl == 0) {
+        // W_kk' = R_k P2 R_k'^T + Va tau_k'^T + tau_k (R_k' p1)^T;  W_k'k = W_kk'^T
+        double RaP[9], W[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) RaP[3 * r + c] = Ra[3 * r] * P2[c] + Ra[3 * r + 1] * P2[3 + c] + Ra[3 * r + 2] * P2[6 + c];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
             for (int c = 0; c < 3; ++c)
-                for (int i = 0; i < 3; ++i) q = fma(Rk[3 * c + i], Dk[(size_t)(S1 * i + s + 1) * 3 + c], q);
-            for (int c = 0; c < 3; ++c) q = fma(sk.eta[((size_t)k * 3 + c) * K + s], Dk[(size_t)(NPSI - 1) * 3 + c], q);
-            a += q;
+                W[3 * r + c] = (RaP[3 * r] * Rb[3 * c] + RaP[3 * r + 1] * Rb[3 * c + 1] + RaP[3 * r + 2] * Rb[3 * c + 2]) + Va[r] * tb[c] + ta[r] * Rbp1[c];
+        double* x0 = X16 + (size_t)(2 * p) * 16;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) x0[e] = W[e];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) { x0[9 + e] = Va[e]; x0[12 + e] = Vb[e]; }
+        x0[15] = t0;
+        double* x1 = x0 + 16;
+        if (k != k2) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) x1[3 * r + c] = W[3 * c + r];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) { x1[9 + e] = Vb[e]; x1[12 + e] = Va[e]; }
+            x1[15] = t0;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x1[e] = 0.0;
         }
-        YFs[s] = a;
+        if (p == 0) {      // the all-zero row the padded lists of k_assemble point at
+            double* xz = X16 + (size_t)(2 * NP) * 16;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) xz[e] = 0.0;
+        }
+    } else if (pair_on && lane_on) {
+        const int s = sl - 1;
+        const double* ea = sk.eta + (size_t)k * 3 * K;       // eta_k[r][s]
+        const double* eb = sk.eta + (size_t)k2 * 3 * K;
+        double ya[3], yb[3];                                 // R_k tphi, R_k' tphi
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            ya[r] = Ra[3 * r] * tph[0] + Ra[3 * r + 1] * tph[1] + Ra[3 * r + 2] * tph[2];
+            yb[r] = Rb[3 * r] * tph[0] + Rb[3 * r + 1] * tph[1] + Rb[3 * r + 2] * tph[2];
+        }
+        const double eas[3] = {ea[s], ea[K + s], ea[2 * K + s]}, ebs[3] = {eb[s], eb[K + s], eb[2 * K + s]};
+        auto record = [&](const double (&RA)[9], const double (&RB)[9], const double (&VA)[3], const double (&TA)[3], const double (&ylin)[3],
+                          const double (&eB)[3], int op) {
+            // Y = R_a Qs R_b^T + V_a eta_b,s^T + tau_a ylin^T,  U = ylin + t0 eta_b,s
+            double RQ[9], Y[9];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) RQ[3 * r + c] = RA[3 * r] * Q[c] + RA[3 * r + 1] * Q[3 + c] + RA[3 * r + 2] * Q[6 + c];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    Y[3 * r + c] = (RQ[3 * r] * RB[3 * c] + RQ[3 * r + 1] * RB[3 * c + 1] + RQ[3 * r + 2] * RB[3 * c + 2]) + VA[r] * eB[c] + TA[r] * ylin[c];
+            double* rc = REC + ((size_t)op * K + s) * 6;
+            rc[0] = Y[5] - Y[7]; rc[1] = Y[6] - Y[2]; rc[2] = Y[1] - Y[3];
+            rc[3] = fma(t0, eB[0], ylin[0]); rc[4] = fma(t0, eB[1], ylin[1]); rc[5] = fma(t0, eB[2], ylin[2]);
+            yx += (Y[0] + Y[4]) + Y[8];
+        };
+        record(Ra, Rb, Va, ta, yb, ebs, 2 * p);
+        if (k != k2) record(Rb, Ra, Vb, tb, ya, eas, 2 * p + 1);
+        else {
+            double* rc = REC + ((size_t)(2 * p + 1) * K + s) * 6;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) rc[e] = 0.0;
+        }
+        // column t = s of Z~': nu (zz + eta_k,s2 . yb + eta_k',s2 . ya + t0 eta_k,s2 . eta_k',t)   (nu zz is already in zc)
+#pragma unroll
+        for (int s2 = 0; s2 < (KC ? KC : AVT_MAX_SHAPE); ++s2) {
+            if (s2 < K) {
+                const double e0 = ea[s2], e1 = ea[K + s2], e2 = ea[2 * K + s2];
+                const double f0 = eb[s2], f1 = eb[K + s2], f2 = eb[2 * K + s2];
+                const double add = (e0 * yb[0] + e1 * yb[1] + e2 * yb[2]) + (f0 * ya[0] + f1 * ya[1] + f2 * ya[2]) + t0 * (e0 * ebs[0] + e1 * ebs[1] + e2 * ebs[2]);
+                zc[s2] = fma(nu, add, zc[s2]);
+            }
+        }
+    }
+    // the workgroup's shape-shape columns / traces, added in group order
+    if (sl >= 1 && lane_on) {
+        double* zr = ZR + (size_t)gid * (K * K + K);
+#pragma unroll
+        for (int s2 = 0; s2 < (KC ? KC : AVT_MAX_SHAPE); ++s2) if (s2 < K) zr[s2 * K + (sl - 1)] = pair_on ? zc[s2] : 0.0;
+        zr[K * K + (sl - 1)] = pair_on ? yx : 0.0;
     }
     __syncthreads();
-    // ---------------- phase B0: per-joint partner sums
+    double* Zg = scr + mom_off_z(d) + (size_t)blockIdx.x * (K * K + K);
+    for (int e = t; e < K * K + K; e += 256) {
+        double a = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) a += ZR[(size_t)g * (K * K + K) + e];
+        Zg[e] = a;
+    }
+}
+
+static size_t pairpass_lds_bytes(const AvtDims& d) {
+    return sizeof(double) * ((size_t)mom_skel_doubles(d) + 16 * (size_t)(d.K * d.K + d.K)) + sizeof(int) * AVT_MAX_JOINTS + 64;
+}
+
+// =================================================================================================
+// k_assemble<KC, NTH>.  grid (1, frames).  The dense system of the frame's trial point from the
+// pair results (tools/moment_proto2.py::assemble, phases A' and B).  Everything here is latency, so every phase is many short
+// independent items; list walks go four entries at a time (the lists are padded with an index of an all-zero row).
+//   B-a  X16 -> LDS; data side (u_k, Dl_k, YF per joint); PR[k][s] = partner sums of the records; Z, sum tr W;
+//   B-b  XD_k pieces, per-joint partner sums PK;   B-c  subtree sums TK, TR;   B-d  every block of H.
+// =================================================================================================
+struct MomTab { const unsigned short *opk_start, *opk, *sub_start, *sub, *s2_start, *s2, *s2_jj; };
+__host__ __device__ inline int mom_tab_words(const AvtDims& d) { return (2 * (d.J + 1) + d.mom_nopk + d.mom_nsub + (d.mom_nb2 + 1) + d.mom_ns2l + d.mom_nb2 + 3) & ~3; }
+__host__ __device__ inline int mom_asm_doubles(const AvtDims& d) {
+    const int J = d.J, K = d.K;
+    return (2 * d.mom_np + 1) * 16 + 2 * (J + 1) * 16 + 2 * (J + 1) * K * 6 + J * 9 + J * 4 + J * K + (K * K + K) + 2 * K + 8;
+}
+
+#define MOM_ASM_NTH 1024     // threads of the assembly workgroup: every phase is latency, more items in flight is what helps
+#define MOM_MAXOPS 12      // ordered pairs per lever joint the unrolled partner sums cover in one go (longer lists loop)
+
+template <int KC, int NTH>
+__global__ __launch_bounds__(NTH) void k_assemble(DeviceModel dm, FrameBuffers fb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const AvtDims& d = dm.d;
+    const int f = blockIdx.y + fb.f0, t = threadIdx.x;
+    const int try_slot = 1 - fb.ctl[f].cur_slot;
+    const int J = d.J, K = KC ? KC : d.K, S1 = K + 1, NP = d.mom_np, NPSI = d.mom_npsi, P = d.P, HS = d.HS;
+    double* skm = (double*)smem;
+    double* X16 = skm + mom_skel_doubles(d);    // [2 NP + 1][16]
+    double* PK = X16 + (2 * NP + 1) * 16;       // [J + 1][16]  axial(sum W), sum Va, sum Vb, sum t0, axial(XD), Dl; row J: zeros
+    double* TK = PK + (J + 1) * 16;             // [J + 1][16]  subtree sums of PK
+    double* PR = TK + (J + 1) * 16;             // [J + 1][K][6]
+    double* TR = PR + (J + 1) * K * 6;          // [J + 1][K][6]
+    double* Uk = TR + (J + 1) * K * 6;          // [J][3][3] sum_s om_s Dphi_k[i][s][c]
+    double* XQ = Uk + J * 9;                    // [J][4] axial(XD_k), tr XD_k
+    double* YFk = XQ + J * 4;                   // [J][K]
+    double* ZS = YFk + J * K;                   // [K K + K]
+    double* YFs = ZS + K * K + K;               // [K]
+    double* misc = YFs + K;                     // [K + 8]
+    int* s_parent = (int*)(misc + K + 8);
+    unsigned short* tabm = (unsigned short*)(s_parent + AVT_MAX_JOINTS);
+    MomSkel sk;
+    mom_skel_from_prep<NTH>(d, fb.prep + ((size_t)f * 2 + try_slot) * d.prep_size, fb.ctl[f].centre, skm, s_parent, dm.parent, sk);
+    MomTab tb;
+    {
+        unsigned short* q = tabm;
+        auto put = [&](const int* src, int n) { unsigned short* dst = q; for (int e = t; e < n; e += NTH) dst[e] = (unsigned short)src[e]; q += n; return (const unsigned short*)dst; };
+        tb.opk_start = put(dm.mom_opk_start, J + 1); tb.opk = put(dm.mom_opk, d.mom_nopk); tb.sub_start = put(dm.mom_sub_start, J + 1);
+        tb.sub = put(dm.mom_sub, d.mom_nsub); tb.s2_start = put(dm.mom_s2_start, d.mom_nb2 + 1); tb.s2 = put(dm.mom_s2, d.mom_ns2l); tb.s2_jj = put(dm.mom_s2_jj, d.mom_nb2);
+    }
+    const double* scr = fb.mom_rec + (size_t)f * mom_frame_scratch(d);
+    const double* REC = scr + mom_off_rec(d);
+    const double* Zg = scr + mom_off_z(d);
+    const double* Df = fb.mom_D + (size_t)f * J * NPSI * 3;
+    double* Hout = fb.Hraw + ((size_t)f * 2 + try_slot) * HS * HS;
+    MPROBE(0);
+    for (int e = t; e < (2 * NP + 1) * 16; e += NTH) X16[e] = scr[e];
+    for (int e = t; e < 16; e += NTH) { PK[J * 16 + e] = 0.0; }
+    for (int e = t; e < K * 6; e += NTH) PR[(size_t)J * K * 6 + e] = 0.0;
+    for (int e = t; e < K * K + K; e += NTH) {           // the pair-pass workgroups' shape-shape columns / traces, in workgroup order
+        double a = 0.0;
+        for (int g = 0; g < mom_nwg(d); ++g) a += Zg[(size_t)g * (K * K + K) + e];
+        ZS[e] = a;
+    }
+    __syncthreads();      // skeleton tables, index lists
+    MPROBE(1);
+    // ---------------- B-a
+    for (int e = t; e < J * 9; e += NTH) {      // u_k[i][c] = sum_s om_s D_k[(i,s)][c]
+        const int k = e / 9, ic = e - 9 * k, i = ic / 3, c = ic - 3 * i;
+        const double* Dk = Df + (size_t)k * NPSI * 3 + (size_t)(S1 * i) * 3 + c;
+        double a = 0.0;
+        if (KC) {
+            double v[KC + 1];
+#pragma unroll
+            for (int s = 0; s <= KC; ++s) v[s] = Dk[3 * s];
+#pragma unroll
+            for (int s = 0; s <= KC; ++s) a = fma(sk.om[s], v[s], a);
+        } else {
+            for (int s = 0; s < S1; ++s) a = fma(sk.om[s], Dk[3 * s], a);
+        }
+        Uk[e] = a;
+    }
+    for (int e = t; e < J * 3; e += NTH) { const int k = e / 3, c = e - 3 * k; PK[16 * k + 13 + c] = Df[(size_t)k * NPSI * 3 + (size_t)(NPSI - 1) * 3 + c]; }
+    for (int e = t; e < J * K; e += NTH) {      // tr(R_k Dphi_k[s]) + eta_k,s . Dl_k
+        const int k = e / K, s = e - k * K;
+        const double* Dk = Df + (size_t)k * NPSI * 3;
+        const double* Rk = sk.Rw + 9 * k;
+        double v[12];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) v[3 * c + i] = Dk[(size_t)(S1 * i + s + 1) * 3 + c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[9 + c] = Dk[(size_t)(NPSI - 1) * 3 + c];
+        double q = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) q = fma(Rk[3 * c + i], v[3 * c + i], q);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) q = fma(sk.eta[((size_t)k * 3 + c) * K + s], v[9 + c], q);
+        YFk[e] = q;
+    }
+    for (int e = t; e < J * K * 6; e += NTH) {  // PR[k][s][.] = sum over the ordered pairs with lever joint k; all loads of an item in flight
+        const int k = e / (K * 6), r = e - k * K * 6;
+        const int lo = tb.opk_start[k], hi = tb.opk_start[k + 1];
+        double v[MOM_MAXOPS];
+#pragma unroll
+        for (int u = 0; u < MOM_MAXOPS; ++u) v[u] = REC[(size_t)tb.opk[max(min(lo + u, hi - 1), 0)] * K * 6 + r];
+        double a = 0.0;
+#pragma unroll
+        for (int u = 0; u < MOM_MAXOPS; ++u) a += lo + u < hi ? v[u] : 0.0;
+        for (int i = lo + MOM_MAXOPS; i < hi; ++i) a += REC[(size_t)tb.opk[i] * K * 6 + r];
+        PR[e] = hi > lo ? a : 0.0;
+    }
+    __syncthreads();      // X16, Uk
+    MPROBE(2);
+    // ---------------- B-b
     for (int e = t; e < J * 10; e += NTH) {      // PK[k][0..9]: axial(sum W) 3, sum Va 3, sum Vb 3, sum t0
         const int k = e / 10, q = e - 10 * k;
         double a = 0.0;
-        for (int i = dm.mom_opk_start[k]; i < dm.mom_opk_start[k + 1]; ++i) {
-            const double* x = X16 + (size_t)dm.mom_opk[i] * 16;
+        for (int i = tb.opk_start[k]; i < tb.opk_start[k + 1]; ++i) {
+            const double* x = X16 + (size_t)tb.opk[i] * 16;
             a += q == 0 ? x[5] - x[7] : (q == 1 ? x[6] - x[2] : (q == 2 ? x[1] - x[3] : x[9 + (q - 3)]));      // (q = 9: x[15] = t0)
         }
         PK[16 * k + q] = a;
     }
-    for (int e = t; e < J * 3; e += NTH) {
-        const int k = e / 3, c = e - 3 * k;
-        const double* X = XDt + 9 * k;
-        PK[16 * k + 10 + c] = c == 0 ? X[5] - X[7] : (c == 1 ? X[6] - X[2] : X[1] - X[3]);
+    for (int e = t; e < J * 4; e += NTH) {       // XD_k = R_k u_k + tau_k Dl_k^T: its axial vector (PK[10..12]) and trace
+        const int k = e >> 2, q = e & 3;
+        const double* Rk = sk.Rw + 9 * k;
+        const double* u = Uk + 9 * k;
+        const double* dl = PK + 16 * k + 13;
+        auto xd = [&](int r, int c) { return (Rk[3 * r] * u[c] + Rk[3 * r + 1] * u[3 + c] + Rk[3 * r + 2] * u[6 + c]) + sk.tau[3 * k + r] * dl[c]; };
+        const double v = q == 0 ? xd(1, 2) - xd(2, 1) : (q == 1 ? xd(2, 0) - xd(0, 2) : (q == 2 ? xd(0, 1) - xd(1, 0) : (xd(0, 0) + xd(1, 1)) + xd(2, 2)));
+        if (q < 3) PK[16 * k + 10 + q] = v;
+        XQ[e] = v;
     }
-    for (int e = t; e < J * K * 6; e += NTH) {
-        const int k = e / (K * 6), r = e - k * K * 6;
+    if (t < K) { double a = 0.0; for (int k = 0; k < J; ++k) a += YFk[k * K + t]; YFs[t] = a; }
+    if (t >= NTH - 64) {      // sum tr W over the ordered pairs, fixed order (one wave)
+        const int l = t - (NTH - 64);
         double a = 0.0;
-        for (int i = dm.mom_opk_start[k]; i < dm.mom_opk_start[k + 1]; ++i) a += mld(REC + (size_t)dm.mom_opk[i] * K * 6 + r);
-        PR[e] = a;
-    }
-    for (int e = t; e < d.mom_nm1 * 16; e += NTH) {      // rot-rot stage 1
-        const int id = e >> 4, q = e & 15;
-        double a = 0.0;
-        for (int i = dm.mom_m1_start[id]; i < dm.mom_m1_start[id + 1]; ++i) a += X16[(size_t)dm.mom_m1[i] * 16 + q];
-        M1[e] = a;
-    }
-    for (int e = t; e < K * K + K; e += NTH) {           // the groups' shape-shape columns / traces, in group order
-        double a = 0.0;
-        for (int g = 0; g < NG; ++g) a += ZR[(size_t)g * (K * K + K) + e];
-        if (e < K * K) ZR[e] = a; else YXs[e - K * K] = a;       // (group 0's slot is read by nobody else at index e before this write: one thread per e)
-    }
-    if (t == 0) {
-        double xx = 0.0, xf = 0.0;
-        for (int op = 0; op < 2 * NP; ++op) { const double* x = X16 + (size_t)op * 16; xx += (x[0] + x[4]) + x[8]; }
-        for (int k = 0; k < J; ++k) xf += (XDt[9 * k] + XDt[9 * k + 4]) + XDt[9 * k + 8];
-        misc[0] = xx - 2.0 * xf + fb.mom_E[(size_t)f * 2];
+        for (int op = l; op < 2 * NP; op += 64) { const double* x = X16 + (size_t)op * 16; a += (x[0] + x[4]) + x[8]; }
+        a = wave_sum(a);
+        if (l == 0) misc[1] = a;
     }
     __syncthreads();
-    // ---------------- phase B1: subtree sums
+    MPROBE(3);
+    // ---------------- B-c: subtree sums, four list entries at a time
     for (int e = t; e < J * 16; e += NTH) {
         const int j = e >> 4, q = e & 15;
         double a = 0.0;
-        for (int i = dm.mom_sub_start[j]; i < dm.mom_sub_start[j + 1]; ++i) a += PK[16 * dm.mom_sub[i] + q];
+        for (int i = tb.sub_start[j]; i < tb.sub_start[j + 1]; i += 4) {
+            const double v0 = PK[16 * tb.sub[i] + q], v1 = PK[16 * tb.sub[i + 1] + q], v2 = PK[16 * tb.sub[i + 2] + q], v3 = PK[16 * tb.sub[i + 3] + q];
+            a += (v0 + v1) + (v2 + v3);
+        }
         TK[e] = a;
     }
     for (int e = t; e < J * K * 6; e += NTH) {
         const int j = e / (K * 6), r = e - j * K * 6;
         double a = 0.0;
-        for (int i = dm.mom_sub_start[j]; i < dm.mom_sub_start[j + 1]; ++i) a += PR[(size_t)dm.mom_sub[i] * K * 6 + r];
+        for (int i = tb.sub_start[j]; i < tb.sub_start[j + 1]; i += 4) {
+            const double v0 = PR[(size_t)tb.sub[i] * K * 6 + r], v1 = PR[(size_t)tb.sub[i + 1] * K * 6 + r], v2 = PR[(size_t)tb.sub[i + 2] * K * 6 + r],
+                         v3 = PR[(size_t)tb.sub[i + 3] * K * 6 + r];
+            a += (v0 + v1) + (v2 + v3);
+        }
         TR[e] = a;
     }
+    if (t == 0) {
+        double xf = 0.0;
+        for (int k = 0; k < J; ++k) xf += XQ[4 * k + 3];
+        misc[0] = misc[1] - 2.0 * xf;      // (+ sum |d_i - centre|^2: the constant part, k_moments)
+    }
     __syncthreads();
-    // ---------------- phase B2: every block but rot-rot
+    MPROBE(4);
+    // ---------------- B-d: the blocks of H
     auto Hset = [&](int r, int c, double v) { Hout[(size_t)r * HS + c] = v; Hout[(size_t)c * HS + r] = v; };
     const int SH = 3 + 3 * J;
     if (t < 9) { const int r = t / 3, c = t - 3 * r; Hout[(size_t)r * HS + c] = r == c ? TK[9] : 0.0; }
@@ -534,119 +723,91 @@ __device__ __forceinline__ void mom_assemble(const DeviceModel& dm, const FrameB
         Hset(3 + 3 * j + c, SH + s, 2.0 * (a0 * v0 + a1 * v1 + a2 * v2));
     }
     for (int e = t; e < K * 3; e += NTH) { const int s = e / 3, c = e - 3 * s; Hset(SH + s, c, TR[(size_t)s * 6 + 3 + c]); }      // root's subtree = every joint
-    if (t < K) Hset(SH + t, P, YXs[t] - YFs[t]);
-    for (int e = t; e < K * K; e += NTH) { const int s = e / K, u = e - s * K; Hout[(size_t)(SH + s) * HS + SH + u] = ZR[s * K + u] + ZR[u * K + s]; }
-    // ---------------- rot-rot: stage 2 + blocks, one thread per (j <= j')
-    for (int b = t; b < d.mom_nb2; b += NTH) {
-        const int jj = dm.mom_s2_jj[b], j = jj & 0xff, jp = jj >> 8;
-        double S[16], Vt[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < 16; ++q) S[q] = 0.0;
-        for (int i = dm.mom_s2_start[2 * b]; i < dm.mom_s2_start[2 * b + 1]; ++i) {
-            const double* m1 = M1 + (size_t)dm.mom_s2[i] * 16;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) S[q] += m1[q];
+    if (t < K) Hset(SH + t, P, ZS[K * K + t] - YFs[t]);
+    for (int e = t; e < K * K; e += NTH) { const int s = e / K, u = e - s * K; Hout[(size_t)(SH + s) * HS + SH + u] = ZS[s * K + u] + ZS[u * K + s]; }
+    MPROBE(5);
+    // rot-rot.  Block (j <= j') = sum over the ordered pairs (k under j, k' under j') of X16; only the blocks with such pairs are
+    // listed (left leg against right arm: none), the others are structural zeros.  Phase 1: the sums, one item per (block, entry
+    // of X16), into the PR / TR area (free now); phase 2: one item per (block, matrix entry).
+    __syncthreads();
+    double* S16 = PR;      // [nb2][16]  (nb2 * 16 <= 2 (J + 1) K 6 is checked on the host)
+    for (int e = t; e < d.mom_nb2 * 16; e += NTH) {
+        const int b = e >> 4, q = e & 15;
+        double a = 0.0;
+        for (int i = tb.s2_start[b]; i < tb.s2_start[b + 1]; i += 4) {
+            const double v0 = X16[(size_t)tb.s2[i] * 16 + q], v1 = X16[(size_t)tb.s2[i + 1] * 16 + q], v2 = X16[(size_t)tb.s2[i + 2] * 16 + q], v3 = X16[(size_t)tb.s2[i + 3] * 16 + q];
+            a += (v0 + v1) + (v2 + v3);
         }
-        for (int i = dm.mom_s2_start[2 * b + 1]; i < dm.mom_s2_start[2 * b + 2]; ++i) {
-            const double* m1 = M1 + (size_t)dm.mom_s2[i] * 16;
-            Vt[0] += m1[9]; Vt[1] += m1[10]; Vt[2] += m1[11];
-        }
+        S16[e] = a;
+    }
+    for (int e = t; e < d.mom_nz2 * 9; e += NTH) {      // the structural zeros
+        const int b = e / 9, q = e - 9 * b, jj = dm.mom_z2_jj[b], j = jj & 0xff, jp = jj >> 8, r = q / 3, c = q - 3 * r;
+        Hout[(size_t)(3 + 3 * j + r) * HS + 3 + 3 * jp + c] = 0.0;
+        Hout[(size_t)(3 + 3 * jp + c) * HS + 3 + 3 * j + r] = 0.0;
+    }
+    __syncthreads();
+    for (int e = t; e < d.mom_nb2 * 9; e += NTH) {
+        const int b = e / 9, q = e - 9 * b;
+        const int jj = tb.s2_jj[b], j = jj & 0xff, jp = jj >> 8;
+        const double* S = S16 + b * 16;
         const double oj[3] = {sk.oc[3 * j], sk.oc[3 * j + 1], sk.oc[3 * j + 2]}, op[3] = {sk.oc[3 * jp], sk.oc[3 * jp + 1], sk.oc[3 * jp + 2]};
+        // LL = S.W - S.Va o_j'^T - o_j S.Vb^T + S.t0 o_j o_j'^T   (sum over the block of V_k'k = sum of Vb)
         double LL[9];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) LL[3 * r + c] = S[3 * r + c] - S[9 + r] * op[c] - oj[r] * Vt[c] + S[15] * oj[r] * op[c];
+            for (int c = 0; c < 3; ++c) LL[3 * r + c] = S[3 * r + c] - S[9 + r] * op[c] - oj[r] * S[12 + c] + S[15] * oj[r] * op[c];
         const double trL = (LL[0] + LL[4]) + LL[8];
-        double A[9], B[9];      // R_par(j), R_par(j')
         const int pj = sk.parent[j], pp = sk.parent[jp];
+        const int r = q / 3, c = q - 3 * r;
+        // entry (r, c) of 4 (tr(LL) A^T B - A^T LL^T B),  A = R_par(j), B = R_par(j')
+        double Ar[3], Bc[3];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            A[q] = pj < 0 ? ((q == 0 || q == 4 || q == 8) ? 1.0 : 0.0) : sk.Rw[9 * pj + q];
-            B[q] = pp < 0 ? ((q == 0 || q == 4 || q == 8) ? 1.0 : 0.0) : sk.Rw[9 * pp + q];
+        for (int i = 0; i < 3; ++i) {
+            Ar[i] = pj < 0 ? (i == r ? 1.0 : 0.0) : sk.Rw[9 * pj + 3 * i + r];
+            Bc[i] = pp < 0 ? (i == c ? 1.0 : 0.0) : sk.Rw[9 * pp + 3 * i + c];
         }
-        // blk = 4 (tr(LL) A^T B - A^T LL^T B)
-        double LtB[9];
+        const double atb = Ar[0] * Bc[0] + Ar[1] * Bc[1] + Ar[2] * Bc[2];
+        double atl = 0.0;
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) LtB[3 * r + c] = LL[r] * B[c] + LL[3 + r] * B[3 + c] + LL[6 + r] * B[6 + c];      // (LL^T B)[r][c]
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const double atb = A[r] * B[c] + A[3 + r] * B[3 + c] + A[6 + r] * B[6 + c];
-                const double atl = A[r] * LtB[c] + A[3 + r] * LtB[3 + c] + A[6 + r] * LtB[6 + c];
-                const double v = 4.0 * (trL * atb - atl);
-                if (j != jp || r <= c) {      // (a diagonal block: the upper triangle, mirrored - symmetric to the bit)
-                    Hout[(size_t)(3 + 3 * j + r) * HS + 3 + 3 * jp + c] = v;
-                    Hout[(size_t)(3 + 3 * jp + c) * HS + 3 + 3 * j + r] = v;
-                }
-            }
+        for (int i = 0; i < 3; ++i) {
+            const double ltb = LL[i] * Bc[0] + LL[3 + i] * Bc[1] + LL[6 + i] * Bc[2];      // (LL^T B)[i][c]
+            atl = fma(Ar[i], ltb, atl);
+        }
+        const double v = 4.0 * (trL * atb - atl);
+        if (j != jp || r <= c) {      // (a diagonal block: the upper triangle, mirrored - symmetric to the bit)
+            Hout[(size_t)(3 + 3 * j + r) * HS + 3 + 3 * jp + c] = v;
+            Hout[(size_t)(3 + 3 * jp + c) * HS + 3 + 3 * j + r] = v;
+        }
     }
-}
-
-// skeleton tables of the assembly from a prep block (avt_internal.h) in global memory
-template <int NTH>
-__device__ __forceinline__ void mom_skel_from_prep(const AvtDims& d, const double* __restrict__ prep, const double* centre, double* __restrict__ sk_mem,
-                                                   int* __restrict__ s_parent, const int* __restrict__ parent_g, MomSkel& sk) {
-    const int J = d.J, K = d.K, t = threadIdx.x;
-    double* Rw = sk_mem;                 // [9 J]
-    double* oc = Rw + 9 * J;             // [3 J]
-    double* tau = oc + 3 * J;            // [3 J]
-    double* eta = tau + 3 * J;           // [3 J K]
-    double* om = eta + 3 * J * K;        // [K + 1]
-    for (int e = t; e < 9 * J; e += NTH) Rw[e] = prep[prep_off_Rw(d) + e];
-    for (int e = t; e < 3 * J * K; e += NTH) eta[e] = prep[prep_off_G(d) + e];
-    for (int e = t; e < 3 * J; e += NTH) {
-        const int j = e / 3, r = e - 3 * j;
-        const double* Rj = prep + prep_off_Rw(d) + 9 * j;
-        const double* Jh = prep + prep_off_Jh(d) + 3 * j;
-        const double* off = prep + prep_off_off(d);
-        const double o = prep[prep_off_o(d) + e] - centre[r];
-        oc[e] = o;
-        tau[e] = o - (Rj[3 * r] * (Jh[0] + off[0]) + Rj[3 * r + 1] * (Jh[1] + off[1]) + Rj[3 * r + 2] * (Jh[2] + off[2]));
-    }
-    if (t <= K) om[t] = t == 0 ? 1.0 : prep[prep_off_w(d) + t - 1];
-    if (t < J) s_parent[t] = parent_g[t];
-    sk.Rw = Rw; sk.oc = oc; sk.tau = tau; sk.eta = eta; sk.om = om; sk.parent = s_parent;
-}
-__host__ __device__ inline int mom_skel_doubles(const AvtDims& d) { return ((15 * d.J + 3 * d.J * d.K + d.K + 1) + 1) & ~1; }
-
-// =================================================================================================
-// k_assemble.  grid (1 + GMM components, frames), block 256: workgroup 0 of a frame assembles the system of its TRIAL point
-// (the slot 1 - cur_slot, like k_eval + k_reduce did), the others evaluate the pose prior there (avt_prior.h).
-// =================================================================================================
-template <int KC>
-__global__ __launch_bounds__(256) void k_assemble(DeviceModel dm, FrameBuffers fb) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const AvtDims& d = dm.d;
-    const int f = blockIdx.y + fb.f0;
-    const int try_slot = 1 - fb.ctl[f].cur_slot;
-    if (blockIdx.x > 0) { prior_component(dm, fb, f, blockIdx.x - 1, try_slot, (double*)smem); return; }
-    double* skm = (double*)smem;
-    double* scr = skm + mom_skel_doubles(d);
-    int* s_parent = (int*)(scr + mom_scratch_doubles(d, 256));
-    MomSkel sk;
-    mom_skel_from_prep<256>(d, fb.prep + ((size_t)f * 2 + try_slot) * d.prep_size, fb.ctl[f].centre, skm, s_parent, dm.parent, sk);
-    __syncthreads();
-    mom_assemble<256, KC>(dm, fb, f, sk, scr, fb.Hraw + ((size_t)f * 2 + try_slot) * d.HS * d.HS);
+    MPROBE(6);
 }
 
 static size_t assemble_lds_bytes(const AvtDims& d) {
-    return sizeof(double) * ((size_t)mom_skel_doubles(d) + mom_scratch_doubles(d, 256)) + sizeof(int) * AVT_MAX_JOINTS + 64;
+    return sizeof(double) * ((size_t)mom_skel_doubles(d) + mom_asm_doubles(d)) + sizeof(int) * AVT_MAX_JOINTS + sizeof(unsigned short) * (size_t)mom_tab_words(d) + 64;
 }
 
 void launch_assemble(avt_ctx* c, int nframes) {
     const AvtDims& d = c->dm.d;
-    const dim3 grid(1 + d.ncomps, nframes);
-    const size_t lds = std::max(assemble_lds_bytes(d), sizeof(double) * 5 * AVT_MAX_JOINTS);
-    if (d.K == 10) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble<10>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble<0>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb);
+    {
+        const dim3 grid(mom_nwg(d) + d.ncomps, nframes);
+        const size_t lds = std::max(pairpass_lds_bytes(d), sizeof(double) * 5 * AVT_MAX_JOINTS);
+        if (d.K == 10) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairpass<10>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairpass<0>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb);
+    }
+    const dim3 grid(1, nframes);
+    const size_t lds = assemble_lds_bytes(d);
+    if (d.K == 10) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble<10, MOM_ASM_NTH>), grid, dim3(MOM_ASM_NTH), lds, c->cur_stream, c->dm, c->fb);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble<0, MOM_ASM_NTH>), grid, dim3(MOM_ASM_NTH), lds, c->cur_stream, c->dm, c->fb);
 }
+
+size_t avt_moments_frame_scratch(const AvtDims& d) { return mom_frame_scratch(d); }
+size_t avt_moments_T_doubles(const AvtDims& d) { return (size_t)d.mom_np * tri_size(d.mom_npsi); }
 
 int avt_moments_set_attributes() {
     const int cap = 160 * 1024 - 512;
-    return hipFuncSetAttribute((const void*)k_assemble<10>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
-           hipFuncSetAttribute((const void*)k_assemble<0>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess;
+    return hipFuncSetAttribute((const void*)k_assemble<10, MOM_ASM_NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_assemble<0, MOM_ASM_NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_pairpass<10>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_pairpass<0>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess;
 }

@@ -36,9 +36,15 @@ __device__ __forceinline__ void prior_component(const DeviceModel& dm, const Fra
     for (int a0 = 0; a0 < n; a0 += 64) {
         const int a = a0 + (t >> 2), sub = t & 3;
         double sacc = 0.0;
-        if (a < n) {
+        if (a < n) {      // (eight loads of the row in flight at a time: the workgroup is one L2 round trip after another)
             const double* Pr = dm.prior_prec + ((size_t)c * n + a) * n;
-            for (int b = sub; b < n; b += 4) sacc += Pr[b] * s_x[b];
+            for (int b0 = sub; b0 < n; b0 += 32) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = Pr[min(b0 + 4 * u, n - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sacc += b0 + 4 * u < n ? v[u] * s_x[b0 + 4 * u] : 0.0;
+            }
         }
         sacc += __shfl_xor(sacc, 1, 64);
         sacc += __shfl_xor(sacc, 2, 64);

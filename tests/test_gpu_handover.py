@@ -14,6 +14,14 @@ pytestmark = pytest.mark.gpu
 SEEDS = {1: (4,), 2: (5, 6), 3: (0, 5, 8)}
 
 
+def _ctx(api, gmodel, pm, F):
+    """The hand-over belongs to the ROW form of the data term (k_eval's partial tiles reduced inside k_solve's launch); the moment
+    form, the default, has no partial tiles and no hand-over."""
+    ctx = api.Context(gmodel, 24, pm, 60000, F)
+    ctx.set_data_term(ctx.DATA_TERM_ROWS)
+    return ctx
+
+
 def _run(ctx, api, frames, opt):
     p, q, w, st = ctx.optimize_batch([f["data"] for f in frames], [f["labels"] for f in frames], opt,
                                      np.array([f["start"][1] for f in frames]), np.array([api.rot_to_quat(f["start"][2]) for f in frames]),
@@ -30,10 +38,10 @@ def test_a_solver_that_gives_up_waiting_is_an_error_not_a_different_fit(smpl, gm
     faults = clean = 0
     for F in (1, 2, 3):
         frames = [synth.make_frame(smpl, s) for s in SEEDS[F]]
-        good = _run(api.Context(gmodel, 24, pm, 60000, F), api, frames, opt)
+        good = _run(_ctx(api, gmodel, pm, F), api, frames, opt)
         os.environ["AVT_RIDE_TIMEOUT_US"] = "0"
         try:
-            ctx = api.Context(gmodel, 24, pm, 60000, F)
+            ctx = _ctx(api, gmodel, pm, F)
         finally:
             os.environ.pop("AVT_RIDE_TIMEOUT_US", None)
         for _ in range(4):
@@ -48,7 +56,7 @@ def test_a_solver_that_gives_up_waiting_is_an_error_not_a_different_fit(smpl, gm
     assert faults > 0, "the timeout path was never taken: the test does not exercise it"
     # a fault is reported once and cleared: an ordinary context on the same device is unaffected
     frames = [synth.make_frame(smpl, s) for s in SEEDS[1]]
-    ctx = api.Context(gmodel, 24, pm, 60000, 1)
+    ctx = _ctx(api, gmodel, pm, 1)
     assert np.array_equal(_run(ctx, api, frames, opt), _run(ctx, api, frames, opt))
 
 
@@ -66,7 +74,7 @@ def test_few_frame_shapes_under_compute_pressure_from_another_stream(smpl, gmode
     reported = 0
     for F in (1, 2, 3):
         frames = [synth.make_frame(smpl, s) for s in SEEDS[F]]
-        ctx = api.Context(gmodel, 24, pm, 60000, F)
+        ctx = _ctx(api, gmodel, pm, F)
         good = _run(ctx, api, frames, opt)
         for rep in range(3):
             with torch.cuda.stream(side):
