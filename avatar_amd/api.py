@@ -388,7 +388,7 @@ class Context:
         _check(self._lib.avt_get_normal_equations(self.h, C.c_int(frame), dptr(H), dptr(g), C.byref(cost)))
         return H, g, cost.value
 
-    DATA_TERM_ROWS, DATA_TERM_MOMENTS = 0, 1
+    DATA_TERM_ROWS, DATA_TERM_MOMENTS, DATA_TERM_AUTO = 0, 1, 2
 
     def set_data_term(self, form):
         """How the ICP data term of a GN iteration is evaluated (include/avt.h: AVT_DATA_TERM_ROWS / AVT_DATA_TERM_MOMENTS)."""

@@ -157,6 +157,7 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
             // Moment form (avt_moments.hip): the correspondences' sufficient statistics once per ICP iteration, then every GN iteration
             // assembles its normal equations from them - no Jacobian rows, no partial tiles, no reduction.
             { ProfScope ps(c, AVT_K_AGGREGATE); launch_finalize(c, nf); c->fb.const_used = (c->launch_maxN + 2047) / 2048; launch_moments(c, nf); }
+            c->have_moments = true; c->have_records = false;
             if (!fuse_init) { ProfScope ps(c, AVT_K_PREPARE); launch_solve(c, nf, SOLVE_INIT); }
             { ProfScope ps(c, AVT_K_EVAL); launch_assemble(c, nf); }
             for (int it = 1; it <= std::max(1, o->max_iters_per_icp); ++it) {
@@ -172,6 +173,7 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
             continue;
         }
         { ProfScope ps(c, AVT_K_AGGREGATE); launch_finalize(c, nf); launch_records(c, nf); }
+        c->have_records = true; c->have_moments = false;
         if (!fuse_init) { ProfScope ps(c, AVT_K_PREPARE); launch_solve(c, nf, SOLVE_INIT); }
         const bool rides = avt_solve_rides(c, nf);        // few frames: the reduction is part of the solve's launch
         { ProfScope ps(c, AVT_K_EVAL); launch_eval(c, nf, false); }
@@ -220,11 +222,15 @@ int run_optimize(avt_ctx* c, const avt_options* o) {
     if (o->max_iters_per_icp < 0 || o->max_iters_per_icp > 62 || o->icp_iters < 0) { avt_set_error("avt_optimize: bad iteration counts"); return 1; }
     if (sync_params(c, o)) return 1;
     c->ran_max_iters = o->max_iters_per_icp;
-    c->ran_moments_only = false;
     // Large batches run as several frame groups: the latency-bound single-workgroup-per-frame kernels of one group
     // (k_solve, k_finalize, k_reduce) overlap the throughput kernels (k_eval, k_nn) of the others on separate streams.
     // The instrumented (profiling) path keeps the SAME groups and launch shapes and runs them one after the other on
     // the main stream, so that per-launch timings describe the launches the graph replays.
+    {   // which form of the data term this call runs (include/avt.h): the moment form pays from ~100 frames per launch on
+        const int g0 = choose_groups(nf), per_launch = (nf + g0 - 1) / g0;
+        c->fb.use_moments = c->dm.d.mom_ok && (c->data_term == AVT_DATA_TERM_MOMENTS || (c->data_term == AVT_DATA_TERM_AUTO && per_launch >= c->mom_min_frames));
+        c->last_run_moments = c->fb.use_moments != 0;
+    }
     const int ngroups = plan_groups(c, nf);
     const int nfg = (nf + ngroups - 1) / ngroups;       // frames per group (the last group may be smaller)
     c->fb.G = choose_G(nfg, ngroups);
@@ -438,7 +444,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
     c->graph_clock = 0;
     c->params_valid = false;
     c->frames_valid = c->state_valid = false;
-    c->ran_moments_only = false;
+    c->have_moments = c->have_records = false;
     c->concurrent_groups = 1;
     c->render_zkey = nullptr; c->render_label = nullptr; c->render_block = nullptr; c->render_cap_pix = c->render_cap_blk = 0;
     c->render_mkey = nullptr; c->render_depth = nullptr; c->render_fkey = nullptr; c->render_frank = nullptr; c->render_fedge = nullptr;
@@ -521,9 +527,10 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
             dev_alloc(c, &fb.mom_E, (size_t)max_frames * 2) || dev_alloc(c, &fb.mom_rec, (size_t)max_frames * avt_moments_frame_scratch(d)))
             return 1;
         HIP_OK(hipMemsetAsync(fb.mom_D, 0, (size_t)max_frames * J * d.mom_npsi * 3 * sizeof(double), c->stream));      // joints no vertex is assigned to keep zeros
-        fb.use_moments = 1;
-        if (const char* e = getenv("AVT_DATA_TERM")) fb.use_moments = strcmp(e, "rows") != 0;
     }
+    c->data_term = AVT_DATA_TERM_AUTO;
+    c->mom_min_frames = 96;          // frames per launch from which the moment form wins (32 per launch: level, 256: -20 % step time)
+    c->last_run_moments = false;
     {
         AvtRunParams* pr = nullptr;
         if (dev_alloc(c, &pr, 1)) return 1;
@@ -878,11 +885,16 @@ int avt_get_normal_equations(avt_ctx* c, int frame, double* H, double* g, double
     c->fb.G = choose_G(c->nframes);
     c->fb.f0 = 0;
     c->cur_stream = c->stream;
+    // the form of the data term: the one selected (AUTO: the one the last optimize() ran); what that form needs of the resident
+    // correspondences - moments or matched-point records - is made here if the last optimize() ran the other form
+    const bool want_mom = c->dm.d.mom_ok && (c->data_term == AVT_DATA_TERM_MOMENTS || (c->data_term == AVT_DATA_TERM_AUTO && c->last_run_moments));
+    c->fb.use_moments = want_mom;
     launch_solve(c, c->nframes, SOLVE_INIT);
-    if (c->fb.use_moments) {      // (the moments of the last ICP iteration's correspondences are still resident)
+    if (want_mom) {
+        if (!c->have_moments) { c->fb.const_used = (c->launch_maxN + 2047) / 2048; launch_moments(c, c->nframes); c->have_moments = true; }
         launch_assemble(c, c->nframes);
     } else {
-        if (c->ran_moments_only) { launch_records(c, c->nframes); c->ran_moments_only = false; }      // the last optimize() made moments, not records
+        if (!c->have_records) { c->fb.const_used = (c->launch_maxN + 255) / 256; launch_records(c, c->nframes); c->have_records = true; }
         launch_eval(c, c->nframes, false);
         launch_reduce(c, c->nframes);
     }
@@ -905,24 +917,13 @@ int avt_get_normal_equations(avt_ctx* c, int frame, double* H, double* g, double
 }
 
 int avt_set_data_term(avt_ctx* c, int form) {
-    if (!c || (form != AVT_DATA_TERM_ROWS && form != AVT_DATA_TERM_MOMENTS)) { avt_set_error("avt_set_data_term: bad argument"); return 1; }
+    if (!c || (form != AVT_DATA_TERM_ROWS && form != AVT_DATA_TERM_MOMENTS && form != AVT_DATA_TERM_AUTO)) { avt_set_error("avt_set_data_term: bad argument"); return 1; }
     if (form == AVT_DATA_TERM_MOMENTS && !c->dm.d.mom_ok) { avt_set_error("avt_set_data_term: this model has no moment form (K + 1 <= 16 and 3 + 3J + K <= 87 required)"); return 1; }
-    HIP_OK(hipSetDevice(c->device));
-    HIP_OK(hipStreamSynchronize(c->stream));
-    if (form == AVT_DATA_TERM_ROWS && c->fb.use_moments && c->ran_icp_iters > 0) c->ran_moments_only = true;
-    if (form == AVT_DATA_TERM_MOMENTS && !c->fb.use_moments && c->ran_icp_iters > 0 && c->frames_valid && c->state_valid) {
-        // the resident correspondences have no moments yet: make them now, so that avt_get_normal_equations can compare the two forms
-        c->fb.f0 = 0; c->cur_stream = c->stream;
-        c->fb.const_used = (c->launch_maxN + 2047) / 2048;
-        launch_moments(c, c->nframes);
-        if (check_launch("avt_set_data_term")) return 1;
-        HIP_OK(hipStreamSynchronize(c->stream));
-    }
-    c->fb.use_moments = form == AVT_DATA_TERM_MOMENTS;
+    c->data_term = form;
     return 0;
 }
 
-int avt_get_data_term(avt_ctx* c) { return c ? c->fb.use_moments : -1; }
+int avt_get_data_term(avt_ctx* c) { return c ? c->data_term : -1; }
 
 int avt_debug_trace(avt_ctx* c, int frame, double* out64) {
     if (!c || !out64 || frame < 0 || frame >= c->fb.max_frames) { avt_set_error("avt_debug_trace: bad argument"); return 1; }

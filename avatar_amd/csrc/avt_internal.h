@@ -326,7 +326,10 @@ struct avt_ctx {
     AvtRunParams params_host;        // what fb.params currently holds
     bool params_valid;
     bool frames_valid, state_valid;  // resident frames / start state usable by avt_optimize_resident
-    bool ran_moments_only;           // the last optimize() ran the moment form: no matched-point records exist for its correspondences
+    int data_term;                   // AVT_DATA_TERM_* policy (avt_set_data_term)
+    int mom_min_frames;              // AUTO: frames per launch from which the moment form is used
+    bool last_run_moments;           // the form the last optimize() ran
+    bool have_moments, have_records; // what exists for the resident correspondences (avt_get_normal_equations makes the other on demand)
     int concurrent_groups;           // frame groups the current optimize() call runs side by side (sizes the riding launch shapes)
     // persistent scratch of avt_synth_render_frames (z-buffer keys, labels, block counts), grown on demand
     unsigned long long* render_zkey; unsigned char* render_label; int* render_block; size_t render_cap_pix; size_t render_cap_blk;

@@ -80,10 +80,12 @@ def test_moments_batch_matches_single(smpl, gmodel):
     starts = [_start(fr) for fr in frs]
     opt = Options.demo(max_iters_per_icp=6)
     ctx = api.Context(gmodel, 24, pm, 60000, len(frs))
-    assert ctx.data_term() == 1
+    assert ctx.data_term() == ctx.DATA_TERM_AUTO
+    ctx.set_data_term(ctx.DATA_TERM_MOMENTS)
     P, Q, W, st = ctx.optimize_batch([fr["data"] for fr in frs], [fr["labels"] for fr in frs], opt, np.array([s[0] for s in starts]),
                                      np.array([s[1] for s in starts]), np.array([s[2] for s in starts]))
     one = api.Context(gmodel, 24, pm, 60000, 1)
+    one.set_data_term(one.DATA_TERM_MOMENTS)
     for i, fr in enumerate(frs):
         p, q, w, s1 = one.optimize_batch([fr["data"]], [fr["labels"]], opt, starts[i][0][None], starts[i][1][None], starts[i][2][None])
         assert np.array_equal(p[0], P[i]) and np.array_equal(q[0], Q[i]) and np.array_equal(w[0], W[i])
