@@ -601,7 +601,8 @@ __global__ __launch_bounds__(256) void k_compact(DeviceModel dm, FrameBuffers fb
     __shared__ int s_run;
     struct __attribute__((aligned(16))) Ent { double y; int vid; int slot; };
     __shared__ Ent s_ent[NN_SORT_CAP];            // sort_y: the part's visible candidates (y, vertex id, slot of its x and z below)
-    __shared__ double s_xz[2 * NN_SORT_CAP];      // x and z of the candidates in compaction order (gathered once, in pass 0)
+    // (x and z are gathered a second time when the sorted candidates are written: keeping them here as well cost 16 KB of LDS, i.e. the
+    // fourth to sixth workgroup of a CU - the kernel is dependent round trips, so what it has resident is what it runs at)
     if (t == 0) s_run = 0;
     __syncthreads();
     const unsigned char* vis = fb.visible + (size_t)f * V;
@@ -656,8 +657,8 @@ __global__ __launch_bounds__(256) void k_compact(DeviceModel dm, FrameBuffers fb
             double x, y, z;
             if (from_cloud) { const double* cl = fb.cloud + ((size_t)f * V + v) * 3; x = cl[0]; y = cl[1]; z = cl[2]; }
             else { x = fb.pcx[(size_t)f * V + pos]; y = fb.pcy[(size_t)f * V + pos]; z = fb.pcz[(size_t)f * V + pos]; }
-            s_ent[i] = Ent{y, v, i};
-            s_xz[2 * i] = x; s_xz[2 * i + 1] = z;
+            s_ent[i] = Ent{y, v, pos};
+            (void)x; (void)z;
         }
         // bitonic sort by (y, vertex id) in LDS, padded to a power of two with +inf keys (a rank sort - every element counting
         // the elements in front of it - is simpler but quadratic: 62 us against 8 for the 32-frame launch with parts of 900)
@@ -686,7 +687,10 @@ __global__ __launch_bounds__(256) void k_compact(DeviceModel dm, FrameBuffers fb
         for (int i = t; i < n; i += 256) {
             const Ent me = s_ent[i];
             const size_t o = (size_t)f * V + b + i;
-            fb.vcx[o] = s_xz[2 * me.slot]; fb.vcy[o] = me.y; fb.vcz[o] = s_xz[2 * me.slot + 1];
+            double x, z;
+            if (from_cloud) { const double* cl = fb.cloud + ((size_t)f * V + me.vid) * 3; x = cl[0]; z = cl[2]; }
+            else { x = fb.pcx[(size_t)f * V + me.slot]; z = fb.pcz[(size_t)f * V + me.slot]; }
+            fb.vcx[o] = x; fb.vcy[o] = me.y; fb.vcz[o] = z;
             fb.vcid[o] = me.vid;
         }
     }
