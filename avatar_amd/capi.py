@@ -40,7 +40,7 @@ class Options(C.Structure):
     _fields_ = [
         ("beta_pose", C.c_double), ("beta_shape", C.c_double),
         ("nn_step", C.c_int), ("max_iters_per_icp", C.c_int), ("enable_occlusion", C.c_int),
-        ("icp_iters", C.c_int), ("num_threads", C.c_int), ("reserved0", C.c_int),
+        ("icp_iters", C.c_int), ("num_threads", C.c_int), ("lm_policy", C.c_int),
         ("lm_lambda0", C.c_double), ("lm_up", C.c_double), ("lm_down", C.c_double),
         ("lm_lambda_min", C.c_double), ("lm_lambda_max", C.c_double),
     ]
@@ -49,7 +49,7 @@ class Options(C.Structure):
     def reference_defaults(cls):
         """AvatarOptimizer.h:28-39 member defaults + the LM step-rule defaults."""
         return cls(beta_pose=0.1, beta_shape=1.0, nn_step=20, max_iters_per_icp=10, enable_occlusion=1,
-                   icp_iters=1, num_threads=4, reserved0=0, lm_lambda0=1e-3, lm_up=4.0, lm_down=1.0 / 3.0,
+                   icp_iters=1, num_threads=4, lm_policy=0, lm_lambda0=1e-3, lm_up=4.0, lm_down=1.0 / 3.0,
                    lm_lambda_min=1e-12, lm_lambda_max=1e8)
 
     @classmethod

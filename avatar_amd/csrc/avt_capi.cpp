@@ -204,7 +204,7 @@ int sync_params(avt_ctx* c, const avt_options* o) {
     AvtRunParams pr;
     std::memset(&pr, 0, sizeof pr);
     pr.beta_pose = o->beta_pose; pr.beta_shape = o->beta_shape; pr.lambda0 = o->lm_lambda0;
-    pr.lm_up = o->lm_up; pr.lm_down = o->lm_down; pr.lm_min = o->lm_lambda_min; pr.lm_max = o->lm_lambda_max;
+    pr.lm_up = o->lm_up; pr.lm_down = o->lm_down; pr.lm_min = o->lm_lambda_min; pr.lm_max = o->lm_lambda_max; pr.lm_policy = o->lm_policy == 1 ? 1.0 : 0.0;
     if (c->params_valid && std::memcmp(&pr, &c->params_host, sizeof pr) == 0) return 0;
     c->params_host = pr;
     HIP_OK(hipMemcpyAsync((void*)c->fb.params, &c->params_host, sizeof pr, hipMemcpyHostToDevice, c->stream));
@@ -220,6 +220,7 @@ int run_optimize(avt_ctx* c, const avt_options* o) {
     if (nf <= 0 || !c->frames_valid) { avt_set_error("avt_optimize: no frames resident (upload frames first; the stand-alone entry points avt_nn / avt_visibility / avt_lbs_update invalidate them)"); return 1; }
     if (!c->state_valid) { avt_set_error("avt_optimize: no start state resident for these frames (avt_state_upload)"); return 1; }
     if (o->max_iters_per_icp < 0 || o->max_iters_per_icp > 62 || o->icp_iters < 0) { avt_set_error("avt_optimize: bad iteration counts"); return 1; }
+    if (o->lm_policy != 0 && o->lm_policy != 1) { avt_set_error("avt_optimize: lm_policy must be 0 (fixed factors) or 1 (gain ratio)"); return 1; }
     if (sync_params(c, o)) return 1;
     c->ran_max_iters = o->max_iters_per_icp;
     // Large batches run as several frame groups: the latency-bound single-workgroup-per-frame kernels of one group
@@ -529,7 +530,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         HIP_OK(hipMemsetAsync(fb.mom_D, 0, (size_t)max_frames * J * d.mom_npsi * 3 * sizeof(double), c->stream));      // joints no vertex is assigned to keep zeros
     }
     c->data_term = AVT_DATA_TERM_AUTO;
-    c->mom_min_frames = 96;          // frames per launch from which the moment form wins (32 per launch: level, 256: -20 % step time)
+    c->mom_min_frames = 60;          // frames per launch from which the moment form wins (tools/data_term_sweep.sh: 32 per launch 1.39 against 1.21 ms, 64: 1.86 / 1.91, 96: 2.34 / 2.94, 256: 5.25 / 6.41)
     c->last_run_moments = false;
     {
         AvtRunParams* pr = nullptr;

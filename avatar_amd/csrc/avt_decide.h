@@ -16,10 +16,10 @@ struct LastDecisionInputs {
     double v[AVT_G_MAX / 64];                  // this lane's partial sums of sum c|r|^2 of the trial point (workgroups lane, lane + 64, ..) ...
     unsigned long long m[AVT_G_MAX / 64];      // ... and the written-masks of the workgroups they come from
     double pv;                                 // this lane's prior score / shape coefficient (above)
-    unsigned cw;                               // lane l < 32: 32-bit word l of the frame's control block; lanes 32..47: of AvtRunParams
+    unsigned cw;                               // lane l < 40: 32-bit word l of the frame's control block; lanes 40..55: of AvtRunParams
 };
 static_assert(AVT_MAX_COMPS == 16 && AVT_MAX_SHAPE == 16, "lane layout of LastDecisionInputs::pv");
-static_assert(sizeof(AvtFrameCtl) == 128 && sizeof(AvtRunParams) == 64, "lane layout of LastDecisionInputs::cw");
+static_assert(sizeof(AvtFrameCtl) == 160 && sizeof(AvtRunParams) == 64, "lane layout of LastDecisionInputs::cw");
 
 __device__ __forceinline__ LastDecisionInputs lm_last_load(const DeviceModel& dm, const FrameBuffers& fb, int f) {
     const AvtDims& d = dm.d;
@@ -40,7 +40,7 @@ __device__ __forceinline__ LastDecisionInputs lm_last_load(const DeviceModel& dm
     const double* src = is_prior ? fb.prior + (((size_t)f * 2 + sl) * AVT_MAX_COMPS + (there ? c : 0)) * AVT_PRIOR_STRIDE
                                  : fb.x + ((size_t)f * 2 + sl) * xs + 3 + 4 * J + (there ? c : 0);
     in.pv = *src;
-    const unsigned* cws = lane < 32 ? (const unsigned*)(fb.ctl + f) + lane : (const unsigned*)fb.params + (lane & 15);
+    const unsigned* cws = lane < 40 ? (const unsigned*)(fb.ctl + f) + lane : (const unsigned*)fb.params + ((lane - 40) & 15);
     in.cw = *cws;
     return in;
 }
@@ -57,11 +57,13 @@ __device__ __forceinline__ int lm_last_decide(const DeviceModel& dm, const Frame
     auto cword = [&](int w) { return __builtin_amdgcn_readlane((int)in.cw, w); };
     auto cdbl = [&](int w) { return __hiloint2double(cword(w + 1), cword(w)); };
 #define AVT_CTL_W(field) ((int)(offsetof(AvtFrameCtl, field) / 4))
-#define AVT_PAR_W(field) (32 + (int)(offsetof(AvtRunParams, field) / 4))
+#define AVT_PAR_W(field) (40 + (int)(offsetof(AvtRunParams, field) / 4))
     const double sbp = cdbl(AVT_CTL_W(sbp)), sbs = cdbl(AVT_CTL_W(sbs)), cost_cur0 = cdbl(AVT_CTL_W(dec_cost_cur)), cost_const = cdbl(AVT_CTL_W(cost_const));
     double lambda = cdbl(AVT_CTL_W(dec_lambda));
+    const double pred0 = cdbl(AVT_CTL_W(dec_pred)), nu0 = cdbl(AVT_CTL_W(dec_nu));
     const int cur0 = cword(AVT_CTL_W(dec_cur_slot)), try_valid = cword(AVT_CTL_W(dec_try_valid));
     const double lm_up = cdbl(AVT_PAR_W(lm_up)), lm_down = cdbl(AVT_PAR_W(lm_down)), lm_min = cdbl(AVT_PAR_W(lm_min)), lm_max = cdbl(AVT_PAR_W(lm_max));
+    const bool gain = cdbl(AVT_PAR_W(lm_policy)) != 0.0;
 #undef AVT_CTL_W
 #undef AVT_PAR_W
     // a workgroup without batches wrote nothing: its tile is stale memory
@@ -100,8 +102,16 @@ __device__ __forceinline__ int lm_last_decide(const DeviceModel& dm, const Frame
         cost += 0.5 * s;
     }
     bool accepted = false;
-    if (try_valid) {
-        if (cost < cost_cur0) { accepted = true; lambda = fmax(lambda * lm_down, lm_min); }
+    double nu = nu0;
+    if (try_valid) {      // the same rule as k_solve's (avt_lm.hip)
+        if (cost < cost_cur0) {
+            accepted = true;
+            if (gain) {
+                const double u = 2.0 * ((cost_cur0 - cost) / pred0) - 1.0;
+                lambda = fmin(fmax(lambda * fmax(1.0 / 3.0, 1.0 - u * u * u), lm_min), lm_max);
+                nu = 2.0;
+            } else lambda = fmax(lambda * lm_down, lm_min);
+        } else if (gain) { lambda = fmin(lambda * nu, lm_max); nu *= 2.0; }
         else lambda = fmin(lambda * lm_up, lm_max);
     }
     if (writer) {
@@ -110,7 +120,7 @@ __device__ __forceinline__ int lm_last_decide(const DeviceModel& dm, const Frame
         const int it = ctl.gn_iterations + 1;
         ctl.gn_iterations = it;
         if (it < 40) fb.trace[(size_t)f * 64 + it] = cost_cur;
-        ctl.lambda = lambda;
+        ctl.lambda = lambda; ctl.nu = nu;
     }
     return accepted ? try0 : cur0;
 }

@@ -375,10 +375,10 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 1) void k_eval(DeviceModel dm,
     const int M = ctl.M;
     const int try_slot = 1 - ctl.cur_slot;
     if (!COST && g == G - 1 && t < 64) {      // what the solver roles of the k_solve launch behind this one decide on (AvtSolveSnap); the last workgroup of a frame has the fewest batches
-        static_assert(sizeof(AvtFrameCtl) == 128 && sizeof(AvtSpecCtl) == 56, "snapshot copy below");
+        static_assert(sizeof(AvtFrameCtl) == 160 && sizeof(AvtSpecCtl) == 88, "snapshot copy below");
         double* sn = (double*)(fb.snap + f);
-        if (t < 16) sn[t] = ((const double*)&ctl)[t];
-        else if (t < 23) sn[t] = ((const double*)(fb.spec + f))[t - 16];
+        if (t < 20) sn[t] = ((const double*)&ctl)[t];
+        else if (t < 31) sn[t] = ((const double*)(fb.spec + f))[t - 20];
         else if (t >= 32 && t < 32 + K) fb.snap[f].xw[t - 32] = fb.x[((size_t)f * 2 + try_slot) * d.xsize + 3 + 4 * J + (t - 32)];
     }
     const int nb = (M + AVT_EVAL_PTS - 1) / AVT_EVAL_PTS;

@@ -124,6 +124,10 @@ struct AvtFrameCtl {
     // rewrites the fields above, so the inputs live in fields nobody writes during that launch.
     int dec_cur_slot, dec_try_valid;
     double dec_cost_cur, dec_lambda;
+    // gain-ratio damping schedule (avt_options::lm_policy = 1): the decrease the quadratic model predicts for the trial point,
+    // 1/2 delta^T (lambda D delta - g), and the factor the next rejection multiplies lambda by (Nielsen: 2, 4, 8 .. in a run of
+    // rejections); dec_*: the copies the accept test of the last trial point reads
+    double pred, nu, dec_pred, dec_nu;
 };
 
 // the knobs of optimize() the kernels read (avt_options), kept in device memory so that they are not baked into the
@@ -136,6 +140,7 @@ struct AvtSpecCtl {
     int next, n;                   // next speculative step to use, how many the last full solve launch made
     int valid[AVT_MAX_SPEC];       // its factorisation succeeded
     double lambda[AVT_MAX_SPEC];   // the damping it was made with (= what the accept test would have set)
+    double pred[AVT_MAX_SPEC];     // the decrease its quadratic model predicts (gain-ratio schedule)
 };
 
 // What the solver roles of a riding k_solve launch decide on (avt_lm.hip): the control block, the speculative-step queue and the
@@ -153,7 +158,7 @@ struct AvtSolveSnap {
 #define AVT_FAULT_RIDE_TIMEOUT 1u   // a solver role of a riding k_solve launch gave up waiting for the reduction workgroups of its launch
 
 struct AvtRunParams {
-    double beta_pose, beta_shape, lambda0, lm_up, lm_down, lm_min, lm_max, pad;
+    double beta_pose, beta_shape, lambda0, lm_up, lm_down, lm_min, lm_max, lm_policy;      // lm_policy: avt_options::lm_policy as a double (0 / 1)
 };
 
 struct DeviceModel {

@@ -355,6 +355,7 @@ __global__ __launch_bounds__(1024) void k_finalize(DeviceModel dm, FrameBuffers 
         ctl.sbs = beta_shape * sqrt((double)total_t) / 15.0;
         if (first_icp) {
             ctl.lambda = lambda0;
+            ctl.nu = 2.0; ctl.pred = 0.0;
             ctl.gn_iterations = 0;
             ctl.accepted = 0;
         }

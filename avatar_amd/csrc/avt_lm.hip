@@ -665,7 +665,8 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     double* s_PB = Lblk + nblk * 18;                        // [96 or 192][4] the four panel columns of a round
     double* s_W = s_PB + (TRI ? MFG_PB_DOUBLES : MF_PB_DOUBLES);         // [max(HS, 4J) + 2]  reciprocal pivots, later the new quaternions
     double* s_delta = s_W + ((max(HS, 4 * J) + 3) & ~1);    // [HS]
-    double* s_x = s_delta + HS + 2;                         // [2][xsize] both state slots
+    double* s_gD = s_delta + HS + 2;                        // [2][HS] gradient and diagonal of the undamped system (predicted decrease of the step, gain-ratio schedule)
+    double* s_x = s_gD + 2 * HS;                            // [2][xsize] both state slots
     const PrepLayout L = prep_layout(J, K, d.xsize);
     // skeleton scratch: behind the factor (SMPL shape: staged at kernel start, hidden behind the factorisation) or ON it
     // (triangular shape: the factor is dead once the back substitution is done)
@@ -788,13 +789,15 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     }
     const double hpp0 = hload(H0 + (size_t)P * HS + P), hpp1 = hload(H0 + (size_t)HS * HS + (size_t)P * HS + P);
     const double lm_up = fb.params->lm_up, lm_down = fb.params->lm_down, lm_min = fb.params->lm_min, lm_max = fb.params->lm_max;   // same round trip
+    const bool gain = fb.params->lm_policy != 0.0;          // gain-ratio damping schedule (avt_options::lm_policy)
     // RIDE: every solver role decides on the snapshot the evaluation launch made (AvtSolveSnap): the solver rewrites the live
     // control block further down, and a speculative workgroup may start late
     const AvtFrameCtl& cin = RIDE ? snap_ctl : ctl;
     const int cur0 = cin.cur_slot, try_valid = cin.try_valid, comp_cur0 = cin.comp_cur;
     const double sbp = cin.sbp, sbs = cin.sbs, cost_cur0 = cin.cost_cur;
     double cost_const = cin.cost_const;
-    double lambda = cin.lambda;
+    double lambda = cin.lambda, nu = cin.nu;
+    const double pred0 = cin.pred;
     __shared__ double s_cc;
     if (mode == SOLVE_FIRST && t < 64) {   // the constant part of the data cost (k_records' trailing workgroups), once per ICP iteration
         double a = 0.0;
@@ -844,7 +847,14 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         accepted = true;
         cur = try0;
     } else if (try_valid) {
-        if (cost < cost_cur0) { accepted = true; cur = try0; lambda = fmax(lambda * lm_down, lm_min); }
+        if (cost < cost_cur0) {
+            accepted = true; cur = try0;
+            if (gain) {      // rho = actual / predicted decrease; lambda *= max(1/3, 1 - (2 rho - 1)^3), the rejection factor starts over
+                const double u = 2.0 * ((cost_cur0 - cost) / pred0) - 1.0;
+                lambda = fmin(fmax(lambda * fmax(1.0 / 3.0, 1.0 - u * u * u), lm_min), lm_max);
+                nu = 2.0;
+            } else lambda = fmax(lambda * lm_down, lm_min);
+        } else if (gain) { lambda = fmin(lambda * nu, lm_max); nu *= 2.0; }
         else lambda = fmin(lambda * lm_up, lm_max);
     }
     const double cost_cur = accepted ? cost : cost_cur0;
@@ -859,7 +869,10 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     const bool use_spec = RIDE && rejected && sp_next < sp_n && spin.valid[min(sp_next, AVT_MAX_SPEC - 1)] != 0;
     if (RIDE && role > 0 && use_spec) return;
     if (RIDE && role > 0) {      // my damping: what `role` rejections in a row would make of the solver's
-        for (int i = 0; i < role; ++i) lambda = fmin(lambda * lm_up, lm_max);
+        for (int i = 0; i < role; ++i) {
+            if (gain) { lambda = fmin(lambda * nu, lm_max); nu *= 2.0; }
+            else lambda = fmin(lambda * lm_up, lm_max);
+        }
     }
     if (t == 0 && role == 0) {
         ctl.cur_slot = cur;
@@ -886,6 +899,8 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
             sp.next = k + 1;
             ctl.lambda = lam; ctl.try_valid = 1;
             ctl.dec_cur_slot = cur; ctl.dec_try_valid = 1; ctl.dec_cost_cur = cost_cur; ctl.dec_lambda = lam;
+            // (the accept test above already took this rejection into lambda / nu: the installed step was made with exactly that lambda)
+            ctl.pred = spin.pred[k]; ctl.nu = nu; ctl.dec_pred = spin.pred[k]; ctl.dec_nu = nu;
         }
         return;
     }
@@ -922,11 +937,12 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
             // rows < P: H + priors, diagonal damped
             double vh = v0;
             vh += (in_pose_c && pr_ >= 0 && pr_ < n) ? sc2 * prv : 0.0;
-            if (row == col) { vh += shape_c ? sbs * sbs : 0.0; vh += lambda * vh; }
+            if (row == col) { vh += shape_c ? sbs * sbs : 0.0; if (own && col < P) s_gD[HS + col] = vh; vh += lambda * vh; }
             // row P: -(J^T r) including the priors
             double vg = v0;
             vg += in_pose_c ? gs * gqc : 0.0;
             vg += shape_c ? sbs * (xqc * sbs) : 0.0;
+            if (own && row == P && col < P) s_gD[col] = vg;
             const bool inside = row <= P && col < P;
             const double val = inside ? (row < P ? vh : -vg) : ((row == col) ? 1.0 : 0.0);
             out[v] = own ? val : 0.0;
@@ -995,6 +1011,13 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
             else backsub_blocked<0>(Lblk, s_R, NB, P, t, s_delta);
         }
         __syncthreads();
+        if (t < 64) {      // predicted decrease of the quadratic model, 1/2 delta^T (lambda D delta - g) (fixed butterfly)
+            double a = 0.0;
+            for (int i = t; i < P; i += 64) { const double dl = s_delta[i]; a += dl * (lambda * s_gD[HS + i] * dl - s_gD[i]); }
+            a = 0.5 * wave_sum(a);
+            if (t == 0) s_gD[0] = a;      // (s_gD[0] was read by lane 0 before the wave's sum completed)
+        }
+        __syncthreads();
         if constexpr (TRI) {   // the factor is dead: the skeleton constants take its place
             prep_stage_constants<NTH>(dm, L, B, s_items, s_level);
             __syncthreads();
@@ -1030,15 +1053,18 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         for (int e = t; e < 4 * J; e += NTH) s_qnew[e] = xc[3 + e];
         if constexpr (TRI) { __syncthreads(); prep_stage_constants<NTH>(dm, L, B, s_items, s_level); __syncthreads(); }
         prep_set_state(d, L, B, xc + 3, xc + 3 + 4 * J, xc);
-        lambda = fmin(lambda * lm_up, lm_max);
+        if (gain) { lambda = fmin(lambda * nu, lm_max); nu *= 2.0; }
+        else lambda = fmin(lambda * lm_up, lm_max);
     }
+    const double pred_new = ok ? s_gD[0] : 0.0;
     if (t == 0 && role == 0) {
         ctl.lambda = lambda; ctl.try_valid = ok ? 1 : 0;
         // what the accept test of the trial point just made reads if no further solve follows (avt_decide.h)
         ctl.dec_cur_slot = cur; ctl.dec_try_valid = ok ? 1 : 0; ctl.dec_cost_cur = cost_cur; ctl.dec_lambda = lambda;
+        ctl.pred = pred_new; ctl.nu = nu; ctl.dec_pred = pred_new; ctl.dec_nu = nu;
         if (RIDE) { sp.next = 0; sp.n = fb.nspec; }          // the speculative workgroups of this launch are making steps 0 .. nspec - 1
     }
-    if (RIDE && t == 0 && role > 0) { sp.valid[role - 1] = ok ? 1 : 0; sp.lambda[role - 1] = lambda; }
+    if (RIDE && t == 0 && role > 0) { sp.valid[role - 1] = ok ? 1 : 0; sp.lambda[role - 1] = lambda; sp.pred[role - 1] = pred_new; }
     if (RIDE && role > 0 && !ok) return;                     // (a refused speculative factorisation: the slot stays invalid)
     __syncthreads();
     TPROBE(5);
@@ -1058,7 +1084,7 @@ static size_t solve_lds_bytes(const AvtDims& d) {
     const PrepLayout L = prep_layout(d.J, d.K, d.xsize);
     const size_t nblk = solve_big(d) ? (size_t)NB * (NB + 1) / 2 : (size_t)NB * NB;
     const size_t prep_bytes = sizeof(double) * (size_t)L.ndoubles + sizeof(int) * (2 * (size_t)L.nitems + 2 * AVT_MAX_JOINTS + 4);
-    const size_t fixed = sizeof(double) * (((std::max(HS, 4 * d.J) + 3) & ~1) + HS + 2 + ((2 * d.xsize + 1) & ~1));
+    const size_t fixed = sizeof(double) * (((std::max(HS, 4 * d.J) + 3) & ~1) + HS + 2 + 2 * HS + ((2 * d.xsize + 1) & ~1));
     const size_t factor = sizeof(double) * nblk * 18;
     return (solve_big(d) ? std::max(factor, prep_bytes) + sizeof(double) * MFG_PB_DOUBLES + fixed
                          : factor + sizeof(double) * MF_PB_DOUBLES + fixed + prep_bytes) + 64;

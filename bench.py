@@ -114,6 +114,7 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
     gts = [synth.sample_ground_truth(smpl, g) for g in gids]
     starts = [synth.perturb_start(*gts[i], gids[i]) for i in range(F)]
     ctx = api.Context(gm, 24, pm, 200000 if dense else 65536, F, device=local_rank)
+    ctx.set_data_term({"rows": ctx.DATA_TERM_ROWS, "moments": ctx.DATA_TERM_MOMENTS, "auto": ctx.DATA_TERM_AUTO}[args.data_term])
     opt = Options.demo(icp_iters=args.icp_iters)
     npts = ctx.render_frames(np.array([g[0] for g in gts]), np.array([g[1] for g in gts]), np.array([g[2] for g in gts]),
                              res_scale=2 if dense else 1)                      # inputs resident in HBM
@@ -662,6 +663,7 @@ def main():
     ap.add_argument("--no-seed-spread", action="store_true", help="skip the single-frame spread over 12 seeds")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
+    ap.add_argument("--data-term", choices=["auto", "rows", "moments"], default="auto", help="form of the ICP data term (include/avt.h AVT_DATA_TERM_*); auto = the library's choice by launch shape")
     ap.add_argument("--scale-only", action="store_true", help="headline + 64 frames/GPU only (the default for --gpus N > 1: what a scaling record needs)")
     ap.add_argument("--detail-file", default=os.path.join(ROOT, "bench_detail.json"), help="where the full result object goes (the stdout line is the compact one)")
     args = ap.parse_args()

@@ -87,7 +87,7 @@ typedef struct avt_options {
     int enable_occlusion;       /* enableOcclusion = true: back-face visibility (AvatarOptimizer.cpp:1349-1367) */
     int icp_iters;              /* optimize(..., icp_iters = 1, ...) */
     int num_threads;            /* optimize(..., num_threads = 4): accepted, ignored on the GPU path */
-    int reserved0;
+    int lm_policy;              /* damping schedule: 0 (default) fixed factors lm_up / lm_down; 1 gain ratio (Nielsen): see DESIGN.md section 4 */
     double lm_lambda0;          /* initial damping (relative to diag H); default 1e-3 */
     double lm_up;               /* damping multiplier on a rejected step; default 4 */
     double lm_down;             /* damping multiplier on an accepted step; default 1/3 */
@@ -220,7 +220,7 @@ int avt_get_normal_equations(avt_ctx* c, int frame, double* H /* P x P */, doubl
  *                          every iteration (AvatarCostFunctorCache::updateData + the ICP cost functor, AvatarOptimizer.cpp:505-644);
  *   AVT_DATA_TERM_MOMENTS  the correspondences' sufficient statistics are accumulated once per ICP iteration and every iteration
  *                          contracts them with the state (avt_moments.hip);
- *   AVT_DATA_TERM_AUTO     (default) the moment form from ~100 frames per launch on, where it is the faster one; rows below.
+ *   AVT_DATA_TERM_AUTO     (default) the moment form from ~60 frames per launch on, where it is the faster one; rows below.
  * Takes effect for the following calls; avt_get_normal_equations evaluates with the form selected here (AUTO: the form the last
  * optimize() ran), so tests can compare the two on the same correspondences. */
 enum { AVT_DATA_TERM_ROWS = 0, AVT_DATA_TERM_MOMENTS = 1, AVT_DATA_TERM_AUTO = 2 };

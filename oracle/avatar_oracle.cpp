@@ -1056,7 +1056,7 @@ int orc_optimize(const orc_model* m, int num_parts, const int* part_map, const d
         avatar_update(*m, w, p, Rcm.data(), cloud.data(), nullptr, nullptr);
     };
     do_update();  // precondition of optimize(): ava.cloud is current (:1356,:1390)
-    double lambda = o->lm_lambda0;
+    double lambda = o->lm_lambda0, nu = 2.0;
     avt_stats s{};
     for (int icp = 0; icp < o->icp_iters; ++icp) {
         static const bool timing = getenv("ORC_TIMING") != nullptr;   // phase timing of the baseline (stderr)
@@ -1076,6 +1076,15 @@ int orc_optimize(const orc_model* m, int num_parts, const int* part_map, const d
         if (timing) fprintf(stderr, "[orc] first evaluate %.3f ms\n", now() - t_c);
         s.initial_cost = cur.cost;
         if (trace_cost) trace_cost[(size_t)icp * (o->max_iters_per_icp + 1)] = cur.cost;
+        // damping schedule (avt_options::lm_policy): 0 = fixed factors lm_up / lm_down; 1 = gain ratio (Nielsen 1999):
+        // rho = actual / predicted decrease, predicted = 1/2 delta^T (lambda D delta - g); accepted: lambda *= max(1/3, 1 - (2 rho - 1)^3),
+        // nu = 2; rejected or not factorable: lambda *= nu, nu *= 2
+        const bool gain = o->lm_policy == 1;
+        if (icp == 0) nu = 2.0;
+        auto reject = [&]() {
+            if (gain) { lambda = std::min(lambda * nu, o->lm_lambda_max); nu *= 2.0; }
+            else lambda = std::min(lambda * o->lm_up, o->lm_lambda_max);
+        };
         for (int it = 0; it < o->max_iters_per_icp; ++it) {
             int acc = 0;
             if (corr.total > 0 && lm_solve(cur.H.data(), cur.g.data(), P, lambda, delta.data())) {
@@ -1084,18 +1093,27 @@ int orc_optimize(const orc_model* m, int num_parts, const int* part_map, const d
                          nthreads, tr);
                 if (tr.cost < cur.cost) {
                     acc = 1;
+                    if (gain) {
+                        double pred = 0.0;
+                        for (int i = 0; i < P; ++i) pred += delta[i] * (lambda * cur.H[(size_t)i * P + i] * delta[i] - cur.g[i]);
+                        pred *= 0.5;
+                        const double rho = (cur.cost - tr.cost) / pred, u = 2.0 * rho - 1.0;
+                        lambda = std::min(std::max(lambda * std::max(1.0 / 3.0, 1.0 - u * u * u), o->lm_lambda_min), o->lm_lambda_max);
+                        nu = 2.0;
+                    } else {
+                        lambda = std::max(lambda * o->lm_down, o->lm_lambda_min);
+                    }
                     std::copy(p2.begin(), p2.end(), p);
                     std::copy(q2.begin(), q2.end(), q);
                     std::copy(w2.begin(), w2.end(), w);
                     std::swap(cur, tr);
-                    lambda = std::max(lambda * o->lm_down, o->lm_lambda_min);
                     ++s.accepted_steps;
                 } else {
-                    lambda = std::min(lambda * o->lm_up, o->lm_lambda_max);
+                    reject();
                 }
             } else {
                 acc = -1;
-                lambda = std::min(lambda * o->lm_up, o->lm_lambda_max);
+                reject();
             }
             ++s.gn_iterations;
             if (trace_acc) trace_acc[(size_t)icp * o->max_iters_per_icp + it] = acc;
