@@ -390,6 +390,22 @@ class Context:
 
     DATA_TERM_ROWS, DATA_TERM_MOMENTS, DATA_TERM_AUTO = 0, 1, 2
 
+    def tuning(self):
+        """The knobs this context runs with (include/avt.h avt_tuning) as a capi.Tuning."""
+        t = capi.Tuning()
+        _check(self._lib.avt_ctx_get_tuning(self.h, C.byref(t)))
+        return t
+
+    def set_tuning(self, **kw):
+        """Changes knobs of this context (avt_ctx_set_tuning): e.g. ctx.set_tuning(nspec=0, nn_slab=0)."""
+        t = self.tuning()
+        for k, v in kw.items():
+            if k not in dict(t._fields_):
+                raise KeyError(k)
+            setattr(t, k, int(v))
+        _check(self._lib.avt_ctx_set_tuning(self.h, C.byref(t)))
+        return self
+
     def set_data_term(self, form):
         """How the ICP data term of a GN iteration is evaluated (include/avt.h: AVT_DATA_TERM_ROWS / AVT_DATA_TERM_MOMENTS)."""
         _check(self._lib.avt_set_data_term(self.h, C.c_int(int(form))))

@@ -62,6 +62,20 @@ class Options(C.Structure):
         return o
 
 
+class Tuning(C.Structure):
+    """include/avt.h avt_tuning: launch-shape and algorithm knobs of a context (defaults = the measured optima)."""
+    _fields_ = [(n, C.c_int) for n in ("use_graph", "groups", "g", "gcap", "vis_frame_min", "ride", "ride_strips", "ride_sizing_groups", "nspec",
+                                       "nn_force_part", "nn_slab", "mom_min_frames", "debug", "reserved")] + [("ride_timeout_us", C.c_longlong)]
+    DEFAULTS = dict(use_graph=1, groups=0, g=0, gcap=128, vis_frame_min=64, ride=1, ride_strips=0, ride_sizing_groups=0, nspec=4, nn_force_part=0,
+                    nn_slab=1, mom_min_frames=60, debug=0, reserved=0, ride_timeout_us=2000000)
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+
+    def non_default(self):
+        return {k: v for k, v in self.as_dict().items() if v != self.DEFAULTS[k]}
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("initial_cost", C.c_double), ("final_cost", C.c_double), ("lambda_", C.c_double),
@@ -201,6 +215,8 @@ def load_library():
         "avt_get_cloud": [vp, C.c_int, c_double_p],
         "avt_get_posed": [vp, C.c_int, c_double_p, c_double_p, c_double_p],
         "avt_get_normal_equations": [vp, C.c_int, c_double_p, c_double_p, c_double_p],
+        "avt_ctx_get_tuning": [vp, C.POINTER(Tuning)],
+        "avt_ctx_set_tuning": [vp, C.POINTER(Tuning)],
         "avt_set_data_term": [vp, C.c_int],
         "avt_get_data_term": [vp],
         "avt_debug_trace": [vp, C.c_int, c_double_p],
@@ -249,7 +265,7 @@ EXPORTED_SYMBOLS = [
     "avt_model_dims", "avt_model_main_joint", "avt_model_joint_regression", "avt_model_tile_layout", "avt_ctx_create", "avt_ctx_destroy",
     "avt_sync", "avt_lbs_update", "avt_visibility", "avt_nn", "avt_optimize", "avt_optimize_batch",
     "avt_frames_upload", "avt_synth_render_frames", "avt_synth_render_frames_mode", "avt_synth_render_images", "avt_frames_download", "avt_state_upload", "avt_optimize_resident", "avt_state_reset", "avt_state_download",
-    "avt_get_correspondences", "avt_get_cloud", "avt_get_posed", "avt_get_normal_equations", "avt_set_data_term", "avt_get_data_term", "avt_debug_trace", "avt_launch_shape", "avt_profile_begin", "avt_profile_select", "avt_profile_end",
+    "avt_get_correspondences", "avt_get_cloud", "avt_get_posed", "avt_get_normal_equations", "avt_ctx_get_tuning", "avt_ctx_set_tuning", "avt_set_data_term", "avt_get_data_term", "avt_debug_trace", "avt_launch_shape", "avt_profile_begin", "avt_profile_select", "avt_profile_end",
     # include/avt_shard.h
     "avt_shard_owner", "avt_shard_local_count", "avt_shard_local_index", "avt_shard_global_frame", "avt_model_pack_size", "avt_model_pack",
     "avt_model_unpack", "avt_shard_unique_id", "avt_shard_create", "avt_shard_create_loopback", "avt_shard_destroy", "avt_shard_rank", "avt_shard_world", "avt_shard_backend",

@@ -58,31 +58,29 @@ int dev_upload(avt_ctx* c, T** p, const std::vector<T>& v) {
     return 0;
 }
 
-// frame groups of one optimize(): measured on MI355X, two groups pay off from ~32 frames, more never do
-// (AVT_GROUPS overrides; tuning knob)
-int choose_groups(int nframes) {
+// frame groups of one optimize(): measured on MI355X, two groups pay off from ~32 frames, more never do (avt_tuning::groups overrides)
+int choose_groups(int nframes, const avt_tuning& tun) {
     int n = nframes >= 32 ? 2 : 1;      // measured: 24 frames 0.866 (one group) / 0.899 ms (two), 32: 0.964 / 0.954, 40: 1.075 / 1.026
-    if (const char* e = getenv("AVT_GROUPS")) n = atoi(e);
-    if (getenv("AVT_ONE_GROUP")) n = 1;
+    if (tun.groups > 0) n = tun.groups;
     return std::max(1, std::min(std::min(n, AVT_MAX_GROUPS), nframes));
 }
 
 // Frame groups of one optimize() call.  Two or three frames: one frame per group when the one-frame launch shape has the speculative
 // solver workgroups - in a shared launch a rejection saves its factorisation only if every frame of the launch
 // rejects, on a stream of its own every frame keeps its own pace (2 frames 0.477 -> 0.457 ms, 3 frames 0.607 -> 0.526; four: 0.637 -> 0.709).
-int choose_G(int nframes, int ngroups = 1);
+int choose_G(int nframes, int ngroups, const avt_tuning& tun);
 int plan_groups(avt_ctx* c, int nf) {
-    int ngroups = choose_groups(nf);
-    if ((nf == 2 || nf == 3) && !getenv("AVT_GROUPS") && !getenv("AVT_ONE_GROUP")) {
+    int ngroups = choose_groups(nf, c->tun);
+    if ((nf == 2 || nf == 3) && c->tun.groups <= 0) {
         const int g_keep = c->fb.G;
-        c->fb.G = choose_G(1);
+        c->fb.G = choose_G(1, 1, c->tun);
         if (avt_solve_rides(c, 1)) ngroups = nf;
         c->fb.G = g_keep;
     }
     return ngroups;
 }
 
-int choose_G(int nframes, int ngroups) {
+int choose_G(int nframes, int ngroups, const avt_tuning& tun) {
     // k_eval workgroups per frame.  Up to 64 frames per launch: 768 workgroups = one resident round at 3 per CU (more rounds
     // cost more in partial tiles and prologues than they balance: 128 frames per group 645 k against 609 k GN it/s with twice as
     // many).  From 128 frames per launch on: 1536, two rounds, so that the hardware's dispatch evens out frames with different
@@ -92,14 +90,56 @@ int choose_G(int nframes, int ngroups) {
     // 512 / 640 / 768 workgroups per launch: 32 frames 0.934 / 0.928 / 0.966; 48: 1.073 / 1.091 / 1.120; 64: 1.227 / 1.246 / 1.271;
     // 96: 1.625 / 1.623 / 1.622; 128: 2.080 / 1.954 / 1.982; 256 frames: 3.73 / 3.64 / 3.50, 1536: 3.50).
     const int target = nframes >= 128 ? 1536 : (ngroups >= 2 ? (nframes <= 40 ? 512 : 640) : 768);
-    int gcap = 128;
-    if (const char* e = getenv("AVT_GCAP")) gcap = std::max(2, std::min(AVT_G_MAX, atoi(e)));
+    const int gcap = std::max(2, std::min(AVT_G_MAX, tun.gcap));
     int g = std::max(2, std::min(gcap, target / std::max(1, nframes)));
     // G >= 64 also selects the few-frames launch shapes (strided batches, k_reduce_strip, the trial point set up in k_lbs's
     // grid): they win up to 6 frames (8 frames: 0.762 ms against 0.712 with G = 63; 12: 0.822 / 0.770)
     if (nframes >= 7) g = std::min(g, 63);
-    if (const char* e = getenv("AVT_G")) return std::max(1, std::min(g, atoi(e)));   // tuning knob, never above the allocation
+    if (tun.g > 0) return std::max(1, std::min(g, tun.g));   // tuning knob, never above the allocation
     return g;
+}
+
+// the defaults of avt_tuning, then - ONCE, here - what the environment says (AVT_<FIELD>); unknown AVT_* names are reported
+extern "C" char** environ;
+avt_tuning tuning_from_environment() {
+    avt_tuning t;
+    std::memset(&t, 0, sizeof t);
+    t.use_graph = 1; t.groups = 0; t.g = 0; t.gcap = 128; t.vis_frame_min = 64; t.ride = 1; t.ride_strips = 0; t.ride_sizing_groups = 0;
+    t.nspec = AVT_MAX_SPEC; t.nn_force_part = 0; t.nn_slab = 1; t.mom_min_frames = 60; t.debug = 0; t.ride_timeout_us = 2000000;
+    struct Knob { const char* name; int* field; };
+    const Knob knobs[] = {{"AVT_USE_GRAPH", &t.use_graph}, {"AVT_GROUPS", &t.groups}, {"AVT_G", &t.g}, {"AVT_GCAP", &t.gcap}, {"AVT_VIS_FRAME_MIN", &t.vis_frame_min},
+                          {"AVT_RIDE", &t.ride}, {"AVT_RIDE_STRIPS", &t.ride_strips}, {"AVT_RIDE_SIZING_GROUPS", &t.ride_sizing_groups}, {"AVT_NSPEC", &t.nspec},
+                          {"AVT_NN_FORCE_PART", &t.nn_force_part}, {"AVT_NN_SLAB", &t.nn_slab}, {"AVT_MOM_MIN_FRAMES", &t.mom_min_frames}, {"AVT_DEBUG", &t.debug}};
+    // names other parts of the repository own (the batch split, the Python loader, bench.py, instrumented builds)
+    const char* others[] = {"AVT_LIB", "AVT_RCCL_LIB", "AVT_SHARD_SELF_SENDRECV", "AVT_SHARD_LOOPBACK_TIMEOUT_S", "AVT_BENCH_SHARE_GPU0", "AVT_TIMING"};
+    for (char** e = environ; e && *e; ++e) {
+        if (std::strncmp(*e, "AVT_", 4) != 0) continue;
+        const char* eq = std::strchr(*e, '=');
+        if (!eq) continue;
+        const std::string name(*e, eq - *e);
+        const char* val = eq + 1;
+        bool known = false;
+        for (const Knob& k : knobs) if (name == k.name) { *k.field = atoi(val); known = true; }
+        if (name == "AVT_RIDE_TIMEOUT_US") { t.ride_timeout_us = std::max(0ll, atoll(val)); known = true; }
+        // the spellings of earlier rounds
+        if (name == "AVT_NO_GRAPH") { t.use_graph = 0; known = true; }
+        if (name == "AVT_ONE_GROUP") { t.groups = 1; known = true; }
+        if (name == "AVT_NO_RIDE") { t.ride = 0; known = true; }
+        if (name == "AVT_NN_NO_SLAB") { t.nn_slab = 0; known = true; }
+        if (name == "AVT_RIDE_SIZING") { t.ride_sizing_groups = std::strcmp(val, "groups") == 0; known = true; }
+        for (const char* o : others) if (name == o) known = true;
+        if (!known) fprintf(stderr, "libavatar_hip: environment variable %s is not a knob of this library (include/avt.h, avt_tuning) - ignored\n", name.c_str());
+    }
+    return t;
+}
+
+int validate_tuning(const avt_tuning& t) {
+    if (t.groups < 0 || t.groups > AVT_MAX_GROUPS || t.g < 0 || t.gcap < 2 || t.vis_frame_min < 0 || t.nspec < 0 || t.nspec > AVT_MAX_SPEC ||
+        (t.ride_strips != 0 && t.ride_strips != 4 && t.ride_strips != 8) || t.mom_min_frames < 1 || t.ride_timeout_us < 0) {
+        avt_set_error("avt_tuning: a field is out of range (include/avt.h)");
+        return 1;
+    }
+    return 0;
 }
 
 hipEvent_t next_event(avt_ctx* c) {
@@ -228,15 +268,15 @@ int run_optimize(avt_ctx* c, const avt_options* o) {
     // The instrumented (profiling) path keeps the SAME groups and launch shapes and runs them one after the other on
     // the main stream, so that per-launch timings describe the launches the graph replays.
     {   // which form of the data term this call runs (include/avt.h): the moment form pays from ~100 frames per launch on
-        const int g0 = choose_groups(nf), per_launch = (nf + g0 - 1) / g0;
-        c->fb.use_moments = c->dm.d.mom_ok && (c->data_term == AVT_DATA_TERM_MOMENTS || (c->data_term == AVT_DATA_TERM_AUTO && per_launch >= c->mom_min_frames));
+        const int g0 = choose_groups(nf, c->tun), per_launch = (nf + g0 - 1) / g0;
+        c->fb.use_moments = c->dm.d.mom_ok && (c->data_term == AVT_DATA_TERM_MOMENTS || (c->data_term == AVT_DATA_TERM_AUTO && per_launch >= c->tun.mom_min_frames));
         c->last_run_moments = c->fb.use_moments != 0;
     }
     const int ngroups = plan_groups(c, nf);
     const int nfg = (nf + ngroups - 1) / ngroups;       // frames per group (the last group may be smaller)
-    c->fb.G = choose_G(nfg, ngroups);
+    c->fb.G = choose_G(nfg, ngroups, c->tun);
     c->concurrent_groups = ngroups;
-    if (!c->use_graph || c->profiling) {
+    if (!c->tun.use_graph || c->profiling) {
         for (int gi = 0; gi < ngroups; ++gi) {
             const int f0 = gi * nfg, n = std::min(nfg, nf - f0);
             if (n > 0) enqueue_optimize(c, o, f0, n, c->stream);
@@ -436,7 +476,8 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
     c->ran_icp_iters = 0;
     c->ran_max_iters = 0;
     c->launch_maxN = 0;
-    c->use_graph = getenv("AVT_NO_GRAPH") == nullptr;
+    c->tun = tuning_from_environment();
+    if (validate_tuning(c->tun)) return 1;
     c->lbs_cleared = false;
     c->scatter_in_compact = false;
     c->nn_from_cloud = false;
@@ -461,10 +502,8 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
     if (avt_solve_set_attributes() || avt_eval_set_attributes() || avt_lbs_set_attributes() || avt_moments_set_attributes()) { avt_set_error("avt_ctx_create: hipFuncSetAttribute failed"); return 1; }
     DeviceModel& dm = c->dm;
     dm.d = m->d;
-    {   // visibility as one workgroup per frame when the frame's x, y fit the LDS (AVT_VIS_FRAME_MIN: experiments)
-        const char* e = getenv("AVT_VIS_FRAME_MIN");
-        c->vis_frame_min = avt_visibility_frame_lds(m->d) <= 150 * 1024 ? (e ? atoi(e) : 64) : 0;
-    }
+    // visibility as one workgroup per frame when the frame's x, y fit the LDS
+    c->vis_frame_min = avt_visibility_frame_lds(m->d) <= 150 * 1024 ? c->tun.vis_frame_min : 0;
     dm.d.num_parts = num_parts;
     const int V = dm.d.V, J = dm.d.J;
     c->part_map.assign(part_map, part_map + J);   // >= J entries (AvatarOptimizer.cpp:1229)
@@ -498,15 +537,17 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
     std::memset(&fb, 0, sizeof(fb));
     fb.max_frames = max_frames;
     fb.max_points = max_points;
-    fb.G = choose_G(max_frames);
+    fb.G = choose_G(max_frames, 1, c->tun);
     fb.const_blocks = (max_points + 255) / 256;
     fb.bucket_tiles = (max_points + 2047) / 2048;
     const size_t FN = (size_t)max_frames * max_points, FV = (size_t)max_frames * V;
     const AvtDims& d = dm.d;
     // eval workgroups over all frames, for every way run_optimize may split them into groups
     size_t part_cap = 0;
+    avt_tuning widest = c->tun;      // (the largest cap a later avt_ctx_set_tuning may ask for)
+    widest.gcap = AVT_G_MAX; widest.g = 0;
     for (int nf = 1; nf <= max_frames; ++nf)
-        for (int k = 1; k <= std::min(AVT_MAX_GROUPS, nf); ++k) part_cap = std::max(part_cap, (size_t)nf * std::max(choose_G((nf + k - 1) / k, 1), choose_G((nf + k - 1) / k, 2)));
+        for (int k = 1; k <= std::min(AVT_MAX_GROUPS, nf); ++k) part_cap = std::max(part_cap, (size_t)nf * std::max(choose_G((nf + k - 1) / k, 1, widest), choose_G((nf + k - 1) / k, 2, widest)));
     char* cntsum = nullptr;
     if (dev_alloc(c, &fb.data_raw, FN * 3) || dev_alloc(c, &fb.labels_raw, FN) || dev_alloc(c, &fb.dx, FN) || dev_alloc(c, &fb.dy, FN) ||
         dev_alloc(c, &fb.dz, FN) || dev_alloc(c, &fb.dorig, FN) || dev_alloc(c, &fb.part_off, (size_t)max_frames * (num_parts + 1)) || dev_alloc(c, &fb.part_cnt, (size_t)max_frames * 2 * (AVT_MAX_PARTS + 1)) || dev_alloc(c, &fb.tile_hist, (size_t)max_frames * ((max_points + 2047) / 2048) * (AVT_MAX_PARTS + 1)) ||
@@ -517,7 +558,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         dev_alloc(c, &fb.const_part, (size_t)max_frames * fb.const_blocks) ||
         dev_alloc(c, &fb.x, (size_t)max_frames * 2 * d.xsize) || dev_alloc(c, &fb.x_start, (size_t)max_frames * 2 * d.xsize) ||
         dev_alloc(c, &fb.ctl_start, (size_t)max_frames) || dev_alloc(c, &fb.prep, (size_t)max_frames * 2 * d.prep_size) ||
-        dev_alloc(c, &fb.rec, (size_t)max_frames * d.nb_max * 4 * d.rec_quad) || dev_alloc(c, &fb.partial, part_cap * d.NPAIR * 256) || dev_alloc(c, &fb.wmask, part_cap) || dev_alloc(c, &fb.bmask, (size_t)max_frames * d.nb_max) || dev_alloc(c, &fb.erange, (size_t)max_frames * AVT_ERANGE) || dev_alloc(c, &fb.Hraw, (size_t)max_frames * 2 * d.HS * d.HS) ||
+        dev_alloc(c, &fb.rec, (size_t)max_frames * d.nb_max * 4 * d.rec_quad) || dev_alloc(c, &fb.partial, part_cap * d.NPAIR * 256) || dev_alloc(c, &fb.wmask, part_cap) || dev_alloc(c, &fb.bmask, (size_t)max_frames * d.nb_max) || dev_alloc(c, &fb.erange, (size_t)max_frames * AVT_ERANGE) || dev_alloc(c, &fb.Hraw, (size_t)max_frames * 2 * d.HS * d.HS) || dev_alloc(c, &fb.solve_gd, (size_t)max_frames * 2 * d.HS) ||
         dev_alloc(c, &fb.prior, (size_t)max_frames * 2 * AVT_MAX_COMPS * AVT_PRIOR_STRIDE) || dev_alloc(c, &fb.ctl, (size_t)max_frames) ||
         dev_alloc(c, &fb.jointpos, (size_t)max_frames * 3 * J) || dev_alloc(c, &fb.jointtrans, (size_t)max_frames * 12 * J) ||
         dev_alloc(c, &fb.trace, (size_t)max_frames * 64))
@@ -530,7 +571,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         HIP_OK(hipMemsetAsync(fb.mom_D, 0, (size_t)max_frames * J * d.mom_npsi * 3 * sizeof(double), c->stream));      // joints no vertex is assigned to keep zeros
     }
     c->data_term = AVT_DATA_TERM_AUTO;
-    c->mom_min_frames = 60;          // frames per launch from which the moment form wins (tools/data_term_sweep.sh: 32 per launch 1.39 against 1.21 ms, 64: 1.86 / 1.91, 96: 2.34 / 2.94, 256: 5.25 / 6.41)
+    // (tun.mom_min_frames = 60: tools/data_term_sweep.sh, ms per step moments / rows: 32 frames per launch 1.39 / 1.21, 64: 1.86 / 1.91, 96: 2.34 / 2.94, 256: 5.25 / 6.41)
     c->last_run_moments = false;
     {
         AvtRunParams* pr = nullptr;
@@ -543,16 +584,12 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
     HIP_OK(hipMemsetAsync(fb.ctl, 0, (size_t)max_frames * sizeof(AvtFrameCtl), c->stream));
     HIP_OK(hipMemsetAsync(fb.ride_ctr, 0, (size_t)max_frames * sizeof(unsigned), c->stream));
     HIP_OK(hipMemsetAsync(fb.fault, 0, (size_t)max_frames * sizeof(unsigned), c->stream));
-    {   // wall_clock64() ticks at 100 MHz; default 2 s.  AVT_RIDE_TIMEOUT_US=0 makes every wait that is not already satisfied fail (tests)
-        long long us = 2000000;
-        if (const char* e = getenv("AVT_RIDE_TIMEOUT_US")) us = std::max(0ll, atoll(e));
-        fb.ride_timeout = us * 100;
-    }
+    fb.ride_timeout = c->tun.ride_timeout_us * 100;      // wall_clock64() ticks at 100 MHz; 0 makes every wait that is not already satisfied fail (tests)
     HIP_OK(hipMemsetAsync(fb.spec, 0, (size_t)max_frames * sizeof(AvtSpecCtl), c->stream));
     fb.nspec = 0; fb.seq = 0;
     HIP_OK(hipMemsetAsync(fb.part_cnt, 0, (size_t)max_frames * 2 * (AVT_MAX_PARTS + 1) * sizeof(int), c->stream));   // invariant of launch_bucket
     HIP_OK(hipStreamSynchronize(c->stream));
-    if (getenv("AVT_DEBUG")) avt_eval_report_occupancy(dm.d);
+    if (c->tun.debug) avt_eval_report_occupancy(dm.d);
     return 0;
 }
 
@@ -883,7 +920,7 @@ int avt_get_normal_equations(avt_ctx* c, int frame, double* H, double* g, double
     // at the CURRENT point here - trial point := current point (SOLVE_INIT), one full evaluation, one reduction - with the
     // correspondences of the last ICP iteration.  The current point, its cost and the LM state are left untouched.
     const int G_keep = c->fb.G;
-    c->fb.G = choose_G(c->nframes);
+    c->fb.G = choose_G(c->nframes, 1, c->tun);
     c->fb.f0 = 0;
     c->cur_stream = c->stream;
     // the form of the data term: the one selected (AUTO: the one the last optimize() ran); what that form needs of the resident
@@ -917,6 +954,30 @@ int avt_get_normal_equations(avt_ctx* c, int frame, double* H, double* g, double
     AVT_API_GUARD_END("avt_get_normal_equations")
 }
 
+int avt_ctx_get_tuning(avt_ctx* c, avt_tuning* out) {
+    if (!c || !out) { avt_set_error("avt_ctx_get_tuning: null argument"); return 1; }
+    *out = c->tun;
+    return 0;
+}
+
+int avt_ctx_set_tuning(avt_ctx* c, const avt_tuning* t) {
+    AVT_API_GUARD_BEGIN
+    if (!c || !t) { avt_set_error("avt_ctx_set_tuning: null argument"); return 1; }
+    if (validate_tuning(*t)) return 1;
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    {   // the launch sequences captured so far were made with the old knobs
+        std::lock_guard<std::mutex> graph_lock(g_graph_mutex);
+        for (auto& e : c->graphs) (void)hipGraphExecDestroy(e.exec);
+        c->graphs.clear();
+    }
+    c->tun = *t;
+    c->vis_frame_min = avt_visibility_frame_lds(c->dm.d) <= 150 * 1024 ? c->tun.vis_frame_min : 0;
+    c->fb.ride_timeout = c->tun.ride_timeout_us * 100;
+    return 0;
+    AVT_API_GUARD_END("avt_ctx_set_tuning")
+}
+
 int avt_set_data_term(avt_ctx* c, int form) {
     if (!c || (form != AVT_DATA_TERM_ROWS && form != AVT_DATA_TERM_MOMENTS && form != AVT_DATA_TERM_AUTO)) { avt_set_error("avt_set_data_term: bad argument"); return 1; }
     if (form == AVT_DATA_TERM_MOMENTS && !c->dm.d.mom_ok) { avt_set_error("avt_set_data_term: this model has no moment form (K + 1 <= 16 and 3 + 3J + K <= 87 required)"); return 1; }
@@ -940,7 +1001,7 @@ int avt_launch_shape(avt_ctx* c, int* groups, int* frames_per_group, int* eval_w
     const int ng = plan_groups(c, c->nframes), nfg = (c->nframes + ng - 1) / ng;
     if (groups) *groups = ng;
     if (frames_per_group) *frames_per_group = nfg;
-    if (eval_workgroups_per_frame) *eval_workgroups_per_frame = choose_G(nfg, ng);
+    if (eval_workgroups_per_frame) *eval_workgroups_per_frame = choose_G(nfg, ng, c->tun);
     return 0;
 }
 

@@ -270,6 +270,7 @@ struct FrameBuffers {
     int* erange;          // [max_frames][AVT_ERANGE] frame batches (G < 64): evaluation workgroup g takes batches [erange[g], erange[g+1]) (k_solve INIT)
     double* partial;      // [max_frames][G][NPAIR][256]
     unsigned long long* wmask;   // [max_frames][G] tile pairs workgroup g of the frame wrote to `partial` (bit = pair); k_reduce skips the rest
+    double* solve_gd;     // [max_frames][2][HS] k_solve<1024>: gradient and diagonal of the undamped system (avt_lm.hip)
     double* Hraw;         // [max_frames][2][HS*HS] reduced data-term [J|r]^T W [J|r] (full symmetric) per state slot
     double* prior;        // [max_frames][2][AVT_MAX_COMPS][AVT_PRIOR_STRIDE] GMM scores / Prec*(x-mu) per state slot
     AvtFrameCtl* ctl;     // [max_frames]
@@ -323,8 +324,7 @@ struct avt_ctx {
     bool lbs_cleared;                // the preceding k_lbs reset visibility / correspondence bookkeeping
     bool nn_from_cloud;              // inside optimize(), frame batches: k_compact gathers the candidates from the cloud (no pcx/pcy/pcz)
     bool scatter_in_compact;         // launch_visibility left the scatter pass of the bucketing to the k_compact launch that follows
-    int vis_frame_min;               // frames per launch from which visibility runs as one workgroup per frame (0: never)
-    bool use_graph;                  // replay the optimize() launch sequence as a hipGraph (AVT_NO_GRAPH=1 disables)
+    int vis_frame_min;               // frames per launch from which visibility runs as one workgroup per frame (0: never; tun.vis_frame_min where the LDS allows)
     struct GraphEntry { std::string key; hipGraphExec_t exec; unsigned long long last_used; };
     std::vector<GraphEntry> graphs;  // small LRU cache keyed on the launch SHAPE only (frames, groups, grids, iteration counts)
     unsigned long long graph_clock;
@@ -332,7 +332,7 @@ struct avt_ctx {
     bool params_valid;
     bool frames_valid, state_valid;  // resident frames / start state usable by avt_optimize_resident
     int data_term;                   // AVT_DATA_TERM_* policy (avt_set_data_term)
-    int mom_min_frames;              // AUTO: frames per launch from which the moment form is used
+    avt_tuning tun;                  // launch-shape / algorithm knobs (include/avt.h): defaults, then the environment ONCE at creation, then avt_ctx_set_tuning
     bool last_run_moments;           // the form the last optimize() ran
     bool have_moments, have_records; // what exists for the resident correspondences (avt_get_normal_equations makes the other on demand)
     int concurrent_groups;           // frame groups the current optimize() call runs side by side (sizes the riding launch shapes)

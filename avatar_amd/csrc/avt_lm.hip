@@ -665,8 +665,11 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     double* s_PB = Lblk + nblk * 18;                        // [96 or 192][4] the four panel columns of a round
     double* s_W = s_PB + (TRI ? MFG_PB_DOUBLES : MF_PB_DOUBLES);         // [max(HS, 4J) + 2]  reciprocal pivots, later the new quaternions
     double* s_delta = s_W + ((max(HS, 4 * J) + 3) & ~1);    // [HS]
-    double* s_gD = s_delta + HS + 2;                        // [2][HS] gradient and diagonal of the undamped system (predicted decrease of the step, gain-ratio schedule)
-    double* s_x = s_gD + 2 * HS;                            // [2][xsize] both state slots
+    // [2][HS] gradient and diagonal of the undamped system (predicted decrease of the step, gain-ratio schedule); the 1024-thread
+    // shape has no LDS left for it (P = 178: 158.5 of 159.5 KB) and keeps it in the frame's global scratch - written and read by
+    // this workgroup only, a barrier in between
+    double* s_gD = TRI ? fb.solve_gd + (size_t)f * 2 * HS : s_delta + HS + 2;
+    double* s_x = s_delta + HS + 2 + (TRI ? 0 : 2 * HS);    // [2][xsize] both state slots
     const PrepLayout L = prep_layout(J, K, d.xsize);
     // skeleton scratch: behind the factor (SMPL shape: staged at kernel start, hidden behind the factorisation) or ON it
     // (triangular shape: the factor is dead once the back substitution is done)
@@ -1084,7 +1087,7 @@ static size_t solve_lds_bytes(const AvtDims& d) {
     const PrepLayout L = prep_layout(d.J, d.K, d.xsize);
     const size_t nblk = solve_big(d) ? (size_t)NB * (NB + 1) / 2 : (size_t)NB * NB;
     const size_t prep_bytes = sizeof(double) * (size_t)L.ndoubles + sizeof(int) * (2 * (size_t)L.nitems + 2 * AVT_MAX_JOINTS + 4);
-    const size_t fixed = sizeof(double) * (((std::max(HS, 4 * d.J) + 3) & ~1) + HS + 2 + 2 * HS + ((2 * d.xsize + 1) & ~1));
+    const size_t fixed = sizeof(double) * (((std::max(HS, 4 * d.J) + 3) & ~1) + HS + 2 + (solve_big(d) ? 0 : 2 * HS) + ((2 * d.xsize + 1) & ~1));
     const size_t factor = sizeof(double) * nblk * 18;
     return (solve_big(d) ? std::max(factor, prep_bytes) + sizeof(double) * MFG_PB_DOUBLES + fixed
                          : factor + sizeof(double) * MF_PB_DOUBLES + fixed + prep_bytes) + 64;
@@ -1117,24 +1120,19 @@ static void launch_solve_shape(avt_ctx* c, int nframes, int mode, size_t lds) {
 // speculative solver workgroups per frame (AVT_NSPEC, default 2) next to the solver, as many as leave the grid resident
 // Residency is a matter of speed, not of correctness (see the wait in k_solve).  AVT_RIDE_SIZING=groups sizes the shapes by the
 // frame groups that run side by side (two / three frames: one group each) instead of by the one launch.
-static int ride_concurrency(const avt_ctx* c) {
-    static const bool by_groups = [] { const char* e = getenv("AVT_RIDE_SIZING"); return e && !strcmp(e, "groups"); }();
-    return by_groups ? std::max(1, c->concurrent_groups) : 1;
-}
+static int ride_concurrency(const avt_ctx* c) { return c->tun.ride_sizing_groups ? std::max(1, c->concurrent_groups) : 1; }
 static int ride_nspec(const avt_ctx* c, int nframes, int strips) {
     // over twelve frames, one frame each: 0 / 2 / 3 / 4 speculative workgroups 0.5045 / 0.4305 / 0.4217 / 0.4166 ms (rejections come
     // in runs of up to five).  Frame batches gain nothing from them - a launch lasts as long as its slowest frame, and with four
     // frames or more some frame always needs a full solve (4 / 8 / 16 / 64 frames: 0.639 / 0.712 / 0.786 / 1.247 ms without,
     // 0.643 / 0.712 / 0.793 / 1.317 ms with four speculative workgroups per frame) - so only the riding shapes have them.
-    int want = AVT_MAX_SPEC;
-    if (const char* e = getenv("AVT_NSPEC")) want = std::max(0, std::min(AVT_MAX_SPEC, atoi(e)));
+    int want = std::max(0, std::min(AVT_MAX_SPEC, c->tun.nspec));
     while (want > 0 && ride_concurrency(c) * nframes * (1 + want + strips * c->dm.d.NPAIR) > c->num_cus) --want;
     return want;
 }
 static int ride_strips(const avt_ctx* c, int nframes) {      // 8 strips per pair while the whole grid is resident (one SMPL frame), else 4, else none
-    if (c->fb.G < 64 || solve_big(c->dm.d) || getenv("AVT_NO_RIDE") || c->fb.use_moments) return 0;      // (moment form: k_assemble writes the system, nothing to reduce)
-    int want = 8;
-    if (const char* e = getenv("AVT_RIDE_STRIPS")) want = atoi(e) >= 8 ? 8 : 4;     // the two instantiated shapes; anything else would launch a grid its kernel was not built for
+    if (c->fb.G < 64 || solve_big(c->dm.d) || !c->tun.ride || c->fb.use_moments) return 0;      // (moment form: k_assemble writes the system, nothing to reduce)
+    const int want = c->tun.ride_strips ? c->tun.ride_strips : 8;      // the two instantiated shapes (avt_ctx_set_tuning admits 4 and 8 only)
     for (int s = want; s >= 4; s -= 4) if (ride_concurrency(c) * nframes * (1 + s * c->dm.d.NPAIR) <= c->num_cus) return s;
     return 0;
 }

@@ -699,8 +699,7 @@ __global__ __launch_bounds__(256) void k_compact(DeviceModel dm, FrameBuffers fb
 
 // few queries: the latency shape of the nearest-neighbour stage (4 lanes per query); many: one lane per query, one part per workgroup
 bool avt_nn_few(const avt_ctx* c, int nframes) {
-    const bool force_part = getenv("AVT_NN_FORCE_PART") != nullptr;      // tests: the throughput shape on small inputs too
-    return !force_part && (long long)nframes * c->launch_maxN <= 400000;
+    return !c->tun.nn_force_part && (long long)nframes * c->launch_maxN <= 400000;      // (nn_force_part: tests run the throughput shape on small inputs too)
 }
 
 void launch_nn(avt_ctx* c, int nframes) {
@@ -721,7 +720,7 @@ void launch_nn(avt_ctx* c, int nframes) {
     const int nscat = c->scatter_in_compact ? std::max(1, (maxN + BUCKET_TILE - 1) / BUCKET_TILE) : 0;
     c->scatter_in_compact = false;
     // (the throughput scan walks y-sorted candidates outwards from the wave's slab of queries; the latency shape keeps ascending vertex order)
-    const bool no_slab = getenv("AVT_NN_NO_SLAB") != nullptr;          // (read per enqueue: a launch-shape knob like AVT_G)
+    const bool no_slab = !c->tun.nn_slab;
     hipLaunchKernelGGL(k_compact, dim3(c->dm.d.num_parts + nscat, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb, c->nn_from_cloud ? 1 : 0,
                        (!few && !no_slab) ? 1 : 0);
     if (few) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn<4>), dim3((maxN + 63) / 64, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);

@@ -101,7 +101,7 @@ def _max_over_ranks(x, torch, dist, world, backend):
     return float(te.item())
 
 
-def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, rank, world, local_rank, dense, shard=None, regions=REGIONS):
+def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, rank, world, local_rank, dense, shard=None, regions=REGIONS, lm_policy=0):
     """Times `steps` optimize() calls over this rank's F resident frames, `regions` times; returns the per-config dict.
     Global frame g = rank + world * i is frame i of this rank (avt_shard partition); with a shard handle every step also
     enqueues the result all-gather (RCCL, device buffers) behind optimize()."""
@@ -115,7 +115,7 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
     starts = [synth.perturb_start(*gts[i], gids[i]) for i in range(F)]
     ctx = api.Context(gm, 24, pm, 200000 if dense else 65536, F, device=local_rank)
     ctx.set_data_term({"rows": ctx.DATA_TERM_ROWS, "moments": ctx.DATA_TERM_MOMENTS, "auto": ctx.DATA_TERM_AUTO}[args.data_term])
-    opt = Options.demo(icp_iters=args.icp_iters)
+    opt = Options.demo(icp_iters=args.icp_iters, lm_policy=lm_policy)
     npts = ctx.render_frames(np.array([g[0] for g in gts]), np.array([g[1] for g in gts]), np.array([g[2] for g in gts]),
                              res_scale=2 if dense else 1)                      # inputs resident in HBM
     p0 = np.array([s[1] for s in starts])
@@ -231,6 +231,8 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
                               "note": "8 flop x (visible model points of the query's part, summed over the queries of frame 0) x frames per launch / mean duration "
                                       "of the nearest-neighbour class in the instrumented pass (HIP events; batches: k_compact + k_nn_part together); no FMA "
                                       "contraction by design (bit-exact against nanoflann), so the reachable issue rate is half the FMA peak"}
+    res["tuning"] = {"values": ctx.tuning().as_dict(), "non_default": sorted(ctx.tuning().non_default()), "data_term": args.data_term,
+                     "data_term_run": "moments" if (args.data_term == "moments" or (args.data_term == "auto" and nfg >= ctx.tuning().mom_min_frames)) else "rows"}
     res["points_per_frame"] = int(Nmean)
     res["matched_model_points"] = int(M)
     res["final_cost_frame0"] = st[0].final_cost
@@ -579,7 +581,7 @@ def _triple(c):
     """value / roofline.frac / roofline_nn.frac of a secondary configuration."""
     if not c:
         return None
-    return {"value": _r(c.get("value"), 1), "ms_per_step": _r(c.get("ms_per_step"), 4), "roofline_kernel": (c.get("roofline") or {}).get("kernel"),
+    return {"value": _r(c.get("value"), 1), "ms_per_step": _r(c.get("ms_per_step"), 4), "data_term": c.get("data_term"), "roofline_kernel": (c.get("roofline") or {}).get("kernel"),
             "roofline_frac": _r((c.get("roofline") or {}).get("frac"), 5), "roofline_nn_frac": _r((c.get("roofline_nn") or {}).get("frac"), 5)}
 
 
@@ -615,12 +617,15 @@ def compact_line(out):
     bs = out.get("batch_split") or {}
     line["batch_split"] = {"enabled": bs.get("enabled"), "world": bs.get("world"), "backend": str(bs.get("backend", ""))[:24],
                            "ok": bool((bs.get("run") or {}).get("gathered_equals_local", False))}
+    if out.get("gain_ratio_schedule"):
+        g = out["gain_ratio_schedule"]
+        line["gain_ratio_schedule"] = {k: g.get(k) for k in ("value", "accepted_fraction", "accepted_gn_iterations_per_s", "final_cost_frame0")}
     if out.get("tuning"):
         line["tuning_non_default"] = out["tuning"].get("non_default", [])
     line["detail"] = "bench_detail.json"
     s = json.dumps(line, separators=(",", ":"))
     if len(s) >= COMPACT_LIMIT:         # never let the contract line outgrow the driver's parser: drop the optional parts
-        for k in ("configs", "roofline_nn", "batch_split", "tuning_non_default"):
+        for k in ("configs", "roofline_nn", "batch_split", "tuning_non_default", "gain_ratio_schedule"):
             line.pop(k, None)
             s = json.dumps(line, separators=(",", ":"))
             if len(s) < COMPACT_LIMIT:
@@ -750,6 +755,9 @@ def main():
         if args.saturation_frames > 0 and not args.scale_only:
             r3 = measure(api, synth, Options, torch, dist, smpl, gm, args, args.saturation_frames, 5, 2, rank, world, local_rank, False, shard,
                          max(3, args.regions // 3))
+    rg = None
+    if F == 1 and not args.dense and not args.scale_only:      # the gain-ratio damping schedule (avt_options.lm_policy = 1) on the headline frame
+        rg = measure(api, synth, Options, torch, dist, smpl, gm, args, 1, max(10, args.steps // 2), 3, rank, world, local_rank, False, None, max(3, args.regions // 3), lm_policy=1)
     rd = rd16 = rd64 = None
     if F == 1 and not args.dense and not args.no_dense_config and not args.scale_only:      # configs[4]: the dense stress frame, alone and in batches
         rd = measure(api, synth, Options, torch, dist, smpl, gm, args, 1, max(10, args.steps // 2), 3, rank, world, local_rank, True, shard, max(3, args.regions // 3))
@@ -780,7 +788,7 @@ def main():
                     "ms_per_step_min_max": [round(rr["elapsed_min"] / rr["steps"] * 1e3, 4), round(rr["elapsed_max"] / rr["steps"] * 1e3, 4)],
                     "frames_per_gpu": rr["F"], "points_per_frame": rr["points_per_frame"], "accepted_fraction": round(rr["accepted_fraction"], 4), "roofline": rr["roofline"],
                     **({"roofline_nn": rr["roofline_nn"]} if "roofline_nn" in rr else {}), "eval_kernel": rr["eval_kernel"], "kernels": rr["kernels"],
-                    **({"shard": rr["shard"]} if "shard" in rr else {})}
+                    "data_term": rr["tuning"]["data_term_run"], **({"shard": rr["shard"]} if "shard" in rr else {})}
 
         out = {
             "metric": "Gauss-Newton iterations/sec (30k-pt cloud, 10 shape + 24-joint pose)",
@@ -795,13 +803,17 @@ def main():
             "timing": {"regions": r["regions"], "steps_per_region": args.steps, "statistic": "median region, max over ranks per region",
                        "ms_per_step_min_max": [round(r["elapsed_min"] / args.steps * 1e3, 4), round(r["elapsed_max"] / args.steps * 1e3, 4)]},
             "roofline": r["roofline"], **({"roofline_nn": r["roofline_nn"]} if "roofline_nn" in r else {}), "eval_kernel": r["eval_kernel"], "kernels": r["kernels"],
-            "final_cost_frame0": r["final_cost_frame0"], "accepted_steps_frame0": r["accepted_steps_frame0"],
+            "final_cost_frame0": r["final_cost_frame0"], "accepted_steps_frame0": r["accepted_steps_frame0"], "tuning": r["tuning"],
             "batch_split": {**shard_info, **({"run": r["shard"]} if "shard" in r else {}), **({"check": chk} if chk is not None else {})},
         }
         if r2 is not None:
             out["throughput_config"] = cfg(r2, "BASELINE configs[2]: 64 independent ~30k-pt frames per GPU, same optimize()")
         if r3 is not None:
             out["saturation_config"] = cfg(r3, f"{args.saturation_frames} frames per GPU (where the frames-per-GPU curve flattens)")
+        if rg is not None:
+            out["gain_ratio_schedule"] = {"workload": "the headline frame with avt_options.lm_policy = 1 (gain-ratio damping, DESIGN.md section 4)", "value": round(rg["value"], 2),
+                                          "ms_per_step": round(rg["elapsed"] / rg["steps"] * 1e3, 4), "accepted_fraction": round(rg["accepted_fraction"], 4),
+                                          "accepted_gn_iterations_per_s": round(rg["value"] * rg["accepted_fraction"], 2), "final_cost_frame0": rg["final_cost_frame0"]}
         if rd is not None:
             out["dense_config"] = cfg(rd, "BASELINE configs[4]: ONE dense frame (2560x1440 render, ~150k points), same optimize()")
             out["dense_batch_config"] = {"16_frames": cfg(rd16, "16 dense frames per GPU (one frame group)"),

@@ -231,6 +231,31 @@ int avt_get_data_term(avt_ctx* c);
  * s_memtime probes, see tools/kernel_timing_probe.py) */
 int avt_debug_trace(avt_ctx* c, int frame, double* out64);
 
+/* Launch-shape and algorithm knobs of a context.  The defaults are the measured optima (DESIGN.md sections 5 and 7); they exist for
+ * experiments and for tests that must force a particular code path.  avt_ctx_create fills the structure from the defaults and then
+ * ONCE from the environment (AVT_<FIELD NAME IN UPPER CASE>, e.g. AVT_NSPEC=0; unknown AVT_* names are reported on stderr): nothing in
+ * the library reads the environment afterwards, and what a context runs with can be read back and recorded.  avt_ctx_set_tuning
+ * validates, drops the cached launch graphs and takes effect for the following calls. */
+typedef struct avt_tuning {
+    int use_graph;           /* 1: optimize() replays one hipGraph per launch shape; 0: plain launches (AVT_NO_GRAPH=1 sets 0) */
+    int groups;              /* frame groups (streams) of one optimize(); 0 = automatic (2 from 32 frames on, one frame per group for 2-3 frames) */
+    int g;                   /* row form: evaluation workgroups per frame, 0 = automatic */
+    int gcap;                /* ... and their cap in the few-frames shape (128) */
+    int vis_frame_min;       /* frames per launch from which visibility runs as one workgroup per frame (64; 0 = never) */
+    int ride;                /* 1: up to three frames the reduction rides in k_solve's launch */
+    int ride_strips;         /* 0 = automatic, else 4 or 8 strips per tile pair */
+    int ride_sizing_groups;  /* 1: size the riding shapes by the frame groups running side by side instead of by the one launch */
+    int nspec;               /* speculative solver workgroups per frame beside the solver (0 .. 4) */
+    int nn_force_part;       /* 1: the throughput shape of the nearest neighbour on small inputs too */
+    int nn_slab;             /* 1: that shape walks y-sorted candidates outwards from the wave's slab of queries; 0: full scan */
+    int mom_min_frames;      /* AVT_DATA_TERM_AUTO: frames per launch from which the moment form is used (60) */
+    int debug;               /* 1: occupancy report on stderr at context creation */
+    int reserved;
+    long long ride_timeout_us; /* how long a solver role waits for the riding reduction before it raises the frame's fault (2 000 000) */
+} avt_tuning;
+int avt_ctx_get_tuning(avt_ctx* c, avt_tuning* out);
+int avt_ctx_set_tuning(avt_ctx* c, const avt_tuning* t);
+
 /* How optimize() will launch over the resident frames: the batch runs as `groups` frame groups of `frames_per_group` frames
  * (each kernel of the sequence is launched once per group, on the group's own stream when replayed as a hipGraph), the
  * evaluation kernel with `eval_workgroups_per_frame` workgroups per frame.  Lets a profiler label launches by shape. */

@@ -30,7 +30,7 @@ def _run(ctx, api, frames, opt):
 
 
 def test_a_solver_that_gives_up_waiting_is_an_error_not_a_different_fit(smpl, gmodel):
-    """AVT_RIDE_TIMEOUT_US=0 (read when the context is created): a solver role whose reduction has not yet delivered gives up at
+    """avt_tuning.ride_timeout_us = 0: a solver role whose reduction has not yet delivered gives up at
     once.  Every call then either fails with status 3 or - the reduction happened to be there - returns the undisturbed bits."""
     from avatar_amd import api
     pm = synth.identity_part_map()
@@ -39,11 +39,7 @@ def test_a_solver_that_gives_up_waiting_is_an_error_not_a_different_fit(smpl, gm
     for F in (1, 2, 3):
         frames = [synth.make_frame(smpl, s) for s in SEEDS[F]]
         good = _run(_ctx(api, gmodel, pm, F), api, frames, opt)
-        os.environ["AVT_RIDE_TIMEOUT_US"] = "0"
-        try:
-            ctx = _ctx(api, gmodel, pm, F)
-        finally:
-            os.environ.pop("AVT_RIDE_TIMEOUT_US", None)
+        ctx = _ctx(api, gmodel, pm, F).set_tuning(ride_timeout_us=0)
         for _ in range(4):
             try:
                 out = _run(ctx, api, frames, opt)

@@ -89,3 +89,31 @@ def test_moments_batch_matches_single(smpl, gmodel):
     for i, fr in enumerate(frs):
         p, q, w, s1 = one.optimize_batch([fr["data"]], [fr["labels"]], opt, starts[i][0][None], starts[i][1][None], starts[i][2][None])
         assert np.array_equal(p[0], P[i]) and np.array_equal(q[0], Q[i]) and np.array_equal(w[0], W[i])
+
+
+def test_tuning_is_a_structure_not_the_environment(smpl, gmodel):
+    """include/avt.h avt_tuning: read back, changed through the setter, validated; the AUTO data term follows mom_min_frames."""
+    from avatar_amd import api, capi
+    pm = synth.identity_part_map()
+    ctx = api.Context(gmodel, 24, pm, 60000, 4)
+    t = ctx.tuning()
+    assert t.as_dict() == {k: v for k, v in capi.Tuning.DEFAULTS.items() if k != "reserved"} and t.non_default() == {}
+    ctx.set_tuning(nspec=2, mom_min_frames=2)
+    assert ctx.tuning().non_default() == {"nspec": 2, "mom_min_frames": 2}
+    with pytest.raises(api.AvtError):
+        ctx.set_tuning(ride_strips=5)
+    with pytest.raises(KeyError):
+        ctx.set_tuning(no_such_knob=1)
+    # four frames with the moment form from two frames per launch on == the same frames with the form selected explicitly
+    frs = [synth.make_frame(smpl, 30 + s) for s in range(4)]
+    starts = [_start(fr) for fr in frs]
+    args = ([fr["data"] for fr in frs], [fr["labels"] for fr in frs], Options.demo(max_iters_per_icp=4), np.array([s[0] for s in starts]),
+            np.array([s[1] for s in starts]), np.array([s[2] for s in starts]))
+    a = ctx.optimize_batch(*args)
+    ctx2 = api.Context(gmodel, 24, pm, 60000, 4)
+    ctx2.set_data_term(ctx2.DATA_TERM_MOMENTS)
+    b = ctx2.optimize_batch(*args)
+    assert all(np.array_equal(x, y) for x, y in zip(a[:3], b[:3]))
+    ctx3 = api.Context(gmodel, 24, pm, 60000, 4)      # default: rows for four frames - close, not bit-equal
+    c = ctx3.optimize_batch(*args)
+    assert np.abs(c[0] - a[0]).max() < 1e-9 and not np.array_equal(c[0], a[0])

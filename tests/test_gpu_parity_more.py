@@ -293,55 +293,33 @@ def test_in_launch_hand_over_is_reproducible(smpl, gmodel):
 def test_speculative_steps_do_not_change_a_bit(smpl, gmodel):
     """One and two frames: the solve launch factors the steps a run of rejections will ask for beside the one needed now, and a
     rejection installs the step that is already there.  With the speculative workgroups switched off
-    (AVT_NSPEC=0, read when the launch is enqueued) every step is factored when it is asked for: same bytes."""
-    import os
+    (avt_tuning.nspec = 0) every step is factored when it is asked for: same bytes."""
     from avatar_amd import api
     pm = synth.identity_part_map()
     outs = {}
-    old = os.environ.get("AVT_NSPEC")
-    try:
-        for nspec in ("0", "4", "1"):
-            os.environ["AVT_NSPEC"] = nspec
-            res = []
-            for F, seeds in ((1, (4, 8)), (2, (5, 6))):       # frames with runs of three to five rejections
-                frs = [synth.make_frame(smpl, s) for s in seeds[:F]] if F == 2 else None
-                for s in (seeds if F == 1 else (0,)):
-                    fl = [synth.make_frame(smpl, s)] if F == 1 else frs
-                    ctx = api.Context(gmodel, 24, pm, 60000, F)
-                    p, q, w, st = ctx.optimize_batch([f["data"] for f in fl], [f["labels"] for f in fl], Options.demo(icp_iters=2),
-                                                     np.array([f["start"][1] for f in fl]), np.array([api.rot_to_quat(f["start"][2]) for f in fl]),
-                                                     np.array([f["start"][0] for f in fl]))
-                    res += [p.ravel(), q.ravel(), w.ravel(), np.array([x.final_cost for x in st]), np.array([x.accepted_steps for x in st], float)]
-            outs[nspec] = np.concatenate(res)
-    finally:
-        if old is None: os.environ.pop("AVT_NSPEC", None)
-        else: os.environ["AVT_NSPEC"] = old
+    for nspec in (0, 4, 1):
+        res = []
+        for F, seeds in ((1, (4, 8)), (2, (5, 6))):       # frames with runs of three to five rejections
+            frs = [synth.make_frame(smpl, s) for s in seeds[:F]] if F == 2 else None
+            for s in (seeds if F == 1 else (0,)):
+                fl = [synth.make_frame(smpl, s)] if F == 1 else frs
+                ctx = api.Context(gmodel, 24, pm, 60000, F).set_tuning(nspec=nspec)
+                assert ctx.tuning().nspec == nspec
+                p, q, w, st = ctx.optimize_batch([f["data"] for f in fl], [f["labels"] for f in fl], Options.demo(icp_iters=2),
+                                                 np.array([f["start"][1] for f in fl]), np.array([api.rot_to_quat(f["start"][2]) for f in fl]),
+                                                 np.array([f["start"][0] for f in fl]))
+                res += [p.ravel(), q.ravel(), w.ravel(), np.array([x.final_cost for x in st]), np.array([x.accepted_steps for x in st], float)]
+        outs[str(nspec)] = np.concatenate(res)
     assert np.array_equal(outs["0"], outs["4"]) and np.array_equal(outs["0"], outs["1"])
     assert outs["0"].size > 400
-
-
-def _with_env(name, value):
-    import contextlib
-    import os
-
-    @contextlib.contextmanager
-    def cm():
-        old = os.environ.get(name)
-        os.environ[name] = value
-        try:
-            yield
-        finally:
-            if old is None: os.environ.pop(name, None)
-            else: os.environ[name] = old
-    return cm()
 
 
 def test_slab_scan_against_nanoflann_goldens(smpl, omodel, gmodel):
     """The throughput shape of the nearest neighbour (k_compact sorting each part's visible candidates by (y, vertex id), k_nn_part
     walking outwards from the wave's slab of queries until the y gap alone exceeds the worst best distance) on the reference's own
     nanoflann outputs: the four small cases, 38 k and 125 k queries, and the coarse 6-part map whose parts are larger than the
-    sort's capacity (they take the unsorted full scan).  AVT_NN_FORCE_PART routes the stand-alone avt_nn through that shape.
-    Bit-exact, and identical with the slab switched off (AVT_NN_NO_SLAB)."""
+    sort's capacity (they take the unsorted full scan).  avt_tuning.nn_force_part routes the stand-alone avt_nn through that shape.
+    Bit-exact, and identical with the slab switched off (avt_tuning.nn_slab = 0)."""
     import os
     import sys
     from avatar_amd import api
@@ -350,19 +328,18 @@ def test_slab_scan_against_nanoflann_goldens(smpl, omodel, gmodel):
     import make_nn_golden_full as mk
     zf = np.load(os.path.join(here, "golden", "nn_golden_full.npz"))
     zs = np.load(os.path.join(here, "golden", "nn_golden.npz"))
-    with _with_env("AVT_NN_FORCE_PART", "1"):
-        for k in range(int(zs["ncase"])):
-            pm = zs[f"part_map_{k}"]; npart = int(zs[f"num_parts_{k}"])
-            ctx = api.Context(gmodel, npart, pm, 60000, 1)
-            got = ctx.nn(zs[f"cloud_{k}"], zs[f"vis_{k}"], zs[f"data_{k}"], zs[f"labels_{k}"])
-            assert np.array_equal(got, zs[f"idx_{k}"]), f"small case {k}"
-        for k, c in enumerate(mk.CASES):
-            pm, npart, cloud, vis, data, labels = mk.case_inputs(smpl, omodel, c)
-            ctx = api.Context(gmodel, npart, pm, len(labels), 1, device=0)
-            got = ctx.nn(cloud, vis, data, labels)
-            assert np.array_equal(got, zf[f"idx_{k}"]), (k, int((got != zf[f"idx_{k}"]).sum()))
-            with _with_env("AVT_NN_NO_SLAB", "1"):
-                assert np.array_equal(ctx.nn(cloud, vis, data, labels), got)
+    for k in range(int(zs["ncase"])):
+        pm = zs[f"part_map_{k}"]; npart = int(zs[f"num_parts_{k}"])
+        ctx = api.Context(gmodel, npart, pm, 60000, 1).set_tuning(nn_force_part=1)
+        got = ctx.nn(zs[f"cloud_{k}"], zs[f"vis_{k}"], zs[f"data_{k}"], zs[f"labels_{k}"])
+        assert np.array_equal(got, zs[f"idx_{k}"]), f"small case {k}"
+    for k, c in enumerate(mk.CASES):
+        pm, npart, cloud, vis, data, labels = mk.case_inputs(smpl, omodel, c)
+        ctx = api.Context(gmodel, npart, pm, len(labels), 1, device=0).set_tuning(nn_force_part=1)
+        got = ctx.nn(cloud, vis, data, labels)
+        assert np.array_equal(got, zf[f"idx_{k}"]), (k, int((got != zf[f"idx_{k}"]).sum()))
+        ctx.set_tuning(nn_slab=0)
+        assert np.array_equal(ctx.nn(cloud, vis, data, labels), got)
 
 
 def test_slab_scan_settles_exact_ties_by_vertex_id(smpl, omodel, gmodel):
@@ -386,9 +363,8 @@ def test_slab_scan_settles_exact_ties_by_vertex_id(smpl, omodel, gmodel):
     sel = slice(0, None, 3)
     data, labels = fr["data"][sel], fr["labels"][sel]
     ref = omodel.nn(pm, 24, cloud, vis, data, labels)
-    with _with_env("AVT_NN_FORCE_PART", "1"):
-        ctx = api.Context(gmodel, 24, pm, 60000, 1)
-        got = ctx.nn(cloud, vis, data, labels)
+    ctx = api.Context(gmodel, 24, pm, 60000, 1).set_tuning(nn_force_part=1)
+    got = ctx.nn(cloud, vis, data, labels)
     assert np.array_equal(got, ref), int((got != ref).sum())
     # the ties were real: most matched vertices have a twin at the same position with another id
     m = ref[ref >= 0]
