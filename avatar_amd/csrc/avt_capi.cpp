@@ -422,7 +422,7 @@ int download_state(avt_ctx* c, double* p, double* q, double* w, avt_stats* st) {
         char msg[256];
         snprintf(msg, sizeof msg, "optimize: %d frame(s) carry a device fault (first: frame %d, bits 0x%x%s); their result is not valid", nbad, bad,
                  fault[bad], (fault[bad] & AVT_FAULT_RIDE_TIMEOUT) ? ": a solver gave up waiting for the in-launch reduction" : "");
-        HIP_OK(hipMemsetAsync(c->fb.fault, 0, (size_t)nf * sizeof(unsigned), c->stream));
+        HIP_OK(hipMemsetAsync(c->fb.fault, 0, (size_t)c->fb.max_frames * sizeof(unsigned), c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));
         avt_set_error(msg);
         return AVT_STATUS_DEVICE_FAULT;
@@ -558,7 +558,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         dev_alloc(c, &fb.const_part, (size_t)max_frames * fb.const_blocks) ||
         dev_alloc(c, &fb.x, (size_t)max_frames * 2 * d.xsize) || dev_alloc(c, &fb.x_start, (size_t)max_frames * 2 * d.xsize) ||
         dev_alloc(c, &fb.ctl_start, (size_t)max_frames) || dev_alloc(c, &fb.prep, (size_t)max_frames * 2 * d.prep_size) ||
-        dev_alloc(c, &fb.rec, (size_t)max_frames * d.nb_max * 4 * d.rec_quad) || dev_alloc(c, &fb.partial, part_cap * d.NPAIR * 256) || dev_alloc(c, &fb.wmask, part_cap) || dev_alloc(c, &fb.bmask, (size_t)max_frames * d.nb_max) || dev_alloc(c, &fb.erange, (size_t)max_frames * AVT_ERANGE) || dev_alloc(c, &fb.Hraw, (size_t)max_frames * 2 * d.HS * d.HS) || dev_alloc(c, &fb.solve_gd, (size_t)max_frames * 2 * d.HS) ||
+        dev_alloc(c, &fb.rec, (size_t)max_frames * d.nb_max * 4 * d.rec_quad) || dev_alloc(c, &fb.partial, part_cap * d.NPAIR * 256) || dev_alloc(c, &fb.wmask, part_cap) || dev_alloc(c, &fb.bmask, (size_t)max_frames * d.nb_max) || dev_alloc(c, &fb.erange, (size_t)max_frames * AVT_ERANGE) || dev_alloc(c, &fb.Hraw, (size_t)max_frames * 2 * d.HS * d.HS) ||
         dev_alloc(c, &fb.prior, (size_t)max_frames * 2 * AVT_MAX_COMPS * AVT_PRIOR_STRIDE) || dev_alloc(c, &fb.ctl, (size_t)max_frames) ||
         dev_alloc(c, &fb.jointpos, (size_t)max_frames * 3 * J) || dev_alloc(c, &fb.jointtrans, (size_t)max_frames * 12 * J) ||
         dev_alloc(c, &fb.trace, (size_t)max_frames * 64))

@@ -270,7 +270,6 @@ struct FrameBuffers {
     int* erange;          // [max_frames][AVT_ERANGE] frame batches (G < 64): evaluation workgroup g takes batches [erange[g], erange[g+1]) (k_solve INIT)
     double* partial;      // [max_frames][G][NPAIR][256]
     unsigned long long* wmask;   // [max_frames][G] tile pairs workgroup g of the frame wrote to `partial` (bit = pair); k_reduce skips the rest
-    double* solve_gd;     // [max_frames][2][HS] k_solve<1024>: gradient and diagonal of the undamped system (avt_lm.hip)
     double* Hraw;         // [max_frames][2][HS*HS] reduced data-term [J|r]^T W [J|r] (full symmetric) per state slot
     double* prior;        // [max_frames][2][AVT_MAX_COMPS][AVT_PRIOR_STRIDE] GMM scores / Prec*(x-mu) per state slot
     AvtFrameCtl* ctl;     // [max_frames]

@@ -267,8 +267,9 @@ void launch_visibility(avt_ctx* c, int nframes, int enable, bool with_bucket_sca
 // Invariant: the label histogram / scatter cursors (part_cnt) are all zero between API calls.  optimize() restores it in
 // k_finalize (one memset node less per call); the stand-alone avt_nn path clears after itself (clear_after).
 // avt_state_reset: start state -> working state, both buffers in one launch
-__global__ __launch_bounds__(256) void k_state_reset(FrameBuffers fb, int nx, int nctl) {
+__global__ __launch_bounds__(256) void k_state_reset(FrameBuffers fb, int nx, int nctl, int nframes) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nframes) fb.fault[i] = 0;
     if (i < nx) fb.x[i] = fb.x_start[i];
     const int* src = (const int*)fb.ctl_start;
     int* dst = (int*)fb.ctl;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) void k_state_reset(FrameBuffers fb, int nx, in
 
 void launch_state_reset(avt_ctx* c, int nframes) {
     const int nx = nframes * 2 * c->dm.d.xsize, nctl = nframes * (int)(sizeof(AvtFrameCtl) / sizeof(int));
-    hipLaunchKernelGGL(k_state_reset, dim3((std::max(nx, nctl) + 255) / 256), dim3(256), 0, c->stream, c->fb, nx, nctl);
+    hipLaunchKernelGGL(k_state_reset, dim3((std::max(nx, nctl) + 255) / 256), dim3(256), 0, c->stream, c->fb, nx, nctl, nframes);
 }
 
 void launch_bucket(avt_ctx* c, int nframes, bool clear_after) {
@@ -302,7 +303,8 @@ __global__ __launch_bounds__(1024) void k_finalize(DeviceModel dm, FrameBuffers 
     const int f = blockIdx.x + fb.f0, t = threadIdx.x, V = dm.d.V;
     AvtFrameCtl& ctl = fb.ctl[f];
     if (t < 2 * (AVT_MAX_PARTS + 1)) fb.part_cnt[(size_t)f * 2 * (AVT_MAX_PARTS + 1) + t] = 0;   // bucketing is over: restore the invariant
-    if (t == 0) { fb.ride_ctr[f] = 0; fb.spec[f].n = 0; fb.spec[f].next = 0; }   // a new ICP iteration: no reduction has ridden yet, no speculative step exists
+    if (t == 0) { fb.ride_ctr[f] = 0; fb.spec[f].n = 0; fb.spec[f].next = 0; }
+    if (t == 0 && first_icp) fb.fault[f] = 0;      // a fault belongs to the optimize() call that raised it: one nobody downloaded must not mark this call's fit   // a new ICP iteration: no reduction has ridden yet, no speculative step exists
     __shared__ int s_wave_m[16], s_wave_t[16];
     const int chunk = (V + 1023) / 1024;
     const int lo = min(V, t * chunk), hi = min(V, lo + chunk);

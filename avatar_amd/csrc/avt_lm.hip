@@ -668,8 +668,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     // [2][HS] gradient and diagonal of the undamped system (predicted decrease of the step, gain-ratio schedule); the 1024-thread
     // shape has no LDS left for it (P = 178: 158.5 of 159.5 KB) and keeps it in the frame's global scratch - written and read by
     // this workgroup only, a barrier in between
-    double* s_gD = TRI ? fb.solve_gd + (size_t)f * 2 * HS : s_delta + HS + 2;
-    double* s_x = s_delta + HS + 2 + (TRI ? 0 : 2 * HS);    // [2][xsize] both state slots
+    double* s_x = s_delta + HS + 2;                         // [2][xsize] both state slots
     const PrepLayout L = prep_layout(J, K, d.xsize);
     // skeleton scratch: behind the factor (SMPL shape: staged at kernel start, hidden behind the factorisation) or ON it
     // (triangular shape: the factor is dead once the back substitution is done)
@@ -721,7 +720,9 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     AvtFrameCtl snap_ctl;
     AvtSpecCtl snap_sp;
     double snap_xw[AVT_MAX_SHAPE];
+    unsigned fault_at_start = 0;      // (requested with everything else: a load of its own in front of the wait would be a round trip on the chain)
     if constexpr (RIDE) {
+        fault_at_start = fb.fault[f];
         snap_ctl = fb.snap[f].ctl; snap_sp = fb.snap[f].sp;
 #pragma unroll
         for (int k = 0; k < AVT_MAX_SHAPE; ++k) snap_xw[k] = k < K ? fb.snap[f].xw[k] : 0.0;
@@ -751,9 +752,11 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
             // (download_state, avt_shard_gather_download) instead of handing out a fit made from a half-reduced system.
             const unsigned want = (unsigned)(fb.seq * RIDE * d.NPAIR);
             const long long t0 = wall_clock64();
+            // (a frame that already carries a fault of this call fails fast: every later launch would wait the full time again)
+            const long long limit = fault_at_start ? 0 : fb.ride_timeout;
             bool there;
             while (!(there = __hip_atomic_load(fb.ride_ctr + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) &&
-                   wall_clock64() - t0 < fb.ride_timeout)
+                   wall_clock64() - t0 < limit)
                 __builtin_amdgcn_s_sleep(1);
             if (!there) atomicOr(fb.fault + f, AVT_FAULT_RIDE_TIMEOUT);
         }
@@ -940,12 +943,11 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
             // rows < P: H + priors, diagonal damped
             double vh = v0;
             vh += (in_pose_c && pr_ >= 0 && pr_ < n) ? sc2 * prv : 0.0;
-            if (row == col) { vh += shape_c ? sbs * sbs : 0.0; if (own && col < P) s_gD[HS + col] = vh; vh += lambda * vh; }
+            if (row == col) { vh += shape_c ? sbs * sbs : 0.0; vh += lambda * vh; }
             // row P: -(J^T r) including the priors
             double vg = v0;
             vg += in_pose_c ? gs * gqc : 0.0;
             vg += shape_c ? sbs * (xqc * sbs) : 0.0;
-            if (own && row == P && col < P) s_gD[col] = vg;
             const bool inside = row <= P && col < P;
             const double val = inside ? (row < P ? vh : -vg) : ((row == col) ? 1.0 : 0.0);
             out[v] = own ? val : 0.0;
@@ -1006,19 +1008,33 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     double* xn = role == 0 ? x0 + (size_t)ntry * xs : fb.x_spec + ((size_t)f * AVT_MAX_SPEC + (role - 1)) * xs;
     double* prep_out = role == 0 ? prep0 + (size_t)ntry * d.prep_size : fb.prep_spec + ((size_t)f * AVT_MAX_SPEC + (role - 1)) * d.prep_size;
     double* s_qnew = s_W;                                   // [4J] quaternions of the new trial point (s_W is free again)
+    double pred_new = 0.0;                                  // (wave 0)
     if (ok) {
         // ---- back substitution by wave 0 (the other waves wait at the barrier)
         if (t < 64) {
             if constexpr (TRI) backsub_tri(Lblk, s_R, NB, P, t, s_delta);
             else if (NB == 22) backsub_blocked<22>(Lblk, s_R, NB, P, t, s_delta);
             else backsub_blocked<0>(Lblk, s_R, NB, P, t, s_delta);
-        }
-        __syncthreads();
-        if (t < 64) {      // predicted decrease of the quadratic model, 1/2 delta^T (lambda D delta - g) (fixed butterfly)
-            double a = 0.0;
-            for (int i = t; i < P; i += 64) { const double dl = s_delta[i]; a += dl * (lambda * s_gD[HS + i] * dl - s_gD[i]); }
-            a = 0.5 * wave_sum(a);
-            if (t == 0) s_gD[0] = a;      // (s_gD[0] was read by lane 0 before the wave's sum completed)
+            if (gain) {
+                // Predicted decrease of the quadratic model, 1/2 delta^T (lambda D delta - g), by the same wave (fixed butterfly).  g and the
+                // undamped diagonal D are formed again from the reduced system and the priors, entry by entry as sys_tile forms them
+                // (same operations, same bits) - only this schedule pays for them, the fixed-factor one never sees this block.
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const double* Hc = H0 + (size_t)cur * HS * HS;
+                double a = 0.0;
+                for (int i = t; i < P; i += 64) {
+                    const int pc = i - 6, sk = i - (3 + 3 * J);
+                    const bool in_pose = use_pose && pc >= 0 && pc < n, shape_c = sbs > 0.0 && sk >= 0;
+                    double Dii = hload(Hc + (size_t)i * HS + i), gi = hload(Hc + (size_t)P * HS + i);
+                    Dii += in_pose ? sc2 * Pr[(size_t)pc * n + pc] : 0.0;
+                    Dii += shape_c ? sbs * sbs : 0.0;
+                    gi += in_pose ? gs * pri[2 + pc] : 0.0;
+                    gi += shape_c ? sbs * (xc[3 + 4 * J + (sk >= 0 ? sk : 0)] * sbs) : 0.0;
+                    const double dl = s_delta[i];
+                    a += dl * (lambda * Dii * dl - gi);
+                }
+                pred_new = 0.5 * wave_sum(a);
+            }
         }
         __syncthreads();
         if constexpr (TRI) {   // the factor is dead: the skeleton constants take its place
@@ -1059,7 +1075,6 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         if (gain) { lambda = fmin(lambda * nu, lm_max); nu *= 2.0; }
         else lambda = fmin(lambda * lm_up, lm_max);
     }
-    const double pred_new = ok ? s_gD[0] : 0.0;
     if (t == 0 && role == 0) {
         ctl.lambda = lambda; ctl.try_valid = ok ? 1 : 0;
         // what the accept test of the trial point just made reads if no further solve follows (avt_decide.h)
@@ -1087,7 +1102,7 @@ static size_t solve_lds_bytes(const AvtDims& d) {
     const PrepLayout L = prep_layout(d.J, d.K, d.xsize);
     const size_t nblk = solve_big(d) ? (size_t)NB * (NB + 1) / 2 : (size_t)NB * NB;
     const size_t prep_bytes = sizeof(double) * (size_t)L.ndoubles + sizeof(int) * (2 * (size_t)L.nitems + 2 * AVT_MAX_JOINTS + 4);
-    const size_t fixed = sizeof(double) * (((std::max(HS, 4 * d.J) + 3) & ~1) + HS + 2 + (solve_big(d) ? 0 : 2 * HS) + ((2 * d.xsize + 1) & ~1));
+    const size_t fixed = sizeof(double) * (((std::max(HS, 4 * d.J) + 3) & ~1) + HS + 2 + ((2 * d.xsize + 1) & ~1));
     const size_t factor = sizeof(double) * nblk * 18;
     return (solve_big(d) ? std::max(factor, prep_bytes) + sizeof(double) * MFG_PB_DOUBLES + fixed
                          : factor + sizeof(double) * MF_PB_DOUBLES + fixed + prep_bytes) + 64;

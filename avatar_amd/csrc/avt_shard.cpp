@@ -249,6 +249,7 @@ struct LoopGroup {
     std::vector<const void*> slot;                 // one published pointer per rank (broadcast root / all-gather blocks)
     std::vector<std::deque<LoopMail>> mail;        // [source * world + destination] posted sends, oldest first
     std::vector<int> outstanding;                  // per source rank: posted sends not yet copied out by their receivers
+    std::vector<char> present;                     // per rank: a member with this rank exists
 };
 struct LoopComm { LoopGroup* g; int rank; };
 struct LoopPending { int depth = 0; std::vector<LoopSend> sends; struct R { int src; void* ptr; size_t bytes; }; std::vector<R> recvs; ncclComm_t comm = nullptr; hipStream_t stream = nullptr; };
@@ -289,7 +290,14 @@ const char* loop_GetErrorString(ncclResult_t r) {
 ncclResult_t loop_CommDestroy(ncclComm_t c) {
     LoopComm* lc = (LoopComm*)c;
     std::lock_guard<std::mutex> lk(loop_registry_mutex);
-    if (--lc->g->refs == 0) { loop_registry.erase(lc->g->name); delete lc->g; }
+    LoopGroup* g = lc->g;
+    --g->joined;
+    if (lc->rank >= 0 && lc->rank < (int)g->present.size()) g->present[lc->rank] = 0;
+    if (--g->refs == 0) {
+        auto it = loop_registry.find(g->name);
+        if (it != loop_registry.end() && it->second == g) loop_registry.erase(it);      // (a broken group was already taken out of the registry)
+        delete g;
+    }
     delete lc;
     return ncclSuccess;
 }
@@ -477,16 +485,21 @@ extern "C" int avt_shard_create_loopback(int device, int rank, int world, const 
     {
         std::lock_guard<std::mutex> lk(loop_registry_mutex);
         auto it = loop_registry.find(group);
+        if (it != loop_registry.end() && it->second->broken) {      // a group that timed out stays broken for its members; a fresh create under the same name starts clean
+            loop_registry.erase(it);
+            it = loop_registry.end();
+        }
         if (it == loop_registry.end()) {
             g = new LoopGroup();
-            g->name = group; g->world = world; g->slot.assign(world, nullptr); g->mail.resize((size_t)world * world); g->outstanding.assign(world, 0);
+            g->name = group; g->world = world; g->present.assign(world, 0); g->slot.assign(world, nullptr); g->mail.resize((size_t)world * world); g->outstanding.assign(world, 0);
             if (const char* e = getenv("AVT_SHARD_LOOPBACK_TIMEOUT_S")) g->timeout_s = std::max(0.1, atof(e));
             loop_registry[group] = g;
         } else {
             g = it->second;
             if (g->world != world || g->joined >= world) { avt_set_error("avt_shard_create_loopback: group exists with another world size, or is full"); return 1; }
+            if (g->present[rank]) { avt_set_error("avt_shard_create_loopback: this rank is already a member of the group"); return 1; }
         }
-        ++g->joined; ++g->refs;
+        ++g->joined; ++g->refs; g->present[rank] = 1;
     }
     avt_shard* s = new avt_shard();
     s->api = loop_api(); s->device = device; s->rank = rank; s->world = world;

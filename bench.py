@@ -42,6 +42,7 @@ LIMITER = {
     "lbs": "HBM/L2 streaming of the shape planes", "bucket": "LDS + global atomics", "visibility": "launch latency (few frames); one pass over the cloud, faces from LDS (batches)",
     "aggregate": "launch latency / gathers", "prepare": "latency (skeleton pass)",
     "decide": "cost-only evaluation of the last trial point (its accept test is taken inside the k_lbs launch that follows)",
+    "eval_moments": "L2 / MALL latency of the moment re-reads (k_pairpass: 9 (K+1) + 4 gathers of 8 B per lane, two workgroups per CU at 186 registers) and short dependent LDS chains (k_assemble)",
 }
 
 
@@ -51,7 +52,8 @@ def algorithmic_bytes_per_gn_iter(N, V, K, P):
 
 
 # symbol-name fragments (eval: the full evaluation k_eval<.., false>; solve: k_solve<.., SOLVE_NORMAL>; reduce: k_reduce<1> / k_reduce_strip<NS>)
-KERNEL_SYMBOL = {"eval": "Lb0EEv11DeviceModel12FrameBuffersi", "solve": "k_solveILi256ELb0ELi2", "reduce": "k_reduce", "nn": "k_nn", "lbs": "k_lbs"}
+KERNEL_SYMBOL = {"eval": "Lb0EEv11DeviceModel12FrameBuffersi", "solve": "k_solveILi256ELb0ELi2", "reduce": "k_reduce", "nn": "k_nn", "lbs": "k_lbs",
+                 "eval_moments": ("k_pairpass", "k_assemble")}      # moment form: the evaluation class is the pair pass + the assembly
 
 
 def pmc_traffic(frames_per_launch, kernel_class, points_per_frame):
@@ -66,8 +68,12 @@ def pmc_traffic(frames_per_launch, kernel_class, points_per_frame):
         n = d.get("points_per_frame")
         if n is None or abs(float(n) - points_per_frame) > 0.05 * points_per_frame:
             return None
-        hit = [v for k, v in d["kernels"].items() if KERNEL_SYMBOL.get(kernel_class, "?") in k]
-        return int(hit[0]["hbm_bytes"]) if hit else None
+        frag = KERNEL_SYMBOL.get(kernel_class, "?")
+        frags = frag if isinstance(frag, tuple) else (frag,)
+        hits = [[v for k, v in d["kernels"].items() if fr in k] for fr in frags]
+        if any(not h for h in hits):
+            return None
+        return int(sum(h[0]["hbm_bytes"] for h in hits))
     except Exception:
         return None
 
@@ -197,10 +203,12 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
     achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
     # whole-pipeline view: every GN iteration of every frame moves bytes_iter algorithmic bytes; time = the step
     pipe = F * bytes_iter * opt.icp_iters * opt.max_iters_per_icp / (med / steps) / 1e9
-    res["roofline"] = {"kernel": "k_" + dominant, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(nfg, dominant, Nmean),
+    moments_run = args.data_term == "moments" or (args.data_term == "auto" and nfg >= ctx.tuning().mom_min_frames)
+    dom_key = "eval_moments" if (dominant == "eval" and moments_run) else dominant
+    res["roofline"] = {"kernel": "k_pairpass + k_assemble" if dom_key == "eval_moments" else "k_" + dominant, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(nfg, dom_key, Nmean),
                        "chosen_because": ("two frame groups overlap: the evaluation bounds the step" if groups >= 2 else "largest share of device time on the one stream"),
-                       "limiter": LIMITER.get(dominant, "?"),
+                       "limiter": LIMITER.get(dom_key, "?"),
                        "avg_launch_us": round(avg_ms * 1e3, 3), "launches_timed": prof_timed[dominant][1],
                        "launch_shape": {"frames_per_launch": nfg, "frame_groups": groups, "eval_workgroups_per_frame": G},
                        "algorithmic_bytes_per_launch": int(bytes_launch),
@@ -215,7 +223,9 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
     tfl = nfg * 3.0 * M * P * (P + 1) / (ev_ms * 1e-3) / 1e12 if ev_ms > 0 else 0.0
     res["eval_kernel"] = {"avg_launch_us_with_events": round(ev_ms * 1e3, 3), "jtj_tflops_f64": round(tfl, 4), "mfma_peak_tflops": FP64_MFMA_PEAK_TFLOPS,
                           "mfma_frac": round(tfl / FP64_MFMA_PEAK_TFLOPS, 6),
-                          "note": "dense-equivalent 3 M P (P+1) flops per frame; the block-sparse contraction executes about 30 % of them"}
+                          "note": ("moment form: the rows are not rebuilt; dense-equivalent 3 M P (P+1) flops per frame as if they were (the assembly executes about 0.9 MFLOP per frame, "
+                                   "the moments 11 MFLOP once per ICP iteration)" if moments_run else
+                                   "dense-equivalent 3 M P (P+1) flops per frame; the block-sparse contraction executes about 30 % of them")}
     # second object: the nearest-neighbour scan against the fp64 VALU peak (8 flop per candidate; candidates = visible
     # model points of the query's part, counted exactly for frame 0 and scaled by the frames of a launch)
     nnp = prof.get("nn")

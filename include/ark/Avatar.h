@@ -48,11 +48,16 @@ struct AvatarModel {
      *  model.npz the reference's deprecated ad-hoc text format is read (AvatarModel.cpp:128-288: skeleton.txt, model.pcd,
      *  shapekey/ *.pcd, joint_shape_regressor.txt or joint_regressor.txt, mesh.txt).
      *  @param limit_one_joint_per_point the optimiser's forward model binds every point to its largest-weight joint only
-     *  (AvatarModel.cpp:190-196; the reference honours it in the legacy format, here it applies to either); update() keeps all weights. */
+     *  (AvatarModel.cpp:190-196).  Like the reference it takes effect in the legacy format only: with a model.npz it is ignored (:23-127 never
+     *  read it) - a warning says so; avt_model_desc::limit_one_joint_per_point is there for callers that want it on any model.  update() keeps all weights. */
     explicit AvatarModel(const std::string& model_dir = "", bool limit_one_joint_per_point = false)
         : MODEL_DIR(model_dir), limitOneJointPerPoint(limit_one_joint_per_point) {
         if (model_dir.empty()) { std::fprintf(stderr, "avatar (MI355X): no model directory given (the reference's data download is not bundled)\n"); std::exit(1); }
         if (!std::ifstream(model_dir + "/model.npz")) { loadLegacy(model_dir); return; }
+        if (limitOneJointPerPoint) {
+            std::fprintf(stderr, "avatar (MI355X): limit_one_joint_per_point is ignored for model.npz, as in the reference (AvatarModel.cpp:23-127)\n");
+            applyLimitOneJoint = false;
+        }
         std::map<std::string, npz::Array> z;
         try { z = npz::load(model_dir + "/model.npz"); }
         catch (const std::exception& e) { std::fprintf(stderr, "avatar (MI355X): %s\n", e.what()); std::exit(1); }
@@ -114,6 +119,7 @@ struct AvatarModel {
     bool useJointShapeRegressor = true;
     const std::string MODEL_DIR;
     const bool limitOneJointPerPoint = false;
+    bool applyLimitOneJoint = true;         // false: the flag was given with a model.npz, where the reference ignores it
 
     avt_model* handle = nullptr;   // C-ABI handle
 
@@ -255,7 +261,7 @@ struct AvatarModel {
         d.jreg_colptr = r_colptr.data(); d.jreg_row = r_row.data(); d.jreg_val = r_val.data();
         d.prior_ncomps = posePrior.nComps > 0 ? posePrior.nComps : 0; d.prior_ndims = posePrior.nDims;
         d.prior_weight = posePrior.weight.data(); d.prior_mean = posePrior.mean.data(); d.prior_cov = posePrior.cov.data();
-        d.limit_one_joint_per_point = limitOneJointPerPoint ? 1 : 0;
+        d.limit_one_joint_per_point = (limitOneJointPerPoint && applyLimitOneJoint) ? 1 : 0;
         if (!legacyJsr.empty()) { d.joint_shape_reg_base = legacyJsrBase.data(); d.joint_shape_reg = legacyJsr.data(); }
         ARK_AVT_CHECK(avt_model_create(&d, &handle));
         mainJoint.resize(nV);
