@@ -6,7 +6,7 @@
 #   the instrumented pass of bench.py uses the same shapes as the graph replay.
 # Output: gpurun_out/prof_<tag>/ and gpurun_out/<round>_*.txt / *.json (copy what is to be judged into profiles/).
 set -u
-RND=${RND:-r03}
+RND=${RND:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
@@ -30,14 +30,14 @@ for CFG in ${FRAMES:-1 64 512 1d 16d 64d}; do
       $O/${RND}_pmc_${nfg}_frames_per_launch${TAG}.json $npts > /dev/null
 done
 if [ "${SQ:-1}" = 1 ]; then
-  for F in ${SQ_FRAMES:-1 64}; do
+  for F in ${SQ_FRAMES:-1 64 512}; do
     cmd="python $R/bench.py --frames $F --steps 3 --warmup 1 $COMMON"
     out=$O/${RND}_pmc_sq_counters_${F}_frames.txt
     : > $out
     for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH SQ_WAIT_ANY"; do
       n=$(echo $set | cut -d" " -f1)
       rocprofv3 --pmc $set -d $O/prof_sq_${F}_$n -o p -- $cmd > $O/prof_sq_${F}_$n.log 2>&1
-      python $R/tools/pmc_counters.py $(find $O/prof_sq_${F}_$n -name "*.db" | head -1) k_eval k_solve k_nn k_reduce >> $out
+      python $R/tools/pmc_counters.py $(find $O/prof_sq_${F}_$n -name "*.db" | head -1) k_eval k_solve k_nn k_reduce k_pairpass k_assemble k_moments k_compact >> $out
     done
   done
 fi
