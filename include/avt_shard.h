@@ -55,7 +55,11 @@ int avt_shard_create(int device, int rank, int world, const char id[AVT_SHARD_ID
  * exchanges below become device-to-device copies behind host-side rendezvous.  For single-process hosts that drive their GPUs
  * from threads, and for exercising the multi-rank exchange code on a one-GPU box (RCCL refuses two ranks on one GPU).  Every
  * exchange is collective: each rank's thread must make the call.  A rank that does not arrive within
- * AVT_SHARD_LOOPBACK_TIMEOUT_S (default 20 s) makes its peers' calls FAIL instead of hang. */
+ * AVT_SHARD_LOOPBACK_TIMEOUT_S (default 20 s) makes its peers' calls FAIL instead of hang.  A group that broke this way stays broken for its
+ * members; creating the ranks again under the same name starts a fresh group, and a rank can be a member only once.
+ * Note for thread-per-GPU hosts: every hipGraphLaunch of the process goes through ONE mutex inside the library (HIP 7.0's hipGraphLaunch is not
+ * safe against a hipGraphLaunch from another thread, profiles/r03_hipgraphlaunch_thread_crash.txt), and a two-branch graph costs ~230 us of host
+ * time to enqueue: the optimize() calls of the threads serialise on it.  One process per GPU (the RCCL transport) does not share that lock. */
 int avt_shard_create_loopback(int device, int rank, int world, const char* group, avt_shard** out);
 void avt_shard_destroy(avt_shard* s);
 int avt_shard_rank(const avt_shard* s);
