@@ -288,7 +288,6 @@ static void build_moment_tables(avt_model* m) {
             m->mom_s2_jj.push_back(j | (jp << 8));
         }
     d.mom_nz2 = (int)m->mom_z2_jj.size();
-    if ((int)m->mom_s2_jj.size() * 16 > 2 * (J + 1) * K * 6) d.mom_ok = 0;      // the block sums reuse the records' LDS area (k_assemble)
     d.mom_nb2 = (int)m->mom_s2_jj.size();
     d.mom_nm1 = 0;
     m->mom_m1_start.assign(1, 0); m->mom_m1.clear();

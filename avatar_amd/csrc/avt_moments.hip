@@ -533,7 +533,8 @@ struct MomTab { const unsigned short *opk_start, *opk, *sub_start, *sub, *s2_sta
 __host__ __device__ inline int mom_tab_words(const AvtDims& d) { return (2 * (d.J + 1) + d.mom_nopk + d.mom_nsub + (d.mom_nb2 + 1) + d.mom_ns2l + d.mom_nb2 + 3) & ~3; }
 __host__ __device__ inline int mom_asm_doubles(const AvtDims& d) {
     const int J = d.J, K = d.K;
-    return (2 * d.mom_np + 1) * 16 + 2 * (J + 1) * 16 + 2 * (J + 1) * K * 6 + J * 9 + J * 4 + J * K + (K * K + K) + 2 * K + 8;
+    const int prtr = 2 * (J + 1) * K * 6 > d.mom_nb2 * 16 ? 2 * (J + 1) * K * 6 : d.mom_nb2 * 16;      // PR | TR, later the rot-rot block sums
+    return (2 * d.mom_np + 1) * 16 + 2 * (J + 1) * 16 + prtr + J * 9 + J * 4 + J * K + (K * K + K) + 2 * K + 8;
 }
 
 #define MOM_ASM_NTH 1024     // threads of the assembly workgroup: every phase is latency, more items in flight is what helps
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(NTH) void k_assemble(DeviceModel dm, FrameBuffers f
     double* TK = PK + (J + 1) * 16;             // [J + 1][16]  subtree sums of PK
     double* PR = TK + (J + 1) * 16;             // [J + 1][K][6]
     double* TR = PR + (J + 1) * K * 6;          // [J + 1][K][6]
-    double* Uk = TR + (J + 1) * K * 6;          // [J][3][3] sum_s om_s Dphi_k[i][s][c]
+    double* Uk = PR + (2 * (J + 1) * K * 6 > d.mom_nb2 * 16 ? 2 * (J + 1) * K * 6 : d.mom_nb2 * 16);          // [J][3][3] sum_s om_s Dphi_k[i][s][c]
     double* XQ = Uk + J * 9;                    // [J][4] axial(XD_k), tr XD_k
     double* YFk = XQ + J * 4;                   // [J][K]
     double* ZS = YFk + J * K;                   // [K K + K]
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(NTH) void k_assemble(DeviceModel dm, FrameBuffers f
     // listed (left leg against right arm: none), the others are structural zeros.  Phase 1: the sums, one item per (block, entry
     // of X16), into the PR / TR area (free now); phase 2: one item per (block, matrix entry).
     __syncthreads();
-    double* S16 = PR;      // [nb2][16]  (nb2 * 16 <= 2 (J + 1) K 6 is checked on the host)
+    double* S16 = PR;      // [nb2][16]  (the PR | TR area is sized for it)
     for (int e = t; e < d.mom_nb2 * 16; e += NTH) {
         const int b = e >> 4, q = e & 15;
         double a = 0.0;

@@ -117,3 +117,33 @@ def test_tuning_is_a_structure_not_the_environment(smpl, gmodel):
     ctx3 = api.Context(gmodel, 24, pm, 60000, 4)      # default: rows for four frames - close, not bit-equal
     c = ctx3.optimize_batch(*args)
     assert np.abs(c[0] - a[0]).max() < 1e-9 and not np.array_equal(c[0], a[0])
+
+
+def test_moment_form_on_other_model_shapes(smpl):
+    """The run-time-K instantiations (k_pairpass<0>, k_assemble<0>; SMPL's K = 10 has its own) and a model whose points carry one joint
+    each (limit_one_joint_per_point: only diagonal pairs): normal equations equal to the row form's and the oracle's, the fit equal to the oracle's."""
+    from avatar_amd import api
+    from oracle import oracle as orc
+    pm = synth.identity_part_map()
+    fr = synth.make_frame(smpl, 12)
+    p0, q0, _ = _start(fr)
+    n = len(fr["labels"])
+    small = dict(smpl)
+    small["shapedirs"] = np.ascontiguousarray(np.asarray(smpl["shapedirs"])[:, :, :7])
+    for model, limit, K in ((small, False, 7), (smpl, True, 10)):
+        gm = api.AvatarModel(model, limit_one_joint_per_point=limit)
+        om = orc.OracleModel(model, limit_one_joint_per_point=limit)
+        w0 = np.asarray(fr["start"][0])[:K]
+        opt = Options.demo(max_iters_per_icp=5)
+        ctx = api.Context(gm, 24, pm, n, 2)
+        ctx.set_data_term(ctx.DATA_TERM_MOMENTS)
+        p, q, w, st = ctx.optimize_batch([fr["data"]] * 2, [fr["labels"]] * 2, opt, np.repeat(p0[None], 2, 0), np.repeat(q0[None], 2, 0), np.repeat(w0[None], 2, 0))
+        ref = om.optimize(pm, 24, fr["data"], fr["labels"], opt, p0, q0, w0, aggregate=1)
+        assert st[1].accepted_steps == ref["stats"].accepted_steps
+        assert np.abs(p[1] - ref["p"]).max() < 1e-7 and np.abs(q[1] - ref["q"]).max() < 1e-7 and np.abs(w[1] - ref["w"]).max() < 1e-6
+        Hm, gm_, _ = ctx.normal_equations(1)
+        ctx.set_data_term(ctx.DATA_TERM_ROWS)
+        Hr, gr, _ = ctx.normal_equations(1)
+        corr = ctx.correspondences(1, n)
+        _, og, oH, _ = om.evaluate(p[1], q[1], w[1], corr, fr["data"], 0.0, 0.0, aggregate=1)
+        assert _rel(Hm, oH) < 1e-10 and _rel(gm_, og) < 1e-9 and _rel(Hm, Hr) < 1e-11 and _rel(gm_, gr) < 1e-9, (K, limit)
