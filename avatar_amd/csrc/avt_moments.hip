@@ -39,6 +39,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // packed upper triangle (row-major, diagonal included) of a symmetric n x n matrix: element (a <= b) at tri_off(a, n) + b - a
 __host__ __device__ inline int tri_off(int a, int n) { return a * n - (a * (a - 1)) / 2; }
 __host__ __device__ inline int tri_size(int n) { return n * (n + 1) / 2; }
+__host__ __device__ inline int mom_tstride(int n) { return (tri_size(n) + 1) & ~1; }      // doubles between the packed T blocks of consecutive pairs (16-byte aligned blocks)
 
 // =================================================================================================
 // k_moments<NTP>.  One 256-thread workgroup per (frame, unordered pair).  The pair's static vertex list is compacted to the matched
@@ -111,7 +112,7 @@ __device__ __forceinline__ void moments_store(const FrameBuffers& fb, const AvtD
     constexpr int NTPAIR = NTP * (NTP + 1) / 2, NSLOT = (NTPAIR + NTP + 3) / 4;
     const int NPSI = d.mom_npsi, r16 = ln & 15, kk = ln >> 4;
     // accumulator element v of lane (c16 = l & 15, g4 = l >> 4): row 4 v + g4, column c16 of the tile; the upper triangle is kept
-    double* T = fb.mom_T + ((size_t)f * d.mom_np + p) * tri_size(NPSI);
+    double* T = fb.mom_T + ((size_t)f * d.mom_np + p) * mom_tstride(NPSI);
     double* D = fb.mom_D + ((size_t)f * d.J + k) * NPSI * 3;
 #pragma unroll
     for (int sl = 0; sl < NSLOT; ++sl) {
@@ -282,7 +283,7 @@ __device__ __forceinline__ void mom_skel_from_prep(const AvtDims& d, const doubl
 //   X16 [2 np + 1][16]   per ordered pair (op = 2 p: k -> k', 2 p + 1: k' -> k): W (9, row-major), Va, Vb, t0; the last row stays zero
 //   REC [2 np][K][6]     per (ordered pair, shape key): axial(Y), U
 //   Z   [nwg][K K + K]   per pair-pass workgroup: its pairs' shape-shape columns and sum tr(Y)
-__host__ __device__ inline int mom_nwg(const AvtDims& d) { return (d.mom_np + 15) / 16; }
+__host__ __device__ inline int mom_nwg(const AvtDims& d) { return (d.mom_np + 7) / 8; }      // pair-pass workgroups per frame (MOM_PP_PAIRS = 8 pairs each)
 __host__ __device__ inline size_t mom_off_rec(const AvtDims& d) { return (size_t)(2 * d.mom_np + 1) * 16; }
 __host__ __device__ inline size_t mom_off_z(const AvtDims& d) { return mom_off_rec(d) + (size_t)2 * d.mom_np * d.K * 6; }
 __host__ __device__ inline size_t mom_frame_scratch(const AvtDims& d) { return (mom_off_z(d) + (size_t)mom_nwg(d) * (d.K * d.K + d.K) + 7) & ~(size_t)7; }
@@ -294,48 +295,88 @@ __host__ __device__ inline size_t mom_frame_scratch(const AvtDims& d) { return (
 //   P2, p1 by a butterfly over the group; lane 0 writes X16 of both orders, lanes 1 .. K the per-(ordered pair, shape key) records;
 //   the lanes' shape-shape columns and sum tr(Y) are added over the workgroup's pairs in group order through LDS.
 // =================================================================================================
+#define MOM_PP_PAIRS 8        // pairs (16-lane groups) per pair-pass workgroup
 template <int KC>
-__global__ __launch_bounds__(256) void k_pairpass(DeviceModel dm, FrameBuffers fb) {
+__global__ __launch_bounds__(16 * MOM_PP_PAIRS) void k_pairpass(DeviceModel dm, FrameBuffers fb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NTH = 16 * MOM_PP_PAIRS;
     const AvtDims& d = dm.d;
     const int f = blockIdx.y + fb.f0, t = threadIdx.x;
     const int J = d.J, K = KC ? KC : d.K, S1 = K + 1, NP = d.mom_np, NPSI = KC ? 3 * (KC + 1) + 1 : d.mom_npsi;
+    const int TS = mom_tstride(NPSI), JS = 15 + 3 * K, GS = (2 * JS + S1 + 1) & ~1;      // doubles of a pair's T block / of one joint's tables / of a group's slice
     const int try_slot = 1 - fb.ctl[f].cur_slot;
-    if ((int)blockIdx.x >= mom_nwg(d)) { prior_component(dm, fb, f, blockIdx.x - mom_nwg(d), try_slot, (double*)smem); return; }      // trailing workgroups: the GMM pose prior, one component each (avt_prior.h)
-    double* skm = (double*)smem;
-    double* ZR = skm + mom_skel_doubles(d);                     // [16][K K + K]
-    int* s_parent = (int*)(ZR + 16 * (K * K + K));
-    MomSkel sk;
-    mom_skel_from_prep<256>(d, fb.prep + ((size_t)f * 2 + try_slot) * d.prep_size, fb.ctl[f].centre, skm, s_parent, dm.parent, sk);
     double* scr = fb.mom_rec + (size_t)f * mom_frame_scratch(d);
     double* X16 = scr;
     double* REC = scr + mom_off_rec(d);
     const int gid = t >> 4, sl = t & 15;
-    const int p = blockIdx.x * 16 + gid;
+    const int p = blockIdx.x * MOM_PP_PAIRS + gid;
     const bool pair_on = p < NP, lane_on = sl < S1;
     const int pc = pair_on ? p : 0;
     const int k = dm.mom_pair[2 * pc], k2 = dm.mom_pair[2 * pc + 1];
-    const double* Tp = fb.mom_T + ((size_t)f * NP + pc) * tri_size(NPSI);
+    // ---- staging: the pair's packed T (TS doubles, one contiguous block: the whole workgroup streams MOM_PP_PAIRS consecutive blocks) and
+    // the two joints' tables go through the group's own LDS; a group lives inside one wave, so the hand-over is wave-local
+    double* tl = (double*)smem + (size_t)gid * TS;                                   // [TS]
+    double* gsl = (double*)smem + (size_t)MOM_PP_PAIRS * TS + (size_t)gid * GS;      // [GS]: joint k | joint k' (Rw 9, o 3, Jh 3, eta 3 K) | omega
+    double* ZR = (double*)smem + (size_t)MOM_PP_PAIRS * (TS + GS);                  // [MOM_PP_PAIRS][K K + K]
+    {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const d2* Tg = (const d2*)(fb.mom_T + ((size_t)f * NP + pc) * TS);
+        const int nv = TS >> 1;
+        constexpr int NLD = KC == 10 ? 19 : 0;                                      // 596 / 2 / 16 rounded up (SMPL); other K: the loop below
+        const double* prep = fb.prep + ((size_t)f * 2 + try_slot) * d.prep_size;
+        auto jsrc = [&](int j, int e) -> const double* {                              // element e of joint j's tables in the prep block
+            return e < 9 ? prep + prep_off_Rw(d) + 9 * j + e : (e < 12 ? prep + prep_off_o(d) + 3 * j + (e - 9) : (e < 15 ? prep + prep_off_Jh(d) + 3 * j + (e - 12) : prep + prep_off_G(d) + (size_t)3 * K * j + (e - 15)));
+        };
+        if (NLD) {
+            d2 v[NLD ? NLD : 1];
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) { const int i = 16 * u + sl; v[u] = i < nv ? Tg[i] : (d2){0.0, 0.0}; }
+            for (int e = sl; e < 2 * JS; e += 16) gsl[e] = *jsrc(e < JS ? k : k2, e < JS ? e : e - JS);
+            if (lane_on) gsl[2 * JS + sl] = sl == 0 ? 1.0 : prep[prep_off_w(d) + sl - 1];
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) { const int i = 16 * u + sl; if (i < nv) ((d2*)tl)[i] = v[u]; }
+        } else {
+            for (int e = sl; e < 2 * JS; e += 16) gsl[e] = *jsrc(e < JS ? k : k2, e < JS ? e : e - JS);
+            if (lane_on) gsl[2 * JS + sl] = sl == 0 ? 1.0 : prep[prep_off_w(d) + sl - 1];
+            for (int i = sl; i < nv; i += 16) ((d2*)tl)[i] = Tg[i];
+        }
+    }
+    const double* offp = fb.prep + ((size_t)f * 2 + try_slot) * d.prep_size + prep_off_off(d);
+    const double off0 = offp[0], off1 = offp[1], off2 = offp[2];
+    const double cen0 = fb.ctl[f].centre[0], cen1 = fb.ctl[f].centre[1], cen2 = fb.ctl[f].centre[2];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double* RwA = gsl, *RwB = gsl + JS;
+    const double* etaA = gsl + 15, *etaB = gsl + JS + 15;      // eta_k[r][s] at [r K + s]
+    const double* omL = gsl + 2 * JS;
+    // tau = o - centre - R (Jh + off): the joint's constant in x_mk = R_k Phi_m omega + tau_k, relative to the frame centre
+    double tauA[3], tauB[3];
+    {
+        const double ja0 = gsl[12] + off0, ja1 = gsl[13] + off1, ja2 = gsl[14] + off2, jb0 = gsl[JS + 12] + off0, jb1 = gsl[JS + 13] + off1, jb2 = gsl[JS + 14] + off2;
+        const double ca[3] = {cen0, cen1, cen2};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            tauA[r] = (gsl[9 + r] - ca[r]) - (RwA[3 * r] * ja0 + RwA[3 * r + 1] * ja1 + RwA[3 * r + 2] * ja2);
+            tauB[r] = (gsl[JS + 9 + r] - ca[r]) - (RwB[3 * r] * jb0 + RwB[3 * r + 1] * jb1 + RwB[3 * r + 2] * jb2);
+        }
+    }
     const int col = lane_on ? sl : 0;
     // my three columns c = S1 i' + col of the packed triangle: element (r, c) at (r <= c ? rowoff(r) + c : coloff[i'] + r)
     int coloff[3], cidx[3];
 #pragma unroll
     for (int i2 = 0; i2 < 3; ++i2) { cidx[i2] = S1 * i2 + col; coloff[i2] = tri_off(cidx[i2], NPSI) - cidx[i2]; }
-    auto tload = [&](int r, int i2) { return Tp[r <= cidx[i2] ? tri_off(r, NPSI) - r + cidx[i2] : coloff[i2] + r]; };
-    // all loads of T that do not need the skeleton are requested before the barrier
+    auto tload = [&](int r, int i2) { return tl[r <= cidx[i2] ? tri_off(r, NPSI) - r + cidx[i2] : coloff[i2] + r]; };
     double v0[9], tph[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int i2 = 0; i2 < 3; ++i2) v0[3 * i + i2] = tload(S1 * i, i2);
 #pragma unroll
-    for (int i2 = 0; i2 < 3; ++i2) tph[i2] = Tp[coloff[i2] + NPSI - 1];
-    const double t0 = Tp[tri_size(NPSI) - 1];
-    __syncthreads();
+    for (int i2 = 0; i2 < 3; ++i2) tph[i2] = tl[coloff[i2] + NPSI - 1];
+    const double t0 = tl[tri_size(NPSI) - 1];
     double zc[KC ? KC : AVT_MAX_SHAPE], yx = 0.0;
 #pragma unroll
     for (int s = 0; s < (KC ? KC : AVT_MAX_SHAPE); ++s) zc[s] = 0.0;
-    const double om_l = lane_on ? sk.om[sl] : 0.0;
+    const double om_l = lane_on ? omL[sl] : 0.0;
     const double nu = k == k2 ? 0.5 : 1.0;
     double Q[9];
 #pragma unroll
@@ -345,14 +386,14 @@ __global__ __launch_bounds__(256) void k_pairpass(DeviceModel dm, FrameBuffers f
         {   // R_k^T R_k' (the rotations themselves are fetched again behind the loop: they would only occupy registers in it)
             double A[9], B[9];
 #pragma unroll
-            for (int e = 0; e < 9; ++e) { A[e] = sk.Rw[9 * k + e]; B[e] = sk.Rw[9 * k2 + e]; }
+            for (int e = 0; e < 9; ++e) { A[e] = RwA[e]; B[e] = RwB[e]; }
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int i2 = 0; i2 < 3; ++i2) G[3 * i + i2] = A[i] * B[i2] + A[3 + i] * B[3 + i2] + A[6 + i] * B[6 + i2];
         }
         auto use = [&](int s, const double (&v)[9], double& zout) {
-            const double oms = sk.om[s];
+            const double oms = omL[s];
             double zz = 0.0;
 #pragma unroll
             for (int e = 0; e < 9; ++e) { Q[e] = fma(oms, v[e], Q[e]); zz = fma(G[e], v[e], zz); }
@@ -394,9 +435,9 @@ __global__ __launch_bounds__(256) void k_pairpass(DeviceModel dm, FrameBuffers f
     }
     double Ra[9], Rb[9], ta[3], tb[3];
 #pragma unroll
-    for (int e = 0; e < 9; ++e) { Ra[e] = sk.Rw[9 * k + e]; Rb[e] = sk.Rw[9 * k2 + e]; }
+    for (int e = 0; e < 9; ++e) { Ra[e] = RwA[e]; Rb[e] = RwB[e]; }
 #pragma unroll
-    for (int e = 0; e < 3; ++e) { ta[e] = sk.tau[3 * k + e]; tb[e] = sk.tau[3 * k2 + e]; }
+    for (int e = 0; e < 3; ++e) { ta[e] = tauA[e]; tb[e] = tauB[e]; }
     // group sums over the lanes (fixed butterfly: every lane of the group ends with the same bits)
     double P2[9], p1[3];
 #pragma unroll
@@ -456,8 +497,8 @@ __global__ __launch_bounds__(256) void k_pairpass(DeviceModel dm, FrameBuffers f
         }
     } else if (pair_on && lane_on) {
         const int s = sl - 1;
-        const double* ea = sk.eta + (size_t)k * 3 * K;       // eta_k[r][s]
-        const double* eb = sk.eta + (size_t)k2 * 3 * K;
+        const double* ea = etaA;                             // eta_k[r][s]
+        const double* eb = etaB;
         double ya[3], yb[3];                                 // R_k tphi, R_k' tphi
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -510,16 +551,25 @@ __global__ __launch_bounds__(256) void k_pairpass(DeviceModel dm, FrameBuffers f
     }
     __syncthreads();
     double* Zg = scr + mom_off_z(d) + (size_t)blockIdx.x * (K * K + K);
-    for (int e = t; e < K * K + K; e += 256) {
+    for (int e = t; e < K * K + K; e += NTH) {
         double a = 0.0;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) a += ZR[(size_t)g * (K * K + K) + e];
+        for (int g = 0; g < MOM_PP_PAIRS; ++g) a += ZR[(size_t)g * (K * K + K) + e];
         Zg[e] = a;
     }
 }
 
+// the GMM pose prior of the trial point, one workgroup per (component, frame) (avt_prior.h).  A launch of its own: in the pair pass's
+// grid every one of these small workgroups would hold that kernel's 52 KB of LDS, a third of a CU
+__global__ __launch_bounds__(128) void k_prior(DeviceModel dm, FrameBuffers fb) {
+    __shared__ double s_scratch[5 * AVT_MAX_JOINTS];
+    const int f = blockIdx.y + fb.f0;
+    prior_component<128>(dm, fb, f, blockIdx.x, 1 - fb.ctl[f].cur_slot, s_scratch);
+}
+
 static size_t pairpass_lds_bytes(const AvtDims& d) {
-    return sizeof(double) * ((size_t)mom_skel_doubles(d) + 16 * (size_t)(d.K * d.K + d.K)) + sizeof(int) * AVT_MAX_JOINTS + 64;
+    const int TS = mom_tstride(d.mom_npsi), GS = (2 * (15 + 3 * d.K) + d.K + 2) & ~1;
+    return sizeof(double) * ((size_t)MOM_PP_PAIRS * (TS + GS) + (size_t)MOM_PP_PAIRS * (d.K * d.K + d.K)) + 64;
 }
 
 // =================================================================================================
@@ -791,10 +841,11 @@ static size_t assemble_lds_bytes(const AvtDims& d) {
 void launch_assemble(avt_ctx* c, int nframes) {
     const AvtDims& d = c->dm.d;
     {
-        const dim3 grid(mom_nwg(d) + d.ncomps, nframes);
-        const size_t lds = std::max(pairpass_lds_bytes(d), sizeof(double) * 5 * AVT_MAX_JOINTS);
-        if (d.K == 10) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairpass<10>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairpass<0>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb);
+        if (d.ncomps > 0) hipLaunchKernelGGL(k_prior, dim3(d.ncomps, nframes), dim3(128), 0, c->cur_stream, c->dm, c->fb);
+        const dim3 grid(mom_nwg(d), nframes);
+        const size_t lds = pairpass_lds_bytes(d);
+        if (d.K == 10) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairpass<10>), grid, dim3(16 * MOM_PP_PAIRS), lds, c->cur_stream, c->dm, c->fb);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairpass<0>), grid, dim3(16 * MOM_PP_PAIRS), lds, c->cur_stream, c->dm, c->fb);
     }
     const dim3 grid(1, nframes);
     const size_t lds = assemble_lds_bytes(d);
@@ -803,7 +854,7 @@ void launch_assemble(avt_ctx* c, int nframes) {
 }
 
 size_t avt_moments_frame_scratch(const AvtDims& d) { return mom_frame_scratch(d); }
-size_t avt_moments_T_doubles(const AvtDims& d) { return (size_t)d.mom_np * tri_size(d.mom_npsi); }
+size_t avt_moments_T_doubles(const AvtDims& d) { return (size_t)d.mom_np * mom_tstride(d.mom_npsi); }
 
 int avt_moments_set_attributes() {
     const int cap = 160 * 1024 - 512;

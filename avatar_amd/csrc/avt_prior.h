@@ -6,6 +6,7 @@
 #include "avt_device.h"
 
 // scratch: 2*ndims doubles of LDS
+template <int NTH = 256>
 __device__ __forceinline__ void prior_component(const DeviceModel& dm, const FrameBuffers& fb, int f, int c, int try_slot, double* scratch) {
     const AvtDims d = dm.d;
     const int t = threadIdx.x;
@@ -32,8 +33,8 @@ __device__ __forceinline__ void prior_component(const DeviceModel& dm, const Fra
         s_x[3 * t] = ax0 * ang - mu[3 * t]; s_x[3 * t + 1] = ax1 * ang - mu[3 * t + 1]; s_x[3 * t + 2] = ax2 * ang - mu[3 * t + 2];
     }
     __syncthreads();
-    // y = Prec_c (x - mu_c): 4 lanes per row, 64 rows per pass
-    for (int a0 = 0; a0 < n; a0 += 64) {
+    // y = Prec_c (x - mu_c): 4 lanes per row, NTH / 4 rows per pass
+    for (int a0 = 0; a0 < n; a0 += NTH / 4) {
         const int a = a0 + (t >> 2), sub = t & 3;
         double sacc = 0.0;
         if (a < n) {      // (eight loads of the row in flight at a time: the workgroup is one L2 round trip after another)
