@@ -56,7 +56,7 @@ __host__ __device__ inline int mom_tstride(int n) { return (tri_size(n) + 1) & ~
 #define KPROBE(i) do {} while (0)
 #endif
 #define MOM_SEG 1024          // static list entries compacted per pass (4 per thread)
-#define MOM_UN 4              // rounds whose fragments a wave requests together
+#define MOM_UN 2              // rounds whose fragments a wave requests together
 
 // the rounds of one compacted list segment for wave WV: its tiles are g = WV, WV + 4, .. of [upper tile pairs | D tiles]
 template <int NTP, int WV>

@@ -6,6 +6,7 @@
 #include "avt_device.h"
 
 // scratch: 2*ndims doubles of LDS
+#define PRIOR_BATCH 18
 template <int NTH = 256>
 __device__ __forceinline__ void prior_component(const DeviceModel& dm, const FrameBuffers& fb, int f, int c, int try_slot, double* scratch) {
     const AvtDims d = dm.d;
@@ -37,14 +38,14 @@ __device__ __forceinline__ void prior_component(const DeviceModel& dm, const Fra
     for (int a0 = 0; a0 < n; a0 += NTH / 4) {
         const int a = a0 + (t >> 2), sub = t & 3;
         double sacc = 0.0;
-        if (a < n) {      // (eight loads of the row in flight at a time: the workgroup is one L2 round trip after another)
+        if (a < n) {      // (PRIOR_BATCH loads of the row in flight at a time - SMPL's 69 columns over four lanes are one batch -: the workgroup is one L2 round trip after another)
             const double* Pr = dm.prior_prec + ((size_t)c * n + a) * n;
-            for (int b0 = sub; b0 < n; b0 += 32) {
-                double v[8];
+            for (int b0 = sub; b0 < n; b0 += 4 * PRIOR_BATCH) {
+                double v[PRIOR_BATCH];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = Pr[min(b0 + 4 * u, n - 1)];
+                for (int u = 0; u < PRIOR_BATCH; ++u) v[u] = Pr[min(b0 + 4 * u, n - 1)];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) sacc += b0 + 4 * u < n ? v[u] * s_x[b0 + 4 * u] : 0.0;
+                for (int u = 0; u < PRIOR_BATCH; ++u) sacc += b0 + 4 * u < n ? v[u] * s_x[b0 + 4 * u] : 0.0;
             }
         }
         sacc += __shfl_xor(sacc, 1, 64);

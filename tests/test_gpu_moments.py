@@ -147,3 +147,25 @@ def test_moment_form_on_other_model_shapes(smpl):
         corr = ctx.correspondences(1, n)
         _, og, oH, _ = om.evaluate(p[1], q[1], w[1], corr, fr["data"], 0.0, 0.0, aggregate=1)
         assert _rel(Hm, oH) < 1e-10 and _rel(gm_, og) < 1e-9 and _rel(Hm, Hr) < 1e-11 and _rel(gm_, gr) < 1e-9, (K, limit)
+
+
+def test_moment_form_ragged_batch_with_empty_frame(smpl, omodel, gmodel):
+    """An empty frame and a sparse one inside a batch through the moment form: the empty frame is left untouched, the others fit like the oracle."""
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    frs = [synth.make_frame(smpl, s) for s in (15, 16)]
+    datas = [frs[0]["data"], np.zeros((0, 3)), frs[1]["data"][:777]]
+    labs = [frs[0]["labels"], np.zeros(0, np.int32), frs[1]["labels"][:777]]
+    starts = [_start(frs[0]), _start(frs[0]), _start(frs[1])]
+    opt = Options.demo(max_iters_per_icp=5)
+    ctx = api.Context(gmodel, 24, pm, 60000, 3)
+    ctx.set_data_term(ctx.DATA_TERM_MOMENTS)
+    args = (datas, labs, opt, np.array([s[0] for s in starts]), np.array([s[1] for s in starts]), np.array([s[2] for s in starts]))
+    p1, q1, w1, st1 = ctx.optimize_batch(*args)
+    p2, q2, w2, st2 = ctx.optimize_batch(*args)
+    assert np.array_equal(p1, p2) and np.array_equal(q1, q2) and np.array_equal(w1, w2)      # bit-wise reproducible
+    assert st1[1].num_correspondences == 0 and np.array_equal(p1[1], starts[1][0]) and np.array_equal(w1[1], starts[1][2])
+    for f in (0, 2):
+        ref = omodel.optimize(pm, 24, datas[f], labs[f], opt, *starts[f], aggregate=1)
+        assert st1[f].accepted_steps == ref["stats"].accepted_steps
+        assert np.abs(p1[f] - ref["p"]).max() < 1e-6 and np.abs(w1[f] - ref["w"]).max() < 1e-5
