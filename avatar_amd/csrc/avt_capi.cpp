@@ -531,7 +531,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         dev_upload(c, &dm.mom_pair, m->mom_pair) || dev_upload(c, &dm.mom_lstart, m->mom_lstart) || dev_upload(c, &dm.mom_lv, m->mom_lv) || dev_upload(c, &dm.mom_lw, m->mom_lw) ||
         dev_upload(c, &dm.mom_psi, m->mom_psi) || dev_upload(c, &dm.mom_opk_start, m->mom_opk_start) || dev_upload(c, &dm.mom_opk, m->mom_opk) ||
         dev_upload(c, &dm.mom_sub_start, m->mom_sub_start) || dev_upload(c, &dm.mom_sub, m->mom_sub) || dev_upload(c, &dm.mom_m1_start, m->mom_m1_start) ||
-        dev_upload(c, &dm.mom_m1, m->mom_m1) || dev_upload(c, &dm.mom_s2_start, m->mom_s2_start) || dev_upload(c, &dm.mom_s2, m->mom_s2) || dev_upload(c, &dm.mom_s2_jj, m->mom_s2_jj) || dev_upload(c, &dm.mom_z2_jj, m->mom_z2_jj))
+        dev_upload(c, &dm.mom_m1, m->mom_m1) || dev_upload(c, &dm.mom_s2_start, m->mom_s2_start) || dev_upload(c, &dm.mom_s2, m->mom_s2) || dev_upload(c, &dm.mom_s2_jj, m->mom_s2_jj) || dev_upload(c, &dm.mom_z2_jj, m->mom_z2_jj) || dev_upload(c, &dm.mom_tab16, m->mom_tab16))
         return 1;
     FrameBuffers& fb = c->fb;
     std::memset(&fb, 0, sizeof(fb));

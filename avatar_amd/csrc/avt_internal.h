@@ -57,6 +57,8 @@ struct AvtDims {
     int mom_nb2, mom_nz2;    // (j <= j') rot-rot blocks with / without ordered pairs under them
     int mom_lmax;            // longest per-pair vertex list
     int mom_nopk, mom_nsub, mom_nm1l, mom_ns2l;   // lengths of the index lists mom_opk, mom_sub, mom_m1, mom_s2
+    int mom_nseg;            // 16-entry segments of the rot-rot lists
+    int mom_toff[8];         // word offsets of the lists inside DeviceModel::mom_tab16 (opk_start, opk, sub_start, sub, bseg, seg, jj, end)
 };
 
 // prep block layout (doubles), one per frame per slot: what an evaluation needs about the skeleton state
@@ -218,6 +220,7 @@ struct DeviceModel {
     int* mom_s2;          // ... stage-1 entry ids
     int* mom_s2_jj;       // [nb2] j | j' << 8
     int* mom_z2_jj;       // [nz2] the blocks that are structural zeros
+    unsigned short* mom_tab16;   // the 16-bit index lists of k_assemble as one block (AvtDims::mom_toff)
 };
 
 struct FrameBuffers {
@@ -297,6 +300,7 @@ struct avt_model {
     // moment form (build_moment_tables)
     std::vector<int> mom_pair, mom_lstart, mom_lv, mom_opk_start, mom_opk, mom_sub_start, mom_sub, mom_m1_start, mom_m1, mom_s2_start, mom_s2, mom_s2_jj, mom_z2_jj;
     std::vector<double> mom_lw, mom_psi;
+    std::vector<unsigned short> mom_tab16;
 };
 
 struct avt_ctx {

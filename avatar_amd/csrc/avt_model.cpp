@@ -266,33 +266,61 @@ static void build_moment_tables(avt_model* m) {
         for (int c = 0; c < J; ++c) if (under(c, k)) m->mom_sub.push_back(c);
         m->mom_sub_start[k + 1] = (int)m->mom_sub.size();
     }
-    // subtree lists padded to a multiple of four with J (an all-zero row of the per-joint arrays): the assembly walks them four at a time
+    // Index lists of the assembly (k_assemble), 16-bit, as ONE block the kernel copies into LDS: every list is padded so that it is
+    // walked in fixed-size trips without bounds checks - with an index of an all-zero row (2 np for X16 rows, J for per-joint rows).
+    //   opk   per lever joint k: its ordered pairs, padded to 4
+    //   sub   per joint j: the joints under it (itself included), padded to 8
+    //   seg   rot-rot: block (j <= j') sums the ordered pairs (k under j, k' under j'); a block's list is cut into SEGMENTS of 16 (padded)
+    //         so that no thread walks more than one segment; bseg[b] .. bseg[b + 1]: the segments of block b; jj[b] = j | j' << 8.
+    //         Only the blocks with such pairs are listed (left leg against right arm: none); z2: the others, structural zeros.
+    {
+        std::vector<int> st(J + 1, 0), li;
+        for (int k = 0; k < J; ++k) {
+            for (int e = m->mom_opk_start[k]; e < m->mom_opk_start[k + 1]; ++e) li.push_back(m->mom_opk[e]);
+            while (li.size() % 4) li.push_back(2 * NP);
+            st[k + 1] = (int)li.size();
+        }
+        m->mom_opk_start = st; m->mom_opk = li;
+    }
     {
         std::vector<int> st(J + 1, 0), li;
         for (int k = 0; k < J; ++k) {
             for (int e = m->mom_sub_start[k]; e < m->mom_sub_start[k + 1]; ++e) li.push_back(m->mom_sub[e]);
-            while (li.size() % 4) li.push_back(J);
+            while (li.size() % 8) li.push_back(J);
             st[k + 1] = (int)li.size();
         }
         m->mom_sub_start = st; m->mom_sub = li;
     }
-    // rot-rot: block (j <= j') sums the ordered pairs (k, k') with k under j and k' under j'; lists padded with 2 np (an all-zero X16 row)
     m->mom_s2_start.assign(1, 0); m->mom_s2.clear(); m->mom_s2_jj.clear(); m->mom_z2_jj.clear();
     for (int j = 0; j < J; ++j)
         for (int jp = j; jp < J; ++jp) {
-            const size_t before = m->mom_s2.size();
-            for (int op = 0; op < 2 * NP; ++op) if (exists(op) && under(first(op), j) && under(second(op), jp)) m->mom_s2.push_back(op);
-            if (m->mom_s2.size() == before) { m->mom_z2_jj.push_back(j | (jp << 8)); continue; }      // a structural zero block
-            while (m->mom_s2.size() % 4) m->mom_s2.push_back(2 * NP);
-            m->mom_s2_start.push_back((int)m->mom_s2.size());
+            std::vector<int> ops;
+            for (int op = 0; op < 2 * NP; ++op) if (exists(op) && under(first(op), j) && under(second(op), jp)) ops.push_back(op);
+            if (ops.empty()) { m->mom_z2_jj.push_back(j | (jp << 8)); continue; }      // a structural zero block
+            while (ops.size() % 16) ops.push_back(2 * NP);
+            m->mom_s2.insert(m->mom_s2.end(), ops.begin(), ops.end());
+            m->mom_s2_start.push_back((int)m->mom_s2.size() / 16);      // in segments
             m->mom_s2_jj.push_back(j | (jp << 8));
         }
     d.mom_nz2 = (int)m->mom_z2_jj.size();
     d.mom_nb2 = (int)m->mom_s2_jj.size();
+    d.mom_nseg = (int)m->mom_s2.size() / 16;
     d.mom_nm1 = 0;
     m->mom_m1_start.assign(1, 0); m->mom_m1.clear();
     d.mom_nopk = (int)m->mom_opk.size(); d.mom_nsub = (int)m->mom_sub.size(); d.mom_nm1l = 0; d.mom_ns2l = (int)m->mom_s2.size();
-    if ((int)m->mom_s2.size() > 65535) d.mom_ok = 0;      // 16-bit index lists
+    {   // the block: [opk_start | opk | sub_start | sub | bseg | seg | jj], every part starting on a multiple of four words
+        m->mom_tab16.clear();
+        auto put = [&](const std::vector<int>& v, int& off) {
+            while (m->mom_tab16.size() % 4) m->mom_tab16.push_back(0);
+            off = (int)m->mom_tab16.size();
+            for (int x : v) m->mom_tab16.push_back((unsigned short)x);
+        };
+        put(m->mom_opk_start, d.mom_toff[0]); put(m->mom_opk, d.mom_toff[1]); put(m->mom_sub_start, d.mom_toff[2]); put(m->mom_sub, d.mom_toff[3]);
+        put(m->mom_s2_start, d.mom_toff[4]); put(m->mom_s2, d.mom_toff[5]); put(m->mom_s2_jj, d.mom_toff[6]);
+        while (m->mom_tab16.size() % 4) m->mom_tab16.push_back(0);
+        d.mom_toff[7] = (int)m->mom_tab16.size();
+    }
+    if ((int)m->mom_s2.size() > 65535 || 2 * NP + 1 > 65535) d.mom_ok = 0;      // 16-bit index lists
 }
 
 static int avt_model_create_impl(const avt_model_desc* desc, avt_model** out) {

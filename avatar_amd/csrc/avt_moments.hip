@@ -579,12 +579,13 @@ static size_t pairpass_lds_bytes(const AvtDims& d) {
 //   B-a  X16 -> LDS; data side (u_k, Dl_k, YF per joint); PR[k][s] = partner sums of the records; Z, sum tr W;
 //   B-b  XD_k pieces, per-joint partner sums PK;   B-c  subtree sums TK, TR;   B-d  every block of H.
 // =================================================================================================
-struct MomTab { const unsigned short *opk_start, *opk, *sub_start, *sub, *s2_start, *s2, *s2_jj; };
-__host__ __device__ inline int mom_tab_words(const AvtDims& d) { return (2 * (d.J + 1) + d.mom_nopk + d.mom_nsub + (d.mom_nb2 + 1) + d.mom_ns2l + d.mom_nb2 + 3) & ~3; }
+struct MomTab { const unsigned short *opk_start, *opk, *sub_start, *sub, *bseg, *seg, *jj; };
+__host__ __device__ inline int mom_tab_words(const AvtDims& d) { return d.mom_toff[7]; }
 __host__ __device__ inline int mom_asm_doubles(const AvtDims& d) {
     const int J = d.J, K = d.K;
-    const int prtr = 2 * (J + 1) * K * 6 > d.mom_nb2 * 16 ? 2 * (J + 1) * K * 6 : d.mom_nb2 * 16;      // PR | TR, later the rot-rot block sums
-    return (2 * d.mom_np + 1) * 16 + 2 * (J + 1) * 16 + prtr + J * 9 + J * 4 + J * K + (K * K + K) + 2 * K + 8;
+    const int rr = (d.mom_nseg + d.mom_nb2) * 16;      // rot-rot: segment sums + block sums
+    const int prtr = 2 * (J + 1) * K * 6 > rr ? 2 * (J + 1) * K * 6 : rr;      // PR | TR, later the rot-rot sums
+    return (2 * d.mom_np + 1) * 16 + 2 * (J + 1) * 16 + prtr + J * 9 + J * 4 + J * K + (K * K + K) + 2 * K + 8 + K * ((J + 3) / 4);
 }
 
 #define MOM_ASM_NTH 1024     // threads of the assembly workgroup: every phase is latency, more items in flight is what helps
@@ -603,23 +604,29 @@ __global__ __launch_bounds__(NTH) void k_assemble(DeviceModel dm, FrameBuffers f
     double* TK = PK + (J + 1) * 16;             // [J + 1][16]  subtree sums of PK
     double* PR = TK + (J + 1) * 16;             // [J + 1][K][6]
     double* TR = PR + (J + 1) * K * 6;          // [J + 1][K][6]
-    double* Uk = PR + (2 * (J + 1) * K * 6 > d.mom_nb2 * 16 ? 2 * (J + 1) * K * 6 : d.mom_nb2 * 16);          // [J][3][3] sum_s om_s Dphi_k[i][s][c]
+    const int rrsz = (d.mom_nseg + d.mom_nb2) * 16;
+    double* Uk = PR + (2 * (J + 1) * K * 6 > rrsz ? 2 * (J + 1) * K * 6 : rrsz);          // [J][3][3] sum_s om_s Dphi_k[i][s][c]
     double* XQ = Uk + J * 9;                    // [J][4] axial(XD_k), tr XD_k
     double* YFk = XQ + J * 4;                   // [J][K]
     double* ZS = YFk + J * K;                   // [K K + K]
     double* YFs = ZS + K * K + K;               // [K]
     double* misc = YFs + K;                     // [K + 8]
-    int* s_parent = (int*)(misc + K + 8);
+    double* YF4 = misc + K + 8;                 // [K][ceil(J / 4)] YF summed over four joints
+    int* s_parent = (int*)(YF4 + K * ((J + 3) / 4));
     unsigned short* tabm = (unsigned short*)(s_parent + AVT_MAX_JOINTS);
     MomSkel sk;
     mom_skel_from_prep<NTH>(d, fb.prep + ((size_t)f * 2 + try_slot) * d.prep_size, fb.ctl[f].centre, skm, s_parent, dm.parent, sk);
     MomTab tb;
-    {
-        unsigned short* q = tabm;
-        auto put = [&](const int* src, int n) { unsigned short* dst = q; for (int e = t; e < n; e += NTH) dst[e] = (unsigned short)src[e]; q += n; return (const unsigned short*)dst; };
-        tb.opk_start = put(dm.mom_opk_start, J + 1); tb.opk = put(dm.mom_opk, d.mom_nopk); tb.sub_start = put(dm.mom_sub_start, J + 1);
-        tb.sub = put(dm.mom_sub, d.mom_nsub); tb.s2_start = put(dm.mom_s2_start, d.mom_nb2 + 1); tb.s2 = put(dm.mom_s2, d.mom_ns2l); tb.s2_jj = put(dm.mom_s2_jj, d.mom_nb2);
+    {   // the index lists: one block of 16-bit words, copied eight bytes at a time
+        const unsigned long long* src = (const unsigned long long*)dm.mom_tab16;
+        unsigned long long* dst = (unsigned long long*)tabm;
+        for (int e = t; e < d.mom_toff[7] / 4; e += NTH) dst[e] = src[e];
+        tb.opk_start = tabm + d.mom_toff[0]; tb.opk = tabm + d.mom_toff[1]; tb.sub_start = tabm + d.mom_toff[2]; tb.sub = tabm + d.mom_toff[3];
+        tb.bseg = tabm + d.mom_toff[4]; tb.seg = tabm + d.mom_toff[5]; tb.jj = tabm + d.mom_toff[6];
     }
+    // (every phase is a handful of short items per thread; the loops of a phase start at different threads so that no thread queues one item
+    // of each kind behind another)
+    auto rot = [&](int k) { return (t + k * (NTH / 4)) & (NTH - 1); };
     const double* scr = fb.mom_rec + (size_t)f * mom_frame_scratch(d);
     const double* REC = scr + mom_off_rec(d);
     const double* Zg = scr + mom_off_z(d);
@@ -631,7 +638,13 @@ __global__ __launch_bounds__(NTH) void k_assemble(DeviceModel dm, FrameBuffers f
     for (int e = t; e < K * 6; e += NTH) PR[(size_t)J * K * 6 + e] = 0.0;
     for (int e = t; e < K * K + K; e += NTH) {           // the pair-pass workgroups' shape-shape columns / traces, in workgroup order
         double a = 0.0;
-        for (int g = 0; g < mom_nwg(d); ++g) a += Zg[(size_t)g * (K * K + K) + e];
+        for (int g0 = 0; g0 < mom_nwg(d); g0 += 8) {      // (eight partials requested together)
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = Zg[(size_t)min(g0 + u, mom_nwg(d) - 1) * (K * K + K) + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += g0 + u < mom_nwg(d) ? v[u] : 0.0;
+        }
         ZS[e] = a;
     }
     __syncthreads();      // skeleton tables, index lists
@@ -652,8 +665,8 @@ __global__ __launch_bounds__(NTH) void k_assemble(DeviceModel dm, FrameBuffers f
         }
         Uk[e] = a;
     }
-    for (int e = t; e < J * 3; e += NTH) { const int k = e / 3, c = e - 3 * k; PK[16 * k + 13 + c] = Df[(size_t)k * NPSI * 3 + (size_t)(NPSI - 1) * 3 + c]; }
-    for (int e = t; e < J * K; e += NTH) {      // tr(R_k Dphi_k[s]) + eta_k,s . Dl_k
+    for (int e = rot(1); e < J * 3; e += NTH) { const int k = e / 3, c = e - 3 * k; PK[16 * k + 13 + c] = Df[(size_t)k * NPSI * 3 + (size_t)(NPSI - 1) * 3 + c]; }
+    for (int e = rot(2); e < J * K; e += NTH) {      // tr(R_k Dphi_k[s]) + eta_k,s . Dl_k
         const int k = e / K, s = e - k * K;
         const double* Dk = Df + (size_t)k * NPSI * 3;
         const double* Rk = sk.Rw + 9 * k;
@@ -673,31 +686,38 @@ __global__ __launch_bounds__(NTH) void k_assemble(DeviceModel dm, FrameBuffers f
         for (int c = 0; c < 3; ++c) q = fma(sk.eta[((size_t)k * 3 + c) * K + s], v[9 + c], q);
         YFk[e] = q;
     }
-    for (int e = t; e < J * K * 6; e += NTH) {  // PR[k][s][.] = sum over the ordered pairs with lever joint k; all loads of an item in flight
+    for (int e = rot(3); e < J * K * 6; e += NTH) {  // PR[k][s][.] = sum over the ordered pairs with lever joint k; all loads of an item in flight
         const int k = e / (K * 6), r = e - k * K * 6;
         const int lo = tb.opk_start[k], hi = tb.opk_start[k + 1];
         double v[MOM_MAXOPS];
+        int op[MOM_MAXOPS];
 #pragma unroll
-        for (int u = 0; u < MOM_MAXOPS; ++u) v[u] = REC[(size_t)tb.opk[max(min(lo + u, hi - 1), 0)] * K * 6 + r];
+        for (int u = 0; u < MOM_MAXOPS; ++u) op[u] = tb.opk[max(min(lo + u, hi - 1), 0)];
+#pragma unroll
+        for (int u = 0; u < MOM_MAXOPS; ++u) v[u] = REC[(size_t)min(op[u], 2 * NP - 1) * K * 6 + r];      // (the padding index 2 NP has no record: masked below)
         double a = 0.0;
 #pragma unroll
-        for (int u = 0; u < MOM_MAXOPS; ++u) a += lo + u < hi ? v[u] : 0.0;
-        for (int i = lo + MOM_MAXOPS; i < hi; ++i) a += REC[(size_t)tb.opk[i] * K * 6 + r];
+        for (int u = 0; u < MOM_MAXOPS; ++u) a += (lo + u < hi && op[u] < 2 * NP) ? v[u] : 0.0;
+        for (int i = lo + MOM_MAXOPS; i < hi; ++i) if (tb.opk[i] < 2 * NP) a += REC[(size_t)tb.opk[i] * K * 6 + r];
         PR[e] = hi > lo ? a : 0.0;
     }
     __syncthreads();      // X16, Uk
     MPROBE(2);
     // ---------------- B-b
-    for (int e = t; e < J * 10; e += NTH) {      // PK[k][0..9]: axial(sum W) 3, sum Va 3, sum Vb 3, sum t0
+    for (int e = t; e < J * 10; e += NTH) {      // PK[k][0..9]: axial(sum W) 3, sum Va 3, sum Vb 3, sum t0; four pairs per trip (the list is padded with the zero row)
         const int k = e / 10, q = e - 10 * k;
+        const int i0 = q == 0 ? 5 : (q == 1 ? 6 : (q == 2 ? 1 : 9 + (q - 3))), i1 = q == 0 ? 7 : (q == 1 ? 2 : 3);      // q < 3: x[i0] - x[i1]; else x[i0] (q = 9: x[15] = t0)
         double a = 0.0;
-        for (int i = tb.opk_start[k]; i < tb.opk_start[k + 1]; ++i) {
-            const double* x = X16 + (size_t)tb.opk[i] * 16;
-            a += q == 0 ? x[5] - x[7] : (q == 1 ? x[6] - x[2] : (q == 2 ? x[1] - x[3] : x[9 + (q - 3)]));      // (q = 9: x[15] = t0)
+        for (int i = tb.opk_start[k]; i < tb.opk_start[k + 1]; i += 4) {
+            const double* x0 = X16 + (size_t)tb.opk[i] * 16; const double* x1 = X16 + (size_t)tb.opk[i + 1] * 16;
+            const double* x2 = X16 + (size_t)tb.opk[i + 2] * 16; const double* x3 = X16 + (size_t)tb.opk[i + 3] * 16;
+            const double p0 = x0[i0], p1 = x1[i0], p2 = x2[i0], p3 = x3[i0];
+            const double m0 = q < 3 ? x0[i1] : 0.0, m1 = q < 3 ? x1[i1] : 0.0, m2 = q < 3 ? x2[i1] : 0.0, m3 = q < 3 ? x3[i1] : 0.0;
+            a += ((p0 - m0) + (p1 - m1)) + ((p2 - m2) + (p3 - m3));
         }
         PK[16 * k + q] = a;
     }
-    for (int e = t; e < J * 4; e += NTH) {       // XD_k = R_k u_k + tau_k Dl_k^T: its axial vector (PK[10..12]) and trace
+    for (int e = rot(1); e < J * 4; e += NTH) {       // XD_k = R_k u_k + tau_k Dl_k^T: its axial vector (PK[10..12]) and trace
         const int k = e >> 2, q = e & 3;
         const double* Rk = sk.Rw + 9 * k;
         const double* u = Uk + 9 * k;
@@ -707,7 +727,11 @@ __global__ __launch_bounds__(NTH) void k_assemble(DeviceModel dm, FrameBuffers f
         if (q < 3) PK[16 * k + 10 + q] = v;
         XQ[e] = v;
     }
-    if (t < K) { double a = 0.0; for (int k = 0; k < J; ++k) a += YFk[k * K + t]; YFs[t] = a; }
+    for (int e = rot(2); e < K * ((J + 3) / 4); e += NTH) {      // YF over four joints at a time (summed up in the next phase)
+        const int g4 = (J + 3) / 4, s = e / g4, g = e - s * g4;
+        const double v0 = YFk[min(4 * g, J - 1) * K + s], v1 = YFk[min(4 * g + 1, J - 1) * K + s], v2 = YFk[min(4 * g + 2, J - 1) * K + s], v3 = YFk[min(4 * g + 3, J - 1) * K + s];
+        YF4[e] = ((4 * g < J ? v0 : 0.0) + (4 * g + 1 < J ? v1 : 0.0)) + ((4 * g + 2 < J ? v2 : 0.0) + (4 * g + 3 < J ? v3 : 0.0));
+    }
     if (t >= NTH - 64) {      // sum tr W over the ordered pairs, fixed order (one wave)
         const int l = t - (NTH - 64);
         double a = 0.0;
@@ -717,27 +741,31 @@ __global__ __launch_bounds__(NTH) void k_assemble(DeviceModel dm, FrameBuffers f
     }
     __syncthreads();
     MPROBE(3);
-    // ---------------- B-c: subtree sums, four list entries at a time
+    // ---------------- B-c: subtree sums, eight list entries at a time
     for (int e = t; e < J * 16; e += NTH) {
         const int j = e >> 4, q = e & 15;
         double a = 0.0;
-        for (int i = tb.sub_start[j]; i < tb.sub_start[j + 1]; i += 4) {
-            const double v0 = PK[16 * tb.sub[i] + q], v1 = PK[16 * tb.sub[i + 1] + q], v2 = PK[16 * tb.sub[i + 2] + q], v3 = PK[16 * tb.sub[i + 3] + q];
-            a += (v0 + v1) + (v2 + v3);
+        for (int i = tb.sub_start[j]; i < tb.sub_start[j + 1]; i += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = PK[16 * tb.sub[i + u] + q];
+            a += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         }
         TK[e] = a;
     }
-    for (int e = t; e < J * K * 6; e += NTH) {
+    for (int e = rot(1); e < J * K * 6; e += NTH) {
         const int j = e / (K * 6), r = e - j * K * 6;
         double a = 0.0;
-        for (int i = tb.sub_start[j]; i < tb.sub_start[j + 1]; i += 4) {
-            const double v0 = PR[(size_t)tb.sub[i] * K * 6 + r], v1 = PR[(size_t)tb.sub[i + 1] * K * 6 + r], v2 = PR[(size_t)tb.sub[i + 2] * K * 6 + r],
-                         v3 = PR[(size_t)tb.sub[i + 3] * K * 6 + r];
-            a += (v0 + v1) + (v2 + v3);
+        for (int i = tb.sub_start[j]; i < tb.sub_start[j + 1]; i += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = PR[(size_t)tb.sub[i + u] * K * 6 + r];
+            a += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         }
         TR[e] = a;
     }
-    if (t == 0) {
+    if (t >= NTH - 64 && t - (NTH - 64) < K) { const int sq = t - (NTH - 64), g4 = (J + 3) / 4; double a = 0.0; for (int g = 0; g < g4; ++g) a += YF4[sq * g4 + g]; YFs[sq] = a; }
+    if (t == NTH / 2) {
         double xf = 0.0;
         for (int k = 0; k < J; ++k) xf += XQ[4 * k + 3];
         misc[0] = misc[1] - 2.0 * xf;      // (+ sum |d_i - centre|^2: the constant part, k_moments)
@@ -781,25 +809,36 @@ __global__ __launch_bounds__(NTH) void k_assemble(DeviceModel dm, FrameBuffers f
     // listed (left leg against right arm: none), the others are structural zeros.  Phase 1: the sums, one item per (block, entry
     // of X16), into the PR / TR area (free now); phase 2: one item per (block, matrix entry).
     __syncthreads();
-    double* S16 = PR;      // [nb2][16]  (the PR | TR area is sized for it)
-    for (int e = t; e < d.mom_nb2 * 16; e += NTH) {
-        const int b = e >> 4, q = e & 15;
-        double a = 0.0;
-        for (int i = tb.s2_start[b]; i < tb.s2_start[b + 1]; i += 4) {
-            const double v0 = X16[(size_t)tb.s2[i] * 16 + q], v1 = X16[(size_t)tb.s2[i + 1] * 16 + q], v2 = X16[(size_t)tb.s2[i + 2] * 16 + q], v3 = X16[(size_t)tb.s2[i + 3] * 16 + q];
-            a += (v0 + v1) + (v2 + v3);
-        }
-        S16[e] = a;
+    double* SEG = PR;                          // [nseg][16] sums of the 16-entry segments ...
+    double* S16 = PR + d.mom_nseg * 16;        // [nb2][16]  ... and of the blocks (the PR | TR area is sized for both)
+    for (int e = t; e < d.mom_nseg * 16; e += NTH) {
+        const int sg = e >> 4, q = e & 15;
+        const unsigned short* li = tb.seg + 16 * sg;
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = X16[(size_t)li[u] * 16 + q];
+        SEG[e] = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) + (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
     }
-    for (int e = t; e < d.mom_nz2 * 9; e += NTH) {      // the structural zeros
+    for (int e = rot(2); e < d.mom_nz2 * 9; e += NTH) {      // the structural zeros
         const int b = e / 9, q = e - 9 * b, jj = dm.mom_z2_jj[b], j = jj & 0xff, jp = jj >> 8, r = q / 3, c = q - 3 * r;
         Hout[(size_t)(3 + 3 * j + r) * HS + 3 + 3 * jp + c] = 0.0;
         Hout[(size_t)(3 + 3 * jp + c) * HS + 3 + 3 * j + r] = 0.0;
     }
     __syncthreads();
+    for (int e = t; e < d.mom_nb2 * 16; e += NTH) {      // a block's segments, in order
+        const int b = e >> 4, q = e & 15;
+        const int s0 = tb.bseg[b], s1 = tb.bseg[b + 1];
+        double a = 0.0;
+        for (int sg = s0; sg < s1; sg += 4) {
+            const double v0 = SEG[sg * 16 + q], v1 = SEG[min(sg + 1, s1 - 1) * 16 + q], v2 = SEG[min(sg + 2, s1 - 1) * 16 + q], v3 = SEG[min(sg + 3, s1 - 1) * 16 + q];
+            a += v0; a += sg + 1 < s1 ? v1 : 0.0; a += sg + 2 < s1 ? v2 : 0.0; a += sg + 3 < s1 ? v3 : 0.0;
+        }
+        S16[e] = a;
+    }
+    __syncthreads();
     for (int e = t; e < d.mom_nb2 * 9; e += NTH) {
         const int b = e / 9, q = e - 9 * b;
-        const int jj = tb.s2_jj[b], j = jj & 0xff, jp = jj >> 8;
+        const int jj = tb.jj[b], j = jj & 0xff, jp = jj >> 8;
         const double* S = S16 + b * 16;
         const double oj[3] = {sk.oc[3 * j], sk.oc[3 * j + 1], sk.oc[3 * j + 2]}, op[3] = {sk.oc[3 * jp], sk.oc[3 * jp + 1], sk.oc[3 * jp + 2]};
         // LL = S.W - S.Va o_j'^T - o_j S.Vb^T + S.t0 o_j o_j'^T   (sum over the block of V_k'k = sum of Vb)
