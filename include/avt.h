@@ -248,7 +248,7 @@ typedef struct avt_tuning {
     int nspec;               /* speculative solver workgroups per frame beside the solver (0 .. 4) */
     int nn_force_part;       /* 1: the throughput shape of the nearest neighbour on small inputs too */
     int nn_slab;             /* 1: that shape walks y-sorted candidates outwards from the wave's slab of queries; 0: full scan */
-    int mom_min_frames;      /* AVT_DATA_TERM_AUTO: frames per launch from which the moment form is used (60) */
+    int mom_min_frames;      /* AVT_DATA_TERM_AUTO: frames per launch from which the moment form is used (40) */
     int debug;               /* 1: occupancy report on stderr at context creation */
     int reserved;
     long long ride_timeout_us; /* how long a solver role waits for the riding reduction before it raises the frame's fault (2 000 000) */
