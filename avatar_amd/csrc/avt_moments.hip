@@ -55,51 +55,49 @@ __host__ __device__ inline int mom_tstride(int n) { return (tri_size(n) + 1) & ~
 #else
 #define KPROBE(i) do {} while (0)
 #endif
-#define MOM_SEG 1024          // static list entries compacted per pass (4 per thread)
+#define MOM_SEG 512           // static list entries compacted per pass
+#define MOM_EPT (MOM_SEG / 256)     // ... per thread
 #define MOM_UN 2              // rounds whose fragments a wave requests together
 
-// the rounds of one compacted list segment for wave WV: its tiles are g = WV, WV + 4, .. of [upper tile pairs | D tiles]
-template <int NTP, int WV>
-__device__ __forceinline__ void moments_rounds(const DeviceModel& dm, const long long* __restrict__ fs, int V, const int* __restrict__ s_v,
-                                               const double* __restrict__ s_w, const double* __restrict__ s_a, int mseg, bool diag, int ln,
+// the rounds of one compacted list segment for wave WV: its tiles are g = WV, WV + 4, .. of [upper tile pairs | D tiles].
+// The segment is padded to a multiple of 4 MOM_UN entries with weight-zero entries (no masks in the loop), an entry is the byte offset of its
+// psi row, its weight and - for a diagonal pair - a_mk (sum_i d_i - c centre), all in LDS: the only global loads here are the psi fragments.
+template <int NTP, int WV, bool diag>
+__device__ __forceinline__ void moments_rounds(const DeviceModel& dm, const unsigned* __restrict__ s_off, const double* __restrict__ s_w,
+                                               const double* __restrict__ s_bd, int mseg, int ln,
                                                v4f64 (&acc)[(NTP * (NTP + 1) / 2 + NTP + 3) / 4]) {
-    constexpr int NTPAIR = NTP * (NTP + 1) / 2, NSLOT = (NTPAIR + NTP + 3) / 4, PW = 16 * NTP;
+    constexpr int NTPAIR = NTP * (NTP + 1) / 2, NSLOT = (NTPAIR + NTP + 3) / 4;
     constexpr int firstD = ((NTPAIR - WV + 3) / 4) * 4 + WV;                    // the wave's first tile index >= NTPAIR
     constexpr bool hasD = firstD < NTPAIR + NTP;
     const int r16 = ln & 15, kk = ln >> 4;
-    const int nr = (mseg + 3) >> 2;
+    const int nr = __builtin_amdgcn_readfirstlane((mseg + 4 * MOM_UN - 1) / (4 * MOM_UN) * MOM_UN);      // (a scalar: a loop the compiler takes for divergent keeps the accumulators in vector registers and copies them around every matrix instruction)
+    const char* psi = (const char*)(dm.mom_psi + r16);
+    const double* bdrow = s_bd + (r16 < 3 ? r16 : 0) * (MOM_SEG + 4 * MOM_UN);
     for (int r0 = 0; r0 < nr; r0 += MOM_UN) {
         double fr[MOM_UN][NTP], wgt[MOM_UN], bd[MOM_UN];
-        bool on[MOM_UN];
 #pragma unroll
         for (int u = 0; u < MOM_UN; ++u) {
             const int idx = 4 * (r0 + u) + kk;
-            on[u] = idx < mseg;
-            const int v = on[u] ? s_v[idx] : 0;
-            wgt[u] = on[u] ? s_w[idx] : 0.0;
-            const double* ps = dm.mom_psi + (size_t)v * PW + r16;
+            const double* ps = (const double*)(psi + s_off[idx]);
+            wgt[u] = s_w[idx];
 #pragma unroll
             for (int q = 0; q < NTP; ++q) fr[u][q] = ps[16 * q];
             bd[u] = 0.0;
-            if (hasD && diag && on[u] && r16 < 3) bd[u] = s_a[idx] * ((double)fs[(size_t)r16 * V + v] / AVT_FIX_SCALE);      // B = a_mk (sum_i d_i - c centre), columns 0..2
+            if (hasD && diag) { const double b = bdrow[idx]; bd[u] = r16 < 3 ? b : 0.0; }      // B = a_mk (sum_i d_i - c centre), columns 0..2
         }
 #pragma unroll
         for (int u = 0; u < MOM_UN; ++u) {
-            if (r0 + u < nr) {      // wave-uniform
 #pragma unroll
-                for (int q = 0; q < NTP; ++q) fr[u][q] = on[u] ? fr[u][q] : 0.0;
+            for (int sl = 0; sl < NSLOT; ++sl) {
+                const int g = WV + 4 * sl;          // compile-time after unrolling
+                if (g < NTPAIR) {
+                    int ti = 0, pp = g;
 #pragma unroll
-                for (int sl = 0; sl < NSLOT; ++sl) {
-                    const int g = WV + 4 * sl;          // compile-time after unrolling
-                    if (g < NTPAIR) {
-                        int ti = 0, pp = g;
-#pragma unroll
-                        for (int i = 0; i < NTP; ++i) if (pp >= NTP - ti && ti == i) { pp -= NTP - ti; ++ti; }
-                        const int tj = ti + pp;
-                        acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[u][ti] * wgt[u], fr[u][tj], acc[sl], 0, 0, 0);
-                    } else if (g < NTPAIR + NTP) {
-                        if (diag) acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[u][g - NTPAIR], bd[u], acc[sl], 0, 0, 0);
-                    }
+                    for (int i = 0; i < NTP; ++i) if (pp >= NTP - ti && ti == i) { pp -= NTP - ti; ++ti; }
+                    const int tj = ti + pp;
+                    acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[u][ti] * wgt[u], fr[u][tj], acc[sl], 0, 0, 0);
+                } else if (g < NTPAIR + NTP) {
+                    if (diag) acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[u][g - NTPAIR], bd[u], acc[sl], 0, 0, 0);
                 }
             }
         }
@@ -140,12 +138,12 @@ __device__ __forceinline__ void moments_store(const FrameBuffers& fb, const AvtD
 }
 
 template <int NTP>
-__global__ __launch_bounds__(256) void k_moments(DeviceModel dm, FrameBuffers fb) {
+__global__ __launch_bounds__(256, 4) void k_moments(DeviceModel dm, FrameBuffers fb) {
     const AvtDims& d = dm.d;
     const int f = blockIdx.y + fb.f0, t = threadIdx.x, V = d.V, NP = d.mom_np;
     const int bx = blockIdx.x;
-    __shared__ int s_v[MOM_SEG];
-    __shared__ double s_w[MOM_SEG], s_a[MOM_SEG];
+    __shared__ unsigned s_off[MOM_SEG + 4 * MOM_UN];
+    __shared__ double s_w[MOM_SEG + 4 * MOM_UN], s_bd[3 * (MOM_SEG + 4 * MOM_UN)];
     __shared__ int s_wcnt[4];
     __shared__ double s_red[4];
     const int* cnt = fb.cnt + (size_t)f * V;
@@ -182,20 +180,20 @@ __global__ __launch_bounds__(256) void k_moments(DeviceModel dm, FrameBuffers fb
     const v4f64 z4 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) acc[i] = z4;
-    const int wv = t >> 6, ln = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6), ln = t & 63;      // (a scalar: the switch over the wave's share below must not look divergent)
     for (int base = 0; base < n; base += MOM_SEG) {
-        // ---- compaction of entries base + 4 t .. base + 4 t + 3 (order kept)
-        int vv[4], cc[4], mine = 0;
-        double wa[4], wb[4];
+        // ---- compaction of entries base + MOM_EPT t .. base + MOM_EPT (t + 1) - 1 (order kept)
+        int vv[MOM_EPT], cc[MOM_EPT], mine = 0;
+        double wa[MOM_EPT], wb[MOM_EPT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = min(base + 4 * t + u, n - 1);
+        for (int u = 0; u < MOM_EPT; ++u) {
+            const int e = min(base + MOM_EPT * t + u, n - 1);
             vv[u] = dm.mom_lv[lo + e];
             wa[u] = dm.mom_lw[2 * (size_t)(lo + e)]; wb[u] = dm.mom_lw[2 * (size_t)(lo + e) + 1];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = base + 4 * t + u;
+        for (int u = 0; u < MOM_EPT; ++u) {
+            const int e = base + MOM_EPT * t + u;
             cc[u] = e < n ? cnt[vv[u]] : 0;
             mine += cc[u] > 0;
         }
@@ -206,16 +204,34 @@ __global__ __launch_bounds__(256) void k_moments(DeviceModel dm, FrameBuffers fb
         int pos = incl - mine, mseg = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { if (w < wv) pos += s_wcnt[w]; mseg += s_wcnt[w]; }
+        long long fv[MOM_EPT][3];
+        if (diag) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (cc[u] > 0) { s_v[pos] = vv[u]; s_w[pos] = (double)cc[u] * wa[u] * wb[u]; s_a[pos] = wa[u]; ++pos; }
+            for (int u = 0; u < MOM_EPT; ++u)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) fv[u][i] = cc[u] > 0 ? fs[(size_t)i * V + vv[u]] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < MOM_EPT; ++u)
+            if (cc[u] > 0) {
+                s_off[pos] = (unsigned)vv[u] * (unsigned)(16 * NTP * sizeof(double)); s_w[pos] = (double)cc[u] * wa[u] * wb[u];
+                if (diag) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) s_bd[i * (MOM_SEG + 4 * MOM_UN) + pos] = wa[u] * ((double)fv[u][i] / AVT_FIX_SCALE);
+                }
+                ++pos;
+            }
+        if (t < 4 * MOM_UN && mseg + t < ((mseg + 4 * MOM_UN - 1) / (4 * MOM_UN)) * (4 * MOM_UN)) {      // weight-zero entries up to a whole number of trips
+            s_off[mseg + t] = 0; s_w[mseg + t] = 0.0;
+            s_bd[mseg + t] = 0.0; s_bd[MOM_SEG + 4 * MOM_UN + mseg + t] = 0.0; s_bd[2 * (MOM_SEG + 4 * MOM_UN) + mseg + t] = 0.0;
+        }
         __syncthreads();
         KPROBE(2);
         switch (wv) {
-            case 0: moments_rounds<NTP, 0>(dm, fs, V, s_v, s_w, s_a, mseg, diag, ln, acc); break;
-            case 1: moments_rounds<NTP, 1>(dm, fs, V, s_v, s_w, s_a, mseg, diag, ln, acc); break;
-            case 2: moments_rounds<NTP, 2>(dm, fs, V, s_v, s_w, s_a, mseg, diag, ln, acc); break;
-            default: moments_rounds<NTP, 3>(dm, fs, V, s_v, s_w, s_a, mseg, diag, ln, acc); break;
+            case 0: { if (diag) moments_rounds<NTP, 0, true>(dm, s_off, s_w, s_bd, mseg, ln, acc); else moments_rounds<NTP, 0, false>(dm, s_off, s_w, s_bd, mseg, ln, acc); } break;
+            case 1: { if (diag) moments_rounds<NTP, 1, true>(dm, s_off, s_w, s_bd, mseg, ln, acc); else moments_rounds<NTP, 1, false>(dm, s_off, s_w, s_bd, mseg, ln, acc); } break;
+            case 2: { if (diag) moments_rounds<NTP, 2, true>(dm, s_off, s_w, s_bd, mseg, ln, acc); else moments_rounds<NTP, 2, false>(dm, s_off, s_w, s_bd, mseg, ln, acc); } break;
+            default: { if (diag) moments_rounds<NTP, 3, true>(dm, s_off, s_w, s_bd, mseg, ln, acc); else moments_rounds<NTP, 3, false>(dm, s_off, s_w, s_bd, mseg, ln, acc); } break;
         }
         KPROBE(3);
         if (base + MOM_SEG < n) __syncthreads();      // the list is rewritten by the next pass
