@@ -42,8 +42,21 @@ LIMITER = {
     "lbs": "HBM/L2 streaming of the shape planes", "bucket": "LDS + global atomics", "visibility": "launch latency (few frames); one pass over the cloud, faces from LDS (batches)",
     "aggregate": "launch latency / gathers", "prepare": "latency (skeleton pass)",
     "decide": "cost-only evaluation of the last trial point (its accept test is taken inside the k_lbs launch that follows)",
-    "eval_moments": "L2 / MALL latency of the moment re-reads (k_pairpass: 9 (K+1) + 4 gathers of 8 B per lane, two workgroups per CU at 186 registers) and short dependent LDS chains (k_assemble)",
+    "eval_moments": "latency at low occupancy: k_pairpass stages 8 packed pair moments per 128-thread workgroup through 52 KB of LDS (three workgroups per CU, two dependent L2 round trips each), k_assemble is one 1024-thread workgroup per frame of short dependent LDS chains",
 }
+
+
+def moment_bytes_per_gn_iter(smpl, K, P):
+    """Moment form (avt_moments.hip): what one GN iteration of one frame has to move - the packed moments of every co-assigned
+    joint pair (a symmetric (3 (K + 1) + 1)^2 matrix each) and the per-joint data moments in, the dense system out."""
+    W = np.asarray(smpl["weights"])
+    top = np.argsort(-W, axis=1)[:, :4]
+    pairs = set()
+    for v in range(W.shape[0]):
+        js = [int(j) for j in top[v] if W[v, j] > 0]
+        pairs.update((a, b) for a in js for b in js if a <= b)
+    npsi = 3 * (K + 1) + 1
+    return 8 * (len(pairs) * ((npsi * (npsi + 1) // 2 + 1) & ~1) + W.shape[1] * npsi * 3 + (P + 1) * (P + 1)), len(pairs)
 
 
 def algorithmic_bytes_per_gn_iter(N, V, K, P):
@@ -53,7 +66,7 @@ def algorithmic_bytes_per_gn_iter(N, V, K, P):
 
 # symbol-name fragments (eval: the full evaluation k_eval<.., false>; solve: k_solve<.., SOLVE_NORMAL>; reduce: k_reduce<1> / k_reduce_strip<NS>)
 KERNEL_SYMBOL = {"eval": "Lb0EEv11DeviceModel12FrameBuffersi", "solve": "k_solveILi256ELb0ELi2", "reduce": "k_reduce", "nn": "k_nn", "lbs": "k_lbs",
-                 "eval_moments": ("k_pairpass", "k_assemble")}      # moment form: the evaluation class is the pair pass + the assembly
+                 "eval_moments": ("k_prior", "k_pairpass", "k_assemble")}      # moment form: the evaluation class is the pair pass + the assembly
 
 
 def pmc_traffic(frames_per_launch, kernel_class, points_per_frame):
@@ -205,17 +218,28 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
     pipe = F * bytes_iter * opt.icp_iters * opt.max_iters_per_icp / (med / steps) / 1e9
     moments_run = args.data_term == "moments" or (args.data_term == "auto" and nfg >= ctx.tuning().mom_min_frames)
     dom_key = "eval_moments" if (dominant == "eval" and moments_run) else dominant
-    res["roofline"] = {"kernel": "k_pairpass + k_assemble" if dom_key == "eval_moments" else "k_" + dominant, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    survey_equiv = None
+    if dom_key == "eval_moments":
+        # the moment form does not touch the clouds in a GN iteration: its kernels are priced on what THEY have to move (the packed moments
+        # in, the system out); the SURVEY 8(d) figure of the row form over the same launch time is kept beside it as an equivalent
+        survey_equiv = {"algorithmic_bytes_per_launch": int(bytes_launch), "achieved": round(achieved, 3), "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                        "note": "SURVEY 8(d) bytes of the row form (clouds re-read every GN iteration) over this launch time: what the row form would have to sustain to keep up"}
+        mom_iter, mom_pairs = moment_bytes_per_gn_iter(smpl, K, P)
+        bytes_launch = nfg * mom_iter
+        achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
+    res["roofline"] = {"kernel": "k_prior + k_pairpass + k_assemble" if dom_key == "eval_moments" else "k_" + dominant, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(nfg, dom_key, Nmean),
                        "chosen_because": ("two frame groups overlap: the evaluation bounds the step" if groups >= 2 else "largest share of device time on the one stream"),
                        "limiter": LIMITER.get(dom_key, "?"),
                        "avg_launch_us": round(avg_ms * 1e3, 3), "launches_timed": prof_timed[dominant][1],
                        "launch_shape": {"frames_per_launch": nfg, "frame_groups": groups, "eval_workgroups_per_frame": G},
-                       "algorithmic_bytes_per_launch": int(bytes_launch),
+                       "algorithmic_bytes_per_launch": int(bytes_launch), "survey_8d_equivalent": survey_equiv,
                        "pipeline": {"achieved": round(pipe, 3), "unit": "GB/s", "frac": round(pipe / HBM_PEAK_GBS, 6),
                                     "note": "frames x SURVEY 8(d) bytes per GN iteration x GN iterations per step / median step time (all kernels)"},
-                       "note": "achieved = frames per launch x SURVEY 8(d) bytes per GN iteration / mean launch time of the dominant kernel class "
-                               "(HIP events, this run, same launch shape as the replayed graph); bound = the roofline SURVEY 8(d) prescribes, "
+                       "note": ("achieved = frames per launch x bytes the moment form moves per GN iteration (packed pair moments + data moments in, system out) / mean launch time of k_prior + k_pairpass + k_assemble "
+                                if dom_key == "eval_moments" else "achieved = frames per launch x SURVEY 8(d) bytes per GN iteration / mean launch time of the dominant kernel class ") +
+                               
+"(HIP events, this run, same launch shape as the replayed graph); bound = the roofline SURVEY 8(d) prescribes, "
                                "limiter = what actually bounds the kernel; traffic = HBM bytes per launch of this launch shape from the "
                                "committed rocprofv3 PMC passes (profiles/), null if not collected for this shape"}
     ev = prof["eval"]
