@@ -311,7 +311,28 @@ __host__ __device__ inline size_t mom_frame_scratch(const AvtDims& d) { return (
 //   P2, p1 by a butterfly over the group; lane 0 writes X16 of both orders, lanes 1 .. K the per-(ordered pair, shape key) records;
 //   the lanes' shape-shape columns and sum tr(Y) are added over the workgroup's pairs in group order through LDS.
 // =================================================================================================
+// sum over the 16 lanes of a DPP row, every lane ending with the same bits (the two operands of each add are the same pair of numbers in
+// both lanes): quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror - register moves, no LDS permutes
+template <int CTRL>
+__device__ __forceinline__ double mom_dpp(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double mom_row_sum(double v) {
+    v += mom_dpp<0xB1>(v);
+    v += mom_dpp<0x4E>(v);
+    v += mom_dpp<0x141>(v);
+    v += mom_dpp<0x140>(v);
+    return v;
+}
+
 #define MOM_PP_PAIRS 8        // pairs (16-lane groups) per pair-pass workgroup
+#ifdef AVT_TIMING
+#define PPROBE(i) do { if (threadIdx.x == 0 && blockIdx.x == 5) fb.trace[(size_t)f * 64 + 24 + (i)] = (double)clock64(); } while (0)
+#else
+#define PPROBE(i) do {} while (0)
+#endif
 template <int KC>
 __global__ __launch_bounds__(16 * MOM_PP_PAIRS) void k_pairpass(DeviceModel dm, FrameBuffers fb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -325,6 +346,7 @@ __global__ __launch_bounds__(16 * MOM_PP_PAIRS) void k_pairpass(DeviceModel dm, 
     double* X16 = scr;
     double* REC = scr + mom_off_rec(d);
     const int gid = t >> 4, sl = t & 15;
+    PPROBE(0);
     const int p = blockIdx.x * MOM_PP_PAIRS + gid;
     const bool pair_on = p < NP, lane_on = sl < S1;
     const int pc = pair_on ? p : 0;
@@ -361,6 +383,7 @@ __global__ __launch_bounds__(16 * MOM_PP_PAIRS) void k_pairpass(DeviceModel dm, 
     const double off0 = offp[0], off1 = offp[1], off2 = offp[2];
     const double cen0 = fb.ctl[f].centre[0], cen1 = fb.ctl[f].centre[1], cen2 = fb.ctl[f].centre[2];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    PPROBE(1);
     const double* RwA = gsl, *RwB = gsl + JS;
     const double* etaA = gsl + 15, *etaB = gsl + JS + 15;      // eta_k[r][s] at [r K + s]
     const double* omL = gsl + 2 * JS;
@@ -449,6 +472,7 @@ __global__ __launch_bounds__(16 * MOM_PP_PAIRS) void k_pairpass(DeviceModel dm, 
             }
         }
     }
+    PPROBE(2);
     double Ra[9], Rb[9], ta[3], tb[3];
 #pragma unroll
     for (int e = 0; e < 9; ++e) { Ra[e] = RwA[e]; Rb[e] = RwB[e]; }
@@ -461,12 +485,10 @@ __global__ __launch_bounds__(16 * MOM_PP_PAIRS) void k_pairpass(DeviceModel dm, 
 #pragma unroll
     for (int e = 0; e < 3; ++e) p1[e] = om_l * tph[e];
 #pragma unroll
-    for (int sft = 8; sft >= 1; sft >>= 1) {
+    for (int e = 0; e < 9; ++e) P2[e] = mom_row_sum(P2[e]);
 #pragma unroll
-        for (int e = 0; e < 9; ++e) P2[e] += __shfl_xor(P2[e], sft, 64);
-#pragma unroll
-        for (int e = 0; e < 3; ++e) p1[e] += __shfl_xor(p1[e], sft, 64);
-    }
+    for (int e = 0; e < 3; ++e) p1[e] = mom_row_sum(p1[e]);
+    PPROBE(3);
     double Rap1[3], Rbp1[3], Va[3], Vb[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -475,44 +497,12 @@ __global__ __launch_bounds__(16 * MOM_PP_PAIRS) void k_pairpass(DeviceModel dm, 
         Va[r] = fma(t0, ta[r], Rap1[r]);
         Vb[r] = fma(t0, tb[r], Rbp1[r]);
     }
-    if (pair_on && sl == 0) {
-        // W_kk' = R_k P2 R_k'^T + Va tau_k'^T + tau_k (R_k' p1)^T;  W_k'k = W_kk'^T
-        double RaP[9], W[9];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) RaP[3 * r + c] = Ra[3 * r] * P2[c] + Ra[3 * r + 1] * P2[3 + c] + Ra[3 * r + 2] * P2[6 + c];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                W[3 * r + c] = (RaP[3 * r] * Rb[3 * c] + RaP[3 * r + 1] * Rb[3 * c + 1] + RaP[3 * r + 2] * Rb[3 * c + 2]) + Va[r] * tb[c] + ta[r] * Rbp1[c];
-        double* x0 = X16 + (size_t)(2 * p) * 16;
-#pragma unroll
-        for (int e = 0; e < 9; ++e) x0[e] = W[e];
-#pragma unroll
-        for (int e = 0; e < 3; ++e) { x0[9 + e] = Va[e]; x0[12 + e] = Vb[e]; }
-        x0[15] = t0;
-        double* x1 = x0 + 16;
-        if (k != k2) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) x1[3 * r + c] = W[3 * c + r];
-#pragma unroll
-            for (int e = 0; e < 3; ++e) { x1[9 + e] = Vb[e]; x1[12 + e] = Va[e]; }
-            x1[15] = t0;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) x1[e] = 0.0;
-        }
-        if (p == 0) {      // the all-zero row the padded lists of k_assemble point at
-            double* xz = X16 + (size_t)(2 * NP) * 16;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) xz[e] = 0.0;
-        }
-    } else if (pair_on && lane_on) {
-        const int s = sl - 1;
+    if (pair_on && lane_on) {
+        // Lanes 1 .. K: the records of shape key s = lane - 1,  Y = R_a Qs R_b^T + V_a eta_b,s^T + tau_a ylin^T,  U = ylin + t0 eta_b,s.
+        // Lane 0 runs the SAME instructions on other operands and gets W_kk' = R_k P2 R_k'^T + Va tau_k'^T + tau_k (R_k' p1)^T  (W_k'k = W_kk'^T)
+        // - a branch of its own would be executed in series with the records.
+        const bool lane0 = sl == 0;
+        const int s = lane0 ? 0 : sl - 1;
         const double* ea = etaA;                             // eta_k[r][s]
         const double* eb = etaB;
         double ya[3], yb[3];                                 // R_k tphi, R_k' tphi
@@ -522,42 +512,77 @@ __global__ __launch_bounds__(16 * MOM_PP_PAIRS) void k_pairpass(DeviceModel dm, 
             yb[r] = Rb[3 * r] * tph[0] + Rb[3 * r + 1] * tph[1] + Rb[3 * r + 2] * tph[2];
         }
         const double eas[3] = {ea[s], ea[K + s], ea[2 * K + s]}, ebs[3] = {eb[s], eb[K + s], eb[2 * K + s]};
-        auto record = [&](const double (&RA)[9], const double (&RB)[9], const double (&VA)[3], const double (&TA)[3], const double (&ylin)[3],
-                          const double (&eB)[3], int op) {
-            // Y = R_a Qs R_b^T + V_a eta_b,s^T + tau_a ylin^T,  U = ylin + t0 eta_b,s
-            double RQ[9], Y[9];
+        double Qs[9], yl0[3], eB0[3];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Qs[e] = lane0 ? P2[e] : Q[e];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) { yl0[e] = lane0 ? Rbp1[e] : yb[e]; eB0[e] = lane0 ? tb[e] : ebs[e]; }
+        auto sandwich = [&](const double (&RA)[9], const double (&RB)[9], const double (&QQ)[9], const double (&VA)[3], const double (&TA)[3],
+                            const double (&ylin)[3], const double (&eB)[3], double (&Y)[9]) {
+            double RQ[9];
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) RQ[3 * r + c] = RA[3 * r] * Q[c] + RA[3 * r + 1] * Q[3 + c] + RA[3 * r + 2] * Q[6 + c];
+                for (int c = 0; c < 3; ++c) RQ[3 * r + c] = RA[3 * r] * QQ[c] + RA[3 * r + 1] * QQ[3 + c] + RA[3 * r + 2] * QQ[6 + c];
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
                     Y[3 * r + c] = (RQ[3 * r] * RB[3 * c] + RQ[3 * r + 1] * RB[3 * c + 1] + RQ[3 * r + 2] * RB[3 * c + 2]) + VA[r] * eB[c] + TA[r] * ylin[c];
-            double* rc = REC + ((size_t)op * K + s) * 6;
-            rc[0] = Y[5] - Y[7]; rc[1] = Y[6] - Y[2]; rc[2] = Y[1] - Y[3];
-            rc[3] = fma(t0, eB[0], ylin[0]); rc[4] = fma(t0, eB[1], ylin[1]); rc[5] = fma(t0, eB[2], ylin[2]);
-            yx += (Y[0] + Y[4]) + Y[8];
         };
-        record(Ra, Rb, Va, ta, yb, ebs, 2 * p);
-        if (k != k2) record(Rb, Ra, Vb, tb, ya, eas, 2 * p + 1);
-        else {
-            double* rc = REC + ((size_t)(2 * p + 1) * K + s) * 6;
+        double Y[9];
+        sandwich(Ra, Rb, Qs, Va, ta, yl0, eB0, Y);
+        if (lane0) {
+            double* x0 = X16 + (size_t)(2 * p) * 16;
 #pragma unroll
-            for (int e = 0; e < 6; ++e) rc[e] = 0.0;
+            for (int e = 0; e < 9; ++e) x0[e] = Y[e];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) { x0[9 + e] = Va[e]; x0[12 + e] = Vb[e]; }
+            x0[15] = t0;
+            double* x1 = x0 + 16;
+            const bool two = k != k2;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) x1[3 * r + c] = two ? Y[3 * c + r] : 0.0;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) { x1[9 + e] = two ? Vb[e] : 0.0; x1[12 + e] = two ? Va[e] : 0.0; }
+            x1[15] = two ? t0 : 0.0;
+            if (p == 0) {      // the all-zero row the padded lists of k_assemble point at
+                double* xz = X16 + (size_t)(2 * NP) * 16;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) xz[e] = 0.0;
+            }
+        } else {
+            double* rc = REC + ((size_t)(2 * p) * K + s) * 6;
+            rc[0] = Y[5] - Y[7]; rc[1] = Y[6] - Y[2]; rc[2] = Y[1] - Y[3];
+            rc[3] = fma(t0, ebs[0], yb[0]); rc[4] = fma(t0, ebs[1], yb[1]); rc[5] = fma(t0, ebs[2], yb[2]);
+            yx += (Y[0] + Y[4]) + Y[8];
         }
-        // column t = s of Z~': nu (zz + eta_k,s2 . yb + eta_k',s2 . ya + t0 eta_k,s2 . eta_k',t)   (nu zz is already in zc)
+        if (!lane0) {
+            double* rc = REC + ((size_t)(2 * p + 1) * K + s) * 6;
+            if (k != k2) {
+                sandwich(Rb, Ra, Q, Vb, tb, ya, eas, Y);
+                rc[0] = Y[5] - Y[7]; rc[1] = Y[6] - Y[2]; rc[2] = Y[1] - Y[3];
+                rc[3] = fma(t0, eas[0], ya[0]); rc[4] = fma(t0, eas[1], ya[1]); rc[5] = fma(t0, eas[2], ya[2]);
+                yx += (Y[0] + Y[4]) + Y[8];
+            } else {
 #pragma unroll
-        for (int s2 = 0; s2 < (KC ? KC : AVT_MAX_SHAPE); ++s2) {
-            if (s2 < K) {
-                const double e0 = ea[s2], e1 = ea[K + s2], e2 = ea[2 * K + s2];
-                const double f0 = eb[s2], f1 = eb[K + s2], f2 = eb[2 * K + s2];
-                const double add = (e0 * yb[0] + e1 * yb[1] + e2 * yb[2]) + (f0 * ya[0] + f1 * ya[1] + f2 * ya[2]) + t0 * (e0 * ebs[0] + e1 * ebs[1] + e2 * ebs[2]);
-                zc[s2] = fma(nu, add, zc[s2]);
+                for (int e = 0; e < 6; ++e) rc[e] = 0.0;
+            }
+            // column t = s of Z~': nu (zz + eta_k,s2 . yb + eta_k',s2 . ya + t0 eta_k,s2 . eta_k',t)   (nu zz is already in zc)
+#pragma unroll
+            for (int s2 = 0; s2 < (KC ? KC : AVT_MAX_SHAPE); ++s2) {
+                if (s2 < K) {
+                    const double e0 = ea[s2], e1 = ea[K + s2], e2 = ea[2 * K + s2];
+                    const double f0 = eb[s2], f1 = eb[K + s2], f2 = eb[2 * K + s2];
+                    const double add = (e0 * yb[0] + e1 * yb[1] + e2 * yb[2]) + (f0 * ya[0] + f1 * ya[1] + f2 * ya[2]) + t0 * (e0 * ebs[0] + e1 * ebs[1] + e2 * ebs[2]);
+                    zc[s2] = fma(nu, add, zc[s2]);
+                }
             }
         }
     }
+    PPROBE(4);
     // the workgroup's shape-shape columns / traces, added in group order
     if (sl >= 1 && lane_on) {
         double* zr = ZR + (size_t)gid * (K * K + K);
@@ -573,6 +598,7 @@ __global__ __launch_bounds__(16 * MOM_PP_PAIRS) void k_pairpass(DeviceModel dm, 
         for (int g = 0; g < MOM_PP_PAIRS; ++g) a += ZR[(size_t)g * (K * K + K) + e];
         Zg[e] = a;
     }
+    PPROBE(5);
 }
 
 // the GMM pose prior of the trial point, one workgroup per (component, frame) (avt_prior.h).  A launch of its own: in the pair pass's

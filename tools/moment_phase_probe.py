@@ -29,3 +29,6 @@ print('  total %.0f clocks' % t.sum())
 
 t = np.diff(buf[50:57])
 print('k_moments, pair workgroup 20 of frame 0 (last pass), clocks: setup+list loads+cnt gather %.0f | scan+compaction %.0f | rounds %.0f | barrier %.0f | cross-wave sum %.0f | stores %.0f | total %.0f' % (t[0], t[1], t[2], t[3], t[4], t[5], t.sum()))
+
+t = np.diff(buf[24:30])
+print('k_pairpass, workgroup 5 of frame 0, clocks: ids + loads issued + staged in LDS %.0f | contraction (99 LDS reads per lane) %.0f | group sums %.0f | records, stores %.0f | workgroup sum of Z %.0f | total %.0f' % (t[0], t[1], t[2], t[3], t[4], t.sum()))
