@@ -571,7 +571,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         HIP_OK(hipMemsetAsync(fb.mom_D, 0, (size_t)max_frames * J * d.mom_npsi * 3 * sizeof(double), c->stream));      // joints no vertex is assigned to keep zeros
     }
     c->data_term = AVT_DATA_TERM_AUTO;
-    // (tun.mom_min_frames = 60: tools/data_term_sweep.sh, ms per step moments / rows: 32 frames per launch 1.39 / 1.21, 64: 1.86 / 1.91, 96: 2.34 / 2.94, 256: 5.25 / 6.41)
+    // (tun.mom_min_frames = 40: tools/data_term_sweep.sh, ms per step moments / rows: 32 frames per launch 1.26 / 1.22, 48: 1.44 / 1.62, 64: 1.64 / 1.90, 128: 2.43 / 3.39, 256: 4.31 / 6.31)
     c->last_run_moments = false;
     {
         AvtRunParams* pr = nullptr;

@@ -220,7 +220,7 @@ int avt_get_normal_equations(avt_ctx* c, int frame, double* H /* P x P */, doubl
  *                          every iteration (AvatarCostFunctorCache::updateData + the ICP cost functor, AvatarOptimizer.cpp:505-644);
  *   AVT_DATA_TERM_MOMENTS  the correspondences' sufficient statistics are accumulated once per ICP iteration and every iteration
  *                          contracts them with the state (avt_moments.hip);
- *   AVT_DATA_TERM_AUTO     (default) the moment form from ~60 frames per launch on, where it is the faster one; rows below.
+ *   AVT_DATA_TERM_AUTO     (default) the moment form from 40 frames per launch on (avt_tuning.mom_min_frames), where it is the faster one; rows below.
  * Takes effect for the following calls; avt_get_normal_equations evaluates with the form selected here (AUTO: the form the last
  * optimize() ran), so tests can compare the two on the same correspondences. */
 enum { AVT_DATA_TERM_ROWS = 0, AVT_DATA_TERM_MOMENTS = 1, AVT_DATA_TERM_AUTO = 2 };
