@@ -169,3 +169,25 @@ def test_moment_form_ragged_batch_with_empty_frame(smpl, omodel, gmodel):
         ref = omodel.optimize(pm, 24, datas[f], labs[f], opt, *starts[f], aggregate=1)
         assert st1[f].accepted_steps == ref["stats"].accepted_steps
         assert np.abs(p1[f] - ref["p"]).max() < 1e-6 and np.abs(w1[f] - ref["w"]).max() < 1e-5
+
+
+def test_switching_the_form_back_and_forth_reproduces_the_system_and_the_cost(smpl, gmodel):
+    """avt_get_normal_equations makes what the selected form needs on demand; the two forms' cost constants share one buffer,
+    so every switch must rebuild it: rows -> moments -> rows -> moments gives the same system and cost each time."""
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    fr = synth.make_frame(smpl, 11)
+    p0, q0, w0 = _start(fr)
+    n = len(fr["labels"])
+    ctx = api.Context(gmodel, 24, pm, n, 3)
+    ctx.set_data_term(ctx.DATA_TERM_ROWS)
+    ctx.optimize_batch([fr["data"]] * 3, [fr["labels"]] * 3, Options.demo(max_iters_per_icp=3), np.repeat(p0[None], 3, 0), np.repeat(q0[None], 3, 0), np.repeat(w0[None], 3, 0))
+    seen = {}
+    for rnd in range(2):
+        for name, term in (("rows", ctx.DATA_TERM_ROWS), ("moments", ctx.DATA_TERM_MOMENTS)):
+            ctx.set_data_term(term)
+            H, g, cost = ctx.normal_equations(1)
+            if name in seen:
+                assert np.array_equal(H, seen[name][0]) and np.array_equal(g, seen[name][1]) and cost == seen[name][2], (name, rnd)
+            seen[name] = (H, g, cost)
+    assert abs(seen["moments"][2] - seen["rows"][2]) <= 1e-9 * abs(seen["rows"][2])
