@@ -299,7 +299,10 @@ __device__ __forceinline__ void mom_skel_from_prep(const AvtDims& d, const doubl
 //   X16 [2 np + 1][16]   per ordered pair (op = 2 p: k -> k', 2 p + 1: k' -> k): W (9, row-major), Va, Vb, t0; the last row stays zero
 //   REC [2 np][K][6]     per (ordered pair, shape key): axial(Y), U
 //   Z   [nwg][K K + K]   per pair-pass workgroup: its pairs' shape-shape columns and sum tr(Y)
-__host__ __device__ inline int mom_nwg(const AvtDims& d) { return (d.mom_np + 7) / 8; }      // pair-pass workgroups per frame (MOM_PP_PAIRS = 8 pairs each)
+#ifndef MOM_PP_PAIRS
+#define MOM_PP_PAIRS 4        // pairs (16-lane groups) per pair-pass workgroup
+#endif
+__host__ __device__ inline int mom_nwg(const AvtDims& d) { return (d.mom_np + MOM_PP_PAIRS - 1) / MOM_PP_PAIRS; }      // pair-pass workgroups per frame
 __host__ __device__ inline size_t mom_off_rec(const AvtDims& d) { return (size_t)(2 * d.mom_np + 1) * 16; }
 __host__ __device__ inline size_t mom_off_z(const AvtDims& d) { return mom_off_rec(d) + (size_t)2 * d.mom_np * d.K * 6; }
 __host__ __device__ inline size_t mom_frame_scratch(const AvtDims& d) { return (mom_off_z(d) + (size_t)mom_nwg(d) * (d.K * d.K + d.K) + 7) & ~(size_t)7; }
@@ -327,7 +330,6 @@ __device__ __forceinline__ double mom_row_sum(double v) {
     return v;
 }
 
-#define MOM_PP_PAIRS 8        // pairs (16-lane groups) per pair-pass workgroup
 #ifdef AVT_TIMING
 #define PPROBE(i) do { if (threadIdx.x == 0 && blockIdx.x == 5) fb.trace[(size_t)f * 64 + 24 + (i)] = (double)clock64(); } while (0)
 #else
