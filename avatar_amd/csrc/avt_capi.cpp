@@ -105,7 +105,7 @@ avt_tuning tuning_from_environment() {
     avt_tuning t;
     std::memset(&t, 0, sizeof t);
     t.use_graph = 1; t.groups = 0; t.g = 0; t.gcap = 128; t.vis_frame_min = 64; t.ride = 1; t.ride_strips = 0; t.ride_sizing_groups = 0;
-    t.nspec = AVT_MAX_SPEC; t.nn_force_part = 0; t.nn_slab = 1; t.mom_min_frames = 40; t.debug = 0; t.ride_timeout_us = 2000000;
+    t.nspec = AVT_MAX_SPEC; t.nn_force_part = 0; t.nn_slab = 1; t.mom_min_frames = 32; t.debug = 0; t.ride_timeout_us = 2000000;
     struct Knob { const char* name; int* field; };
     const Knob knobs[] = {{"AVT_USE_GRAPH", &t.use_graph}, {"AVT_GROUPS", &t.groups}, {"AVT_G", &t.g}, {"AVT_GCAP", &t.gcap}, {"AVT_VIS_FRAME_MIN", &t.vis_frame_min},
                           {"AVT_RIDE", &t.ride}, {"AVT_RIDE_STRIPS", &t.ride_strips}, {"AVT_RIDE_SIZING_GROUPS", &t.ride_sizing_groups}, {"AVT_NSPEC", &t.nspec},
@@ -571,7 +571,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         HIP_OK(hipMemsetAsync(fb.mom_D, 0, (size_t)max_frames * J * d.mom_npsi * 3 * sizeof(double), c->stream));      // joints no vertex is assigned to keep zeros
     }
     c->data_term = AVT_DATA_TERM_AUTO;
-    // (tun.mom_min_frames = 40: tools/data_term_sweep.sh, ms per step moments / rows: 32 frames per launch 1.26 / 1.22, 48: 1.44 / 1.62, 64: 1.64 / 1.90, 128: 2.43 / 3.39, 256: 4.31 / 6.31)
+    // (tun.mom_min_frames = 32: tools/data_term_sweep.sh, ms per step moments / rows: 16 frames per launch 1.01 / 0.95, 24: 1.10 / 1.08, 32: 1.18 / 1.22, 64: 1.57 / 1.92, 128: 2.33 / 3.39, 256: 4.31 / 6.34)
     c->last_run_moments = false;
     {
         AvtRunParams* pr = nullptr;

@@ -347,6 +347,10 @@ __global__ __launch_bounds__(16 * MOM_PP_PAIRS) void k_pairpass(DeviceModel dm, 
     double* scr = fb.mom_rec + (size_t)f * mom_frame_scratch(d);
     double* X16 = scr;
     double* REC = scr + mom_off_rec(d);
+    if ((int)blockIdx.x >= mom_nwg(d)) {      // trailing workgroups: the GMM pose prior of the trial point, one component each (avt_prior.h)
+        prior_component<NTH>(dm, fb, f, (int)blockIdx.x - mom_nwg(d), try_slot, (double*)smem);
+        return;
+    }
     const int gid = t >> 4, sl = t & 15;
     PPROBE(0);
     const int p = blockIdx.x * MOM_PP_PAIRS + gid;
@@ -924,8 +928,12 @@ static size_t assemble_lds_bytes(const AvtDims& d) {
 void launch_assemble(avt_ctx* c, int nframes) {
     const AvtDims& d = c->dm.d;
     {
-        if (d.ncomps > 0) hipLaunchKernelGGL(k_prior, dim3(d.ncomps, nframes), dim3(128), 0, c->cur_stream, c->dm, c->fb);
-        const dim3 grid(mom_nwg(d), nframes);
+        // the pose prior: workgroups in the pair pass's grid up to 128 frames per launch (one launch and its boundary less on the chain: 64 frames
+        // per GPU 1.25 -> 1.17 ms), a launch of its own above (its 2 k small workgroups then take the slots of the pair workgroups the kernel
+        // is made of: 512 frames per GPU 4.28 against 4.42 ms)
+        const bool prior_rides = 16 * MOM_PP_PAIRS >= 64 && nframes <= 128;
+        if (d.ncomps > 0 && !prior_rides) hipLaunchKernelGGL(k_prior, dim3(d.ncomps, nframes), dim3(128), 0, c->cur_stream, c->dm, c->fb);
+        const dim3 grid(mom_nwg(d) + (prior_rides ? d.ncomps : 0), nframes);
         const size_t lds = pairpass_lds_bytes(d);
         if (d.K == 10) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairpass<10>), grid, dim3(16 * MOM_PP_PAIRS), lds, c->cur_stream, c->dm, c->fb);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairpass<0>), grid, dim3(16 * MOM_PP_PAIRS), lds, c->cur_stream, c->dm, c->fb);
