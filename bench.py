@@ -171,8 +171,9 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
     # the roofline object describes the kernel on the CRITICAL path.  One frame group: the class with the most device time
     # (one frame: k_solve).  Two frame groups on two streams: the single-workgroup-per-frame solves of one group hide behind the
     # evaluation of the other, so the evaluation is the class that bounds the step whatever the summed device times say.
-    if groups >= 2:
-        dominant = "eval"
+    moments_run = args.data_term == "moments" or (args.data_term == "auto" and nfg >= ctx.tuning().mom_min_frames)
+    if groups >= 2 and not moments_run:
+        dominant = "eval"      # (moment form: every class of the GN loop is a short launch of the same chain - the one with the most device time stands)
     for _ in range(warmup):
         step()
     # HIP events only around the dominant kernel class, on the stream it is launched on, over K steps
@@ -216,7 +217,6 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
     achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
     # whole-pipeline view: every GN iteration of every frame moves bytes_iter algorithmic bytes; time = the step
     pipe = F * bytes_iter * opt.icp_iters * opt.max_iters_per_icp / (med / steps) / 1e9
-    moments_run = args.data_term == "moments" or (args.data_term == "auto" and nfg >= ctx.tuning().mom_min_frames)
     dom_key = "eval_moments" if (dominant == "eval" and moments_run) else dominant
     survey_equiv = None
     if dom_key == "eval_moments":
@@ -229,7 +229,7 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
         achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
     res["roofline"] = {"kernel": "k_prior + k_pairpass + k_assemble" if dom_key == "eval_moments" else "k_" + dominant, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(nfg, dom_key, Nmean),
-                       "chosen_because": ("two frame groups overlap: the evaluation bounds the step" if groups >= 2 else "largest share of device time on the one stream"),
+                       "chosen_because": ("two frame groups overlap: the evaluation bounds the step" if (groups >= 2 and not moments_run) else "largest share of device time"),
                        "limiter": LIMITER.get(dom_key, "?"),
                        "avg_launch_us": round(avg_ms * 1e3, 3), "launches_timed": prof_timed[dominant][1],
                        "launch_shape": {"frames_per_launch": nfg, "frame_groups": groups, "eval_workgroups_per_frame": G},
