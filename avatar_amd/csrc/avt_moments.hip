@@ -617,7 +617,8 @@ __global__ __launch_bounds__(128) void k_prior(DeviceModel dm, FrameBuffers fb) 
 
 static size_t pairpass_lds_bytes(const AvtDims& d) {
     const int TS = mom_tstride(d.mom_npsi), GS = (2 * (15 + 3 * d.K) + d.K + 2) & ~1;
-    return sizeof(double) * ((size_t)MOM_PP_PAIRS * (TS + GS) + (size_t)MOM_PP_PAIRS * (d.K * d.K + d.K)) + 64;
+    const size_t pairs = sizeof(double) * ((size_t)MOM_PP_PAIRS * (TS + GS) + (size_t)MOM_PP_PAIRS * (d.K * d.K + d.K)) + 64;
+    return std::max(pairs, sizeof(double) * 6 * AVT_MAX_JOINTS + 64);      // (the prior's workgroups in this grid: avt_prior.h's scratch)
 }
 
 // =================================================================================================
