@@ -191,3 +191,35 @@ def test_switching_the_form_back_and_forth_reproduces_the_system_and_the_cost(sm
                 assert np.array_equal(H, seen[name][0]) and np.array_equal(g, seen[name][1]) and cost == seen[name][2], (name, rnd)
             seen[name] = (H, g, cost)
     assert abs(seen["moments"][2] - seen["rows"][2]) <= 1e-9 * abs(seen["rows"][2])
+
+
+def test_moment_form_launch_shapes_agree_bit_for_bit(smpl, gmodel):
+    """The pose prior of the moment form rides in the pair pass's grid up to 128 frames per launch and is a launch of its own above
+    (avt_moments.hip launch_assemble); a frame's fit must not depend on which: 130 frames in ONE launch group, 130 frames in two groups
+    of 65 and the frames one at a time give the same bits."""
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    frs = [synth.make_frame(smpl, s) for s in (41, 42, 43)]
+    starts = [_start(fr) for fr in frs]
+    opt = Options.demo(max_iters_per_icp=4)
+    n = max(len(fr["labels"]) for fr in frs)
+    F = 130
+    pick = [i % 3 for i in range(F)]
+    args = ([frs[i]["data"] for i in pick], [frs[i]["labels"] for i in pick], opt, np.array([starts[i][0] for i in pick]),
+            np.array([starts[i][1] for i in pick]), np.array([starts[i][2] for i in pick]))
+    res = []
+    for groups in (1, 2):
+        ctx = api.Context(gmodel, 24, pm, n, F)
+        ctx.set_tuning(groups=groups)
+        ctx.set_data_term(ctx.DATA_TERM_MOMENTS)
+        res.append(ctx.optimize_batch(*args))
+        del ctx
+    one = api.Context(gmodel, 24, pm, n, 1)
+    one.set_data_term(one.DATA_TERM_MOMENTS)
+    for i in range(3):
+        p, q, w, _ = one.optimize_batch([frs[i]["data"]], [frs[i]["labels"]], opt, starts[i][0][None], starts[i][1][None], starts[i][2][None])
+        for r in res:
+            for j in (i, i + 3, F - 3 + i):      # first, second and last occurrence of the frame in the batch (pick[F - 3 + i] == (F - 3 + i) % 3)
+                if pick[j] != i:
+                    continue
+                assert np.array_equal(r[0][j], p[0]) and np.array_equal(r[1][j], q[0]) and np.array_equal(r[2][j], w[0]), (i, j)
