@@ -18,8 +18,9 @@
 //
 //   k_moments    grid (np + cost-constant blocks, frames): workgroup p < np accumulates T_p (packed upper triangle) and, for a
 //                diagonal pair, D_k; the others sum |d_i - centre|^2 over the matched data points;
-//   k_pairpass   grid (ceil(np / 16) + GMM components, frames): one 16-lane group per joint pair contracts its T with the trial state
-//                (phase A); the trailing workgroups evaluate the pose prior there, one component each;
+//   k_pairpass   grid (ceil(np / 4) [+ GMM components], frames), 64 threads: one 16-lane group per joint pair contracts its T with the
+//                trial state (phase A); up to 128 frames per launch trailing workgroups evaluate the pose prior there, one component
+//                each - above that the prior is a launch of its own (k_prior);
 //   k_assemble   grid (1, frames): turns the pair results into the dense system of the trial point in Hraw (the layout k_reduce
 //                produces: full symmetric, row / column P = J^T r, [P][P] = sum c |r|^2).
 #include <algorithm>
@@ -308,11 +309,13 @@ __host__ __device__ inline size_t mom_off_z(const AvtDims& d) { return mom_off_r
 __host__ __device__ inline size_t mom_frame_scratch(const AvtDims& d) { return (mom_off_z(d) + (size_t)mom_nwg(d) * (d.K * d.K + d.K) + 7) & ~(size_t)7; }
 
 // =================================================================================================
-// k_pairpass<KC>.  grid (ceil(np / 16), frames), block 256 = sixteen 16-lane groups, one unordered pair (k <= k') each; lane = s'
-// (0 .. K).  tools/moment_proto2.py::assemble "phase A":
-//   Q[i][i'] = sum_s om_s T[(i,s),(i',s')],  zz[s] = sum_ii' (R_k^T R_k')[i][i'] T[(i,s),(i',s')]   - 9 (K + 1) + 4 loads of the packed T,
-//   P2, p1 by a butterfly over the group; lane 0 writes X16 of both orders, lanes 1 .. K the per-(ordered pair, shape key) records;
-//   the lanes' shape-shape columns and sum tr(Y) are added over the workgroup's pairs in group order through LDS.
+// k_pairpass<KC>.  grid (ceil(np / MOM_PP_PAIRS) [+ GMM components], frames), block 16 MOM_PP_PAIRS = 64: one 16-lane group per unordered
+// pair (k <= k'), lane = s' (0 .. K).  tools/moment_proto2.py::assemble "phase A":
+//   the pair's packed T and the two joints' tables are staged in the group's LDS slice (coalesced 16-byte loads, wave-local hand-over);
+//   Q[i][i'] = sum_s om_s T[(i,s),(i',s')],  zz[s] = sum_ii' (R_k^T R_k')[i][i'] T[(i,s),(i',s')]   - 9 (K + 1) + 4 reads of the packed T,
+//   P2, p1 by DPP row sums over the group; lanes 1 .. K write the per-(ordered pair, shape key) records, lane 0 - through the same
+//   instructions - X16 of both orders; the lanes' shape-shape columns and sum tr(Y) are added over the workgroup's pairs in group order
+//   through LDS.  Trailing workgroups (launch_assemble decides): the GMM pose prior of the trial point, one component each.
 // =================================================================================================
 // sum over the 16 lanes of a DPP row, every lane ending with the same bits (the two operands of each add are the same pair of numbers in
 // both lanes): quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror - register moves, no LDS permutes
