@@ -355,7 +355,11 @@ extern "C" void avt_debug_mf_phases(long long* out8, int reset) {
     if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_mf_phase), sizeof(long long) * 8);
     if (reset) { long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mf_phase), z, sizeof z); }
 }
+#ifdef AVT_TIMING_ROUNDS     // (the per-round probes are global read-modify-writes on the factorisation's critical path: they double what they measure, so they are a build of their own)
 #define MFP(i) do { if ((t & 63) == 0 && (W == 0 || W == 3) && blockIdx.x == 0) { const long long _n = clock64(); g_mf_phase[(W == 0 ? 0 : 4) + (i)] += _n - _tl; _tl = _n; } } while (0)
+#else
+#define MFP(i) do {} while (0)
+#endif
 #else
 #define MFP(i) do {} while (0)
 #endif
