@@ -1,6 +1,7 @@
 """In-kernel phase timing (clock64, thread 0) of the last k_solve launch of an optimize() call.
 Needs the instrumented library: make -C avatar_amd/csrc libavatar_hip_timing_lm.so, then
-    AVT_LIB=avatar_amd/csrc/libavatar_hip_timing_lm.so python tools/solve_phase_probe.py [frames]"""
+    AVT_LIB=avatar_amd/csrc/libavatar_hip_timing_lm.so python tools/solve_phase_probe.py [frames]
+The per-round line needs libavatar_hip_timing_lm_rounds.so (its probes inflate the phase totals: read those from the plain timing build)."""
 import ctypes as C
 import os
 import sys
