@@ -223,3 +223,28 @@ def test_moment_form_launch_shapes_agree_bit_for_bit(smpl, gmodel):
                 if pick[j] != i:
                     continue
                 assert np.array_equal(r[0][j], p[0]) and np.array_equal(r[1][j], q[0]) and np.array_equal(r[2][j], w[0]), (i, j)
+
+
+def test_batch_with_three_icp_iterations_the_forms_agree(smpl, gmodel):
+    """66 frames (two launch groups of 33: the default takes the moment form there, the prior's workgroups ride in the pair pass), three ICP
+    iterations: the default equals the moment form selected explicitly bit for bit, and the row form to 1e-10."""
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    frs = [synth.make_frame(smpl, 50 + s) for s in range(4)]
+    F = 66
+    pick = [i % 4 for i in range(F)]
+    st = [_start(fr) for fr in frs]
+    args = ([frs[i]["data"] for i in pick], [frs[i]["labels"] for i in pick], Options.demo(icp_iters=3), np.array([st[i][0] for i in pick]),
+            np.array([st[i][1] for i in pick]), np.array([st[i][2] for i in pick]))
+    n = max(len(fr["labels"]) for fr in frs)
+    res = {}
+    for name, term in (("auto", None), ("rows", 0), ("moments", 1)):
+        ctx = api.Context(gmodel, 24, pm, n, F)
+        if term is not None:
+            ctx.set_data_term(term)
+        res[name] = ctx.optimize_batch(*args)
+        del ctx
+    assert all(np.array_equal(a, b) for a, b in zip(res["auto"][:3], res["moments"][:3]))
+    assert [s.accepted_steps for s in res["rows"][3]] == [s.accepted_steps for s in res["moments"][3]]
+    for a, b in zip(res["rows"][:3], res["moments"][:3]):
+        assert np.abs(a - b).max() < 1e-10
