@@ -296,6 +296,24 @@ class Context:
                                             dptr(q), dptr(w), st))
         return p, q.reshape(F, -1, 4), w, list(st)
 
+    def host_optimize_call(self, data, labels, opt: Options, p0, q0, w0):
+        """The reference's call shape - optimize(const CloudType&, const VectorXi&, ...) on HOST memory (AvatarOptimizer.h:17-19) - as a
+        closure over prepared contiguous arrays: every call is ONE avt_optimize (H2D of the cloud and the start state, the fit, D2H of
+        p / q / w / stats) with no Python-side array work beyond re-installing the 109 start values.  Returns (call, p, q, w, stats)."""
+        data = np.ascontiguousarray(np.asarray(data, np.float64).reshape(-1, 3))
+        lab = np.ascontiguousarray(np.asarray(labels, np.int32))
+        ps, qs, ws = (np.array(a, np.float64).ravel().copy() for a in (p0, q0, w0))
+        p, q, w = ps.copy(), qs.copy(), ws.copy()
+        st = Stats()
+        fn, h, n = self._lib.avt_optimize, self.h, C.c_int(len(lab))
+        a_d, a_l, a_o, a_p, a_q, a_w, a_s = dptr(data), iptr(lab), C.byref(opt), dptr(p), dptr(q), dptr(w), C.byref(st)
+
+        def call():
+            p[:] = ps; q[:] = qs; w[:] = ws
+            _check(fn(h, a_d, a_l, n, a_o, a_p, a_q, a_w, a_s))
+        call._keep = (data, lab, opt)
+        return call, p, q, w, st
+
     def frames_upload(self, datas, labels):
         F = len(datas)
         offs = np.zeros(F + 1, np.int32)
@@ -387,6 +405,20 @@ class Context:
         H = np.empty((P, P)); g = np.empty(P); cost = C.c_double()
         _check(self._lib.avt_get_normal_equations(self.h, C.c_int(frame), dptr(H), dptr(g), C.byref(cost)))
         return H, g, cost.value
+
+    def cost_trace(self, frame=0, n=11):
+        """Objective at entry of the last ICP iteration and after each of its GN iterations (avt_debug_trace): entry i + 1 < entry i
+        means iteration i + 1 accepted its trial point."""
+        buf = np.zeros(64)
+        _check(self._lib.avt_debug_trace(self.h, C.c_int(frame), dptr(buf)))
+        return buf[:n].copy()
+
+    def mfma_count(self, frame=0):
+        """fp64 matrix instructions (2048 flop each) the kernels execute for `frame` with the last optimize()'s correspondences, from their
+        own trip counts (avt_debug_mfma_count): dict eval_rows / moments / solve, None where the form did not run."""
+        a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
+        _check(self._lib.avt_debug_mfma_count(self.h, C.c_int(frame), C.byref(a), C.byref(b), C.byref(c)))
+        return {k: (None if v.value < 0 else int(v.value)) for k, v in (("eval_rows", a), ("moments", b), ("solve", c))}
 
     DATA_TERM_ROWS, DATA_TERM_MOMENTS, DATA_TERM_AUTO = 0, 1, 2
 

@@ -18,7 +18,7 @@ c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
 c_ubyte_p = C.POINTER(C.c_ubyte)
 
-AVT_K_NAMES = ["lbs", "visibility", "bucket", "nn", "aggregate", "prepare", "eval", "reduce", "solve", "decide"]
+AVT_K_NAMES = ["lbs", "visibility", "bucket", "nn", "aggregate", "prepare", "eval", "reduce", "solve", "decide", "moments"]
 AVT_K_COUNT = len(AVT_K_NAMES)
 
 
@@ -220,6 +220,7 @@ def load_library():
         "avt_set_data_term": [vp, C.c_int],
         "avt_get_data_term": [vp],
         "avt_debug_trace": [vp, C.c_int, c_double_p],
+        "avt_debug_mfma_count": [vp, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)],
         "avt_launch_shape": [vp, c_int_p, c_int_p, c_int_p],
         "avt_profile_begin": [vp],
         "avt_profile_select": [vp, C.c_uint],
@@ -235,6 +236,7 @@ def load_library():
         "avt_shard_unique_id": [C.c_char_p],
         "avt_shard_create": [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)],
         "avt_shard_create_loopback": [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)],
+        "avt_shard_create_shm": [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)],
         "avt_shard_destroy": [vp],
         "avt_shard_rank": [vp],
         "avt_shard_world": [vp],
@@ -265,10 +267,10 @@ EXPORTED_SYMBOLS = [
     "avt_model_dims", "avt_model_main_joint", "avt_model_joint_regression", "avt_model_tile_layout", "avt_ctx_create", "avt_ctx_destroy",
     "avt_sync", "avt_lbs_update", "avt_visibility", "avt_nn", "avt_optimize", "avt_optimize_batch",
     "avt_frames_upload", "avt_synth_render_frames", "avt_synth_render_frames_mode", "avt_synth_render_images", "avt_frames_download", "avt_state_upload", "avt_optimize_resident", "avt_state_reset", "avt_state_download",
-    "avt_get_correspondences", "avt_get_cloud", "avt_get_posed", "avt_get_normal_equations", "avt_ctx_get_tuning", "avt_ctx_set_tuning", "avt_set_data_term", "avt_get_data_term", "avt_debug_trace", "avt_launch_shape", "avt_profile_begin", "avt_profile_select", "avt_profile_end",
+    "avt_get_correspondences", "avt_get_cloud", "avt_get_posed", "avt_get_normal_equations", "avt_ctx_get_tuning", "avt_ctx_set_tuning", "avt_set_data_term", "avt_get_data_term", "avt_debug_trace", "avt_debug_mfma_count", "avt_launch_shape", "avt_profile_begin", "avt_profile_select", "avt_profile_end",
     # include/avt_shard.h
     "avt_shard_owner", "avt_shard_local_count", "avt_shard_local_index", "avt_shard_global_frame", "avt_model_pack_size", "avt_model_pack",
-    "avt_model_unpack", "avt_shard_unique_id", "avt_shard_create", "avt_shard_create_loopback", "avt_shard_destroy", "avt_shard_rank", "avt_shard_world", "avt_shard_backend",
+    "avt_model_unpack", "avt_shard_unique_id", "avt_shard_create", "avt_shard_create_loopback", "avt_shard_create_shm", "avt_shard_destroy", "avt_shard_rank", "avt_shard_world", "avt_shard_backend",
     "avt_shard_broadcast_model", "avt_shard_scatter_frames", "avt_shard_gather_enqueue", "avt_shard_gather_wait", "avt_shard_gather_download",
     "avt_shard_gather_results", "avt_shard_barrier",
 ]

@@ -196,8 +196,8 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
         if (c->fb.use_moments) {
             // Moment form (avt_moments.hip): the correspondences' sufficient statistics once per ICP iteration, then every GN iteration
             // assembles its normal equations from them - no Jacobian rows, no partial tiles, no reduction.
-            { ProfScope ps(c, AVT_K_AGGREGATE); launch_finalize(c, nf); c->fb.const_used = (c->launch_maxN + 2047) / 2048; launch_moments(c, nf); }
-            c->have_moments = true; c->have_records = false;
+            { ProfScope ps(c, AVT_K_AGGREGATE); launch_finalize(c, nf); }
+            { ProfScope ps(c, AVT_K_MOMENTS); c->fb.const_used = (c->launch_maxN + 2047) / 2048; launch_moments(c, nf); }
             if (!fuse_init) { ProfScope ps(c, AVT_K_PREPARE); launch_solve(c, nf, SOLVE_INIT); }
             { ProfScope ps(c, AVT_K_EVAL); launch_assemble(c, nf); }
             for (int it = 1; it <= std::max(1, o->max_iters_per_icp); ++it) {
@@ -205,15 +205,14 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
                 if (o->max_iters_per_icp == 0) break;
                 { ProfScope ps(c, AVT_K_EVAL); launch_assemble(c, nf); }
             }
-            // the accept test of the last trial point: one more pass of the solve kernel (the step it also makes is never used)
-            if (o->max_iters_per_icp > 0) { ProfScope ps(c, AVT_K_DECIDE); launch_solve(c, nf, SOLVE_NORMAL, o->max_iters_per_icp + 1); }
+            // the accept test of the last trial point: the decision part of the solve kernel alone (SOLVE_DECIDE: no factorisation, no step)
+            if (o->max_iters_per_icp > 0) { ProfScope ps(c, AVT_K_DECIDE); launch_solve(c, nf, SOLVE_DECIDE, o->max_iters_per_icp + 1); }
             { ProfScope ps(c, AVT_K_LBS); const bool more = icp + 1 < o->icp_iters;
               launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 2, more ? vis_init : -1, false, fuse_init && more, false, few && more); }
             c->ran_icp_iters++;
             continue;
         }
         { ProfScope ps(c, AVT_K_AGGREGATE); launch_finalize(c, nf); launch_records(c, nf); }
-        c->have_records = true; c->have_moments = false;
         if (!fuse_init) { ProfScope ps(c, AVT_K_PREPARE); launch_solve(c, nf, SOLVE_INIT); }
         const bool rides = avt_solve_rides(c, nf);        // few frames: the reduction is part of the solve's launch
         { ProfScope ps(c, AVT_K_EVAL); launch_eval(c, nf, false); }
@@ -255,6 +254,19 @@ int sync_params(avt_ctx* c, const avt_options* o) {
 
 constexpr size_t GRAPH_CACHE_ENTRIES = 8;
 
+// which form of the data term an optimize() over nf resident frames runs (include/avt.h, avt_set_data_term): ONE rule for run_optimize,
+// avt_launch_shape and avt_get_normal_equations.  AUTO: the moment form from tun.mom_min_frames frames per launch on.
+bool choose_moments(const avt_ctx* c, int nf) {
+    const int g0 = choose_groups(nf, c->tun), per_launch = (nf + g0 - 1) / g0;
+    return c->dm.d.mom_ok && (c->data_term == AVT_DATA_TERM_MOMENTS || (c->data_term == AVT_DATA_TERM_AUTO && per_launch >= c->tun.mom_min_frames));
+}
+
+// what exists for the resident correspondences after an optimize() call has been enqueued - by launches, by a fresh capture or by the
+// replay of a cached graph alike (set inside enqueue_optimize these flags described the last CAPTURED graph, not the last one run)
+void note_products(avt_ctx* c, const avt_options* o) {
+    if (o->icp_iters > 0) { c->have_moments = c->fb.use_moments != 0; c->have_records = !c->have_moments; }
+}
+
 int run_optimize(avt_ctx* c, const avt_options* o) {
     const int nf = c->nframes;
     if (nf <= 0 || !c->frames_valid) { avt_set_error("avt_optimize: no frames resident (upload frames first; the stand-alone entry points avt_nn / avt_visibility / avt_lbs_update invalidate them)"); return 1; }
@@ -267,11 +279,8 @@ int run_optimize(avt_ctx* c, const avt_options* o) {
     // (k_solve, k_finalize, k_reduce) overlap the throughput kernels (k_eval, k_nn) of the others on separate streams.
     // The instrumented (profiling) path keeps the SAME groups and launch shapes and runs them one after the other on
     // the main stream, so that per-launch timings describe the launches the graph replays.
-    {   // which form of the data term this call runs (include/avt.h): the moment form pays from ~100 frames per launch on
-        const int g0 = choose_groups(nf, c->tun), per_launch = (nf + g0 - 1) / g0;
-        c->fb.use_moments = c->dm.d.mom_ok && (c->data_term == AVT_DATA_TERM_MOMENTS || (c->data_term == AVT_DATA_TERM_AUTO && per_launch >= c->tun.mom_min_frames));
-        c->last_run_moments = c->fb.use_moments != 0;
-    }
+    c->fb.use_moments = choose_moments(c, nf);      // which form of the data term this call runs
+    c->last_run_moments = c->fb.use_moments != 0;
     const int ngroups = plan_groups(c, nf);
     const int nfg = (nf + ngroups - 1) / ngroups;       // frames per group (the last group may be smaller)
     c->fb.G = choose_G(nfg, ngroups, c->tun);
@@ -282,6 +291,7 @@ int run_optimize(avt_ctx* c, const avt_options* o) {
             if (n > 0) enqueue_optimize(c, o, f0, n, c->stream);
         }
         c->ran_icp_iters = o->icp_iters;
+        note_products(c, o);
         return check_launch("optimize launch sequence");
     }
     // The launch sequence depends only on the launch shape: capture it once, replay it afterwards.
@@ -338,6 +348,7 @@ int run_optimize(avt_ctx* c, const avt_options* o) {
     hit->last_used = ++c->graph_clock;
     HIP_OK(hipGraphLaunch(hit->exec, c->stream));
     c->ran_icp_iters = o->icp_iters;
+    note_products(c, o);
     return 0;
 }
 
@@ -356,6 +367,7 @@ int install_frames(avt_ctx* c, int nframes, const int* counts, const double* dat
     }
     const bool same_shape = c->frames_valid && nframes == c->nframes;
     c->frames_valid = false;
+    c->have_moments = c->have_records = false;      // new frames: the moments / records of the old correspondences describe nothing resident
     c->nframes = nframes;
     c->frame_N.assign(counts, counts + nframes);
     c->frame_off.assign(nframes + 1, 0);
@@ -502,6 +514,11 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
     if (avt_solve_set_attributes() || avt_eval_set_attributes() || avt_lbs_set_attributes() || avt_moments_set_attributes()) { avt_set_error("avt_ctx_create: hipFuncSetAttribute failed"); return 1; }
     DeviceModel& dm = c->dm;
     dm.d = m->d;
+    if (!dm.d.mom_ok) c->mom_reason = "K + 1 <= 16 and 3 + 3J + K <= 87 required";
+    else if (avt_moments_lds_need(dm.d) > avt_moments_lds_cap()) {      // AUTO then keeps the row form, avt_set_data_term(MOMENTS) says why
+        dm.d.mom_ok = 0;
+        c->mom_reason = "its assembly needs " + std::to_string(avt_moments_lds_need(dm.d)) + " bytes of LDS per workgroup, " + std::to_string(avt_moments_lds_cap()) + " available";
+    }
     // visibility as one workgroup per frame when the frame's x, y fit the LDS
     c->vis_frame_min = avt_visibility_frame_lds(m->d) <= 150 * 1024 ? c->tun.vis_frame_min : 0;
     dm.d.num_parts = num_parts;
@@ -776,6 +793,7 @@ int avt_synth_render_frames_mode(avt_ctx* c, int nframes, const double* w, const
     HIP_OK(hipMemcpyAsync(ctl.data(), c->fb.ctl, ctl.size() * sizeof(AvtFrameCtl), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
     c->frames_valid = c->state_valid = false;
+    c->have_moments = c->have_records = false;
     c->nframes = nframes;
     c->frame_N.assign(nframes, 0);
     c->frame_off.assign(nframes + 1, 0);
@@ -926,6 +944,7 @@ int avt_get_normal_equations(avt_ctx* c, int frame, double* H, double* g, double
     // the form of the data term: the one selected (AUTO: the one the last optimize() ran); what that form needs of the resident
     // correspondences - moments or matched-point records - is made here if the last optimize() ran the other form
     const bool want_mom = c->dm.d.mom_ok && (c->data_term == AVT_DATA_TERM_MOMENTS || (c->data_term == AVT_DATA_TERM_AUTO && c->last_run_moments));
+    const int use_moments_keep = c->fb.use_moments;      // (restored below: plan_groups / avt_launch_shape read it)
     c->fb.use_moments = want_mom;
     launch_solve(c, c->nframes, SOLVE_INIT);
     if (want_mom) {
@@ -937,6 +956,7 @@ int avt_get_normal_equations(avt_ctx* c, int frame, double* H, double* g, double
         launch_reduce(c, c->nframes);
     }
     c->fb.G = G_keep;
+    c->fb.use_moments = use_moments_keep;
     if (check_launch("avt_get_normal_equations")) return 1;
     HIP_OK(hipStreamSynchronize(c->stream));
     AvtFrameCtl ctl;
@@ -952,6 +972,44 @@ int avt_get_normal_equations(avt_ctx* c, int frame, double* H, double* g, double
     if (cost) *cost = ctl.cost_cur;
     return 0;
     AVT_API_GUARD_END("avt_get_normal_equations")
+}
+
+int avt_debug_mfma_count(avt_ctx* c, int frame, long long* eval_rows, long long* moments, long long* solve) {
+    AVT_API_GUARD_BEGIN
+    if (!c || frame < 0 || frame >= c->nframes) { avt_set_error("avt_debug_mfma_count: bad argument"); return 1; }
+    if (!c->frames_valid || c->ran_icp_iters <= 0) { avt_set_error("avt_debug_mfma_count: no optimize call has run on the resident frames"); return 1; }
+    const AvtDims& d = c->dm.d;
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    if (solve) *solve = avt_solve_mfma_count(d);
+    if (moments) {
+        *moments = -1;
+        if (d.mom_ok) {
+            std::vector<int> cnt(d.V);
+            HIP_OK(hipMemcpyAsync(cnt.data(), c->fb.cnt + (size_t)frame * d.V, cnt.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_OK(hipStreamSynchronize(c->stream));
+            *moments = avt_moments_mfma_count(c->model, cnt.data());
+        }
+    }
+    if (eval_rows) {
+        *eval_rows = -1;
+        if (c->have_records && d.NT <= 6) {
+            // k_records leaves one word per batch of 16 matched points: bits 0..23 = the live tile pairs (avt_eval.hip); k_eval runs the
+            // 12 k-steps (48 rows / 4) of every live pair - the split pair's are dealt over the four waves, 12 in total all the same
+            AvtFrameCtl ctl;
+            HIP_OK(hipMemcpyAsync(&ctl, c->fb.ctl + frame, sizeof(ctl), hipMemcpyDeviceToHost, c->stream));
+            HIP_OK(hipStreamSynchronize(c->stream));
+            const int nb = (ctl.M + AVT_EVAL_PTS - 1) / AVT_EVAL_PTS;
+            std::vector<int> bm(std::max(nb, 1));
+            HIP_OK(hipMemcpyAsync(bm.data(), c->fb.bmask + (size_t)frame * d.nb_max, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_OK(hipStreamSynchronize(c->stream));
+            long long n = 0;
+            for (int b = 0; b < nb; ++b) n += 12ll * __builtin_popcount((unsigned)bm[b] & 0xffffffu);
+            *eval_rows = n;
+        }
+    }
+    return 0;
+    AVT_API_GUARD_END("avt_debug_mfma_count")
 }
 
 int avt_ctx_get_tuning(avt_ctx* c, avt_tuning* out) {
@@ -980,7 +1038,7 @@ int avt_ctx_set_tuning(avt_ctx* c, const avt_tuning* t) {
 
 int avt_set_data_term(avt_ctx* c, int form) {
     if (!c || (form != AVT_DATA_TERM_ROWS && form != AVT_DATA_TERM_MOMENTS && form != AVT_DATA_TERM_AUTO)) { avt_set_error("avt_set_data_term: bad argument"); return 1; }
-    if (form == AVT_DATA_TERM_MOMENTS && !c->dm.d.mom_ok) { avt_set_error("avt_set_data_term: this model has no moment form (K + 1 <= 16 and 3 + 3J + K <= 87 required)"); return 1; }
+    if (form == AVT_DATA_TERM_MOMENTS && !c->dm.d.mom_ok) { avt_set_error("avt_set_data_term: this model has no moment form (" + c->mom_reason + ")"); return 1; }
     c->data_term = form;
     return 0;
 }
@@ -998,7 +1056,10 @@ int avt_debug_trace(avt_ctx* c, int frame, double* out64) {
 
 int avt_launch_shape(avt_ctx* c, int* groups, int* frames_per_group, int* eval_workgroups_per_frame) {
     if (!c || c->nframes <= 0) { avt_set_error("avt_launch_shape: no frames resident"); return 1; }
+    const int use_moments_keep = c->fb.use_moments;
+    c->fb.use_moments = choose_moments(c, c->nframes);      // the shape of the form the next optimize() will choose, whatever ran last
     const int ng = plan_groups(c, c->nframes), nfg = (c->nframes + ng - 1) / ng;
+    c->fb.use_moments = use_moments_keep;
     if (groups) *groups = ng;
     if (frames_per_group) *frames_per_group = nfg;
     if (eval_workgroups_per_frame) *eval_workgroups_per_frame = choose_G(nfg, ng, c->tun);

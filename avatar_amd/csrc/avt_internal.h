@@ -337,6 +337,7 @@ struct avt_ctx {
     int data_term;                   // AVT_DATA_TERM_* policy (avt_set_data_term)
     avt_tuning tun;                  // launch-shape / algorithm knobs (include/avt.h): defaults, then the environment ONCE at creation, then avt_ctx_set_tuning
     bool last_run_moments;           // the form the last optimize() ran
+    std::string mom_reason;          // why this context has no moment form (empty: it has one)
     bool have_moments, have_records; // what exists for the resident correspondences (avt_get_normal_equations makes the other on demand)
     int concurrent_groups;           // frame groups the current optimize() call runs side by side (sizes the riding launch shapes)
     // persistent scratch of avt_synth_render_frames (z-buffer keys, labels, block counts), grown on demand
@@ -350,7 +351,7 @@ struct avt_ctx {
 void avt_set_error(const std::string& s);
 
 // kernel launch wrappers (avt_kernels.hip / avt_nn.hip)
-enum { SOLVE_INIT = 0, SOLVE_FIRST = 1, SOLVE_NORMAL = 2 };
+enum { SOLVE_INIT = 0, SOLVE_FIRST = 1, SOLVE_NORMAL = 2, SOLVE_DECIDE = 3 /* the accept test of the last trial point alone (moment form) */ };
 void launch_lbs(avt_ctx* c, int nframes, const double* x_state_or_null, const double* w, const double* p, const double* R,
                 int from_state, int vis_init /* -1: leave bookkeeping alone; 0/1: reset it, visibility flags to this value */,
                 bool with_bucket_count = false, bool with_init = false, bool decide = false /* from_state 2: accept test of the last trial point first */,
@@ -376,3 +377,7 @@ void launch_assemble(avt_ctx* c, int nframes);            // normal equations of
 int avt_moments_set_attributes();
 size_t avt_moments_frame_scratch(const AvtDims& d);   // doubles per frame of FrameBuffers::mom_rec
 size_t avt_moments_T_doubles(const AvtDims& d);       // doubles per frame of FrameBuffers::mom_T
+long long avt_moments_mfma_count(const avt_model* m, const int* cnt_V);   // matrix instructions of one k_moments pass over a frame with these counts
+long long avt_solve_mfma_count(const AvtDims& d);     // ... of one LDL^T factorisation in k_solve
+size_t avt_moments_lds_need(const AvtDims& d);        // dynamic LDS the moment form's GN-loop kernels ask for ...
+size_t avt_moments_lds_cap();                         // ... and what a workgroup can have

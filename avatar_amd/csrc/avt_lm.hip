@@ -672,7 +672,8 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     // [2][HS] gradient and diagonal of the undamped system (predicted decrease of the step, gain-ratio schedule); the 1024-thread
     // shape has no LDS left for it (P = 178: 158.5 of 159.5 KB) and keeps it in the frame's global scratch - written and read by
     // this workgroup only, a barrier in between
-    double* s_x = s_delta + HS + 2;                         // [2][xsize] both state slots
+    // (SOLVE_DECIDE - the accept test alone, moment form - touches nothing of the above: its launch asks for the two state slots only)
+    double* s_x = MODE == SOLVE_DECIDE ? (double*)smem : s_delta + HS + 2;      // [2][xsize] both state slots
     const PrepLayout L = prep_layout(J, K, d.xsize);
     // skeleton scratch: behind the factor (SMPL shape: staged at kernel start, hidden behind the factorisation) or ON it
     // (triangular shape: the factor is dead once the back substitution is done)
@@ -686,8 +687,8 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
 
     // everything that does not depend on the LM decision is requested now: both state slots and the skeleton constants
     for (int e = t; e < 2 * xs; e += NTH) s_x[e] = x0[e];
-    if (!TRI || mode == SOLVE_INIT) prep_stage_constants<NTH>(dm, L, B, s_items, s_level);
-    if (!TRI && mode != SOLVE_INIT) {   // the never-written blocks of the factor must read as zeros (back substitution)
+    if ((!TRI || mode == SOLVE_INIT) && mode != SOLVE_DECIDE) prep_stage_constants<NTH>(dm, L, B, s_items, s_level);
+    if (!TRI && mode != SOLVE_INIT && mode != SOLVE_DECIDE) {   // the never-written blocks of the factor must read as zeros (back substitution)
         d2v* z = (d2v*)Lblk;
         for (int e = t; e < NBk * NBk * 9; e += NTH) z[e] = (d2v){0.0, 0.0};
     }
@@ -767,7 +768,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         __syncthreads();
     }
     auto hload = [&](const double* q) { if constexpr (RIDE) return ld_agent(q); else return *q; };
-    if constexpr (!TRI) {
+    if constexpr (!TRI && MODE != SOLVE_DECIDE) {
         // (one copy per wave role: tile rows and columns are compile-time constants there, an entry's address is one add)
         const double* Hl = H0 + (size_t)(4 * 0 + mf_g4) * HS + mf_c16;
         auto load_role = [&](auto role) {
@@ -892,6 +893,13 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         if (mode == SOLVE_FIRST) { ctl.cost_initial = cost; ctl.cost_const = cost_const; }
         else { it += 1; ctl.gn_iterations = it; if (accepted) ctl.accepted += 1; }
         if (it < 40) fb.trace[(size_t)f * 64 + it] = cost_cur;
+    }
+    if constexpr (MODE == SOLVE_DECIDE) {
+        // The accept test of the LAST trial point of an ICP iteration in the moment form (no solve follows it): the accept / reject update of
+        // lambda and nothing else - what lm_last_decide (avt_decide.h) does for the row form and the oracle does for both (a full
+        // SOLVE_NORMAL pass here also multiplied lambda when its unused factorisation was refused, and cost a factorisation per frame).
+        if (t == 0) { ctl.lambda = lambda; ctl.nu = nu; }
+        return;
     }
     if (RIDE && use_spec) {      // (role 0) the step exists: install it as the new trial point
         const int k = sp_next, tr = 1 - cur;
@@ -1101,6 +1109,18 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
 
 static bool solve_big(const AvtDims& d) { return d.HS / 4 > 22; }      // more than 253 blocks: the 1024-thread triangular shape
 
+// Matrix instructions of ONE factorisation (mf_rounds / mfg_rounds): every 4-pivot round but the last updates the lower-triangle tiles
+// from the next panel's tile column on (rank-4 update, one v_mfma_f64_16x16x4_f64 per tile)
+long long avt_solve_mfma_count(const AvtDims& d) {
+    const int NR = (d.P + 3) >> 2, T = solve_big(d) ? (d.P + 16) >> 4 : 6;
+    long long n = 0;
+    for (int kb = 0; kb + 1 < NR; ++kb) {
+        const int cb = kb >> 2, cbn = (kb & 3) == 3 ? std::min(cb + 1, T - 1) : cb;
+        for (int c = cbn; c < T; ++c) n += T - c;
+    }
+    return n;
+}
+
 static size_t solve_lds_bytes(const AvtDims& d) {
     const int HS = d.HS, NB = HS / 4;
     const PrepLayout L = prep_layout(d.J, d.K, d.xsize);
@@ -1129,6 +1149,7 @@ static void launch_solve_shape(avt_ctx* c, int nframes, int mode, size_t lds) {
     switch (mode) {
         case SOLVE_INIT: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<NTH, TRI, SOLVE_INIT>), dim3(nframes), dim3(NTH), lds, c->cur_stream, c->dm, c->fb); break;
         case SOLVE_FIRST: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<NTH, TRI, SOLVE_FIRST>), dim3(nframes), dim3(NTH), lds, c->cur_stream, c->dm, c->fb); break;
+        case SOLVE_DECIDE: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<NTH, TRI, SOLVE_DECIDE>), dim3(nframes), dim3(NTH), sizeof(double) * 2 * c->dm.d.xsize + 64, c->cur_stream, c->dm, c->fb); break;
         default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<NTH, TRI, SOLVE_NORMAL>), dim3(nframes), dim3(NTH), lds, c->cur_stream, c->dm, c->fb); break;
     }
 }
@@ -1159,7 +1180,7 @@ bool avt_solve_rides(const avt_ctx* c, int nframes) { return ride_strips(c, nfra
 
 void launch_solve(avt_ctx* c, int nframes, int mode, int seq) {
     const AvtDims& d = c->dm.d;
-    const int rs = mode != SOLVE_INIT ? ride_strips(c, nframes) : 0;
+    const int rs = (mode != SOLVE_INIT && mode != SOLVE_DECIDE) ? ride_strips(c, nframes) : 0;
     c->fb.nspec = 0; c->fb.seq = seq;
     if (rs) {
         c->fb.nspec = ride_nspec(c, nframes, rs);

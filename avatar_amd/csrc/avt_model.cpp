@@ -622,7 +622,7 @@ extern "C" void avt_options_default(avt_options* o) {
 }
 
 extern "C" const char* avt_kernel_name(int k) {
-    static const char* names[AVT_K_COUNT] = {"lbs", "visibility", "bucket", "nn", "aggregate", "prepare", "eval", "reduce", "solve", "decide"};
+    static const char* names[AVT_K_COUNT] = {"lbs", "visibility", "bucket", "nn", "aggregate", "prepare", "eval", "reduce", "solve", "decide", "moments"};
     return (k >= 0 && k < AVT_K_COUNT) ? names[k] : "?";
 }
 

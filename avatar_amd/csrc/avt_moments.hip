@@ -948,11 +948,36 @@ void launch_assemble(avt_ctx* c, int nframes) {
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble<0, MOM_ASM_NTH>), grid, dim3(MOM_ASM_NTH), lds, c->cur_stream, c->dm, c->fb);
 }
 
+// Matrix instructions (v_mfma_f64_16x16x4_f64, 2048 flop each) one k_moments pass over a frame executes, from the kernel's own trip counts:
+// per pair and 512-entry segment of its static list, ceil(matched / (4 MOM_UN)) MOM_UN rounds of one instruction per upper tile pair of psi
+// (+ one per psi tile for D_k of a diagonal pair).  `cnt` = the frame's per-vertex correspondence counts (host copy).  bench.py prices
+// the kernel's matrix-pipe utilisation on THIS number (profiles/: SQ_INSTS_VALU_MFMA_MOPS_F64 of the same launch agrees).
+long long avt_moments_mfma_count(const avt_model* m, const int* cnt) {
+    const AvtDims& d = m->d;
+    const int NTP = d.mom_ntp, NTPAIR = NTP * (NTP + 1) / 2;
+    long long n = 0;
+    for (int p = 0; p < d.mom_np; ++p) {
+        const bool diag = m->mom_pair[2 * p] == m->mom_pair[2 * p + 1];
+        const int lo = m->mom_lstart[p], len = m->mom_lstart[p + 1] - lo;
+        for (int base = 0; base < len; base += MOM_SEG) {
+            int mseg = 0;
+            for (int e = base; e < std::min(len, base + MOM_SEG); ++e) mseg += cnt[m->mom_lv[lo + e]] > 0;
+            const long long rounds = (long long)((mseg + 4 * MOM_UN - 1) / (4 * MOM_UN)) * MOM_UN;
+            n += rounds * (NTPAIR + (diag ? NTP : 0));
+        }
+    }
+    return n;
+}
+
 size_t avt_moments_frame_scratch(const AvtDims& d) { return mom_frame_scratch(d); }
+// both kernels of the GN loop must fit the dynamic-LDS cap set below: the assembly's request grows with the pair count and the rot-rot lists
+// (SMPL: 80 KB), so a model with denser skinning can exceed it although K and P qualify - the context then keeps the row form
+size_t avt_moments_lds_need(const AvtDims& d) { return std::max(assemble_lds_bytes(d), pairpass_lds_bytes(d)); }
+size_t avt_moments_lds_cap() { return 160 * 1024 - 512; }
 size_t avt_moments_T_doubles(const AvtDims& d) { return (size_t)d.mom_np * mom_tstride(d.mom_npsi); }
 
 int avt_moments_set_attributes() {
-    const int cap = 160 * 1024 - 512;
+    const int cap = (int)avt_moments_lds_cap();
     return hipFuncSetAttribute((const void*)k_assemble<10, MOM_ASM_NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
            hipFuncSetAttribute((const void*)k_assemble<0, MOM_ASM_NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
            hipFuncSetAttribute((const void*)k_pairpass<10>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||

@@ -6,8 +6,14 @@
 #include <dlfcn.h>
 #include <link.h>
 #include <rccl/rccl.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cerrno>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +24,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/avt_shard.h"
@@ -395,6 +402,161 @@ RcclApi* loop_api() {
     return &api;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Shared-memory transport: the same collectives between PROCESSES of one node, staged through a POSIX shared-memory
+// segment (device -> segment -> device).  RCCL refuses two ranks on one GPU ("Duplicate GPU detected"), so on a one-GPU box
+// the launch path a real node takes - bench.py --gpus N -> torch.distributed.run -> one process per rank -> avt_shard ->
+// scatter -> optimize -> all-gather - could never run with N > 1; with this transport it does (tests/test_gpu_bench_ranks.py,
+// AVT_BENCH_SHARE_GPU0=1), and a node without RCCL still has a batch split.  It is NOT the fast path: every byte crosses
+// the host twice.
+// Layout: a header, then one mailbox per ordered pair (source, destination): two sequence counters and SHM_CHUNK bytes.
+// A message travels as chunks (a chunk never spans messages); chunk i of a box is written when chunk i - 1 has been taken
+// (seq_empty == i) and published by seq_full = i + 1.  Everything is point-to-point; broadcast and all-gather are made of it.
+// One progress loop serves all pending sends and receives of a call, so grouped exchanges cannot deadlock; a peer that
+// never arrives makes the call fail after AVT_SHARD_LOOPBACK_TIMEOUT_S (default 60 s here) and marks the segment broken.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr size_t SHM_CHUNK = 1u << 20;
+constexpr unsigned SHM_MAGIC = 0x41565453u;      // "AVTS"
+struct ShmHeader {
+    std::atomic<unsigned> magic;
+    std::atomic<int> attached, broken;
+    int world;
+    unsigned long long chunk;
+    char pad[40];
+};
+struct ShmBox {
+    std::atomic<unsigned long long> seq_full, seq_empty;      // chunks published by the source / taken by the destination
+    unsigned long long bytes;                                  // payload of the chunk in flight
+    char pad[40];
+};
+static_assert(sizeof(ShmHeader) == 64 && sizeof(ShmBox) == 64, "shared-memory transport: 64-byte records");
+struct ShmComm {
+    void* base = nullptr; size_t map_bytes = 0;
+    int rank = 0, world = 1;
+    double timeout_s = 60.0;
+    std::vector<unsigned long long> sent, taken;              // per peer: chunks I published to it / took from it
+    ShmHeader* hdr() const { return (ShmHeader*)base; }
+    ShmBox* box(int src, int dst) const { return (ShmBox*)((char*)base + sizeof(ShmHeader)) + (size_t)src * world + dst; }
+    char* payload(int src, int dst) const { return (char*)base + sizeof(ShmHeader) + sizeof(ShmBox) * (size_t)world * world + ((size_t)src * world + dst) * SHM_CHUNK; }
+};
+size_t shm_bytes(int world) { return sizeof(ShmHeader) + (sizeof(ShmBox) + SHM_CHUNK) * (size_t)world * world; }
+struct ShmXfer { int peer; char* ptr; size_t bytes, done; };
+struct ShmPending { int depth = 0; std::vector<ShmXfer> sends, recvs; ncclComm_t comm = nullptr; hipStream_t stream = nullptr; };
+thread_local ShmPending shm_pending;
+
+// all of `sends` and `recvs` (device pointers), FIFO per peer; returns when everything I send has been copied into the
+// segment and everything I receive has arrived in my buffers
+ncclResult_t shm_progress(ShmComm* sc, std::vector<ShmXfer>& sends, std::vector<ShmXfer>& recvs, hipStream_t st) {
+    if (hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;      // what I send is ready
+    if (sc->hdr()->broken.load(std::memory_order_acquire)) return ncclSystemError;
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t left = 0;
+    for (auto& x : sends) left += x.bytes == 0 ? 0 : 1;
+    for (auto& x : recvs) left += x.bytes == 0 ? 0 : 1;
+    std::vector<char> busy_send(sc->world), busy_recv(sc->world);
+    while (left) {
+        bool moved = false;
+        std::fill(busy_send.begin(), busy_send.end(), 0); std::fill(busy_recv.begin(), busy_recv.end(), 0);
+        for (auto& x : sends) {
+            if (x.done == x.bytes) continue;
+            if (busy_send[x.peer]) continue;                     // an earlier message to this peer goes first
+            busy_send[x.peer] = 1;
+            ShmBox* b = sc->box(sc->rank, x.peer);
+            if (b->seq_empty.load(std::memory_order_acquire) != sc->sent[x.peer]) continue;      // the previous chunk is still in the box
+            const size_t n = std::min(SHM_CHUNK, x.bytes - x.done);
+            if (hipMemcpy(sc->payload(sc->rank, x.peer), x.ptr + x.done, n, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+            b->bytes = n;
+            b->seq_full.store(++sc->sent[x.peer], std::memory_order_release);
+            x.done += n; moved = true;
+            if (x.done == x.bytes) --left;
+        }
+        for (auto& x : recvs) {
+            if (x.done == x.bytes) continue;
+            if (busy_recv[x.peer]) continue;
+            busy_recv[x.peer] = 1;
+            ShmBox* b = sc->box(x.peer, sc->rank);
+            if (b->seq_full.load(std::memory_order_acquire) != sc->taken[x.peer] + 1) continue;   // nothing new from this peer
+            const size_t n = (size_t)b->bytes;
+            if (n != std::min(SHM_CHUNK, x.bytes - x.done)) { sc->hdr()->broken.store(1, std::memory_order_release); return ncclInvalidUsage; }   // the two ends disagree about a message size
+            if (hipMemcpy(x.ptr + x.done, sc->payload(x.peer, sc->rank), n, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+            b->seq_empty.store(++sc->taken[x.peer], std::memory_order_release);
+            x.done += n; moved = true;
+            if (x.done == x.bytes) --left;
+        }
+        if (!left) break;
+        if (!moved) {
+            if (sc->hdr()->broken.load(std::memory_order_acquire)) return ncclSystemError;
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > sc->timeout_s) {
+                sc->hdr()->broken.store(1, std::memory_order_release);
+                return ncclSystemError;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    }
+    return ncclSuccess;
+}
+ncclResult_t shm_GetVersion(int* v) { *v = 0; return ncclSuccess; }
+const char* shm_GetErrorString(ncclResult_t r) {
+    return r == ncclSuccess ? "no error" : r == ncclSystemError ? "shared-memory transport: a rank did not arrive (time-out); the segment is broken"
+         : r == ncclInvalidUsage ? "shared-memory transport: the two ends of a transfer disagree about its size" : "shared-memory transport: device copy failed";
+}
+ncclResult_t shm_CommDestroy(ncclComm_t c) {
+    ShmComm* sc = (ShmComm*)c;
+    if (sc->base) munmap(sc->base, sc->map_bytes);
+    delete sc;
+    return ncclSuccess;
+}
+ncclResult_t shm_Broadcast(const void* send, void* recv, size_t count, ncclDataType_t t, int root, ncclComm_t c, hipStream_t st) {
+    ShmComm* sc = (ShmComm*)c;
+    const size_t bytes = count * nccl_type_bytes(t);
+    std::vector<ShmXfer> sends, recvs;
+    if (sc->rank == root) { for (int k = 0; k < sc->world; ++k) if (k != root) sends.push_back({k, (char*)send, bytes, 0}); }
+    else recvs.push_back({root, (char*)recv, bytes, 0});
+    const ncclResult_t r = shm_progress(sc, sends, recvs, st);
+    if (r == ncclSuccess && sc->rank == root && recv != send && bytes && hipMemcpy(recv, send, bytes, hipMemcpyDeviceToDevice) != hipSuccess) return ncclUnhandledCudaError;
+    return r;
+}
+ncclResult_t shm_AllGather(const void* send, void* recv, size_t count, ncclDataType_t t, ncclComm_t c, hipStream_t st) {
+    ShmComm* sc = (ShmComm*)c;
+    const size_t bytes = count * nccl_type_bytes(t);
+    std::vector<ShmXfer> sends, recvs;
+    for (int k = 0; k < sc->world; ++k) if (k != sc->rank) { sends.push_back({k, (char*)send, bytes, 0}); recvs.push_back({k, (char*)recv + (size_t)k * bytes, bytes, 0}); }
+    const ncclResult_t r = shm_progress(sc, sends, recvs, st);
+    char* mine = (char*)recv + (size_t)sc->rank * bytes;
+    if (r == ncclSuccess && mine != (const char*)send && bytes && hipMemcpy(mine, send, bytes, hipMemcpyDeviceToDevice) != hipSuccess) return ncclUnhandledCudaError;
+    return r;
+}
+ncclResult_t shm_flush() {
+    ShmPending& p = shm_pending;
+    if (!p.comm) return ncclSuccess;
+    const ncclResult_t r = shm_progress((ShmComm*)p.comm, p.sends, p.recvs, p.stream);
+    p.sends.clear(); p.recvs.clear(); p.comm = nullptr; p.stream = nullptr;
+    return r;
+}
+ncclResult_t shm_GroupStart() { ++shm_pending.depth; return ncclSuccess; }
+ncclResult_t shm_GroupEnd() { return --shm_pending.depth == 0 ? shm_flush() : ncclSuccess; }
+ncclResult_t shm_Send(const void* ptr, size_t count, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t st) {
+    shm_pending.comm = c; shm_pending.stream = st;
+    shm_pending.sends.push_back({peer, (char*)ptr, count * nccl_type_bytes(t), 0});
+    return shm_pending.depth == 0 ? shm_flush() : ncclSuccess;
+}
+ncclResult_t shm_Recv(void* ptr, size_t count, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t st) {
+    shm_pending.comm = c; shm_pending.stream = st;
+    shm_pending.recvs.push_back({peer, (char*)ptr, count * nccl_type_bytes(t), 0});
+    return shm_pending.depth == 0 ? shm_flush() : ncclSuccess;
+}
+RcclApi* shm_api() {
+    static RcclApi api = [] {
+        RcclApi a;
+        a.path = "shared-memory segment";
+        a.GetVersion = shm_GetVersion; a.CommDestroy = shm_CommDestroy; a.GetErrorString = shm_GetErrorString;
+        a.Broadcast = shm_Broadcast; a.AllGather = shm_AllGather; a.Send = shm_Send; a.Recv = shm_Recv;
+        a.GroupStart = shm_GroupStart; a.GroupEnd = shm_GroupEnd;
+        return a;
+    }();
+    return &api;
+}
+
 }  // namespace
 
 struct avt_shard {
@@ -511,6 +673,80 @@ extern "C" int avt_shard_create_loopback(int device, int rank, int world, const 
         return 1;
     }
     s->backend = std::string("loop-back (threads of one process), group ") + group;
+    *out = s;
+    return 0;
+}
+
+extern "C" int avt_shard_create_shm(int device, int rank, int world, const char id[AVT_SHARD_ID_BYTES], avt_shard** out) {
+    if (!id || !out || world <= 0 || world > 64 || rank < 0 || rank >= world) { avt_set_error("avt_shard_create_shm: bad argument"); return 1; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { avt_set_error("avt_shard_create_shm: device index out of range"); return 2; }
+    HIP_OK(hipSetDevice(device));
+    unsigned long long h = 1469598103934665603ull;      // FNV-1a of the rendezvous bytes names the segment
+    for (int i = 0; i < AVT_SHARD_ID_BYTES; ++i) { h ^= (unsigned char)id[i]; h *= 1099511628211ull; }
+    char name[64];
+    snprintf(name, sizeof name, "/avt_shard_%016llx", h);
+    double timeout_s = 60.0;
+    if (const char* e = getenv("AVT_SHARD_LOOPBACK_TIMEOUT_S")) timeout_s = std::max(0.1, atof(e));
+    const size_t bytes = shm_bytes(world);
+    const auto t0 = std::chrono::steady_clock::now();
+    auto late = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s; };
+    int fd = -1;
+    if (rank == 0) {
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) {
+            avt_set_error(std::string("avt_shard_create_shm: cannot create the segment ") + name + ": " + strerror(errno));
+            if (fd >= 0) { close(fd); shm_unlink(name); }
+            return 1;
+        }
+    } else {
+        struct stat sb;
+        while (true) {      // rank 0 creates and sizes it
+            fd = shm_open(name, O_RDWR, 0600);
+            if (fd >= 0 && fstat(fd, &sb) == 0 && (size_t)sb.st_size >= bytes) break;
+            if (fd >= 0) { close(fd); fd = -1; }
+            if (late()) { avt_set_error(std::string("avt_shard_create_shm: rank 0 never created the segment ") + name); return 1; }
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+    }
+    void* base = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (base == MAP_FAILED) { avt_set_error(std::string("avt_shard_create_shm: mmap: ") + strerror(errno)); if (rank == 0) shm_unlink(name); return 1; }
+    ShmComm* sc = new ShmComm();
+    sc->base = base; sc->map_bytes = bytes; sc->rank = rank; sc->world = world; sc->timeout_s = timeout_s;
+    sc->sent.assign(world, 0); sc->taken.assign(world, 0);
+    ShmHeader* hd = sc->hdr();
+    if (rank == 0) {      // (a fresh segment is zero-filled: counters start at 0)
+        hd->world = world; hd->chunk = SHM_CHUNK;
+        hd->magic.store(SHM_MAGIC, std::memory_order_release);
+    } else {
+        while (hd->magic.load(std::memory_order_acquire) != SHM_MAGIC) {
+            if (late()) { avt_set_error("avt_shard_create_shm: the segment was never initialised"); shm_CommDestroy((ncclComm_t)sc); return 1; }
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        if (hd->world != world || hd->chunk != SHM_CHUNK) { avt_set_error("avt_shard_create_shm: the segment belongs to a group of another shape"); shm_CommDestroy((ncclComm_t)sc); return 1; }
+    }
+    hd->attached.fetch_add(1, std::memory_order_acq_rel);
+    while (hd->attached.load(std::memory_order_acquire) < world) {      // creation is collective, like ncclCommInitRank
+        if (late()) {
+            avt_set_error("avt_shard_create_shm: not every rank attached in time");
+            if (rank == 0) shm_unlink(name);
+            shm_CommDestroy((ncclComm_t)sc);
+            return 1;
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    if (rank == 0) shm_unlink(name);      // everybody holds a mapping: the name can go, the memory lives until the last unmap
+    avt_shard* s = new avt_shard();
+    s->api = shm_api(); s->device = device; s->rank = rank; s->world = world;
+    s->comm = (ncclComm_t)sc;
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+        avt_set_error("avt_shard_create_shm: hipStreamCreate failed");
+        s->api->CommDestroy(s->comm);
+        delete s;
+        return 1;
+    }
+    s->backend = "shared memory (processes of one node, staged through the host)";
     *out = s;
     return 0;
 }

@@ -52,14 +52,19 @@ def unpack_model(block: bytes):
     return h
 
 
-def exchange_unique_id(dist, rank, src=0):
-    """Rank `src` creates the RCCL unique id; everybody receives it through the torch.distributed store."""
+def exchange_unique_id(dist, rank, src=0, rccl=True):
+    """Rank `src` creates the rendezvous bytes - the RCCL unique id, or (rccl=False: the shared-memory transport, which only
+    needs bytes all ranks agree on) 128 random ones; everybody receives them through the torch.distributed store."""
     lib = capi.load_library()
     box = [None]
     if rank == src:
-        buf = C.create_string_buffer(ID_BYTES)
-        _check(lib.avt_shard_unique_id(buf))
-        box[0] = buf.raw
+        if rccl:
+            buf = C.create_string_buffer(ID_BYTES)
+            _check(lib.avt_shard_unique_id(buf))
+            box[0] = buf.raw
+        else:
+            import os
+            box[0] = os.urandom(ID_BYTES)
     dist.broadcast_object_list(box, src=src)
     return box[0]
 
@@ -67,13 +72,16 @@ def exchange_unique_id(dist, rank, src=0):
 class Shard:
     """avt_shard: one RCCL communicator rank bound to one GPU."""
 
-    def __init__(self, device, rank, world, unique_id: bytes = None, loopback_group: str = None):
-        """unique_id: the RCCL rendezvous bytes.  loopback_group: instead of RCCL, the in-process loop-back transport - the
-        ranks are threads of this process that name the same group (avt_shard_create_loopback)."""
+    def __init__(self, device, rank, world, unique_id: bytes = None, loopback_group: str = None, shm: bool = False):
+        """unique_id: the rendezvous bytes.  loopback_group: instead of RCCL, the in-process loop-back transport - the
+        ranks are threads of this process that name the same group (avt_shard_create_loopback).  shm: the ranks are processes
+        of one node that exchange through a shared-memory segment named after unique_id (avt_shard_create_shm)."""
         self._lib = capi.load_library()
         self.h = C.c_void_p()
         if loopback_group is not None:
             _check(self._lib.avt_shard_create_loopback(C.c_int(device), C.c_int(rank), C.c_int(world), loopback_group.encode(), C.byref(self.h)))
+        elif shm:
+            _check(self._lib.avt_shard_create_shm(C.c_int(device), C.c_int(rank), C.c_int(world), unique_id, C.byref(self.h)))
         else:
             _check(self._lib.avt_shard_create(C.c_int(device), C.c_int(rank), C.c_int(world), unique_id, C.byref(self.h)))
         self.rank, self.world = rank, world

@@ -108,7 +108,8 @@ typedef struct avt_stats {
 /* Per-kernel-class device timings (ms, HIP events on the context's stream) accumulated between
  * avt_profile_begin / avt_profile_end.  Profiling inserts event records around every launch. */
 enum { AVT_K_LBS = 0, AVT_K_VISIBILITY, AVT_K_BUCKET, AVT_K_NN, AVT_K_AGGREGATE, AVT_K_PREPARE,
-       AVT_K_EVAL, AVT_K_REDUCE, AVT_K_SOLVE /* the full LM solves */, AVT_K_DECIDE /* the closing accept/reject */, AVT_K_COUNT };
+       AVT_K_EVAL, AVT_K_REDUCE, AVT_K_SOLVE /* the full LM solves */, AVT_K_DECIDE /* the closing accept/reject */,
+       AVT_K_MOMENTS /* moment form: k_moments, once per ICP iteration */, AVT_K_COUNT };
 typedef struct avt_profile {
     double ms[AVT_K_COUNT];
     int launches[AVT_K_COUNT];
@@ -230,6 +231,14 @@ int avt_get_data_term(avt_ctx* c);
 /* diagnostics: 64 doubles per frame (objective after every GN iteration; with -DAVT_TIMING builds also in-kernel
  * s_memtime probes, see tools/kernel_timing_probe.py) */
 int avt_debug_trace(avt_ctx* c, int frame, double* out64);
+
+/* diagnostics: fp64 matrix instructions (v_mfma_f64_16x16x4_f64, 2048 flop each) the kernels EXECUTE for frame `frame` with the
+ * correspondences of the last optimize(), from the kernels' own trip counts (block-sparse: dead tile pairs are skipped):
+ *   eval_rows   one full row-form evaluation (k_eval; -1 when the last optimize() ran the moment form or the skeleton is not the six-tile shape),
+ *   moments     one k_moments pass (once per ICP iteration; -1 when the model has no moment form),
+ *   solve       one LDL^T factorisation of k_solve.
+ * Any pointer may be NULL.  bench.py divides these by the measured launch times for the matrix-pipe utilisation it reports. */
+int avt_debug_mfma_count(avt_ctx* c, int frame, long long* eval_rows, long long* moments, long long* solve);
 
 /* Launch-shape and algorithm knobs of a context.  The defaults are the measured optima (DESIGN.md sections 5 and 7); they exist for
  * experiments and for tests that must force a particular code path.  avt_ctx_create fills the structure from the defaults and then

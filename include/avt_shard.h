@@ -61,6 +61,13 @@ int avt_shard_create(int device, int rank, int world, const char id[AVT_SHARD_ID
  * safe against a hipGraphLaunch from another thread, profiles/r03_hipgraphlaunch_thread_crash.txt), and a two-branch graph costs ~230 us of host
  * time to enqueue: the optimize() calls of the threads serialise on it.  One process per GPU (the RCCL transport) does not share that lock. */
 int avt_shard_create_loopback(int device, int rank, int world, const char* group, avt_shard** out);
+/* The same handle over a SHARED-MEMORY transport: the `world` ranks are PROCESSES of one node (one per rank, like RCCL's), every
+ * exchange is staged through a POSIX shared-memory segment named after the 128 rendezvous bytes (any bytes all ranks agree on; rank 0
+ * creates the segment, creation is collective).  For nodes without a usable RCCL and - what it was written for - for running the whole
+ * multi-process launch path (launcher -> ranks -> scatter -> optimize -> all-gather) with N > 1 ranks on ONE GPU, which RCCL refuses.
+ * Every byte crosses the host twice: not a fast path.  Exchanges complete before they return; a rank that does not arrive within
+ * AVT_SHARD_LOOPBACK_TIMEOUT_S (default 60 s here) makes its peers' calls fail, and the segment stays broken. */
+int avt_shard_create_shm(int device, int rank, int world, const char id[AVT_SHARD_ID_BYTES], avt_shard** out);
 void avt_shard_destroy(avt_shard* s);
 int avt_shard_rank(const avt_shard* s);
 int avt_shard_world(const avt_shard* s);

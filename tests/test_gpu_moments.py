@@ -248,3 +248,74 @@ def test_batch_with_three_icp_iterations_the_forms_agree(smpl, gmodel):
     assert [s.accepted_steps for s in res["rows"][3]] == [s.accepted_steps for s in res["moments"][3]]
     for a, b in zip(res["rows"][:3], res["moments"][:3]):
         assert np.abs(a - b).max() < 1e-10
+
+
+@pytest.mark.gpu
+def test_dense_batch_on_the_moment_form_is_the_oracles_fit(smpl, omodel, gmodel):
+    """What bench.py's `dense_64` leg times: a batch of DENSE frames (2560x1440 renders, ~150 k points) as two frame
+    groups, AUTO => the moment form - checked as a FIT against the oracle, not only through avt_get_normal_equations: frames at both
+    ends of both groups have bit-exact correspondences, the oracle's accept / reject sequence and objective after every GN
+    iteration, and its vertices to 1e-6 (AvatarOptimizer.cpp:505-582 is what the moments replace)."""
+    from avatar_amd import api
+    F = 64
+    pm = synth.identity_part_map()
+    gts = [synth.sample_ground_truth(smpl, 3000 + f) for f in range(F)]
+    starts = [synth.perturb_start(*gts[f], 3000 + f) for f in range(F)]
+    ctx = api.Context(gmodel, 24, pm, 200000, F, device=0)
+    npts = ctx.render_frames(np.array([g[0] for g in gts]), np.array([g[1] for g in gts]), np.array([g[2] for g in gts]), res_scale=2)
+    assert npts.min() > 60000
+    p0 = np.array([s[1] for s in starts]); w0 = np.array([s[0] for s in starts])
+    q0 = api.rot_to_quat(np.array([s[2] for s in starts]).reshape(-1, 3, 3)).reshape(F, 24, 4)
+    ctx.state_upload(p0, q0, w0)
+    opt = Options.demo()
+    assert ctx.data_term() == ctx.DATA_TERM_AUTO and ctx.launch_shape()[:2] == (2, 32)      # two groups of 32 frames per launch: AUTO => moments
+    ctx.optimize_resident(opt)
+    p, q, w, st = ctx.state_download()
+    assert ctx.mfma_count(0)["eval_rows"] is None and ctx.mfma_count(0)["moments"] > 0      # the moment form ran (no matched-point records exist)
+    for i in (0, 31, 32, 63):
+        d, l = ctx.frame_download(i)
+        ref = omodel.optimize(pm, 24, d, l, opt, p0[i], q0[i], w0[i], aggregate=1)
+        assert np.array_equal(ctx.correspondences(i, len(l)), ref["corr"])
+        assert np.abs(ctx.cloud(i) - ref["cloud"]).max() < 1e-6
+        tr = ctx.cost_trace(i)
+        assert np.allclose(tr, ref["trace_cost"][:11], rtol=1e-9, atol=0)
+        assert [int(tr[k + 1] < tr[k]) for k in range(10)] == [int(a == 1) for a in ref["trace_acc"][:10]]
+        assert st[i].accepted_steps == ref["stats"].accepted_steps and st[i].gn_iterations == 10
+        assert abs(st[i].lambda_ - ref["stats"].lambda_) <= 1e-12 * abs(ref["stats"].lambda_)
+        assert np.abs(p[i] - ref["p"]).max() < 1e-7 and np.abs(w[i] - ref["w"]).max() < 1e-6
+
+
+def test_normal_equations_after_a_replayed_graph_are_made_from_fresh_moments(smpl, gmodel):
+    """what exists for the resident correspondences (moments / matched-point records) must describe the last optimize()
+    that RAN, also when it ran as the replay of a cached hipGraph.  rows(S1) -> moments(S1) -> rows(S2) replays the rows graph; the
+    moments in memory then belong to S1's correspondences, and avt_get_normal_equations(MOMENTS) has to rebuild them: it must give what a
+    fresh context gives for rows(S2) -> MOMENTS."""
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    fr = synth.make_frame(smpl, 5)
+    p0, q0, w0 = _start(fr)
+    n = len(fr["labels"])
+    opt = Options.demo(max_iters_per_icp=3)
+    p2 = p0 + np.array([0.03, -0.02, 0.01])          # a second start state: other correspondences, same launch shape
+    ctx = api.Context(gmodel, 24, pm, n, 1)
+    ctx.frames_upload([fr["data"]], [fr["labels"]])
+    for form, p in ((ctx.DATA_TERM_ROWS, p0), (ctx.DATA_TERM_MOMENTS, p0), (ctx.DATA_TERM_ROWS, p2)):
+        ctx.set_data_term(form)
+        ctx.state_upload(p[None], q0[None], w0[None])
+        ctx.optimize_resident(opt)
+    corr_s2 = ctx.correspondences(0, n)
+    ctx.set_data_term(ctx.DATA_TERM_MOMENTS)
+    H1, g1, c1 = ctx.normal_equations(0)
+    fresh = api.Context(gmodel, 24, pm, n, 1)
+    fresh.frames_upload([fr["data"]], [fr["labels"]])
+    fresh.set_data_term(fresh.DATA_TERM_ROWS)
+    fresh.state_upload(p2[None], q0[None], w0[None])
+    fresh.optimize_resident(opt)
+    assert np.array_equal(fresh.correspondences(0, n), corr_s2)
+    ctx0 = api.Context(gmodel, 24, pm, n, 1)
+    ctx0.frames_upload([fr["data"]], [fr["labels"]]); ctx0.set_data_term(ctx0.DATA_TERM_ROWS)
+    ctx0.state_upload(p0[None], q0[None], w0[None]); ctx0.optimize_resident(opt)
+    assert not np.array_equal(ctx0.correspondences(0, n), corr_s2), "the two start states must lead to different correspondences for this test to see anything"
+    fresh.set_data_term(fresh.DATA_TERM_MOMENTS)
+    H2, g2, c2 = fresh.normal_equations(0)
+    assert np.array_equal(H1, H2) and np.array_equal(g1, g2) and c1 == c2
