@@ -105,11 +105,11 @@ avt_tuning tuning_from_environment() {
     avt_tuning t;
     std::memset(&t, 0, sizeof t);
     t.use_graph = 1; t.groups = 0; t.g = 0; t.gcap = 128; t.vis_frame_min = 64; t.ride = 1; t.ride_strips = 0; t.ride_sizing_groups = 0;
-    t.nspec = AVT_MAX_SPEC; t.nn_force_part = 0; t.nn_slab = 1; t.mom_min_frames = 32; t.debug = 0; t.ride_timeout_us = 2000000;
+    t.asm_parts = 1; t.nspec = AVT_MAX_SPEC; t.nn_force_part = 0; t.nn_slab = 1; t.mom_min_frames = 32; t.debug = 0; t.ride_timeout_us = 2000000;
     struct Knob { const char* name; int* field; };
     const Knob knobs[] = {{"AVT_USE_GRAPH", &t.use_graph}, {"AVT_GROUPS", &t.groups}, {"AVT_G", &t.g}, {"AVT_GCAP", &t.gcap}, {"AVT_VIS_FRAME_MIN", &t.vis_frame_min},
                           {"AVT_RIDE", &t.ride}, {"AVT_RIDE_STRIPS", &t.ride_strips}, {"AVT_RIDE_SIZING_GROUPS", &t.ride_sizing_groups}, {"AVT_NSPEC", &t.nspec},
-                          {"AVT_NN_FORCE_PART", &t.nn_force_part}, {"AVT_NN_SLAB", &t.nn_slab}, {"AVT_MOM_MIN_FRAMES", &t.mom_min_frames}, {"AVT_DEBUG", &t.debug}};
+                          {"AVT_NN_FORCE_PART", &t.nn_force_part}, {"AVT_NN_SLAB", &t.nn_slab}, {"AVT_MOM_MIN_FRAMES", &t.mom_min_frames}, {"AVT_ASM_PARTS", &t.asm_parts}, {"AVT_DEBUG", &t.debug}};
     // names other parts of the repository own (the batch split, the Python loader, bench.py, instrumented builds)
     const char* others[] = {"AVT_LIB", "AVT_RCCL_LIB", "AVT_SHARD_SELF_SENDRECV", "AVT_SHARD_LOOPBACK_TIMEOUT_S", "AVT_BENCH_SHARE_GPU0", "AVT_TIMING"};
     for (char** e = environ; e && *e; ++e) {

@@ -59,6 +59,8 @@ struct AvtDims {
     int mom_nopk, mom_nsub, mom_nm1l, mom_ns2l;   // lengths of the index lists mom_opk, mom_sub, mom_m1, mom_s2
     int mom_nseg;            // 16-entry segments of the rot-rot lists
     int mom_toff[8];         // word offsets of the lists inside DeviceModel::mom_tab16 (opk_start, opk, sub_start, sub, bseg, seg, jj, end)
+    int mom_rr_doubles;      // ... and the LDS doubles the largest of them needs for its segment and block sums
+    int mom_rsplit[5];       // k_assemble_parts: rot-rot role r takes the listed blocks [mom_rsplit[r], mom_rsplit[r + 1]) - equal numbers of segments (MOM_ASM_NR <= 4 roles)
 };
 
 // prep block layout (doubles), one per frame per slot: what an evaluation needs about the skeleton state

@@ -305,6 +305,22 @@ static void build_moment_tables(avt_model* m) {
     d.mom_nz2 = (int)m->mom_z2_jj.size();
     d.mom_nb2 = (int)m->mom_s2_jj.size();
     d.mom_nseg = (int)m->mom_s2.size() / 16;
+    {   // the listed blocks dealt to the rot-rot roles of k_assemble_parts in contiguous ranges of (nearly) equal segment counts
+        const int NR = 3;
+        for (int r = 0; r <= 4; ++r) d.mom_rsplit[r] = d.mom_nb2;
+        d.mom_rsplit[0] = 0;
+        for (int r = 1; r < NR; ++r) {
+            const long long want = (long long)d.mom_nseg * r / NR;
+            int b = d.mom_rsplit[r - 1];
+            while (b < d.mom_nb2 && m->mom_s2_start[b] < want) ++b;
+            d.mom_rsplit[r] = b;
+        }
+        d.mom_rr_doubles = 0;
+        for (int r = 0; r < NR; ++r) {
+            const int b0 = d.mom_rsplit[r], b1 = d.mom_rsplit[r + 1];
+            d.mom_rr_doubles = std::max(d.mom_rr_doubles, 16 * ((m->mom_s2_start[b1] - m->mom_s2_start[b0]) + (b1 - b0)));
+        }
+    }
     d.mom_nm1 = 0;
     m->mom_m1_start.assign(1, 0); m->mom_m1.clear();
     d.mom_nopk = (int)m->mom_opk.size(); d.mom_nsub = (int)m->mom_sub.size(); d.mom_nm1l = 0; d.mom_ns2l = (int)m->mom_s2.size();

@@ -925,6 +925,378 @@ __global__ __launch_bounds__(NTH) void k_assemble(DeviceModel dm, FrameBuffers f
     MPROBE(6);
 }
 
+// =================================================================================================
+// k_assemble_parts<KC>.  grid (MOM_ASM_ROLES, frames), 256 threads.  The same assembly as k_assemble, item for item and bit for bit, as
+// SIX independent workgroups per frame instead of one 1024-thread workgroup walking six phases in a row (35 k clocks: staging 4.7 k,
+// data side + partner sums 6 k, per-joint sums 5 k, subtree sums 4 k, blocks 3.5 k, rot-rot 12 k):
+//   role 0            "core": the X16 / data side per-joint sums PK -> subtree sums TK -> translation block, rotation rows against translation
+//                     and residual, shape rows against the residual, shape-shape; 
+//   roles 1 .. NA     the shape keys [s0, s1): partner sums PR of the pair pass's records -> subtree sums TR -> rotation rows against those
+//                     shape columns, shape rows against the translation;
+//   roles NA+1 ..     the rot-rot blocks [AvtDims::mom_rsplit[r], mom_rsplit[r + 1]) - ranges of equal segment counts - and a share of the
+//                     structural zeros.  They depend on the staged X16 alone, which is why they need not wait for the tree sums.
+// No role reads what another writes: every one goes from the pair pass's scratch to its own entries of H.  The dependency chain of a GN
+// iteration is the longest role (the core: five short phases) instead of the sum of all phases; a 256-thread workgroup with <= 46 KB of LDS
+// finds a place on a CU another frame group's kernels are using, which the 1024-thread, 80 KB workgroup did not.
+// =================================================================================================
+#define MOM_ASM_NA 2
+#define MOM_ASM_NR 3
+#define MOM_ASM_ROLES (1 + MOM_ASM_NA + MOM_ASM_NR)
+#define MOM_PARTS_NTH 256
+
+// world rotations, joint origins relative to the frame centre and the parents: what the shape and rot-rot roles need of the skeleton
+__device__ __forceinline__ void mom_skel_light(const AvtDims& d, const double* __restrict__ prep, const double* centre, double* __restrict__ Rw, double* __restrict__ oc,
+                                               int* __restrict__ s_parent, const int* __restrict__ parent_g) {
+    const int J = d.J, t = threadIdx.x;
+    for (int e = t; e < 9 * J; e += MOM_PARTS_NTH) Rw[e] = prep[prep_off_Rw(d) + e];
+    for (int e = t; e < 3 * J; e += MOM_PARTS_NTH) { const int j = e / 3, r = e - 3 * j; oc[e] = prep[prep_off_o(d) + e] - centre[r]; }
+    if (t < J) s_parent[t] = parent_g[t];
+}
+
+template <int KC>
+__device__ __forceinline__ void asm_role_core(const DeviceModel& dm, const FrameBuffers& fb, int f, char* smem) {
+    constexpr int NTH = MOM_PARTS_NTH;
+    const AvtDims& d = dm.d;
+    const int t = threadIdx.x, try_slot = 1 - fb.ctl[f].cur_slot;
+    const int J = d.J, K = KC ? KC : d.K, S1 = K + 1, NP = d.mom_np, NPSI = d.mom_npsi, P = d.P, HS = d.HS;
+    double* skm = (double*)smem;
+    double* PK = skm + mom_skel_doubles(d);     // [J + 1][16]
+    double* TK = PK + (J + 1) * 16;             // [J + 1][16]
+    double* Uk = TK + (J + 1) * 16;             // [J][9]
+    double* XQ = Uk + J * 9;                    // [J][4]
+    double* YFk = XQ + J * 4;                   // [J][K]
+    double* ZS = YFk + J * K;                   // [K K + K]
+    double* YFs = ZS + K * K + K;               // [K]
+    double* misc = YFs + K;                     // [K + 8]
+    double* YF4 = misc + K + 8;                 // [K][ceil(J / 4)]
+    int* s_parent = (int*)(YF4 + K * ((J + 3) / 4));
+    unsigned short* tabm = (unsigned short*)(s_parent + AVT_MAX_JOINTS);      // words [0, mom_toff[4]): opk_start | opk | sub_start | sub
+    MomSkel sk;
+    mom_skel_from_prep<NTH>(d, fb.prep + ((size_t)f * 2 + try_slot) * d.prep_size, fb.ctl[f].centre, skm, s_parent, dm.parent, sk);
+    MomTab tb;
+    {
+        const unsigned long long* src = (const unsigned long long*)dm.mom_tab16;
+        unsigned long long* dst = (unsigned long long*)tabm;
+        for (int e = t; e < d.mom_toff[4] / 4; e += NTH) dst[e] = src[e];
+        tb.opk_start = tabm + d.mom_toff[0]; tb.opk = tabm + d.mom_toff[1]; tb.sub_start = tabm + d.mom_toff[2]; tb.sub = tabm + d.mom_toff[3];
+        tb.bseg = tb.seg = tb.jj = nullptr;
+    }
+    auto rot = [&](int k) { return (t + k * (NTH / 4)) & (NTH - 1); };
+    const double* scr = fb.mom_rec + (size_t)f * mom_frame_scratch(d);
+    const double* X16 = scr;                    // [2 NP + 1][16] read where the pair pass left it (one 128-byte line per ordered pair, L2): staging it costs 21.6 KB of LDS per workgroup
+    const double* Zg = scr + mom_off_z(d);
+    const double* Df = fb.mom_D + (size_t)f * J * NPSI * 3;
+    double* Hout = fb.Hraw + ((size_t)f * 2 + try_slot) * HS * HS;
+    for (int e = t; e < 16; e += NTH) { PK[J * 16 + e] = 0.0; }
+    for (int e = t; e < K * K + K; e += NTH) {           // the pair-pass workgroups' shape-shape columns / traces, in workgroup order
+        double a = 0.0;
+        for (int g0 = 0; g0 < mom_nwg(d); g0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = Zg[(size_t)min(g0 + u, mom_nwg(d) - 1) * (K * K + K) + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += g0 + u < mom_nwg(d) ? v[u] : 0.0;
+        }
+        ZS[e] = a;
+    }
+    // ---------------- B-a (the data side).  The D_k entries of this thread's first item are requested in front of the barrier (they depend on
+    // nothing staged): one L2 round trip hidden behind the staging
+    double uk_v[KC ? KC + 1 : 1];
+    if (KC && t < J * 9) {
+        const int k = t / 9, ic = t - 9 * k, i = ic / 3, c = ic - 3 * i;
+        const double* Dk = Df + (size_t)k * NPSI * 3 + (size_t)(S1 * i) * 3 + c;
+#pragma unroll
+        for (int s = 0; s <= KC; ++s) uk_v[s] = Dk[3 * s];
+    }
+    __syncthreads();      // skeleton tables, index lists
+    if (KC && t < J * 9) {      // u_k[i][c] = sum_s om_s D_k[(i,s)][c]
+        double a = 0.0;
+#pragma unroll
+        for (int s = 0; s <= KC; ++s) a = fma(sk.om[s], uk_v[s], a);
+        Uk[t] = a;
+    }
+    for (int e = KC ? t + NTH : t; e < J * 9; e += NTH) {
+        const int k = e / 9, ic = e - 9 * k, i = ic / 3, c = ic - 3 * i;
+        const double* Dk = Df + (size_t)k * NPSI * 3 + (size_t)(S1 * i) * 3 + c;
+        double a = 0.0;
+        for (int s = 0; s < S1; ++s) a = fma(sk.om[s], Dk[3 * s], a);
+        Uk[e] = a;
+    }
+    for (int e = rot(1); e < J * 3; e += NTH) { const int k = e / 3, c = e - 3 * k; PK[16 * k + 13 + c] = Df[(size_t)k * NPSI * 3 + (size_t)(NPSI - 1) * 3 + c]; }
+    for (int e = rot(2); e < J * K; e += NTH) {      // tr(R_k Dphi_k[s]) + eta_k,s . Dl_k
+        const int k = e / K, s = e - k * K;
+        const double* Dk = Df + (size_t)k * NPSI * 3;
+        const double* Rk = sk.Rw + 9 * k;
+        double v[12];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) v[3 * c + i] = Dk[(size_t)(S1 * i + s + 1) * 3 + c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[9 + c] = Dk[(size_t)(NPSI - 1) * 3 + c];
+        double q = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) q = fma(Rk[3 * c + i], v[3 * c + i], q);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) q = fma(sk.eta[((size_t)k * 3 + c) * K + s], v[9 + c], q);
+        YFk[e] = q;
+    }
+    // (B-b's partner sums of X16 read nothing B-a writes: same phase)
+    for (int e = rot(3); e < J * 10; e += NTH) {      // PK[k][0..9]: axial(sum W) 3, sum Va 3, sum Vb 3, sum t0
+        const int k = e / 10, q = e - 10 * k;
+        const int i0 = q == 0 ? 5 : (q == 1 ? 6 : (q == 2 ? 1 : 9 + (q - 3))), i1 = q == 0 ? 7 : (q == 1 ? 2 : 3);
+        double a = 0.0;
+        for (int i = tb.opk_start[k]; i < tb.opk_start[k + 1]; i += 4) {
+            const double* x0 = X16 + (size_t)tb.opk[i] * 16; const double* x1 = X16 + (size_t)tb.opk[i + 1] * 16;
+            const double* x2 = X16 + (size_t)tb.opk[i + 2] * 16; const double* x3 = X16 + (size_t)tb.opk[i + 3] * 16;
+            const double p0 = x0[i0], p1 = x1[i0], p2 = x2[i0], p3 = x3[i0];
+            const double m0 = q < 3 ? x0[i1] : 0.0, m1 = q < 3 ? x1[i1] : 0.0, m2 = q < 3 ? x2[i1] : 0.0, m3 = q < 3 ? x3[i1] : 0.0;
+            a += ((p0 - m0) + (p1 - m1)) + ((p2 - m2) + (p3 - m3));
+        }
+        PK[16 * k + q] = a;
+    }
+    if (t >= NTH - 64) {      // sum tr W over the ordered pairs, fixed order (one wave)
+        const int l = t - (NTH - 64);
+        double a = 0.0;
+        for (int op = l; op < 2 * NP; op += 64) { const double* x = X16 + (size_t)op * 16; a += (x[0] + x[4]) + x[8]; }
+        a = wave_sum(a);
+        if (l == 0) misc[1] = a;
+    }
+    __syncthreads();      // Uk, Dl, YFk
+    // ---------------- B-b
+    for (int e = t; e < J * 4; e += NTH) {       // XD_k = R_k u_k + tau_k Dl_k^T: its axial vector (PK[10..12]) and trace
+        const int k = e >> 2, q = e & 3;
+        const double* Rk = sk.Rw + 9 * k;
+        const double* u = Uk + 9 * k;
+        const double* dl = PK + 16 * k + 13;
+        auto xd = [&](int r, int c) { return (Rk[3 * r] * u[c] + Rk[3 * r + 1] * u[3 + c] + Rk[3 * r + 2] * u[6 + c]) + sk.tau[3 * k + r] * dl[c]; };
+        const double v = q == 0 ? xd(1, 2) - xd(2, 1) : (q == 1 ? xd(2, 0) - xd(0, 2) : (q == 2 ? xd(0, 1) - xd(1, 0) : (xd(0, 0) + xd(1, 1)) + xd(2, 2)));
+        if (q < 3) PK[16 * k + 10 + q] = v;
+        XQ[e] = v;
+    }
+    for (int e = rot(2); e < K * ((J + 3) / 4); e += NTH) {      // YF over four joints at a time
+        const int g4 = (J + 3) / 4, s = e / g4, g = e - s * g4;
+        const double v0 = YFk[min(4 * g, J - 1) * K + s], v1 = YFk[min(4 * g + 1, J - 1) * K + s], v2 = YFk[min(4 * g + 2, J - 1) * K + s], v3 = YFk[min(4 * g + 3, J - 1) * K + s];
+        YF4[e] = ((4 * g < J ? v0 : 0.0) + (4 * g + 1 < J ? v1 : 0.0)) + ((4 * g + 2 < J ? v2 : 0.0) + (4 * g + 3 < J ? v3 : 0.0));
+    }
+    __syncthreads();
+    // ---------------- B-c: subtree sums, eight list entries at a time
+    for (int e = t; e < J * 16; e += NTH) {
+        const int j = e >> 4, q = e & 15;
+        double a = 0.0;
+        for (int i = tb.sub_start[j]; i < tb.sub_start[j + 1]; i += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = PK[16 * tb.sub[i + u] + q];
+            a += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        TK[e] = a;
+    }
+    if (t >= NTH - 64 && t - (NTH - 64) < K) { const int sq = t - (NTH - 64), g4 = (J + 3) / 4; double a = 0.0; for (int g = 0; g < g4; ++g) a += YF4[sq * g4 + g]; YFs[sq] = a; }
+    if (t == NTH / 2) {
+        double xf = 0.0;
+        for (int k = 0; k < J; ++k) xf += XQ[4 * k + 3];
+        misc[0] = misc[1] - 2.0 * xf;
+    }
+    __syncthreads();
+    // ---------------- B-d: this role's blocks of H
+    auto Hset = [&](int r, int c, double v) { Hout[(size_t)r * HS + c] = v; Hout[(size_t)c * HS + r] = v; };
+    const int SH = 3 + 3 * J;
+    if (t < 9) { const int r = t / 3, c = t - 3 * r; Hout[(size_t)r * HS + c] = r == c ? TK[9] : 0.0; }
+    if (t < 3) Hset(t, P, TK[3 + t] - TK[13 + t]);
+    if (t == 3) Hout[(size_t)P * HS + P] = misc[0];
+    for (int e = rot(1); e < J * 3; e += NTH) {      // rotation rows against translation and residual
+        const int j = e / 3, c = e - 3 * j, pa = sk.parent[j];
+        const double a0 = pa < 0 ? (c == 0 ? 1.0 : 0.0) : sk.Rw[9 * pa + c], a1 = pa < 0 ? (c == 1 ? 1.0 : 0.0) : sk.Rw[9 * pa + 3 + c],
+                     a2 = pa < 0 ? (c == 2 ? 1.0 : 0.0) : sk.Rw[9 * pa + 6 + c];
+        const double* tk = TK + 16 * j;
+        const double o0 = sk.oc[3 * j], o1 = sk.oc[3 * j + 1], o2 = sk.oc[3 * j + 2];
+        const double l0 = tk[3] - tk[9] * o0, l1 = tk[4] - tk[9] * o1, l2 = tk[5] - tk[9] * o2;
+        const int r = 3 + 3 * j + c;
+        Hset(r, 0, 2.0 * (a1 * l2 - a2 * l1)); Hset(r, 1, 2.0 * (a2 * l0 - a0 * l2)); Hset(r, 2, 2.0 * (a0 * l1 - a1 * l0));
+        const double b0 = tk[6] - tk[13], b1 = tk[7] - tk[14], b2 = tk[8] - tk[15];
+        const double r0 = (tk[0] - tk[10]) - (o1 * b2 - o2 * b1), r1 = (tk[1] - tk[11]) - (o2 * b0 - o0 * b2), r2 = (tk[2] - tk[12]) - (o0 * b1 - o1 * b0);
+        Hset(r, P, 2.0 * (a0 * r0 + a1 * r1 + a2 * r2));
+    }
+    if (t >= NTH - 64 && t - (NTH - 64) < K) { const int s = t - (NTH - 64); Hset(SH + s, P, ZS[K * K + s] - YFs[s]); }
+    for (int e = rot(2); e < K * K; e += NTH) { const int s = e / K, u = e - s * K; Hout[(size_t)(SH + s) * HS + SH + u] = ZS[s * K + u] + ZS[u * K + s]; }
+}
+
+template <int KC>
+__device__ __forceinline__ void asm_role_shape(const DeviceModel& dm, const FrameBuffers& fb, int f, int h, char* smem) {
+    constexpr int NTH = MOM_PARTS_NTH;
+    const AvtDims& d = dm.d;
+    const int t = threadIdx.x, try_slot = 1 - fb.ctl[f].cur_slot;
+    const int J = d.J, K = KC ? KC : d.K, NP = d.mom_np, HS = d.HS;
+    const int s0 = (h * K) / MOM_ASM_NA, s1 = ((h + 1) * K) / MOM_ASM_NA, Kh = s1 - s0;
+    double* Rw = (double*)smem;                 // [J][9]
+    double* oc = Rw + 9 * J;                    // [J][3]
+    double* PR = oc + 3 * J + (J & 1);          // [J + 1][Kh][6]
+    double* TR = PR + (J + 1) * Kh * 6;         // [J][Kh][6]
+    int* s_parent = (int*)(TR + J * Kh * 6);
+    unsigned short* tabm = (unsigned short*)(s_parent + AVT_MAX_JOINTS);
+    mom_skel_light(d, fb.prep + ((size_t)f * 2 + try_slot) * d.prep_size, fb.ctl[f].centre, Rw, oc, s_parent, dm.parent);
+    {
+        const unsigned long long* src = (const unsigned long long*)dm.mom_tab16;
+        unsigned long long* dst = (unsigned long long*)tabm;
+        for (int e = t; e < d.mom_toff[4] / 4; e += NTH) dst[e] = src[e];
+    }
+    const unsigned short* opk_start = tabm + d.mom_toff[0], *opk = tabm + d.mom_toff[1], *sub_start = tabm + d.mom_toff[2], *sub = tabm + d.mom_toff[3];
+    const double* scr = fb.mom_rec + (size_t)f * mom_frame_scratch(d);
+    const double* REC = scr + mom_off_rec(d);
+    double* Hout = fb.Hraw + ((size_t)f * 2 + try_slot) * HS * HS;
+    for (int e = t; e < Kh * 6; e += NTH) PR[(size_t)J * Kh * 6 + e] = 0.0;      // the all-zero row the padded subtree lists point at
+    __syncthreads();      // index lists
+    for (int e = t; e < J * Kh * 6; e += NTH) {  // PR[k][s][.] = sum over the ordered pairs with lever joint k; all loads of an item in flight
+        const int k = e / (Kh * 6), rl = e - k * Kh * 6, r = s0 * 6 + rl;      // r: offset inside a pair's [K][6] record block
+        const int lo = opk_start[k], hi = opk_start[k + 1];
+        double v[MOM_MAXOPS];
+        int op[MOM_MAXOPS];
+#pragma unroll
+        for (int u = 0; u < MOM_MAXOPS; ++u) op[u] = opk[max(min(lo + u, hi - 1), 0)];
+#pragma unroll
+        for (int u = 0; u < MOM_MAXOPS; ++u) v[u] = REC[(size_t)min(op[u], 2 * NP - 1) * K * 6 + r];
+        double a = 0.0;
+#pragma unroll
+        for (int u = 0; u < MOM_MAXOPS; ++u) a += (lo + u < hi && op[u] < 2 * NP) ? v[u] : 0.0;
+        for (int i = lo + MOM_MAXOPS; i < hi; ++i) if (opk[i] < 2 * NP) a += REC[(size_t)opk[i] * K * 6 + r];
+        PR[e] = hi > lo ? a : 0.0;
+    }
+    __syncthreads();
+    for (int e = t; e < J * Kh * 6; e += NTH) {  // subtree sums, eight list entries at a time
+        const int j = e / (Kh * 6), r = e - j * Kh * 6;
+        double a = 0.0;
+        for (int i = sub_start[j]; i < sub_start[j + 1]; i += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = PR[(size_t)sub[i + u] * Kh * 6 + r];
+            a += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        TR[e] = a;
+    }
+    __syncthreads();
+    auto Hset = [&](int r, int c, double v) { Hout[(size_t)r * HS + c] = v; Hout[(size_t)c * HS + r] = v; };
+    const int SH = 3 + 3 * J;
+    for (int e = t; e < J * 3 * Kh; e += NTH) {  // rotation rows against this role's shape columns
+        const int j = e / (3 * Kh), rem = e - j * 3 * Kh, c = rem / Kh, sl = rem - c * Kh, pa = s_parent[j];
+        const double a0 = pa < 0 ? (c == 0 ? 1.0 : 0.0) : Rw[9 * pa + c], a1 = pa < 0 ? (c == 1 ? 1.0 : 0.0) : Rw[9 * pa + 3 + c],
+                     a2 = pa < 0 ? (c == 2 ? 1.0 : 0.0) : Rw[9 * pa + 6 + c];
+        const double* tr = TR + ((size_t)j * Kh + sl) * 6;
+        const double o0 = oc[3 * j], o1 = oc[3 * j + 1], o2 = oc[3 * j + 2];
+        const double v0 = tr[0] - (o1 * tr[5] - o2 * tr[4]), v1 = tr[1] - (o2 * tr[3] - o0 * tr[5]), v2 = tr[2] - (o0 * tr[4] - o1 * tr[3]);
+        Hset(3 + 3 * j + c, SH + s0 + sl, 2.0 * (a0 * v0 + a1 * v1 + a2 * v2));
+    }
+    for (int e = t; e < Kh * 3; e += NTH) { const int sl = e / 3, c = e - 3 * sl; Hset(SH + s0 + sl, c, TR[(size_t)sl * 6 + 3 + c]); }      // root's subtree = every joint
+}
+
+__device__ __forceinline__ void asm_role_rotrot(const DeviceModel& dm, const FrameBuffers& fb, int f, int r, char* smem) {
+    constexpr int NTH = MOM_PARTS_NTH;
+    const AvtDims& d = dm.d;
+    const int t = threadIdx.x, try_slot = 1 - fb.ctl[f].cur_slot;
+    const int J = d.J, NP = d.mom_np, HS = d.HS;
+    const int b0 = d.mom_rsplit[r], b1 = d.mom_rsplit[r + 1];
+    double* Rw = (double*)smem;                 // [J][9]
+    double* oc = Rw + 9 * J;                    // [J][3]
+    int* s_parent = (int*)(oc + 3 * J + (J & 1));
+    unsigned short* tabm = (unsigned short*)(s_parent + AVT_MAX_JOINTS);      // words [mom_toff[4], mom_toff[7]): bseg | seg | jj
+    const int w0 = d.mom_toff[4], nw = d.mom_toff[7] - w0;
+    double* SEG = (double*)(tabm + ((nw + 3) & ~3));      // [own segments][16]
+    const unsigned short* bseg = tabm + (d.mom_toff[4] - w0), *seg = tabm + (d.mom_toff[5] - w0), *jjl = tabm + (d.mom_toff[6] - w0);
+    mom_skel_light(d, fb.prep + ((size_t)f * 2 + try_slot) * d.prep_size, fb.ctl[f].centre, Rw, oc, s_parent, dm.parent);
+    {
+        const unsigned long long* src = (const unsigned long long*)(dm.mom_tab16 + w0);      // (every list starts on a multiple of four words)
+        unsigned long long* dst = (unsigned long long*)tabm;
+        for (int e = t; e < nw / 4; e += NTH) dst[e] = src[e];
+    }
+    const double* X16 = fb.mom_rec + (size_t)f * mom_frame_scratch(d);      // [2 NP + 1][16] read in place: the 16 lanes of an item group share one 128-byte row
+    double* Hout = fb.Hraw + ((size_t)f * 2 + try_slot) * HS * HS;
+    {   // this role's share of the structural zeros (they depend on nothing)
+        const int z0 = (int)(((long long)d.mom_nz2 * 9 * r) / MOM_ASM_NR), z1 = (int)(((long long)d.mom_nz2 * 9 * (r + 1)) / MOM_ASM_NR);
+        for (int e = z0 + t; e < z1; e += NTH) {
+            const int b = e / 9, q = e - 9 * b, jj = dm.mom_z2_jj[b], j = jj & 0xff, jp = jj >> 8, rr = q / 3, c = q - 3 * rr;
+            Hout[(size_t)(3 + 3 * j + rr) * HS + 3 + 3 * jp + c] = 0.0;
+            Hout[(size_t)(3 + 3 * jp + c) * HS + 3 + 3 * j + rr] = 0.0;
+        }
+    }
+    __syncthreads();      // lists, skeleton
+    const int sg0 = bseg[b0], sg1 = bseg[b1], nsg = sg1 - sg0, nb = b1 - b0;
+    double* S16 = SEG + (size_t)nsg * 16;       // [own blocks][16]
+    for (int e = t; e < nsg * 16; e += NTH) {
+        const int sg = sg0 + (e >> 4), q = e & 15;
+        const unsigned short* li = seg + 16 * sg;
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = X16[(size_t)li[u] * 16 + q];
+        SEG[e] = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) + (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+    }
+    __syncthreads();
+    for (int e = t; e < nb * 16; e += NTH) {      // a block's segments, in order
+        const int b = b0 + (e >> 4), q = e & 15;
+        const int s0 = bseg[b] - sg0, s1 = bseg[b + 1] - sg0;
+        double a = 0.0;
+        for (int sg = s0; sg < s1; sg += 4) {
+            const double v0 = SEG[sg * 16 + q], v1 = SEG[min(sg + 1, s1 - 1) * 16 + q], v2 = SEG[min(sg + 2, s1 - 1) * 16 + q], v3 = SEG[min(sg + 3, s1 - 1) * 16 + q];
+            a += v0; a += sg + 1 < s1 ? v1 : 0.0; a += sg + 2 < s1 ? v2 : 0.0; a += sg + 3 < s1 ? v3 : 0.0;
+        }
+        S16[e] = a;
+    }
+    __syncthreads();
+    for (int e = t; e < nb * 9; e += NTH) {
+        const int bl = e / 9, q = e - 9 * bl, b = b0 + bl;
+        const int jj = jjl[b], j = jj & 0xff, jp = jj >> 8;
+        const double* S = S16 + bl * 16;
+        const double oj[3] = {oc[3 * j], oc[3 * j + 1], oc[3 * j + 2]}, op[3] = {oc[3 * jp], oc[3 * jp + 1], oc[3 * jp + 2]};
+        double LL[9];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) LL[3 * rr + c] = S[3 * rr + c] - S[9 + rr] * op[c] - oj[rr] * S[12 + c] + S[15] * oj[rr] * op[c];
+        const double trL = (LL[0] + LL[4]) + LL[8];
+        const int pj = s_parent[j], pp = s_parent[jp];
+        const int rr = q / 3, c = q - 3 * rr;
+        double Ar[3], Bc[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            Ar[i] = pj < 0 ? (i == rr ? 1.0 : 0.0) : Rw[9 * pj + 3 * i + rr];
+            Bc[i] = pp < 0 ? (i == c ? 1.0 : 0.0) : Rw[9 * pp + 3 * i + c];
+        }
+        const double atb = Ar[0] * Bc[0] + Ar[1] * Bc[1] + Ar[2] * Bc[2];
+        double atl = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double ltb = LL[i] * Bc[0] + LL[3 + i] * Bc[1] + LL[6 + i] * Bc[2];
+            atl = fma(Ar[i], ltb, atl);
+        }
+        const double v = 4.0 * (trL * atb - atl);
+        if (j != jp || rr <= c) {
+            Hout[(size_t)(3 + 3 * j + rr) * HS + 3 + 3 * jp + c] = v;
+            Hout[(size_t)(3 + 3 * jp + c) * HS + 3 + 3 * j + rr] = v;
+        }
+    }
+}
+
+template <int KC>
+__global__ __launch_bounds__(MOM_PARTS_NTH) void k_assemble_parts(DeviceModel dm, FrameBuffers fb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int f = blockIdx.y + fb.f0, role = blockIdx.x;
+    if (role == 0) asm_role_core<KC>(dm, fb, f, smem);
+    else if (role <= MOM_ASM_NA) asm_role_shape<KC>(dm, fb, f, role - 1, smem);
+    else asm_role_rotrot(dm, fb, f, role - 1 - MOM_ASM_NA, smem);
+}
+
+static size_t assemble_parts_lds_bytes(const AvtDims& d) {
+    const int J = d.J, K = d.K, NP = d.mom_np;
+    const size_t lists_a = sizeof(unsigned short) * (size_t)d.mom_toff[4], lists_r = sizeof(unsigned short) * (size_t)((d.mom_toff[7] - d.mom_toff[4] + 3) & ~3);
+    const size_t core = sizeof(double) * ((size_t)mom_skel_doubles(d) + 2 * (J + 1) * 16 + J * 9 + J * 4 + J * K + (K * K + K) + K + (K + 8) + K * ((J + 3) / 4)) +
+                        sizeof(int) * AVT_MAX_JOINTS + lists_a;
+    const int Kh = (K + MOM_ASM_NA - 1) / MOM_ASM_NA;
+    const size_t shape = sizeof(double) * ((size_t)12 * J + 1 + (2 * J + 1) * Kh * 6) + sizeof(int) * AVT_MAX_JOINTS + lists_a;
+    const size_t rotrot = sizeof(double) * ((size_t)12 * J + 1 + d.mom_rr_doubles) + sizeof(int) * AVT_MAX_JOINTS + lists_r;
+    return std::max(core, std::max(shape, rotrot)) + 64;
+}
+
 static size_t assemble_lds_bytes(const AvtDims& d) {
     return sizeof(double) * ((size_t)mom_skel_doubles(d) + mom_asm_doubles(d)) + sizeof(int) * AVT_MAX_JOINTS + sizeof(unsigned short) * (size_t)mom_tab_words(d) + 64;
 }
@@ -941,6 +1313,13 @@ void launch_assemble(avt_ctx* c, int nframes) {
         const size_t lds = pairpass_lds_bytes(d);
         if (d.K == 10) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairpass<10>), grid, dim3(16 * MOM_PP_PAIRS), lds, c->cur_stream, c->dm, c->fb);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairpass<0>), grid, dim3(16 * MOM_PP_PAIRS), lds, c->cur_stream, c->dm, c->fb);
+    }
+    if (c->tun.asm_parts || assemble_lds_bytes(d) > avt_moments_lds_cap()) {      // six role workgroups of 256 threads per frame (the default)
+        const dim3 grid(MOM_ASM_ROLES, nframes);
+        const size_t lds = assemble_parts_lds_bytes(d);
+        if (d.K == 10) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_parts<10>), grid, dim3(MOM_PARTS_NTH), lds, c->cur_stream, c->dm, c->fb);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_parts<0>), grid, dim3(MOM_PARTS_NTH), lds, c->cur_stream, c->dm, c->fb);
+        return;
     }
     const dim3 grid(1, nframes);
     const size_t lds = assemble_lds_bytes(d);
@@ -972,7 +1351,7 @@ long long avt_moments_mfma_count(const avt_model* m, const int* cnt) {
 size_t avt_moments_frame_scratch(const AvtDims& d) { return mom_frame_scratch(d); }
 // both kernels of the GN loop must fit the dynamic-LDS cap set below: the assembly's request grows with the pair count and the rot-rot lists
 // (SMPL: 80 KB), so a model with denser skinning can exceed it although K and P qualify - the context then keeps the row form
-size_t avt_moments_lds_need(const AvtDims& d) { return std::max(assemble_lds_bytes(d), pairpass_lds_bytes(d)); }
+size_t avt_moments_lds_need(const AvtDims& d) { return std::max(assemble_parts_lds_bytes(d), pairpass_lds_bytes(d)); }      // (the one-workgroup assembly is only selectable where it fits)
 size_t avt_moments_lds_cap() { return 160 * 1024 - 512; }
 size_t avt_moments_T_doubles(const AvtDims& d) { return (size_t)d.mom_np * mom_tstride(d.mom_npsi); }
 
@@ -980,6 +1359,8 @@ int avt_moments_set_attributes() {
     const int cap = (int)avt_moments_lds_cap();
     return hipFuncSetAttribute((const void*)k_assemble<10, MOM_ASM_NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
            hipFuncSetAttribute((const void*)k_assemble<0, MOM_ASM_NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_assemble_parts<10>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_assemble_parts<0>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
            hipFuncSetAttribute((const void*)k_pairpass<10>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
            hipFuncSetAttribute((const void*)k_pairpass<0>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess;
 }

@@ -259,7 +259,7 @@ typedef struct avt_tuning {
     int nn_slab;             /* 1: that shape walks y-sorted candidates outwards from the wave's slab of queries; 0: full scan */
     int mom_min_frames;      /* AVT_DATA_TERM_AUTO: frames per launch from which the moment form is used (32) */
     int debug;               /* 1: occupancy report on stderr at context creation */
-    int reserved;
+    int asm_parts;           /* moment form: 1 (default) the assembly of a frame runs as six independent 256-thread role workgroups, 0 as one 1024-thread workgroup */
     long long ride_timeout_us; /* how long a solver role waits for the riding reduction before it raises the frame's fault (2 000 000) */
 } avt_tuning;
 int avt_ctx_get_tuning(avt_ctx* c, avt_tuning* out);

@@ -319,3 +319,31 @@ def test_normal_equations_after_a_replayed_graph_are_made_from_fresh_moments(smp
     fresh.set_data_term(fresh.DATA_TERM_MOMENTS)
     H2, g2, c2 = fresh.normal_equations(0)
     assert np.array_equal(H1, H2) and np.array_equal(g1, g2) and c1 == c2
+
+
+def test_assembly_as_role_workgroups_gives_the_one_workgroup_assembly_bit_for_bit(smpl, gmodel):
+    """k_assemble_parts (six independent 256-thread role workgroups per frame, the default) computes every entry of the system by the
+    item of k_assemble (one 1024-thread workgroup) that computes it there: same operands, same order, same bits - for the system
+    itself and for a fit of several ICP iterations, one frame and a batch."""
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    frs = [synth.make_frame(smpl, 40 + s) for s in range(5)]
+    nmax = max(len(f["labels"]) for f in frs)
+    p0 = np.array([f["start"][1] for f in frs]); q0 = np.array([api.rot_to_quat(f["start"][2]) for f in frs]); w0 = np.array([f["start"][0] for f in frs])
+    opt = Options.demo(icp_iters=2, max_iters_per_icp=5)
+    res = {}
+    for parts in (0, 1):
+        ctx = api.Context(gmodel, 24, pm, nmax, len(frs))
+        ctx.set_data_term(ctx.DATA_TERM_MOMENTS)
+        ctx.set_tuning(asm_parts=parts)
+        assert ctx.tuning().asm_parts == parts
+        out = ctx.optimize_batch([f["data"] for f in frs], [f["labels"] for f in frs], opt, p0, q0, w0)
+        res[parts] = (out, [ctx.normal_equations(i) for i in (0, 4)], [ctx.cost_trace(i) for i in range(len(frs))])
+    (pa, qa, wa, sta), nea, tra = res[0]
+    (pb, qb, wb, stb), neb, trb = res[1]
+    assert np.array_equal(pa, pb) and np.array_equal(qa, qb) and np.array_equal(wa, wb)
+    for (Ha, ga, ca), (Hb, gb, cb) in zip(nea, neb):
+        assert np.array_equal(Ha, Hb) and np.array_equal(ga, gb) and ca == cb
+        assert np.abs(Hb - Hb.T).max() == 0.0
+    assert all(np.array_equal(a, b) for a, b in zip(tra, trb))
+    assert [s.accepted_steps for s in sta] == [s.accepted_steps for s in stb]
