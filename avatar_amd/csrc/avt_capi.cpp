@@ -457,6 +457,111 @@ int download_state(avt_ctx* c, double* p, double* q, double* w, avt_stats* st) {
     return 0;
 }
 
+// avt_optimize / avt_optimize_batch on HOST pointers - the reference's call shape, optimize(const CloudType&, const VectorXi&, ..)
+// (AvatarOptimizer.h:17-19) - as one pass with ONE host synchronisation: clouds, labels, start states and control blocks are gathered in
+// the context's pinned staging block and leave as asynchronous copies (no pageable-memory staging inside the runtime, no wait between
+// them), the fit is enqueued behind them, k_pack_results puts (p, q, w), the statistics and the fault word of every frame into one block
+// and ONE copy brings it back.  (The four-stage path - upload, upload, run, download, a synchronisation each - measured 81 + 26 + 58 us
+// on top of the 0.41 ms fit of one 38 k-point frame, tools/host_call_breakdown.py.)  Leaves the context exactly as the staged calls do:
+// frames and start state resident, avt_state_reset / avt_optimize_resident usable afterwards.
+int optimize_host_to_host(avt_ctx* c, int nframes, const double* data, const int* labels, const int* offs, const avt_options* o,
+                          double* p, double* q, double* w, avt_stats* st) {
+    const AvtDims& d = c->dm.d;
+    if (nframes <= 0 || nframes > c->fb.max_frames) { avt_set_error("frames: nframes out of range for this context"); return 1; }
+    long long total = 0;
+    int mx = 0;
+    for (int f = 0; f < nframes; ++f) {
+        const int n = offs[f + 1] - offs[f];
+        if (n < 0) { avt_set_error("frames: negative point count (frame_offsets must be non-decreasing)"); return 1; }
+        if (n > c->fb.max_points) { avt_set_error("frames: a frame has more points than max_points_per_frame"); return 1; }
+        mx = std::max(mx, n); total += n;
+    }
+    const int xs = d.xsize, stride = xs + 8;
+    const size_t b_data = (size_t)total * 24, b_lab = ((size_t)total * 4 + 15) & ~(size_t)15, b_x = (size_t)nframes * 2 * xs * 8,
+                 b_ctl = (size_t)nframes * sizeof(AvtFrameCtl), b_res = (size_t)nframes * stride * 8;
+    const size_t need = b_data + b_lab + b_x + b_ctl + b_res + 64;
+    if (c->host_pin_cap < need) {
+        HIP_OK(hipStreamSynchronize(c->stream));
+        if (c->host_pin) (void)hipHostFree(c->host_pin);
+        c->host_pin = nullptr; c->host_pin_cap = 0;
+        const size_t cap = need + need / 4;
+        HIP_OK(hipHostMalloc((void**)&c->host_pin, cap, hipHostMallocDefault));
+        c->host_pin_cap = cap;
+    }
+    if (c->d_results_cap < (size_t)nframes * stride) {
+        HIP_OK(hipStreamSynchronize(c->stream));
+        if (c->d_results) (void)hipFree(c->d_results);
+        c->d_results = nullptr; c->d_results_cap = 0;
+        HIP_OK(hipMalloc((void**)&c->d_results, (size_t)c->fb.max_frames * stride * 8));
+        c->d_results_cap = (size_t)c->fb.max_frames * stride;
+    }
+    char* pin = c->host_pin;
+    double* h_data = (double*)pin; int* h_lab = (int*)(pin + b_data); double* h_x = (double*)(pin + b_data + b_lab);
+    AvtFrameCtl* h_ctl = (AvtFrameCtl*)(pin + b_data + b_lab + b_x); double* h_res = (double*)(pin + b_data + b_lab + b_x + b_ctl);
+    // the context's bookkeeping of the resident frames (install_frames)
+    c->frames_valid = c->state_valid = false;
+    c->have_moments = c->have_records = false;
+    c->nframes = nframes;
+    c->frame_N.resize(nframes); c->frame_off.assign(nframes + 1, 0);
+    for (int f = 0; f < nframes; ++f) { c->frame_N[f] = offs[f + 1] - offs[f]; c->frame_off[f + 1] = c->frame_off[f] + c->frame_N[f]; }
+    c->launch_maxN = std::max(mx, std::min(c->fb.max_points, ((mx + 2047) / 2048) * 2048));
+    std::memcpy(h_data, data + (size_t)offs[0] * 3, b_data);
+    std::memcpy(h_lab, labels + offs[0], (size_t)total * 4);
+    std::memset(h_x, 0, b_x);
+    std::memset((void*)h_ctl, 0, b_ctl);
+    for (int f = 0; f < nframes; ++f) {
+        double* x = h_x + (size_t)f * 2 * xs;
+        std::copy(p + 3 * (size_t)f, p + 3 * (size_t)f + 3, x);
+        std::copy(q + (size_t)4 * d.J * f, q + (size_t)4 * d.J * (f + 1), x + 3);
+        std::copy(w + (size_t)d.K * f, w + (size_t)d.K * (f + 1), x + 3 + 4 * d.J);
+        h_ctl[f].N = c->frame_N[f];
+        h_ctl[f].comp_cur = -1;
+    }
+    for (int f = 0; f < nframes; ++f) {
+        const size_t N = (size_t)c->frame_N[f], off = (size_t)c->frame_off[f];
+        if (N == 0) continue;
+        HIP_OK(hipMemcpyAsync(c->fb.data_raw + (size_t)f * c->fb.max_points * 3, h_data + off * 3, N * 24, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(c->fb.labels_raw + (size_t)f * c->fb.max_points, h_lab + off, N * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_OK(hipMemcpyAsync(c->fb.x, h_x, b_x, hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(c->fb.ctl, h_ctl, b_ctl, hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(c->fb.x_start, c->fb.x, b_x, hipMemcpyDeviceToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(c->fb.ctl_start, c->fb.ctl, b_ctl, hipMemcpyDeviceToDevice, c->stream));
+    c->frames_valid = c->state_valid = true;
+    if (run_optimize(c, o)) return 1;
+    launch_pack_results(c, nframes, c->d_results, stride);
+    HIP_OK(hipMemcpyAsync(h_res, c->d_results, b_res, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));      // the one synchronisation of the call
+    int bad = -1, nbad = 0;
+    unsigned badbits = 0;
+    for (int f = 0; f < nframes; ++f) {
+        const double* x = h_res + (size_t)f * stride;
+        if (x[xs + 7] != 0.0) { if (bad < 0) { bad = f; badbits = (unsigned)x[xs + 7]; } ++nbad; }
+    }
+    if (bad >= 0) {     // reported once, then cleared (download_state's rule)
+        char msg[256];
+        snprintf(msg, sizeof msg, "optimize: %d frame(s) carry a device fault (first: frame %d, bits 0x%x%s); their result is not valid", nbad, bad,
+                 badbits, (badbits & AVT_FAULT_RIDE_TIMEOUT) ? ": a solver gave up waiting for the in-launch reduction" : "");
+        HIP_OK(hipMemsetAsync(c->fb.fault, 0, (size_t)c->fb.max_frames * sizeof(unsigned), c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        avt_set_error(msg);
+        return AVT_STATUS_DEVICE_FAULT;
+    }
+    for (int f = 0; f < nframes; ++f) {
+        const double* x = h_res + (size_t)f * stride;
+        std::copy(x, x + 3, p + 3 * (size_t)f);
+        std::copy(x + 3, x + 3 + 4 * d.J, q + (size_t)4 * d.J * f);
+        std::copy(x + 3 + 4 * d.J, x + xs, w + (size_t)d.K * f);
+        if (st) {
+            const double* t = x + xs;
+            st[f].initial_cost = t[0]; st[f].final_cost = t[1]; st[f].lambda = t[2];
+            st[f].num_correspondences = (int)t[3]; st[f].matched_model_points = (int)t[4];
+            st[f].gn_iterations = (int)t[5]; st[f].accepted_steps = (int)t[6];
+        }
+    }
+    return 0;
+}
+
 }  // namespace
 
 // batch split (avt_shard.cpp): frames received into a device buffer become this context's resident frames
@@ -500,6 +605,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
     c->frames_valid = c->state_valid = false;
     c->have_moments = c->have_records = false;
     c->concurrent_groups = 1;
+    c->host_pin = nullptr; c->host_pin_cap = 0; c->d_results = nullptr; c->d_results_cap = 0;
     c->render_zkey = nullptr; c->render_label = nullptr; c->render_block = nullptr; c->render_cap_pix = c->render_cap_blk = 0;
     c->render_mkey = nullptr; c->render_depth = nullptr; c->render_fkey = nullptr; c->render_frank = nullptr; c->render_fedge = nullptr;
     c->render_cap_paint_pix = c->render_cap_paint_face = 0;
@@ -631,6 +737,8 @@ void avt_ctx_destroy(avt_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void* p : c->allocs) (void)hipFree(p);
+    if (c->host_pin) (void)hipHostFree(c->host_pin);
+    if (c->d_results) (void)hipFree(c->d_results);
     if (c->render_zkey) (void)hipFree(c->render_zkey);
     if (c->render_label) (void)hipFree(c->render_label);
     if (c->render_block) (void)hipFree(c->render_block);
@@ -888,10 +996,7 @@ int avt_optimize_batch(avt_ctx* c, int nframes, const double* data, const int* l
     AVT_API_GUARD_BEGIN
     if (!c || !data || !labels || !frame_offsets || !opt || !p || !q || !w) { avt_set_error("avt_optimize_batch: null argument"); return 1; }
     HIP_OK(hipSetDevice(c->device));
-    if (upload_frames(c, nframes, data, labels, frame_offsets)) return 1;
-    if (upload_state(c, nframes, p, q, w)) return 1;
-    if (run_optimize(c, opt)) return 1;
-    return download_state(c, p, q, w, stats);
+    return optimize_host_to_host(c, nframes, data, labels, frame_offsets, opt, p, q, w, stats);
     AVT_API_GUARD_END("avt_optimize_batch")
 }
 

@@ -342,6 +342,10 @@ struct avt_ctx {
     std::string mom_reason;          // why this context has no moment form (empty: it has one)
     bool have_moments, have_records; // what exists for the resident correspondences (avt_get_normal_equations makes the other on demand)
     int concurrent_groups;           // frame groups the current optimize() call runs side by side (sizes the riding launch shapes)
+    // host-to-host calls (avt_optimize / avt_optimize_batch on host pointers): one pinned staging block for everything that crosses PCIe
+    // in either direction and one device block for the packed results, grown on demand - the call then needs ONE host synchronisation
+    char* host_pin; size_t host_pin_cap;
+    double* d_results; size_t d_results_cap;     // doubles
     // persistent scratch of avt_synth_render_frames (z-buffer keys, labels, block counts), grown on demand
     unsigned long long* render_zkey; unsigned char* render_label; int* render_block; size_t render_cap_pix; size_t render_cap_blk;
     // painter's-order mode only: second key image, float depth image, per-face sort key / order position / edge-on flag
