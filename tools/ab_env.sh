@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 for F in $FRAMES; do
   for V in $VALS; do
     DENSE=""; FF=${F%d}; [ "$F" != "$FF" ] && DENSE="--dense"
-    env $VAR=$V python $R/bench.py --frames $FF $DENSE --steps 10 --warmup 3 --regions 5 --no-cpu-baseline --no-shard --no-label-stage --no-render-stage --no-seed-spread --detail-file /tmp/ab_detail.json "$@" 2>/dev/null | tail -1 > /tmp/ab_line.json
+    env $VAR=$V timeout 180 python $R/bench.py --frames $FF $DENSE --steps 10 --warmup 3 --regions 5 --no-cpu-baseline --no-shard --no-label-stage --no-render-stage --no-seed-spread --detail-file /tmp/ab_detail.json "$@" 2>/dev/null | tail -1 > /tmp/ab_line.json
     python - "$VAR" "$V" "$F" <<'PY'
 import json, sys
 d = json.load(open("/tmp/ab_line.json"))

@@ -6,7 +6,7 @@
 #   the instrumented pass of bench.py uses the same shapes as the graph replay.
 # Output: gpurun_out/prof_<tag>/ and gpurun_out/<round>_*.txt / *.json (copy what is to be judged into profiles/).
 set -u
-RND=${RND:-r04}
+RND=${RND:-r05}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
