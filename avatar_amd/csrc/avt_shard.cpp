@@ -955,15 +955,19 @@ extern "C" int avt_shard_gather_enqueue(avt_shard* s, avt_ctx* c, int B) {
     // per step, 0.62 ms): this costs 6 us per step; putting the all-gather on the shard's own stream instead - so that the
     // exchange of step k overlaps step k+1 - costs 25 us, because the event record / cross-stream wait the hand-over needs
     // sit in the context stream's critical path (double-buffering the send block and waiting on the host: 24 us).
+    // (AVT_SHARD_SELF_SENDRECV - the dry-run switch that pushes a lone rank's own blocks through the transport - keeps the one-rank all-gather too)
+    const bool direct = W == 1 && !mismatch && getenv("AVT_SHARD_SELF_SENDRECV") == nullptr;
     if (mismatch) {
         std::vector<double> rows(blk, 0.0);
         for (int i = 0; i < per; ++i) rows[(size_t)i * stride + c->dm.d.xsize + 7] = (double)AVT_FAULT_NOT_RESIDENT;
         HIP_OK(hipMemcpyAsync(s->d_send, rows.data(), blk * 8, hipMemcpyHostToDevice, c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));
     } else if (nloc) {
-        launch_pack_results(c, nloc, s->d_send, stride);
+        // (one rank: the gathered block IS this rank's block - the results are packed straight into it; an all-gather over one rank is a
+        // device-to-device copy kernel of its own on the stream, 4.3 us per step for the identity)
+        launch_pack_results(c, nloc, direct ? s->d_recv : s->d_send, stride);
     }
-    NCCL_OK(s, s->api->AllGather(s->d_send, s->d_recv, blk, ncclDouble, s->comm, c->stream));
+    if (!direct) NCCL_OK(s, s->api->AllGather(s->d_send, s->d_recv, blk, ncclDouble, s->comm, c->stream));
     s->gather_stream = c->stream;
     if (mismatch) { avt_set_error("avt_shard_gather_enqueue: resident frames differ from this rank's share of the batch (its rows were gathered as faulty)"); return 1; }
     return 0;
