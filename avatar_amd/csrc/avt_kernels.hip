@@ -163,12 +163,200 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
     }
 }
 
+// =================================================================================================
+// k_lbs_multi<FT>: Avatar::update() of FT frames per workgroup (frame batches).  The skinning of a vertex reads its 3 (K + 1) shape-plane
+// values and four (weight, joint) pairs - 312 bytes that are the same for every frame - and k_lbs re-read them from L2 once per frame: at
+// 256 frames per launch that is 550 MB through the L2s per launch, what the kernel waits for.  Here a thread loads
+// them once and applies them to FT frames (FT sets of joint matrices in LDS): same operations in the same order per frame, hence the same
+// bits as k_lbs.  grid (ceil(V / 256) + FT nb, ceil(frames / FT)); from_state 1 (forward kinematics from the current state: the first
+// launch of optimize()) or 2 (from the skeleton tables k_solve made for the current point); the trailing nb workgroups per frame are the
+// label histogram of the data bucketing (first launch).  No accept test and no trial-point workgroup here: the shapes that have them
+// (few frames) keep k_lbs.
+// =================================================================================================
+template <int FT>
+__device__ __forceinline__ void fk_chain_multi(int J, const int* __restrict__ parent, const double* rot, const double* jp, const double* p, double* Rw,
+                                               double* o, const int* lvl) {
+    const int t = threadIdx.x;
+    const int nl = lvl[J];
+    for (int L = 0; L <= nl; ++L) {
+        for (int idx = t; idx < FT * 12 * J; idx += blockDim.x) {
+            const int fi = idx / (12 * J), rem = idx - fi * 12 * J, j = rem / 12, e = rem % 12;
+            if (lvl[j] != L) continue;
+            const double* rotf = rot + (size_t)fi * 9 * J; const double* jpf = jp + (size_t)fi * 3 * J;
+            double* Rwf = Rw + (size_t)fi * 9 * J; double* of = o + (size_t)fi * 3 * J;
+            if (j == 0) {
+                if (e < 9) Rwf[e] = rotf[e];
+                else of[e - 9] = p[3 * fi + e - 9];
+            } else {
+                const int pa = parent[j];
+                const double* Rp = Rwf + 9 * pa;
+                if (e < 9) {
+                    const int r = e / 3, c = e % 3;
+                    Rwf[9 * j + e] = Rp[3 * r] * rotf[9 * j + c] + Rp[3 * r + 1] * rotf[9 * j + 3 + c] + Rp[3 * r + 2] * rotf[9 * j + 6 + c];
+                } else {
+                    const int r = e - 9;
+                    const double d0 = jpf[3 * j] - jpf[3 * pa], d1 = jpf[3 * j + 1] - jpf[3 * pa + 1], d2 = jpf[3 * j + 2] - jpf[3 * pa + 2];
+                    of[3 * j + r] = of[3 * pa + r] + (Rp[3 * r] * d0 + Rp[3 * r + 1] * d1 + Rp[3 * r + 2] * d2);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int FT>
+__global__ __launch_bounds__(256) void k_lbs_multi(DeviceModel dm, FrameBuffers fb, int from_state, int vis_init, int nlbs, int nb, int nframes, int write_pc) {
+    const AvtDims d = dm.d;
+    const int J = d.J, K = d.K, V = d.V;
+    const int t = threadIdx.x, y0 = blockIdx.y * FT;
+    if ((int)blockIdx.x >= nlbs) {      // trailing workgroups: the label histogram of one 2048-point tile of one of my frames
+        const int bx = (int)blockIdx.x - nlbs, fi = bx / nb;
+        if (y0 + fi < nframes) bucket_count_block(dm, fb, fb.f0 + y0 + fi, bx - fi * nb);
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) char lbs_dyn[];
+    // per frame: rot [9 J] | Rw [9 J] | o [3 J] | jp [3 J] | T [12 J] - frame-major inside every array - then w [FT][16], p [FT][3]
+    double* s_rot = (double*)lbs_dyn;
+    double* s_Rw = s_rot + (size_t)FT * 9 * J;
+    double* s_o = s_Rw + (size_t)FT * 9 * J;
+    double* s_jp = s_o + (size_t)FT * 3 * J;
+    double* s_T = s_jp + (size_t)FT * 3 * J;
+    double* s_w = s_T + (size_t)FT * 12 * J;
+    double* s_p = s_w + FT * AVT_MAX_SHAPE;
+    __shared__ int s_parent[AVT_MAX_JOINTS], s_lvl[AVT_MAX_JOINTS + 1];
+    bool on[FT];
+#pragma unroll
+    for (int i = 0; i < FT; ++i) on[i] = y0 + i < nframes;
+    if (from_state == 2) {
+#pragma unroll
+        for (int i = 0; i < FT; ++i) {
+            const int f = fb.f0 + min(y0 + i, nframes - 1);
+            const double* pp = fb.prep + ((size_t)f * 2 + fb.ctl[f].cur_slot) * d.prep_size;
+            for (int e = t; e < 9 * J; e += 256) s_Rw[(size_t)i * 9 * J + e] = pp[prep_off_Rw(d) + e];
+            if (t < 3 * J) { s_o[(size_t)i * 3 * J + t] = pp[prep_off_o(d) + t]; s_jp[(size_t)i * 3 * J + t] = pp[prep_off_Jh(d) + t] + pp[prep_off_off(d) + t % 3]; }
+            if (t < K) s_w[i * AVT_MAX_SHAPE + t] = pp[prep_off_w(d) + t];
+        }
+        __syncthreads();
+    } else {
+        if (t < J) { s_parent[t] = dm.parent[t]; s_lvl[t] = dm.jlevel[t]; }
+        if (t == 0) s_lvl[J] = d.nlevels - 1;
+#pragma unroll
+        for (int i = 0; i < FT; ++i) {
+            const int f = fb.f0 + min(y0 + i, nframes - 1);
+            const double* xs = fb.x + ((size_t)f * 2 + fb.ctl[f].cur_slot) * d.xsize;
+            if (t < K) s_w[i * AVT_MAX_SHAPE + t] = xs[3 + 4 * J + t];
+            if (t < 3) s_p[3 * i + t] = xs[t];
+            if (t < J) quat_to_rot(xs + 3 + 4 * t, s_rot + (size_t)i * 9 * J + 9 * t);
+        }
+        __syncthreads();
+        // jointPos = initialJointPos + jointShapeReg * w   (Avatar.cpp:31-36)
+        for (int e = t; e < FT * 3 * J; e += 256) {
+            const int i = e / (3 * J), tt = e - i * 3 * J;
+            double sacc = 0.0;
+            for (int k = 0; k < K; ++k) sacc += dm.jsr[(size_t)tt * K + k] * s_w[i * AVT_MAX_SHAPE + k];
+            s_jp[e] = dm.jsr_base[tt] + sacc;
+        }
+        __syncthreads();
+        fk_chain_multi<FT>(J, s_parent, s_rot, s_jp, s_p, s_Rw, s_o, s_lvl);
+    }
+    // jointPos_i <- t_i ; t_i -= R_i * jPosInit   (Avatar.cpp:59-64)
+    for (int e = t; e < FT * 3 * J; e += 256) {
+        const int i = e / (3 * J), tt = e - i * 3 * J, j = tt / 3, r = tt % 3;
+        const double* Rwf = s_Rw + (size_t)i * 9 * J; const double* jpf = s_jp + (size_t)i * 3 * J;
+        const double tr = s_o[e] - (Rwf[9 * j + 3 * r] * jpf[3 * j] + Rwf[9 * j + 3 * r + 1] * jpf[3 * j + 1] + Rwf[9 * j + 3 * r + 2] * jpf[3 * j + 2]);
+        s_T[(size_t)i * 12 * J + 12 * j + 9 + r] = tr;
+    }
+    for (int e = t; e < FT * 9 * J; e += 256) {
+        const int i = e / (9 * J), ee = e - i * 9 * J, j = ee / 9, r = (ee % 9) / 3, c = ee % 3;
+        s_T[(size_t)i * 12 * J + 12 * j + 3 * c + r] = s_Rw[e];
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < FT; ++i) {
+            if (!on[i]) continue;
+            const int f = fb.f0 + y0 + i;
+            if (t < 3 * J) fb.jointpos[(size_t)f * 3 * J + t] = s_o[(size_t)i * 3 * J + t];
+            for (int e = t; e < 12 * J; e += 256) fb.jointtrans[(size_t)f * 12 * J + e] = s_T[(size_t)i * 12 * J + e];
+        }
+    }
+    const int v = blockIdx.x * 256 + t;
+    if (v >= V) return;
+    // shapedCloud = keyClouds * w + baseCloud  (Avatar.cpp:26): every plane value is loaded once and used by all FT frames
+    double sx[FT], sy[FT], sz[FT];
+#pragma unroll
+    for (int i = 0; i < FT; ++i) { sx[i] = 0.0; sy[i] = 0.0; sz[i] = 0.0; }
+    for (int k = 0; k < K; ++k) {
+        const double p0 = dm.shape_planes[((size_t)k * 3 + 0) * V + v], p1 = dm.shape_planes[((size_t)k * 3 + 1) * V + v], p2 = dm.shape_planes[((size_t)k * 3 + 2) * V + v];
+#pragma unroll
+        for (int i = 0; i < FT; ++i) {
+            const double wk = s_w[i * AVT_MAX_SHAPE + k];
+            sx[i] += p0 * wk; sy[i] += p1 * wk; sz[i] += p2 * wk;
+        }
+    }
+    {
+        const double b0 = dm.shape_planes[((size_t)K * 3 + 0) * V + v], b1 = dm.shape_planes[((size_t)K * 3 + 1) * V + v], b2 = dm.shape_planes[((size_t)K * 3 + 2) * V + v];
+#pragma unroll
+        for (int i = 0; i < FT; ++i) { sx[i] += b0; sy[i] += b1; sz[i] += b2; }
+    }
+    double wt[4];
+    int wj[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { wt[a] = dm.lbs_w[(size_t)a * V + v]; wj[a] = dm.lbs_j[(size_t)a * V + v]; }
+    const int pp = (dm.part_pos && write_pc) ? dm.part_pos[v] : -1;
+#pragma unroll
+    for (int i = 0; i < FT; ++i) {
+        if (!on[i]) continue;
+        const int f = fb.f0 + y0 + i;
+        // pointTrans = jointTrans * weights (sparse column, CSC order)  (Avatar.cpp:69)
+        double pt[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) pt[e] = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (wt[a] != 0.0) {
+                const double* T = s_T + (size_t)i * 12 * J + 12 * wj[a];
+#pragma unroll
+                for (int e = 0; e < 12; ++e) pt[e] += T[e] * wt[a];
+            }
+        }
+        // cloud.col(i) = pointTrans_i * [shaped_i; 1]  (Avatar.cpp:70-73)
+        const double cx = pt[0] * sx[i] + pt[3] * sy[i] + pt[6] * sz[i] + pt[9];
+        const double cy = pt[1] * sx[i] + pt[4] * sy[i] + pt[7] * sz[i] + pt[10];
+        const double cz = pt[2] * sx[i] + pt[5] * sy[i] + pt[8] * sz[i] + pt[11];
+        double* cl = fb.cloud + (size_t)f * 3 * V + 3 * (size_t)v;
+        cl[0] = cx; cl[1] = cy; cl[2] = cz;
+        if (vis_init >= 0) {
+            fb.visible[(size_t)f * V + v] = (unsigned char)vis_init;
+            fb.cnt[(size_t)f * V + v] = 0;
+            long long* fs = fb.fsum + (size_t)f * 3 * V;
+            fs[v] = 0; fs[(size_t)V + v] = 0; fs[2 * (size_t)V + v] = 0;
+        }
+        if (pp >= 0) {
+            if (vis_init >= 0) fb.vis_sorted[(size_t)f * V + pp] = (unsigned char)vis_init;
+            fb.pcx[(size_t)f * V + pp] = cx;
+            fb.pcy[(size_t)f * V + pp] = cy;
+            fb.pcz[(size_t)f * V + pp] = cz;
+        }
+    }
+}
+
+static size_t lbs_multi_lds(const AvtDims& d, int FT) { return sizeof(double) * ((size_t)FT * (36 * d.J + AVT_MAX_SHAPE + 3) + 2) + 16; }
+
 // with_bucket_count: also histogram the data labels (first half of launch_bucket) in trailing workgroups;
 // with_init: also set up the trial point of the next ICP iteration (one trailing workgroup per frame)
 void launch_lbs(avt_ctx* c, int nframes, const double*, const double* w, const double* p, const double* R, int from_state, int vis_init,
                 bool with_bucket_count, bool with_init, bool decide, bool write_pc) {
     const int nlbs = (c->dm.d.V + 255) / 256;
     const int nb = with_bucket_count ? std::max(1, (c->launch_maxN + BUCKET_TILE - 1) / BUCKET_TILE) : 0;
+    // frame batches: several frames per workgroup (k_lbs_multi) - the shapes without an accept test or a trial-point workgroup in the launch
+    const int FT = (from_state >= 1 && !with_init && !decide && c->tun.lbs_frames != 1) ? (c->tun.lbs_frames > 1 ? c->tun.lbs_frames : (nframes >= 128 ? 4 : (nframes >= 64 ? 2 : 1))) : 1;
+    if (FT > 1) {
+        const dim3 g2(nlbs + FT * nb, (nframes + FT - 1) / FT);
+        if (FT == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lbs_multi<4>), g2, dim3(256), lbs_multi_lds(c->dm.d, 4), c->cur_stream, c->dm, c->fb, from_state, vis_init, nlbs, std::max(nb, 1), nframes, write_pc ? 1 : 0);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lbs_multi<2>), g2, dim3(256), lbs_multi_lds(c->dm.d, 2), c->cur_stream, c->dm, c->fb, from_state, vis_init, nlbs, std::max(nb, 1), nframes, write_pc ? 1 : 0);
+        return;
+    }
     dim3 grid(nlbs + (with_init ? 1 : 0) + nb, nframes);
     const size_t lds = with_init ? prep_init_lds_bytes(c->dm.d) : 0;
     hipLaunchKernelGGL(k_lbs, grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, w, p, R, from_state, vis_init, nlbs, with_init ? 1 : 0,
@@ -181,6 +369,8 @@ bool avt_lbs_can_init(const AvtDims& d) { return prep_init_lds_bytes(d) <= 96 * 
 __global__ void k_visibility_frame(DeviceModel dm, FrameBuffers fb);
 int avt_lbs_set_attributes() {
     return hipFuncSetAttribute((const void*)k_lbs, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_lbs_multi<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_lbs_multi<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
            hipFuncSetAttribute((const void*)k_visibility_frame, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess;
 }
 

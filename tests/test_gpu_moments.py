@@ -347,3 +347,31 @@ def test_assembly_as_role_workgroups_gives_the_one_workgroup_assembly_bit_for_bi
         assert np.abs(Hb - Hb.T).max() == 0.0
     assert all(np.array_equal(a, b) for a, b in zip(tra, trb))
     assert [s.accepted_steps for s in sta] == [s.accepted_steps for s in stb]
+
+
+def test_skinning_several_frames_per_workgroup_gives_the_same_bits(smpl, gmodel):
+    """k_lbs_multi (frame batches: a thread loads a vertex's shape planes and weights once and skins 2 / 4 frames with them) against
+    k_lbs (one frame per workgroup): same operations in the same order per frame - clouds, joint positions and the whole fit equal bit
+    for bit, with a frame count that is not a multiple of the frames per workgroup."""
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    frs = [synth.make_frame(smpl, 60 + s) for s in range(7)]
+    sel = slice(0, None, 4)
+    datas = [f["data"][sel] for f in frs]; labs = [f["labels"][sel] for f in frs]
+    nmax = max(len(l) for l in labs)
+    p0 = np.array([f["start"][1] for f in frs]); q0 = np.array([api.rot_to_quat(f["start"][2]) for f in frs]); w0 = np.array([f["start"][0] for f in frs])
+    opt = Options.demo(icp_iters=2, max_iters_per_icp=4)
+    res = {}
+    for ft in (1, 2, 4):
+        ctx = api.Context(gmodel, 24, pm, nmax, len(frs))
+        ctx.set_data_term(ctx.DATA_TERM_MOMENTS)
+        ctx.set_tuning(lbs_frames=ft)
+        out = ctx.optimize_batch(datas, labs, opt, p0, q0, w0)
+        res[ft] = (out, [ctx.cloud(i) for i in range(len(frs))], [ctx.posed(i) for i in (0, 6)], [ctx.correspondences(i, len(labs[i])) for i in range(len(frs))])
+    for ft in (2, 4):
+        for a, b in zip(res[1][0][:3], res[ft][0][:3]):
+            assert np.array_equal(a, b), ft
+        assert all(np.array_equal(a, b) for a, b in zip(res[1][1], res[ft][1])), ft
+        for pa, pb in zip(res[1][2], res[ft][2]):
+            assert all(np.array_equal(a, b) for a, b in zip(pa, pb)), ft
+        assert all(np.array_equal(a, b) for a, b in zip(res[1][3], res[ft][3])), ft
