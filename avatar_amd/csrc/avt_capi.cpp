@@ -105,11 +105,11 @@ avt_tuning tuning_from_environment() {
     avt_tuning t;
     std::memset(&t, 0, sizeof t);
     t.use_graph = 1; t.groups = 0; t.g = 0; t.gcap = 128; t.vis_frame_min = 64; t.ride = 1; t.ride_strips = 0; t.ride_sizing_groups = 0;
-    t.asm_parts = 1; t.nspec = AVT_MAX_SPEC; t.nn_force_part = 0; t.nn_slab = 1; t.mom_min_frames = 32; t.debug = 0; t.ride_timeout_us = 2000000;
+    t.asm_parts = 1; t.spec_cost = 1; t.nspec = AVT_MAX_SPEC; t.nn_force_part = 0; t.nn_slab = 1; t.mom_min_frames = 32; t.debug = 0; t.ride_timeout_us = 2000000;
     struct Knob { const char* name; int* field; };
     const Knob knobs[] = {{"AVT_USE_GRAPH", &t.use_graph}, {"AVT_GROUPS", &t.groups}, {"AVT_G", &t.g}, {"AVT_GCAP", &t.gcap}, {"AVT_VIS_FRAME_MIN", &t.vis_frame_min},
                           {"AVT_RIDE", &t.ride}, {"AVT_RIDE_STRIPS", &t.ride_strips}, {"AVT_RIDE_SIZING_GROUPS", &t.ride_sizing_groups}, {"AVT_NSPEC", &t.nspec},
-                          {"AVT_NN_FORCE_PART", &t.nn_force_part}, {"AVT_NN_SLAB", &t.nn_slab}, {"AVT_MOM_MIN_FRAMES", &t.mom_min_frames}, {"AVT_ASM_PARTS", &t.asm_parts}, {"AVT_LBS_FRAMES", &t.lbs_frames}, {"AVT_DEBUG", &t.debug}};
+                          {"AVT_NN_FORCE_PART", &t.nn_force_part}, {"AVT_NN_SLAB", &t.nn_slab}, {"AVT_MOM_MIN_FRAMES", &t.mom_min_frames}, {"AVT_ASM_PARTS", &t.asm_parts}, {"AVT_LBS_FRAMES", &t.lbs_frames}, {"AVT_SPEC_COST", &t.spec_cost}, {"AVT_DEBUG", &t.debug}};
     // names other parts of the repository own (the batch split, the Python loader, bench.py, instrumented builds)
     const char* others[] = {"AVT_LIB", "AVT_RCCL_LIB", "AVT_SHARD_SELF_SENDRECV", "AVT_SHARD_LOOPBACK_TIMEOUT_S", "AVT_BENCH_SHARE_GPU0", "AVT_TIMING"};
     for (char** e = environ; e && *e; ++e) {
@@ -135,7 +135,7 @@ avt_tuning tuning_from_environment() {
 
 int validate_tuning(const avt_tuning& t) {
     if (t.groups < 0 || t.groups > AVT_MAX_GROUPS || t.g < 0 || t.gcap < 2 || t.vis_frame_min < 0 || t.nspec < 0 || t.nspec > AVT_MAX_SPEC ||
-        (t.ride_strips != 0 && t.ride_strips != 4 && t.ride_strips != 8) || t.mom_min_frames < 1 || t.ride_timeout_us < 0 || (t.lbs_frames != 0 && t.lbs_frames != 1 && t.lbs_frames != 2 && t.lbs_frames != 4)) {
+        (t.ride_strips != 0 && t.ride_strips != 4 && t.ride_strips != 8) || t.mom_min_frames < 1 || t.ride_timeout_us < 0 || (t.lbs_frames != 0 && t.lbs_frames != 1 && t.lbs_frames != 2 && t.lbs_frames != 4) || t.spec_cost < 0 || t.spec_cost > 1) {
         avt_set_error("avt_tuning: a field is out of range (include/avt.h)");
         return 1;
     }
@@ -174,6 +174,7 @@ int check_launch(const char* what) {
 // the launch sequence of one optimize() over the resident frames
 void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStream_t stream) {
     c->fb.f0 = f0;
+    c->fb.max_iters = o->max_iters_per_icp;
     c->cur_stream = stream;
     c->ran_icp_iters = 0;
     const int vis_init = o->enable_occlusion ? 0 : 1;
@@ -215,13 +216,13 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
         { ProfScope ps(c, AVT_K_AGGREGATE); launch_finalize(c, nf); launch_records(c, nf); }
         if (!fuse_init) { ProfScope ps(c, AVT_K_PREPARE); launch_solve(c, nf, SOLVE_INIT); }
         const bool rides = avt_solve_rides(c, nf);        // few frames: the reduction is part of the solve's launch
-        { ProfScope ps(c, AVT_K_EVAL); launch_eval(c, nf, false); }
+        { ProfScope ps(c, AVT_K_EVAL); launch_eval(c, nf, false, 1); }
         if (!rides) { ProfScope ps(c, AVT_K_REDUCE); launch_reduce(c, nf); }
         for (int it = 1; it <= std::max(1, o->max_iters_per_icp); ++it) {
             { ProfScope ps(c, AVT_K_SOLVE); launch_solve(c, nf, it == 1 ? SOLVE_FIRST : SOLVE_NORMAL, it); }
             if (o->max_iters_per_icp == 0) break;
             if (it < o->max_iters_per_icp) {
-                { ProfScope ps(c, AVT_K_EVAL); launch_eval(c, nf, false); }
+                { ProfScope ps(c, AVT_K_EVAL); launch_eval(c, nf, false, it + 1); }
                 if (!rides) { ProfScope ps(c, AVT_K_REDUCE); launch_reduce(c, nf); }
             } else {   // no solve follows the last trial point: its cost alone; the accept test is taken by the k_lbs launch below
                 ProfScope ps(c, AVT_K_DECIDE);
@@ -701,6 +702,10 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         if (dev_alloc(c, &pr, 1)) return 1;
         fb.params = pr;
     }
+    fb.spec_frames = std::min(max_frames, AVT_SPEC_FRAMES);
+    if (dev_alloc(c, &fb.partial_spec, (size_t)fb.spec_frames * AVT_MAX_SPEC * AVT_G_MAX * 256) || dev_alloc(c, &fb.wmask_spec, (size_t)fb.spec_frames * AVT_MAX_SPEC * AVT_G_MAX) ||
+        dev_alloc(c, &fb.prior_spec, (size_t)fb.spec_frames * AVT_MAX_SPEC * AVT_MAX_COMPS * AVT_PRIOR_STRIDE))
+        return 1;
     fb.fsum = (long long*)cntsum;                                   // 8-byte aligned first
     fb.cnt = (int*)(cntsum + FV * 3 * sizeof(long long));
     HIP_OK(hipMemsetAsync(fb.trace, 0, (size_t)max_frames * 64 * sizeof(double), c->stream));

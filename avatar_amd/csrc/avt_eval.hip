@@ -326,8 +326,11 @@ __host__ __device__ constexpr int rd_maxslots(int NT) { int m = 0; for (int w = 
 __host__ __device__ constexpr int rd_pair(int NT, int ti, int tj) { return ti * NT - (ti * (ti - 1)) / 2 + (tj - ti); }
 
 // COST: the evaluation behind which no solve follows - residual column and tile pair (res, res) only (see build_rows)
-template <int CJ, int CK, int MT, bool COST>
-__global__ __launch_bounds__(256, (CJ != 0) ? 3 : 1) void k_eval(DeviceModel dm, FrameBuffers fb, int nframes) {
+// SPEC: the body as a spec-cost workgroup runs it (COST = true there): the trial path and the speculative steps' path are two
+// instantiations behind ONE scalar branch on the block index in k_eval below - with a run-time flag inside one body the trial path paid
+// 0.5 us per launch for carrying the other (same-box A/B of the two builds, tools/kt_lib_ab.sh)
+template <int CJ, int CK, int MT, bool COST, bool SPEC>
+__device__ __forceinline__ void eval_body(const DeviceModel& dm, const FrameBuffers& fb, int nframes) {
     constexpr bool FIXED = CJ != 0;
     const AvtDims d = dm.d;
     const int J = FIXED ? CJ : d.J, K = FIXED ? CK : d.K, P = 3 + 3 * J + K;
@@ -337,9 +340,32 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 1) void k_eval(DeviceModel dm,
     constexpr int RS = AVT_EVAL_RS;
     constexpr int MAXPW = FIXED ? 6 : (ROWDEAL ? rd_maxslots(MT) : (MT * (MT + 1) / 2 + 3) / 4);
     const int G = fb.G, t = threadIdx.x;
-    const int id = blockIdx.x;
-    if (id >= nframes * G) {   // trailing workgroups: pose prior of the trial point, one (frame, GMM component) each
+    int id = blockIdx.x;
+    // Spec-cost workgroups (riding shapes, behind the evaluation and prior workgroups; the full evaluation's grid only): the COST of the
+    // trial point of every speculative LM step that is still in the queue (AvtSpecCtl: made by the solve launch in front with lambda up,
+    // lambda up^2 ..) - residual column and one tile pair, exactly the instructions of the cost-only evaluation - plus its pose-prior
+    // scores.  The solve launch behind then knows, when it rejects the trial point, which of the queued steps would be rejected as well,
+    // takes those accept tests at once and installs the first step that passes (avt_lm.hip): a run of rejections costs ONE launch pair.
+    int spec_s = 0;
+    const int nspecwg = nframes * fb.nspec_cost * (G + d.ncomps);      // the spec-cost workgroups come FIRST in the grid (k_eval below): dispatched first, they run beside the trial point's instead of behind them
+    if constexpr (SPEC) {
+        const int per = G + d.ncomps, ns = fb.nspec_cost, id2 = id;      // ns slots per frame: slot j = the j-th step still in the queue
+        const int fl = id2 / (ns * per), rem = id2 - fl * ns * per, slot = rem / per, r = rem - slot * per, fsp = fl + fb.f0;
+        const AvtSpecCtl& sp = fb.spec[fsp];
+        const int s = sp.next + slot;
+        // (a launch past the iteration budget - every accept test of the ICP iteration but the last has been taken - evaluates nothing)
+        if (fsp >= fb.spec_frames || s >= sp.n || s >= AVT_MAX_SPEC || !sp.valid[min(s, AVT_MAX_SPEC - 1)] || (fb.seq >= 2 && fb.seq + sp.ahead > fb.max_iters)) return;
+        if (r >= G) {
+            extern __shared__ __attribute__((aligned(16))) char smem_prior[];
+            prior_component_at<256>(dm, fb.x_spec + ((size_t)fsp * AVT_MAX_SPEC + s) * d.xsize,
+                                    fb.prior_spec + (((size_t)fsp * AVT_MAX_SPEC + s) * AVT_MAX_COMPS + (r - G)) * AVT_PRIOR_STRIDE, r - G, (double*)smem_prior);
+            return;
+        }
+        spec_s = s;
+        id = fl * G + r;
+    } else if ((id -= nspecwg) >= nframes * G) {   // trailing workgroups: pose prior of the trial point, one (frame, GMM component) each
         const int id2 = id - nframes * G, fp = id2 / d.ncomps + fb.f0;
+        if (!COST && FIXED && fb.nspec_cost > 0 && fp < fb.spec_frames && fb.seq >= 2 && fb.seq + fb.spec[fp].ahead > fb.max_iters) return;      // past the iteration budget
         extern __shared__ __attribute__((aligned(16))) char smem_prior[];
         prior_component(dm, fb, fp, id2 % d.ncomps, 1 - fb.ctl[fp].cur_slot, (double*)smem_prior);
         return;
@@ -375,12 +401,18 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 1) void k_eval(DeviceModel dm,
     const int M = ctl.M;
     const int try_slot = 1 - ctl.cur_slot;
     if (!COST && g == G - 1 && t < 64) {      // what the solver roles of the k_solve launch behind this one decide on (AvtSolveSnap); the last workgroup of a frame has the fewest batches
-        static_assert(sizeof(AvtFrameCtl) == 160 && sizeof(AvtSpecCtl) == 88, "snapshot copy below");
+        static_assert(sizeof(AvtFrameCtl) == 160 && sizeof(AvtSpecCtl) == 96, "snapshot copy below");
         double* sn = (double*)(fb.snap + f);
         if (t < 20) sn[t] = ((const double*)&ctl)[t];
-        else if (t < 31) sn[t] = ((const double*)(fb.spec + f))[t - 20];
-        else if (t >= 32 && t < 32 + K) fb.snap[f].xw[t - 32] = fb.x[((size_t)f * 2 + try_slot) * d.xsize + 3 + 4 * J + (t - 32)];
+        else if (t < 32) sn[t] = ((const double*)(fb.spec + f))[t - 20];
+        else if (t < 32 + K) fb.snap[f].xw[t - 32] = fb.x[((size_t)f * 2 + try_slot) * d.xsize + 3 + 4 * J + (t - 32)];
     }
+    // Past the iteration budget (folded accept tests, avt_lm.hip): the solve launch behind takes no test and needs no system.  The word is
+    // REQUESTED here, in the round trip of the control block, and TESTED behind the staging of the skeleton tables below - where the
+    // workgroup waits for memory anyway: a test right here would put a round trip of its own in front of every evaluation (+0.6 us per
+    // launch, measured), for the sake of the few idle launches at the end of an ICP iteration.
+    const bool budget_watch = !COST && FIXED && fb.nspec_cost > 0 && f < fb.spec_frames && fb.seq >= 2;
+    const int ahead_now = budget_watch ? fb.spec[f].ahead : 0;
     const int nb = (M + AVT_EVAL_PTS - 1) / AVT_EVAL_PTS;
     const int* er = fb.erange + (size_t)f * AVT_ERANGE + g;       // cost-balanced contiguous ranges (eval_ranges, avt_lm.hip)
     const int b_first = strided ? g : er[0], b_end = strided ? nb : er[1];
@@ -398,10 +430,11 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 1) void k_eval(DeviceModel dm,
     double* s_rec = s_Jt + AVT_EVAL_TILE(NC + 1);                 // [4 waves][RQ]
     double* s_ident = s_rec + 4 * RQ;                             // [9]  R(-1,parent of the root) = I
 
-    const double* prep = fb.prep + ((size_t)f * 2 + try_slot) * d.prep_size;
+    const double* prep = SPEC ? fb.prep_spec + ((size_t)f * AVT_MAX_SPEC + spec_s) * d.prep_size : fb.prep + ((size_t)f * 2 + try_slot) * d.prep_size;
     for (int e = t; e < npre + K + 3; e += 256) s_prep[e] = prep[e < npre ? e : e + 4 * J];
     if (t < 9) s_ident[t] = (t == 0 || t == 4 || t == 8) ? 1.0 : 0.0;
     if (t < RS) s_Jt[(size_t)NC * RS + t] = 0.0;
+    if (budget_watch && fb.seq + ahead_now > fb.max_iters) return;      // (workgroup-uniform; nothing has been written yet)
     // MFMA operand fragments: lane l reads storage column tile_col[tile*16 + (l&15)] (padding -> the zero column), rows k0 + (l>>4)
     // six-tile shape: my wave's five dealt pairs (pair index = bit of the batch word, operand fragments, diagonal or not) and my
     // k-steps of the split pair
@@ -595,7 +628,9 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 1) void k_eval(DeviceModel dm,
         }
     }
     // partial tiles out: element (row = (ln>>4) + 4*reg, col = ln&15) of pair p at [p][reg*64 + ln]
-    double* part = fb.partial + (((size_t)f * G + g) * NPAIR) * 256;
+    // (a spec-cost workgroup writes its one tile - pair res_pair - into the spec step's own block: the base is shifted so that the store below lands there)
+    double* part = SPEC ? fb.partial_spec + (((size_t)f * AVT_MAX_SPEC + spec_s) * AVT_G_MAX + g) * 256 - (size_t)d.res_pair * 256
+                           : fb.partial + (((size_t)f * G + g) * NPAIR) * 256;
     if constexpr (ROWDEAL) {
         auto out_role = [&](auto wc) {
             constexpr int W = decltype(wc)::value;
@@ -628,7 +663,19 @@ __global__ __launch_bounds__(256, (CJ != 0) ? 3 : 1) void k_eval(DeviceModel dm,
             for (int r = 0; r < 4; ++r) part[(size_t)p * 256 + r * 64 + ln] = acc[i][r];
         }
     }
-    if (t == 0) fb.wmask[(size_t)f * G + g] = wm;
+    if (t == 0) {
+        if (SPEC) fb.wmask_spec[((size_t)f * AVT_MAX_SPEC + spec_s) * AVT_G_MAX + g] = wm;
+        else fb.wmask[(size_t)f * G + g] = wm;
+    }
+}
+
+// COST: the evaluation behind which no solve follows - residual column and tile pair (res, res) only (see build_rows)
+template <int CJ, int CK, int MT, bool COST>
+__global__ __launch_bounds__(256, (CJ != 0) ? 3 : 1) void k_eval(DeviceModel dm, FrameBuffers fb, int nframes) {
+    if constexpr (!COST && CJ != 0) {      // the spec-cost workgroups of the riding shapes sit behind the evaluation and prior workgroups (launch_eval)
+        if ((int)blockIdx.x < nframes * fb.nspec_cost * (fb.G + dm.d.ncomps)) { eval_body<CJ, CK, MT, true, true>(dm, fb, nframes); return; }
+    }
+    eval_body<CJ, CK, MT, COST, false>(dm, fb, nframes);
 }
 
 static bool eval_fixed_shape(const AvtDims& d) { return d.J == 24 && d.K == 10; }
@@ -639,9 +686,12 @@ static size_t eval_lds_bytes(const AvtDims& d) {
 }
 
 // cost_only: the last evaluation of an ICP iteration (launch_reduce(.., decide = true) follows)
-void launch_eval(avt_ctx* c, int nframes, bool cost_only) {
+void launch_eval(avt_ctx* c, int nframes, bool cost_only, int next_seq) {
     const AvtDims& d = c->dm.d;
-    dim3 grid((unsigned)nframes * (c->fb.G + std::max(0, d.ncomps)));
+    // riding shapes with speculative solver workgroups: the cost of every queued speculative step beside the trial point (k_eval)
+    const int nspec = (!cost_only && next_seq >= 1 && eval_fixed_shape(d)) ? avt_solve_nspec(c, nframes) : 0;      // (how many of the queued steps: avt_tuning.spec_cost)
+    c->fb.nspec_cost = nspec; c->fb.seq = next_seq;
+    dim3 grid((unsigned)nframes * (c->fb.G + std::max(0, d.ncomps)) * (1 + nspec));
     const size_t lds = eval_lds_bytes(d);
 #define AVT_EVAL_LAUNCH(...) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<__VA_ARGS__>), grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, nframes)
     if (eval_fixed_shape(d)) { if (cost_only) AVT_EVAL_LAUNCH(24, 10, 6, true); else AVT_EVAL_LAUNCH(24, 10, 6, false); }

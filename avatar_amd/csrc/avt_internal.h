@@ -140,11 +140,13 @@ struct AvtFrameCtl {
 // the solve launch factors that system for lambda, lambda up, lambda up^2 .. side by side (one workgroup each); after a rejection
 // the next launch installs the step that is already there instead of factoring again.
 #define AVT_MAX_SPEC 4
+#define AVT_SPEC_FRAMES 4     // frames per context that can have their speculative steps' costs evaluated ahead (one-frame launch shapes: up to three frames)
 struct AvtSpecCtl {
     int next, n;                   // next speculative step to use, how many the last full solve launch made
     int valid[AVT_MAX_SPEC];       // its factorisation succeeded
     double lambda[AVT_MAX_SPEC];   // the damping it was made with (= what the accept test would have set)
     double pred[AVT_MAX_SPEC];     // the decrease its quadratic model predicts (gain-ratio schedule)
+    int ahead, pad;                // accept tests taken AHEAD of their launches in this ICP iteration (folded rejections, avt_lm.hip): the solve launch `seq` takes test number seq - 1 + ahead
 };
 
 // What the solver roles of a riding k_solve launch decide on (avt_lm.hip): the control block, the speculative-step queue and the
@@ -228,8 +230,10 @@ struct DeviceModel {
 struct FrameBuffers {
     int max_frames, max_points;   // per frame
     int G;                        // eval blocks per frame
-    int nspec;                    // speculative solver workgroups per frame in the current k_solve launch (riding shape; 0: none)
-    int seq;                      // which solve of the ICP iteration the current k_solve launch is (1 = FIRST): the riding reduction counts up to seq x its workgroups
+    int nspec;                    // speculative solver workgroups per frame in the current k_solve launch (riding shape; 0: none); k_eval: of the launch that follows
+    int nspec_cost;               // k_solve: workgroups per frame that reduce the speculative steps' costs (= nspec when k_eval evaluated them, else 0)
+    int seq;                      // which solve of the ICP iteration the current k_solve launch is (1 = FIRST): the riding reduction counts up to seq x its workgroups (k_eval: the solve that FOLLOWS it)
+    int max_iters;                // GN iterations per ICP iteration of the call being enqueued (the accept tests a launch sequence may take ahead of its launches are bounded by it)
     int f0;                       // first frame of the frame group a launch covers (grid frame index is relative to it)
     // raw inputs
     double* data_raw;     // [max_frames*max_points][3]
@@ -257,6 +261,11 @@ struct FrameBuffers {
     AvtSpecCtl* spec;                        // [max_frames] speculative steps of the current system (avt_lm.hip)
     double* x_spec;                          // [max_frames][AVT_MAX_SPEC][xsize] their trial states ...
     double* prep_spec;                       // [max_frames][AVT_MAX_SPEC][prep_size] ... and skeleton tables
+    // the COST of every speculative step's trial point, evaluated beside the trial point (spec-cost workgroups of k_eval, riding shapes only):
+    double* partial_spec;                    // [spec_frames][AVT_MAX_SPEC][AVT_G_MAX][256] the partial tile that holds sum c |r|^2 ...
+    unsigned long long* wmask_spec;          // [spec_frames][AVT_MAX_SPEC][AVT_G_MAX] ... which workgroups wrote it
+    double* prior_spec;                      // [spec_frames][AVT_MAX_SPEC][AVT_MAX_COMPS][AVT_PRIOR_STRIDE] GMM scores at those points
+    int spec_frames;                         // frames these three hold (the riding shapes: <= AVT_SPEC_FRAMES); the verdict of the accept test taken on them travels in ride_ctr (avt_lm.hip)
     unsigned char* vis_sorted;               // [max_frames][V] the visibility flags in part-sorted order (inside optimize(): k_nn_vis)
     // correspondence aggregation
     int* cnt;             // [max_frames][V]
@@ -371,7 +380,8 @@ void launch_bucket(avt_ctx* c, int nframes, bool clear_after);
 void launch_state_reset(avt_ctx* c, int nframes);
 void launch_nn(avt_ctx* c, int nframes);
 void launch_finalize(avt_ctx* c, int nframes);
-void launch_eval(avt_ctx* c, int nframes, bool cost_only = false);
+void launch_eval(avt_ctx* c, int nframes, bool cost_only = false, int next_seq = 0 /* which solve of the ICP iteration follows (riding shapes) */);
+int avt_solve_nspec(const avt_ctx* c, int nframes);       // speculative solver workgroups per frame of the k_solve launch that follows an evaluation (0: none)
 void launch_records(avt_ctx* c, int nframes);
 void launch_reduce(avt_ctx* c, int nframes);
 bool avt_solve_rides(const avt_ctx* c, int nframes);      // the reduction rides in k_solve's launch: no launch_reduce in front of launch_solve

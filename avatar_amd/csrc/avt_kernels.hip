@@ -493,7 +493,7 @@ __global__ __launch_bounds__(1024) void k_finalize(DeviceModel dm, FrameBuffers 
     const int f = blockIdx.x + fb.f0, t = threadIdx.x, V = dm.d.V;
     AvtFrameCtl& ctl = fb.ctl[f];
     if (t < 2 * (AVT_MAX_PARTS + 1)) fb.part_cnt[(size_t)f * 2 * (AVT_MAX_PARTS + 1) + t] = 0;   // bucketing is over: restore the invariant
-    if (t == 0) { fb.ride_ctr[f] = 0; fb.spec[f].n = 0; fb.spec[f].next = 0; }
+    if (t == 0) { fb.ride_ctr[f] = 0; fb.spec[f].n = 0; fb.spec[f].next = 0; fb.spec[f].ahead = 0; }
     if (t == 0 && first_icp) fb.fault[f] = 0;      // a fault belongs to the optimize() call that raised it: one nobody downloaded must not mark this call's fit   // a new ICP iteration: no reduction has ridden yet, no speculative step exists
     __shared__ int s_wave_m[16], s_wave_t[16];
     const int chunk = (V + 1023) / 1024;

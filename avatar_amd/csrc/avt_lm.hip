@@ -593,6 +593,85 @@ __device__ __forceinline__ double ld_agent(const double* p) {
     return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
+// The accept test of the FIRST queued speculative step, taken ahead (one workgroup per frame in the riding k_solve launch, beside the
+// strips).  k_eval's spec-cost workgroups left one partial tile per evaluation workgroup: the element that holds sum c |r|^2 is summed
+// over the workgroups by the operations reduce_ride_block below performs for that element of the trial point's system - same slices, same
+// order, same written-mask rule - and the step's objective is formed from it term by term as k_solve forms the trial point's (cost
+// constant, GMM score of the minimising component in ascending order with strict '<', shape prior), so that the test gives what the test
+// on the fully evaluated point would give, bit for bit.  Published (agent scope, read by every solver role of this launch behind its
+// wait): 1.0 = the step FAILS the test against the current point's cost AND may be folded - it exists, is valid, and the solve launch
+// takes test number seq - 1 + ahead with one more still leaving the LAST test of the ICP iteration (number max_iters) to the k_lbs
+// launch; 0.0 otherwise.  Inputs: the snapshot k_eval left (what every solver role decides on).  Counts itself in like the strips.
+// layout of FrameBuffers::ride_ctr: the workgroups that have delivered since k_finalize cleared the word | the launch the fold verdict is for | idle
+#define AVT_RIDE_COUNT_MASK 0xffffu
+#define AVT_RIDE_SEQ_SHIFT 16
+#define AVT_RIDE_SEQ_MASK 0x7fu
+#define AVT_RIDE_IDLE 0x80000000u
+template <int STRIPS>
+__device__ __forceinline__ void reduce_spec_cost(const DeviceModel& dm, const FrameBuffers& fb, int f, int slot, double* s_q) {
+    constexpr int EL = 256 / STRIPS, NSL = 256 / EL, NLD = AVT_G_MAX / NSL;
+    const AvtDims& d = dm.d;
+    const int t = threadIdx.x, el = t % EL, slice = t / EL;
+    const bool have = f < fb.spec_frames;
+    const AvtSolveSnap& sn = fb.snap[f];
+    const int spn = sn.sp.next, s = min(spn + slot, AVT_MAX_SPEC - 1);      // slot 0 = the first step still in the queue when k_eval ran
+    const int pair = d.res_pair, strip = d.res_elem / EL;
+    const int e = strip * EL + el;
+    const int G = fb.G, glo = (G * slice) / NSL, ghi = (G * (slice + 1)) / NSL, ng = ghi - glo;
+    const size_t blk = ((size_t)(have ? f : 0) * AVT_MAX_SPEC + s) * AVT_G_MAX;
+    const double* part = fb.partial_spec + blk * 256 + e;
+    double v[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) v[u] = __builtin_nontemporal_load(part + (size_t)min(glo + u, G - 1) * 256);
+    const unsigned long long wmine = el < ng ? fb.wmask_spec[blk + glo + el] : 0ull;
+    // (the test's other inputs, requested in the same round trip: they depend on the snapshot only)
+    const double cost_cur = sn.ctl.cost_cur, cost_const = sn.ctl.cost_const, sbp = sn.ctl.sbp, sbs = sn.ctl.sbs;
+    const int try_valid = sn.ctl.try_valid, sp_n = sn.sp.n, valid = sn.sp.valid[s], ahead = sn.sp.ahead;
+    const double* ps = fb.prior_spec + ((size_t)(have ? f : 0) * AVT_MAX_SPEC + s) * AVT_MAX_COMPS * AVT_PRIOR_STRIDE;
+    const double* xk = fb.x_spec + ((size_t)f * AVT_MAX_SPEC + s) * d.xsize + 3 + 4 * d.J;
+    const double pv = t < d.ncomps ? ps[(size_t)t * AVT_PRIOR_STRIDE] : 0.0;                 // lane c: score of component c
+    const double xw = (t >= 64 && t - 64 < d.K) ? xk[t - 64] : 0.0;                           // lane 64 + k: shape coefficient k
+    unsigned long long wrote = pair < 64 ? __ballot((int)((wmine >> (pair & 63)) & 1ull)) : ~0ull;
+    if (EL == 32) wrote >>= 32 * (slice & 1);
+    double a = 0.0;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) a += (u < ng && ((wrote >> u) & 1ull)) ? v[u] : 0.0;
+    __shared__ double s_pv[AVT_MAX_COMPS], s_xw[AVT_MAX_SHAPE];
+    if (t < AVT_MAX_COMPS) s_pv[t] = pv;
+    if (t >= 64 && t < 64 + AVT_MAX_SHAPE) s_xw[t - 64] = xw;
+    if (slice > 0) s_q[(slice - 1) * EL + el] = a;
+    __syncthreads();
+    if (slice == 0) {
+#pragma unroll
+        for (int i = 0; i < NSL - 1; ++i) a += s_q[i * EL + el];
+        if (e == d.res_elem) {
+            double ck = 0.5 * a + cost_const;
+            if (sbp > 0.0 && d.ncomps > 0) {
+                double bs = 1.7976931348623157e308;
+                for (int c = 0; c < d.ncomps; ++c) if (s_pv[c] < bs) bs = s_pv[c];
+                ck += 0.5 * sbp * sbp * bs;
+            }
+            if (sbs > 0.0) {
+                double sa = 0.0;
+#pragma unroll
+                for (int kk = 0; kk < AVT_MAX_SHAPE; ++kk) if (kk < d.K) { const double rr = s_xw[kk] * sbs; sa += rr * rr; }
+                ck += 0.5 * sa;
+            }
+            const bool may = have && slot == 0 && try_valid != 0 && spn < sp_n && spn < AVT_MAX_SPEC && valid != 0 && fb.seq >= 2 &&
+                             (fb.seq - 1 + ahead) + 1 <= fb.max_iters - 1;
+            // The verdicts travel IN THE RIDE COUNTER (AVT_RIDE_* below), the one word of this launch every solver role reads anyway
+            // (its poll): a load of their own for them taxed every k_solve launch 0.25-0.5 us, a branch on the snapshot's `ahead` 0.75 us
+            // (same-box A/B, the feature off).  Set before this workgroup counts itself in, by the same thread: final when the count is.
+            unsigned bits = 0u;
+            if (have && fb.seq >= 2 && fb.seq + ahead > fb.max_iters) bits |= AVT_RIDE_IDLE;                      // sticky for the rest of the ICP iteration
+            if (may && !(ck < cost_cur)) bits |= ((unsigned)fb.seq & AVT_RIDE_SEQ_MASK) << AVT_RIDE_SEQ_SHIFT;     // "the first queued step fails: take its test now" - tagged with the launch it is for
+            __hip_atomic_fetch_and(fb.ride_ctr + f, ~(AVT_RIDE_SEQ_MASK << AVT_RIDE_SEQ_SHIFT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (bits) __hip_atomic_fetch_or(fb.ride_ctr + f, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(fb.ride_ctr + f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 template <int STRIPS>
 __device__ __forceinline__ void reduce_ride_block(const DeviceModel& dm, const FrameBuffers& fb, int f, int bx, double* s_q /* 256 doubles of the launch's dynamic LDS */) {
     constexpr int EL = 256 / STRIPS, NSL = 256 / EL, NLD = AVT_G_MAX / NSL;      // elements per strip, slices (of EL lanes), partial tiles per slice
@@ -651,8 +730,10 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // RIDE: grid (frames, 1 + nspec + RIDE NPAIR): y = 0 the solver, y = 1 .. nspec the speculative solvers (the same system with
     // lambda up, lambda up^2 ..: the steps a run of rejected trial points will ask for), the rest the reduction in front of them
+    // (behind the strips, when k_eval evaluated them: one workgroup per speculative step that reduces the step's cost, reduce_spec_cost)
     const int role = RIDE ? (int)blockIdx.y : 0;
     if constexpr (RIDE) {
+        if (role > fb.nspec + RIDE * dm.d.NPAIR) { reduce_spec_cost<RIDE>(dm, fb, blockIdx.x + fb.f0, role - 1 - fb.nspec - RIDE * dm.d.NPAIR, (double*)smem); return; }
         if (role > fb.nspec) { reduce_ride_block<RIDE>(dm, fb, blockIdx.x + fb.f0, role - 1 - fb.nspec, (double*)smem); return; }
     }
     __builtin_amdgcn_s_setprio(3);   // one dependency chain per frame: issue ahead of the evaluation waves of another frame group on this CU
@@ -732,6 +813,12 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
 #pragma unroll
         for (int k = 0; k < AVT_MAX_SHAPE; ++k) snap_xw[k] = k < K ? fb.snap[f].xw[k] : 0.0;
     }
+    // Past the iteration budget: earlier launches of this ICP iteration took accept tests ahead of their launches (folded rejections,
+    // below), every test but the last - which belongs to the k_lbs launch - has been taken, and the trial point is waiting for that one.
+    // Such a launch is idle: its solver roles do not wait for the reduction and leave behind the barrier below.  (A `return` right here -
+    // a branch on the freshly loaded snapshot in front of everything else - cost every install-type launch 0.25 us: same-box A/B.)
+    bool idle = false;
+    unsigned ride_word = 0u;
     // (solver, RIDE) the speculative step the accept test may ask for in a moment: its 10 KB are requested now, while the reduction
     // is still on its way, so that a rejection only has to store them
     // (256-thread shape: 3 + 3J + K <= 87 and K <= 16 bound the prep block by 1496 doubles and the state by 115)
@@ -755,17 +842,24 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
             // process, a profiler serialising dispatch).  The wait is therefore bounded by wall-clock time (2 s by default), and a
             // role that gives up says so: the frame's fault word makes the host calls that return its result fail
             // (download_state, avt_shard_gather_download) instead of handing out a fit made from a half-reduced system.
-            const unsigned want = (unsigned)(fb.seq * RIDE * d.NPAIR);
+            const unsigned want = (unsigned)(fb.seq * (RIDE * d.NPAIR + fb.nspec_cost));      // (< 2^16: AVT_RIDE_COUNT_MASK)
             const long long t0 = wall_clock64();
             // (a frame that already carries a fault of this call fails fast: every later launch would wait the full time again)
             const long long limit = fault_at_start ? 0 : fb.ride_timeout;
             bool there;
-            while (!(there = __hip_atomic_load(fb.ride_ctr + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) &&
+            unsigned word;
+            while (!(there = ((word = __hip_atomic_load(fb.ride_ctr + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & AVT_RIDE_COUNT_MASK) >= want) &&
                    wall_clock64() - t0 < limit)
                 __builtin_amdgcn_s_sleep(1);
             if (!there) atomicOr(fb.fault + f, AVT_FAULT_RIDE_TIMEOUT);
+            s_failf[1] = (int)word;      // the spec-cost workgroup's verdicts ride in the word (reduce_spec_cost): handed to the other threads across the barrier
         }
         __syncthreads();
+        // (behind the second barrier instead - after the requests for the system's entries - this costs an install-type launch 0.2 instead of 0.6 us,
+        // but an idle launch 7.6 instead of 4.8 us: measured both ways, the frames whose rejections come in runs gain more from cheap idle launches)
+        ride_word = (unsigned)s_failf[1];
+        idle = MODE == SOLVE_NORMAL && (ride_word & AVT_RIDE_IDLE) != 0;      // past the iteration budget: nothing to decide, nothing to solve
+        if (idle) return;
     }
     auto hload = [&](const double* q) { if constexpr (RIDE) return ld_agent(q); else return *q; };
     if constexpr (!TRI && MODE != SOLVE_DECIDE) {
@@ -799,6 +893,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         }
     }
     const double hpp0 = hload(H0 + (size_t)P * HS + P), hpp1 = hload(H0 + (size_t)HS * HS + (size_t)P * HS + P);
+
     const double lm_up = fb.params->lm_up, lm_down = fb.params->lm_down, lm_min = fb.params->lm_min, lm_max = fb.params->lm_max;   // same round trip
     const bool gain = fb.params->lm_policy != 0.0;          // gain-ratio damping schedule (avt_options::lm_policy)
     // RIDE: every solver role decides on the snapshot the evaluation launch made (AvtSolveSnap): the solver rewrites the live
@@ -877,7 +972,34 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     const AvtSpecCtl& spin = snap_sp;                       // (RIDE only)
     const int sp_next = RIDE ? spin.next : 0, sp_n = RIDE ? spin.n : 0;
     const bool rejected = mode != SOLVE_FIRST && try_valid && !accepted;
-    const bool use_spec = RIDE && rejected && sp_next < sp_n && spin.valid[min(sp_next, AVT_MAX_SPEC - 1)] != 0;
+    // Folded rejections (RIDE shapes whose k_eval evaluated the queued speculative steps' costs, fb.nspec_cost): the trial point has just
+    // been rejected, so the next trial point is the first queued step - made from the SAME system with the lambda this rejection leaves.
+    // Its cost is known; if it fails the accept test as well, that test (the next GN iteration's) is taken here and now, lambda advances
+    // as it would have, and the step after it is looked at - until one passes (it is installed below, evaluated in full by the next
+    // k_eval launch and accepted by the next solve) or the queue ends (a full solve with the lambda reached).  Same tests on the same
+    // numbers in the same order as one launch pair per rejection: nothing changes but the number of launches that do something.
+    // The budget: this launch takes test number seq - 1 + ahead; the LAST test of the ICP iteration is left to the k_lbs launch.
+    // Folded rejection (riding shapes whose k_eval evaluated the cost of the first queued speculative step, FrameBuffers::nspec_cost = 1).
+    // The trial point has just been rejected, so the next trial point is that step - made from the SAME system with the lambda this
+    // rejection leaves.  Its cost is known: if it fails the accept test as well, that test (the next GN iteration's) is taken here and
+    // now, lambda advances as it would have, and the step behind it is the one to install (or, the queue at its end, a full solve with
+    // the lambda reached).  Same tests on the same numbers in the same order as one launch pair per rejection: nothing changes but the
+    // number of launches that do something.
+    // The test itself is NOT taken here: this launch's spec-cost workgroup (reduce_spec_cost, another CU, beside the strips) forms the
+    // step's objective and publishes one word - "fails, and the iteration budget allows taking its test now" - which arrived with the
+    // system's corner entries.  Everything tried inside the solver's own instruction stream taxed every launch, the feature off: a loop
+    // over the queue behind `if (rejected)` 0.45 us, the same as a function 10 us (a call gives the kernel a private stack), its
+    // inputs requested unconditionally with selects instead of branches 2.1 us (same-box A/B of the builds, tools/kt_lib_ab.sh).
+    int nfold = 0;
+    if constexpr (RIDE) {
+        const bool fold = rejected && fb.nspec_cost > 0 && ((ride_word >> AVT_RIDE_SEQ_SHIFT) & AVT_RIDE_SEQ_MASK) == ((unsigned)fb.seq & AVT_RIDE_SEQ_MASK);
+        nfold = fold ? 1 : 0;
+        const double lam_adv = gain ? fmin(lambda * nu, lm_max) : fmin(lambda * lm_up, lm_max);
+        lambda = fold ? lam_adv : lambda;
+        nu = (fold && gain) ? nu * 2.0 : nu;
+    }
+    const int sp_use = sp_next + nfold;
+    const bool use_spec = RIDE && rejected && sp_use < sp_n && sp_use < AVT_MAX_SPEC && spin.valid[min(sp_use, AVT_MAX_SPEC - 1)] != 0;
     if (RIDE && role > 0 && use_spec) return;
     if (RIDE && role > 0) {      // my damping: what `role` rejections in a row would make of the solver's
         for (int i = 0; i < role; ++i) {
@@ -891,7 +1013,10 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         ctl.comp_cur = comp;
         int it = ctl.gn_iterations;
         if (mode == SOLVE_FIRST) { ctl.cost_initial = cost; ctl.cost_const = cost_const; }
-        else { it += 1; ctl.gn_iterations = it; if (accepted) ctl.accepted += 1; }
+        else {
+            for (int i = 0; i < nfold; ++i) { it += 1; if (it < 40) fb.trace[(size_t)f * 64 + it] = cost_cur; }      // the folded tests: rejections, the objective stays
+            it += 1; ctl.gn_iterations = it; if (accepted) ctl.accepted += 1;
+        }
         if (it < 40) fb.trace[(size_t)f * 64 + it] = cost_cur;
     }
     if constexpr (MODE == SOLVE_DECIDE) {
@@ -902,10 +1027,16 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         return;
     }
     if (RIDE && use_spec) {      // (role 0) the step exists: install it as the new trial point
-        const int k = sp_next, tr = 1 - cur;
+        const int k = sp_use, tr = 1 - cur;
         const double* xsrc = fb.x_spec + ((size_t)f * AVT_MAX_SPEC + k) * xs;
         const double* psrc = fb.prep_spec + ((size_t)f * AVT_MAX_SPEC + k) * d.prep_size;
-        (void)xsrc; (void)psrc;
+        if (nfold > 0) {      // (not the step that was requested at kernel start)
+#pragma unroll
+            for (int i = 0; i < SPN; ++i) {
+                const int e = t + i * NTH;
+                sp_pre[i] = e < xs + d.prep_size ? (e < xs ? xsrc[e] : psrc[e - xs]) : 0.0;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < SPN; ++i) {
             const int e = t + i * NTH;
@@ -914,7 +1045,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         }
         if (t == 0) {
             const double lam = spin.lambda[k];
-            sp.next = k + 1;
+            sp.next = k + 1; sp.ahead = spin.ahead + nfold;
             ctl.lambda = lam; ctl.try_valid = 1;
             ctl.dec_cur_slot = cur; ctl.dec_try_valid = 1; ctl.dec_cost_cur = cost_cur; ctl.dec_lambda = lam;
             // (the accept test above already took this rejection into lambda / nu: the installed step was made with exactly that lambda)
@@ -1092,7 +1223,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         // what the accept test of the trial point just made reads if no further solve follows (avt_decide.h)
         ctl.dec_cur_slot = cur; ctl.dec_try_valid = ok ? 1 : 0; ctl.dec_cost_cur = cost_cur; ctl.dec_lambda = lambda;
         ctl.pred = pred_new; ctl.nu = nu; ctl.dec_pred = pred_new; ctl.dec_nu = nu;
-        if (RIDE) { sp.next = 0; sp.n = fb.nspec; }          // the speculative workgroups of this launch are making steps 0 .. nspec - 1
+        if (RIDE) { sp.next = 0; sp.n = fb.nspec; sp.ahead = (mode == SOLVE_FIRST ? 0 : spin.ahead) + nfold; }          // the speculative workgroups of this launch are making steps 0 .. nspec - 1
     }
     if (RIDE && t == 0 && role > 0) { sp.valid[role - 1] = ok ? 1 : 0; sp.lambda[role - 1] = lambda; sp.pred[role - 1] = pred_new; }
     if (RIDE && role > 0 && !ok) return;                     // (a refused speculative factorisation: the slot stays invalid)
@@ -1161,13 +1292,15 @@ static void launch_solve_shape(avt_ctx* c, int nframes, int mode, size_t lds) {
 // Residency is a matter of speed, not of correctness (see the wait in k_solve).  AVT_RIDE_SIZING=groups sizes the shapes by the
 // frame groups that run side by side (two / three frames: one group each) instead of by the one launch.
 static int ride_concurrency(const avt_ctx* c) { return c->tun.ride_sizing_groups ? std::max(1, c->concurrent_groups) : 1; }
+// how many queued speculative steps have their cost evaluated beside the trial point (k_eval's spec-cost workgroups exist in the six-tile shape)
+static int ride_spec_cost(const avt_ctx* c) { return (c->dm.d.J == 24 && c->dm.d.K == 10 && c->tun.spec_cost > 0) ? 1 : 0; }      // (one step ahead: two and four measured the same over twelve frames and lose on frames that accept)
 static int ride_nspec(const avt_ctx* c, int nframes, int strips) {
     // over twelve frames, one frame each: 0 / 2 / 3 / 4 speculative workgroups 0.5045 / 0.4305 / 0.4217 / 0.4166 ms (rejections come
     // in runs of up to five).  Frame batches gain nothing from them - a launch lasts as long as its slowest frame, and with four
     // frames or more some frame always needs a full solve (4 / 8 / 16 / 64 frames: 0.639 / 0.712 / 0.786 / 1.247 ms without,
     // 0.643 / 0.712 / 0.793 / 1.317 ms with four speculative workgroups per frame) - so only the riding shapes have them.
     int want = std::max(0, std::min(AVT_MAX_SPEC, c->tun.nspec));
-    while (want > 0 && ride_concurrency(c) * nframes * (1 + want + strips * c->dm.d.NPAIR) > c->num_cus) --want;
+    while (want > 0 && ride_concurrency(c) * nframes * (1 + want + std::min(want, ride_spec_cost(c)) + strips * c->dm.d.NPAIR) > c->num_cus) --want;
     return want;
 }
 static int ride_strips(const avt_ctx* c, int nframes) {      // 8 strips per pair while the whole grid is resident (one SMPL frame), else 4, else none
@@ -1177,14 +1310,19 @@ static int ride_strips(const avt_ctx* c, int nframes) {      // 8 strips per pai
     return 0;
 }
 bool avt_solve_rides(const avt_ctx* c, int nframes) { return ride_strips(c, nframes) != 0; }
+int avt_solve_nspec(const avt_ctx* c, int nframes) {
+    const int rs = ride_strips(c, nframes);
+    return rs ? std::min(ride_nspec(c, nframes, rs), ride_spec_cost(c)) : 0;
+}
 
 void launch_solve(avt_ctx* c, int nframes, int mode, int seq) {
     const AvtDims& d = c->dm.d;
     const int rs = (mode != SOLVE_INIT && mode != SOLVE_DECIDE) ? ride_strips(c, nframes) : 0;
-    c->fb.nspec = 0; c->fb.seq = seq;
+    c->fb.nspec = 0; c->fb.nspec_cost = 0; c->fb.seq = seq;
     if (rs) {
         c->fb.nspec = ride_nspec(c, nframes, rs);
-        const dim3 grid(nframes, 1 + c->fb.nspec + rs * d.NPAIR);
+        c->fb.nspec_cost = std::min(c->fb.nspec, ride_spec_cost(c));
+        const dim3 grid(nframes, 1 + c->fb.nspec + rs * d.NPAIR + c->fb.nspec_cost);
 #define AVT_RIDE(M, S) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256, false, M, S>), grid, dim3(256), solve_lds_bytes(d), c->cur_stream, c->dm, c->fb)
         if (mode == SOLVE_FIRST) { if (rs == 8) AVT_RIDE(SOLVE_FIRST, 8); else AVT_RIDE(SOLVE_FIRST, 4); }
         else { if (rs == 8) AVT_RIDE(SOLVE_NORMAL, 8); else AVT_RIDE(SOLVE_NORMAL, 4); }

@@ -7,15 +7,14 @@
 
 // scratch: 2*ndims doubles of LDS
 #define PRIOR_BATCH 18
+// x: the state (p, q, w) the prior is evaluated at; po: where the component's score and Prec (x - mu) go
 template <int NTH = 256>
-__device__ __forceinline__ void prior_component(const DeviceModel& dm, const FrameBuffers& fb, int f, int c, int try_slot, double* scratch) {
+__device__ __forceinline__ void prior_component_at(const DeviceModel& dm, const double* __restrict__ x, double* __restrict__ po, int c, double* scratch) {
     const AvtDims d = dm.d;
     const int t = threadIdx.x;
     const int n = d.ndims, J = d.J;
-    double* po = fb.prior + (((size_t)f * 2 + try_slot) * AVT_MAX_COMPS + c) * AVT_PRIOR_STRIDE;
     double* s_x = scratch;
     double* s_q = scratch + AVT_MAX_JOINTS * 3;
-    const double* x = fb.x + ((size_t)f * 2 + try_slot) * d.xsize;
     if (t < J - 1) {  // Eigen AngleAxis(Quaternion): angle in [0,pi], axis sign follows w
         const double* q = x + 3 + 4 * (t + 1);
         double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
@@ -59,4 +58,9 @@ __device__ __forceinline__ void prior_component(const DeviceModel& dm, const Fra
         sacc = wave_sum(sacc);
         if (t == 0) po[0] = 0.5 * sacc - dm.prior_clog[c];
     }
+}
+
+template <int NTH = 256>
+__device__ __forceinline__ void prior_component(const DeviceModel& dm, const FrameBuffers& fb, int f, int c, int try_slot, double* scratch) {
+    prior_component_at<NTH>(dm, fb.x + ((size_t)f * 2 + try_slot) * dm.d.xsize, fb.prior + (((size_t)f * 2 + try_slot) * AVT_MAX_COMPS + c) * AVT_PRIOR_STRIDE, c, scratch);
 }

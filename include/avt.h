@@ -262,7 +262,9 @@ typedef struct avt_tuning {
     int asm_parts;           /* moment form: 1 (default) the assembly of a frame runs as six independent 256-thread role workgroups, 0 as one 1024-thread workgroup */
     long long ride_timeout_us; /* how long a solver role waits for the riding reduction before it raises the frame's fault (2 000 000) */
     int lbs_frames;          /* frame batches: frames skinned per workgroup (k_lbs_multi); 0 = automatic (4 from 128 frames per launch on, 2 from 64), 1 = one (k_lbs), 2, 4 */
-    int reserved;
+    int spec_cost;           /* riding shapes: 1 (default) the COST of the first queued speculative LM step is evaluated beside the trial point, so that the solve
+                              * launch that rejects the trial point takes that step's accept test as well when it fails too - two rejections in one launch pair
+                              * (DESIGN section 4); 0: one launch pair per rejection */
 } avt_tuning;
 int avt_ctx_get_tuning(avt_ctx* c, avt_tuning* out);
 int avt_ctx_set_tuning(avt_ctx* c, const avt_tuning* t);

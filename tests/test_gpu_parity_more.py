@@ -400,3 +400,35 @@ def test_limit_one_joint_per_point_matches_oracle(smpl, frame0):
     # and it is a different fit from the blended model's (the flag does something)
     ref0 = orc.OracleModel(smpl).optimize(pm, 24, data, labels, opt, p0, q0, w0, aggregate=1)
     assert abs(ref0["stats"].final_cost - ref["stats"].final_cost) > 1e-6 * abs(ref["stats"].final_cost)
+
+
+@pytest.mark.gpu
+def test_folded_accept_tests_do_not_change_a_bit(smpl, omodel, gmodel):
+    """Riding shapes: k_eval evaluates the COST of the queued speculative steps beside the trial point, and the solve launch that rejects
+    the trial point takes the accept tests of the steps that would be rejected as well at once (avt_tuning.spec_cost; 0 = one launch
+    pair per rejection).  Same tests on the same numbers in the same order: parameters, objective trace, damping
+    and iteration counts are bit-identical with and without, on frames whose rejections come in runs of two to five, over several ICP
+    iterations (the iteration budget is per ICP iteration), with both damping policies - and equal to the oracle's sequence."""
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    for seed, policy, icp in ((8, 0, 1), (4, 0, 3), (5, 1, 2)):
+        fr = synth.make_frame(smpl, seed)
+        p0, q0, w0 = _start(fr)
+        n = len(fr["labels"])
+        opt = Options.demo(icp_iters=icp, lm_policy=policy)
+        out = {}
+        for sc in (0, 1):
+            ctx = api.Context(gmodel, 24, pm, n, 1)
+            ctx.set_tuning(spec_cost=sc)
+            p, q, w, st = ctx.optimize_batch([fr["data"]], [fr["labels"]], opt, p0[None], q0[None], w0[None])
+            # (the debug trace is indexed by the CUMULATIVE iteration count: 10 icp + 1 entries, the last ICP iteration's are the last eleven)
+            out[sc] = (p, q, w, st[0].gn_iterations, st[0].accepted_steps, st[0].lambda_, st[0].final_cost, ctx.cost_trace(0, n=10 * icp + 1), ctx.cloud(0))
+        for sc in (1,):
+            for a, b in zip(out[0], out[sc]):
+                assert np.array_equal(np.asarray(a), np.asarray(b)), (seed, sc)
+        ref = omodel.optimize(pm, 24, fr["data"], fr["labels"], opt, p0, q0, w0, aggregate=1)
+        assert out[1][3] == ref["stats"].gn_iterations == 10 * icp and out[1][4] == ref["stats"].accepted_steps
+        assert np.abs(out[1][8] - ref["cloud"]).max() < 1e-6
+        tr = out[1][7][-11:]
+        assert [int(tr[k + 1] < tr[k]) for k in range(10)] == [int(a == 1) for a in ref["trace_acc"][-10:]]
+        assert np.allclose(tr, ref["trace_cost"][-11:], rtol=1e-9, atol=0)
