@@ -209,7 +209,7 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
             // the accept test of the last trial point: the decision part of the solve kernel alone (SOLVE_DECIDE: no factorisation, no step)
             if (o->max_iters_per_icp > 0) { ProfScope ps(c, AVT_K_DECIDE); launch_solve(c, nf, SOLVE_DECIDE, o->max_iters_per_icp + 1); }
             { ProfScope ps(c, AVT_K_LBS); const bool more = icp + 1 < o->icp_iters;
-              launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 2, more ? vis_init : -1, false, fuse_init && more, false, few && more); }
+              launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 2, more ? vis_init : -1, false, fuse_init && more, false, few && more, !more); }      // (the last launch of the call also writes the result records)
             c->ran_icp_iters++;
             continue;
         }
@@ -230,7 +230,7 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
             }
         }
         { ProfScope ps(c, AVT_K_LBS); const bool more = icp + 1 < o->icp_iters;      // the last launch of the call skins only: no bookkeeping reset, no part-sorted copy
-          launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 2, more ? vis_init : -1, false, fuse_init && more, o->max_iters_per_icp > 0, few && more); }   // :1494-1497 (2: from the skeleton tables of the current point)
+          launch_lbs(c, nf, nullptr, nullptr, nullptr, nullptr, 2, more ? vis_init : -1, false, fuse_init && more, o->max_iters_per_icp > 0, few && more, !more); }   // :1494-1497 (2: from the skeleton tables of the current point)
         c->ran_icp_iters++;
     }
     c->lbs_cleared = false;
@@ -266,6 +266,7 @@ bool choose_moments(const avt_ctx* c, int nf) {
 // replay of a cached graph alike (set inside enqueue_optimize these flags described the last CAPTURED graph, not the last one run)
 void note_products(avt_ctx* c, const avt_options* o) {
     if (o->icp_iters > 0) { c->have_moments = c->fb.use_moments != 0; c->have_records = !c->have_moments; }
+    c->results_fresh = o->icp_iters > 0;      // the closing k_lbs launch of the call wrote fb.results (no ICP iteration: no closing launch)
 }
 
 int run_optimize(avt_ctx* c, const avt_options* o) {
@@ -369,6 +370,7 @@ int install_frames(avt_ctx* c, int nframes, const int* counts, const double* dat
     const bool same_shape = c->frames_valid && nframes == c->nframes;
     c->frames_valid = false;
     c->have_moments = c->have_records = false;      // new frames: the moments / records of the old correspondences describe nothing resident
+    c->results_fresh = false;
     c->nframes = nframes;
     c->frame_N.assign(counts, counts + nframes);
     c->frame_off.assign(nframes + 1, 0);
@@ -416,6 +418,7 @@ int upload_state(avt_ctx* c, int nframes, const double* p, const double* q, cons
     HIP_OK(hipMemcpyAsync(c->fb.ctl_start, c->fb.ctl, ctl.size() * sizeof(AvtFrameCtl), hipMemcpyDeviceToDevice, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));  // host vectors go out of scope
     c->state_valid = true;
+    c->results_fresh = false;
     return 0;
 }
 
@@ -489,13 +492,6 @@ int optimize_host_to_host(avt_ctx* c, int nframes, const double* data, const int
         HIP_OK(hipHostMalloc((void**)&c->host_pin, cap, hipHostMallocDefault));
         c->host_pin_cap = cap;
     }
-    if (c->d_results_cap < (size_t)nframes * stride) {
-        HIP_OK(hipStreamSynchronize(c->stream));
-        if (c->d_results) (void)hipFree(c->d_results);
-        c->d_results = nullptr; c->d_results_cap = 0;
-        HIP_OK(hipMalloc((void**)&c->d_results, (size_t)c->fb.max_frames * stride * 8));
-        c->d_results_cap = (size_t)c->fb.max_frames * stride;
-    }
     char* pin = c->host_pin;
     double* h_data = (double*)pin; int* h_lab = (int*)(pin + b_data); double* h_x = (double*)(pin + b_data + b_lab);
     AvtFrameCtl* h_ctl = (AvtFrameCtl*)(pin + b_data + b_lab + b_x); double* h_res = (double*)(pin + b_data + b_lab + b_x + b_ctl);
@@ -529,9 +525,10 @@ int optimize_host_to_host(avt_ctx* c, int nframes, const double* data, const int
     HIP_OK(hipMemcpyAsync(c->fb.x_start, c->fb.x, b_x, hipMemcpyDeviceToDevice, c->stream));
     HIP_OK(hipMemcpyAsync(c->fb.ctl_start, c->fb.ctl, b_ctl, hipMemcpyDeviceToDevice, c->stream));
     c->frames_valid = c->state_valid = true;
+    c->results_fresh = false;
     if (run_optimize(c, o)) return 1;
-    launch_pack_results(c, nframes, c->d_results, stride);
-    HIP_OK(hipMemcpyAsync(h_res, c->d_results, b_res, hipMemcpyDeviceToHost, c->stream));
+    if (!c->results_fresh) { launch_pack_results(c, nframes, c->fb.results, stride); c->results_fresh = true; }      // (a call without ICP iterations has no closing k_lbs launch)
+    HIP_OK(hipMemcpyAsync(h_res, c->fb.results, b_res, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));      // the one synchronisation of the call
     int bad = -1, nbad = 0;
     unsigned badbits = 0;
@@ -606,7 +603,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
     c->frames_valid = c->state_valid = false;
     c->have_moments = c->have_records = false;
     c->concurrent_groups = 1;
-    c->host_pin = nullptr; c->host_pin_cap = 0; c->d_results = nullptr; c->d_results_cap = 0;
+    c->host_pin = nullptr; c->host_pin_cap = 0; c->results_fresh = false;
     c->render_zkey = nullptr; c->render_label = nullptr; c->render_block = nullptr; c->render_cap_pix = c->render_cap_blk = 0;
     c->render_mkey = nullptr; c->render_depth = nullptr; c->render_fkey = nullptr; c->render_frank = nullptr; c->render_fedge = nullptr;
     c->render_cap_paint_pix = c->render_cap_paint_face = 0;
@@ -685,7 +682,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         dev_alloc(c, &fb.rec, (size_t)max_frames * d.nb_max * 4 * d.rec_quad) || dev_alloc(c, &fb.partial, part_cap * d.NPAIR * 256) || dev_alloc(c, &fb.wmask, part_cap) || dev_alloc(c, &fb.bmask, (size_t)max_frames * d.nb_max) || dev_alloc(c, &fb.erange, (size_t)max_frames * AVT_ERANGE) || dev_alloc(c, &fb.Hraw, (size_t)max_frames * 2 * d.HS * d.HS) ||
         dev_alloc(c, &fb.prior, (size_t)max_frames * 2 * AVT_MAX_COMPS * AVT_PRIOR_STRIDE) || dev_alloc(c, &fb.ctl, (size_t)max_frames) ||
         dev_alloc(c, &fb.jointpos, (size_t)max_frames * 3 * J) || dev_alloc(c, &fb.jointtrans, (size_t)max_frames * 12 * J) ||
-        dev_alloc(c, &fb.trace, (size_t)max_frames * 64))
+        dev_alloc(c, &fb.trace, (size_t)max_frames * 64) || dev_alloc(c, &fb.results, (size_t)max_frames * (d.xsize + 8)))
         return 1;
     fb.use_moments = 0;
     if (d.mom_ok) {      // moment form of the data term (avt_moments.hip): T per (frame, joint pair), D per (frame, joint), scratch of the assembly
@@ -743,7 +740,6 @@ void avt_ctx_destroy(avt_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->host_pin) (void)hipHostFree(c->host_pin);
-    if (c->d_results) (void)hipFree(c->d_results);
     if (c->render_zkey) (void)hipFree(c->render_zkey);
     if (c->render_label) (void)hipFree(c->render_label);
     if (c->render_block) (void)hipFree(c->render_block);
@@ -907,6 +903,7 @@ int avt_synth_render_frames_mode(avt_ctx* c, int nframes, const double* w, const
     HIP_OK(hipStreamSynchronize(c->stream));
     c->frames_valid = c->state_valid = false;
     c->have_moments = c->have_records = false;
+    c->results_fresh = false;
     c->nframes = nframes;
     c->frame_N.assign(nframes, 0);
     c->frame_off.assign(nframes + 1, 0);
@@ -985,6 +982,7 @@ int avt_state_reset(avt_ctx* c) {
     if (!c || c->nframes <= 0 || !c->state_valid) { avt_set_error("avt_state_reset: no state resident"); return 1; }
     HIP_OK(hipSetDevice(c->device));
     launch_state_reset(c, c->nframes);
+    c->results_fresh = false;
     return check_launch("k_state_reset");
 }
 

@@ -290,6 +290,8 @@ struct FrameBuffers {
     double* jointpos;     // [max_frames][3J]
     double* jointtrans;   // [max_frames][12J]
     double* trace;        // [max_frames][64] cost trace (debug)
+    double* results;      // [max_frames][xsize + 8] the result record of every frame - current state (p, q, w), seven statistics, the fault word (k_pack_results' layout) -
+                          // written by workgroup 0 of the k_lbs launch that closes optimize(): what the batch split gathers and the host-pointer calls copy back
     const AvtRunParams* params;   // one block per context
     // moment form of the data term (avt_moments.hip): accumulated once per ICP iteration by k_moments
     double* mom_T;        // [max_frames][np][npsi (npsi + 1) / 2] T_kk' = sum_m c_m a_mk a_mk' psi_m psi_m^T, packed upper triangle
@@ -354,7 +356,7 @@ struct avt_ctx {
     // host-to-host calls (avt_optimize / avt_optimize_batch on host pointers): one pinned staging block for everything that crosses PCIe
     // in either direction and one device block for the packed results, grown on demand - the call then needs ONE host synchronisation
     char* host_pin; size_t host_pin_cap;
-    double* d_results; size_t d_results_cap;     // doubles
+    bool results_fresh;              // fb.results describes the resident states (the last optimize() packed them and nothing changed them since)
     // persistent scratch of avt_synth_render_frames (z-buffer keys, labels, block counts), grown on demand
     unsigned long long* render_zkey; unsigned char* render_label; int* render_block; size_t render_cap_pix; size_t render_cap_blk;
     // painter's-order mode only: second key image, float depth image, per-face sort key / order position / edge-on flag
@@ -370,7 +372,7 @@ enum { SOLVE_INIT = 0, SOLVE_FIRST = 1, SOLVE_NORMAL = 2, SOLVE_DECIDE = 3 /* th
 void launch_lbs(avt_ctx* c, int nframes, const double* x_state_or_null, const double* w, const double* p, const double* R,
                 int from_state, int vis_init /* -1: leave bookkeeping alone; 0/1: reset it, visibility flags to this value */,
                 bool with_bucket_count = false, bool with_init = false, bool decide = false /* from_state 2: accept test of the last trial point first */,
-                bool write_pc = true /* also the part-sorted copy of the cloud (pcx/pcy/pcz, vis_sorted) */);
+                bool write_pc = true /* also the part-sorted copy of the cloud (pcx/pcy/pcz, vis_sorted) */, bool pack = false /* workgroup 0 of every frame also writes the frame's result record (fb.results) */);
 int avt_lbs_set_attributes();
 bool avt_lbs_can_init(const AvtDims& d);
 size_t avt_visibility_frame_lds(const AvtDims& d);

@@ -16,9 +16,23 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(DeviceModel dm, FrameBuf
 // the per-vertex loads are SoA and fully coalesced: 3(K+1) shape planes + 4 (weight, joint) pairs in,
 // 3 doubles out => ~336 B/vertex algorithmic traffic.
 // =================================================================================================
+// Result record of a frame (include/avt_shard.h: the current state x = (p, q, w), AVT_SHARD_STAT_DOUBLES statistics): written by the calling workgroup
+__device__ __forceinline__ void pack_result_row(const FrameBuffers& fb, int f, int xsize, int t, int nth) {
+    const AvtFrameCtl& ctl = fb.ctl[f];
+    const double* x = fb.x + ((size_t)f * 2 + ctl.cur_slot) * xsize;
+    double* o = fb.results + (size_t)f * (xsize + 8);
+    for (int e = t; e < xsize; e += nth) o[e] = x[e];
+    if (t == 0) {
+        double* s = o + xsize;
+        s[0] = ctl.cost_initial; s[1] = ctl.cost_cur; s[2] = ctl.lambda; s[3] = (double)ctl.T; s[4] = (double)ctl.M;
+        s[5] = (double)ctl.gn_iterations; s[6] = (double)ctl.accepted;
+        s[7] = (double)fb.fault[f];      // sticky device fault bits of the frame (0 = its result is valid)
+    }
+}
+
 __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, const double* __restrict__ w_in,
                                              const double* __restrict__ p_in, const double* __restrict__ R_in,
-                                             int from_state, int vis_init, int nlbs, int with_init, int decide, int write_pc) {
+                                             int from_state, int vis_init, int nlbs, int with_init, int decide, int write_pc, int pack) {
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, V = d.V;
     const int f = blockIdx.y + fb.f0, t = threadIdx.x;
@@ -113,6 +127,10 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
     if (blockIdx.x == 0) {
         if (t < 3 * J) fb.jointpos[(size_t)f * 3 * J + t] = s_o[t];
         for (int e = t; e < 12 * J; e += 256) fb.jointtrans[(size_t)f * 12 * J + e] = s_T[e];
+        // the launch that closes optimize(): the frame's result record (what k_pack_results wrote in a 4.9 us launch of its own behind every
+        // optimize() whose results are gathered or copied back).  The accept test of the last trial point - its writer is thread 0 of this
+        // workgroup - lies two barriers back: the control block is final.
+        if (pack) pack_result_row(fb, f, d.xsize, t, 256);
     }
     const int v = blockIdx.x * 256 + t;
     if (v >= V) return;
@@ -205,7 +223,7 @@ __device__ __forceinline__ void fk_chain_multi(int J, const int* __restrict__ pa
 }
 
 template <int FT>
-__global__ __launch_bounds__(256) void k_lbs_multi(DeviceModel dm, FrameBuffers fb, int from_state, int vis_init, int nlbs, int nb, int nframes, int write_pc) {
+__global__ __launch_bounds__(256) void k_lbs_multi(DeviceModel dm, FrameBuffers fb, int from_state, int vis_init, int nlbs, int nb, int nframes, int write_pc, int pack) {
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, V = d.V;
     const int t = threadIdx.x, y0 = blockIdx.y * FT;
@@ -278,6 +296,7 @@ __global__ __launch_bounds__(256) void k_lbs_multi(DeviceModel dm, FrameBuffers 
             const int f = fb.f0 + y0 + i;
             if (t < 3 * J) fb.jointpos[(size_t)f * 3 * J + t] = s_o[(size_t)i * 3 * J + t];
             for (int e = t; e < 12 * J; e += 256) fb.jointtrans[(size_t)f * 12 * J + e] = s_T[(size_t)i * 12 * J + e];
+            if (pack) pack_result_row(fb, f, d.xsize, t, 256);      // (the closing launch of optimize(): the frame's result record, see k_lbs)
         }
     }
     const int v = blockIdx.x * 256 + t;
@@ -346,21 +365,21 @@ static size_t lbs_multi_lds(const AvtDims& d, int FT) { return sizeof(double) * 
 // with_bucket_count: also histogram the data labels (first half of launch_bucket) in trailing workgroups;
 // with_init: also set up the trial point of the next ICP iteration (one trailing workgroup per frame)
 void launch_lbs(avt_ctx* c, int nframes, const double*, const double* w, const double* p, const double* R, int from_state, int vis_init,
-                bool with_bucket_count, bool with_init, bool decide, bool write_pc) {
+                bool with_bucket_count, bool with_init, bool decide, bool write_pc, bool pack) {
     const int nlbs = (c->dm.d.V + 255) / 256;
     const int nb = with_bucket_count ? std::max(1, (c->launch_maxN + BUCKET_TILE - 1) / BUCKET_TILE) : 0;
     // frame batches: several frames per workgroup (k_lbs_multi) - the shapes without an accept test or a trial-point workgroup in the launch
     const int FT = (from_state >= 1 && !with_init && !decide && c->tun.lbs_frames != 1) ? (c->tun.lbs_frames > 1 ? c->tun.lbs_frames : (nframes >= 128 ? 4 : (nframes >= 64 ? 2 : 1))) : 1;
     if (FT > 1) {
         const dim3 g2(nlbs + FT * nb, (nframes + FT - 1) / FT);
-        if (FT == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lbs_multi<4>), g2, dim3(256), lbs_multi_lds(c->dm.d, 4), c->cur_stream, c->dm, c->fb, from_state, vis_init, nlbs, std::max(nb, 1), nframes, write_pc ? 1 : 0);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lbs_multi<2>), g2, dim3(256), lbs_multi_lds(c->dm.d, 2), c->cur_stream, c->dm, c->fb, from_state, vis_init, nlbs, std::max(nb, 1), nframes, write_pc ? 1 : 0);
+        if (FT == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lbs_multi<4>), g2, dim3(256), lbs_multi_lds(c->dm.d, 4), c->cur_stream, c->dm, c->fb, from_state, vis_init, nlbs, std::max(nb, 1), nframes, write_pc ? 1 : 0, pack ? 1 : 0);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lbs_multi<2>), g2, dim3(256), lbs_multi_lds(c->dm.d, 2), c->cur_stream, c->dm, c->fb, from_state, vis_init, nlbs, std::max(nb, 1), nframes, write_pc ? 1 : 0, pack ? 1 : 0);
         return;
     }
     dim3 grid(nlbs + (with_init ? 1 : 0) + nb, nframes);
     const size_t lds = with_init ? prep_init_lds_bytes(c->dm.d) : 0;
     hipLaunchKernelGGL(k_lbs, grid, dim3(256), lds, c->cur_stream, c->dm, c->fb, w, p, R, from_state, vis_init, nlbs, with_init ? 1 : 0,
-                       decide && from_state == 2 ? 1 : 0, write_pc ? 1 : 0);
+                       decide && from_state == 2 ? 1 : 0, write_pc ? 1 : 0, pack ? 1 : 0);
 }
 
 // the trial-point workgroup's scratch must fit beside k_lbs's static LDS (large skeletons fall back to the k_solve INIT launch)
@@ -564,17 +583,13 @@ void launch_finalize(avt_ctx* c, int nframes) {
 // x = (p, q, w) followed by AVT_SHARD_STAT_DOUBLES statistics, `stride` doubles per frame.  grid (nframes), block 128.
 // =================================================================================================
 __global__ __launch_bounds__(128) void k_pack_results(FrameBuffers fb, double* __restrict__ out, int xsize, int stride) {
+    // (out == fb.results, stride == xsize + 8: the one layout there is; the closing k_lbs launch of optimize() writes the same rows itself - this kernel
+    // remains for results asked for without an optimize() in front, and for a send block that is not fb.results)
     const int f = blockIdx.x, t = threadIdx.x;
-    const AvtFrameCtl& ctl = fb.ctl[f];
-    const double* x = fb.x + ((size_t)f * 2 + ctl.cur_slot) * xsize;
-    double* o = out + (size_t)f * stride;
-    for (int e = t; e < xsize; e += 128) o[e] = x[e];
-    if (t == 0) {
-        double* s = o + xsize;
-        s[0] = ctl.cost_initial; s[1] = ctl.cost_cur; s[2] = ctl.lambda; s[3] = (double)ctl.T; s[4] = (double)ctl.M;
-        s[5] = (double)ctl.gn_iterations; s[6] = (double)ctl.accepted;
-        s[7] = (double)fb.fault[f];      // sticky device fault bits of the frame (0 = its result is valid); avt_shard_gather_download checks them
-    }
+    (void)stride;
+    FrameBuffers fo = fb;
+    fo.results = out;
+    pack_result_row(fo, f, xsize, t, 128);
 }
 
 void launch_pack_results(avt_ctx* c, int nframes, double* out, int stride) {

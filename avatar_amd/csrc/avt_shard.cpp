@@ -567,6 +567,7 @@ struct avt_shard {
     std::string backend;
     // result gather: per-rank send block and the gathered block, device
     double* d_send = nullptr; double* d_recv = nullptr; size_t gather_cap = 0;   // doubles per rank block
+    const double* gathered = nullptr;      // where the last gather left every rank's block (d_recv; one rank: the context's own result records)
     void* d_stage = nullptr; size_t stage_cap = 0;                              // scatter / broadcast staging, bytes
     void* d_stage2 = nullptr; size_t stage2_cap = 0;
     hipStream_t gather_stream = nullptr;   // the stream the last all-gather was enqueued on
@@ -962,12 +963,17 @@ extern "C" int avt_shard_gather_enqueue(avt_shard* s, avt_ctx* c, int B) {
         for (int i = 0; i < per; ++i) rows[(size_t)i * stride + c->dm.d.xsize + 7] = (double)AVT_FAULT_NOT_RESIDENT;
         HIP_OK(hipMemcpyAsync(s->d_send, rows.data(), blk * 8, hipMemcpyHostToDevice, c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));
-    } else if (nloc) {
-        // (one rank: the gathered block IS this rank's block - the results are packed straight into it; an all-gather over one rank is a
-        // device-to-device copy kernel of its own on the stream, 4.3 us per step for the identity)
-        launch_pack_results(c, nloc, direct ? s->d_recv : s->d_send, stride);
+    } else if (nloc && !c->results_fresh) {      // (no optimize() in front: the records are made now)
+        launch_pack_results(c, nloc, c->fb.results, stride);
+        c->results_fresh = true;
     }
-    if (!direct) NCCL_OK(s, s->api->AllGather(s->d_send, s->d_recv, blk, ncclDouble, s->comm, c->stream));
+    // The result records (p, q, w, statistics, fault word per resident frame) are written by the k_lbs launch that closes optimize()
+    // (FrameBuffers::results): they ARE the send block.  One rank: they are the gathered block as well - an all-gather over one rank is a
+    // device-to-device copy kernel on the stream, 4.3 us per step for the identity.
+    const double* send = (mismatch || (size_t)per > (size_t)c->fb.max_frames) ? s->d_send : c->fb.results;
+    if (!mismatch && send == s->d_send && nloc) HIP_OK(hipMemcpyAsync(s->d_send, c->fb.results, (size_t)nloc * stride * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (!direct) NCCL_OK(s, s->api->AllGather(send, s->d_recv, blk, ncclDouble, s->comm, c->stream));
+    s->gathered = direct ? c->fb.results : s->d_recv;
     s->gather_stream = c->stream;
     if (mismatch) { avt_set_error("avt_shard_gather_enqueue: resident frames differ from this rank's share of the batch (its rows were gathered as faulty)"); return 1; }
     return 0;
@@ -985,10 +991,10 @@ extern "C" int avt_shard_gather_download(avt_shard* s, avt_ctx* c, int B, double
     const AvtDims& d = c->dm.d;
     const int W = s->world, per = (B + W - 1) / W, stride = gather_stride(c), xs = d.xsize, J = d.J, K = d.K;
     const size_t blk = (size_t)per * stride;
-    if (s->gather_cap < blk || !s->d_recv) { avt_set_error("avt_shard_gather_download: nothing was gathered"); return 1; }
+    if (s->gather_cap < blk || !s->d_recv || !s->gathered) { avt_set_error("avt_shard_gather_download: nothing was gathered"); return 1; }
     HIP_OK(hipSetDevice(s->device));
     std::vector<double> host(blk * W);
-    HIP_OK(hipMemcpyAsync(host.data(), s->d_recv, host.size() * 8, hipMemcpyDeviceToHost, c->stream));   // behind the all-gather
+    HIP_OK(hipMemcpyAsync(host.data(), s->gathered, (s->gathered == s->d_recv ? host.size() : std::min(host.size(), (size_t)c->fb.max_frames * stride)) * 8, hipMemcpyDeviceToHost, c->stream));   // behind the all-gather
     HIP_OK(hipStreamSynchronize(c->stream));
     int bad = -1;
     for (int f = 0; f < B; ++f) {

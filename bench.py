@@ -35,14 +35,14 @@ REGIONS = 15                   # the K-step timed region is repeated this many t
 # what actually limits each kernel class (counters under profiles/): the HBM roofline is the yard-stick
 # SURVEY.md §8(d) prescribes, it is NOT what bounds the latency-bound kernels
 LIMITER = {
-    "solve": "latency: one workgroup per frame walking an 85-pivot LDL^T dependency chain (working set in LDS/L2); one or two frames: the steps a run of rejections asks for are factored speculatively beside it, a launch that installs one is ~10 us",
+    "solve": "latency: one workgroup per frame walking an 85-pivot LDL^T dependency chain (working set in LDS/L2); one to three frames: the steps a run of rejections asks for are factored speculatively beside it (a launch that installs one is ~9 us) and the first of them has its accept test taken ahead, so two rejections are one launch pair",
     "eval": "LDS pipe and dependent-latency chains of the row builder at three workgroups per CU; fp64 MFMA contraction behind it",
     "reduce": "L2 round trips (partial tiles live in L2/MALL)",
     "nn": "fp64 VALU issue (8 flop + one v_min per candidate, candidates through scalar loads)",
     "lbs": "HBM/L2 streaming of the shape planes", "bucket": "LDS + global atomics", "visibility": "launch latency (few frames); one pass over the cloud, faces from LDS (batches)",
     "aggregate": "launch latency / gathers", "prepare": "latency (skeleton pass)",
     "decide": "cost-only evaluation of the last trial point (its accept test is taken inside the k_lbs launch that follows)",
-    "eval_moments": "latency at low occupancy: k_pairpass stages 4 packed pair moments per 64-thread workgroup through 26 KB of LDS (six workgroups per CU, two dependent L2 round trips each), k_assemble is one 1024-thread workgroup per frame of short dependent LDS chains",
+    "eval_moments": "latency at low occupancy: k_pairpass stages 4 packed pair moments per 64-thread workgroup through 26 KB of LDS (six workgroups per CU, two dependent L2 round trips each); k_assemble_parts is six independent 256-thread role workgroups per frame whose longest (the core) is four short dependent phases",
     "solve_moments": "latency: one workgroup per frame (decision, 85-pivot LDL^T, back substitution, retraction, skeleton pass); the system it reads is 2 x 62 KB per frame",
 }
 
