@@ -59,7 +59,15 @@ class Options(C.Structure):
         o.beta_pose, o.beta_shape = 0.05, 0.12
         for k, v in kw.items():
             setattr(o, k, v)
+        if o.lm_policy == 1 and "lm_up" not in kw:
+            o.lm_up = cls.GAIN_LM_UP
         return o
+
+    # gain-ratio schedule (lm_policy = 1): the multiplier of the first rejection after an accepted step.  Nielsen's 2 climbs too slowly for
+    # these frames (three rejections in a row after the second step of most of them); over the 12 bench seeds (tools/damping_policy_compare.py)
+    # 2 / 4 / 8 / 16 / 32 accept 0.76 / 0.80 / 0.83 / 0.87 / 0.86 of the iterations of one ICP iteration and end at a mean objective of
+    # 28.39 / 28.10 / 27.91 / 27.98 / 27.87 (fixed factors: 0.57, 28.98)
+    GAIN_LM_UP = 16.0
 
 
 class Tuning(C.Structure):

@@ -275,6 +275,7 @@ int run_optimize(avt_ctx* c, const avt_options* o) {
     if (!c->state_valid) { avt_set_error("avt_optimize: no start state resident for these frames (avt_state_upload)"); return 1; }
     if (o->max_iters_per_icp < 0 || o->max_iters_per_icp > 62 || o->icp_iters < 0) { avt_set_error("avt_optimize: bad iteration counts"); return 1; }
     if (o->lm_policy != 0 && o->lm_policy != 1) { avt_set_error("avt_optimize: lm_policy must be 0 (fixed factors) or 1 (gain ratio)"); return 1; }
+    if (!(o->lm_up > 1.0) || !(o->lm_down > 0.0 && o->lm_down < 1.0)) { avt_set_error("avt_optimize: lm_up must be > 1 and lm_down in (0, 1)"); return 1; }
     if (sync_params(c, o)) return 1;
     c->ran_max_iters = o->max_iters_per_icp;
     // Large batches run as several frame groups: the latency-bound single-workgroup-per-frame kernels of one group

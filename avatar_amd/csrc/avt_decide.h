@@ -108,8 +108,8 @@ __device__ __forceinline__ int lm_last_decide(const DeviceModel& dm, const Frame
             accepted = true;
             if (gain) {
                 const double u = 2.0 * ((cost_cur0 - cost) / pred0) - 1.0;
-                lambda = fmin(fmax(lambda * fmax(1.0 / 3.0, 1.0 - u * u * u), lm_min), lm_max);
-                nu = 2.0;
+                lambda = fmin(fmax(lambda * fmax(lm_down, 1.0 - u * u * u), lm_min), lm_max);
+                nu = lm_up;
             } else lambda = fmax(lambda * lm_down, lm_min);
         } else if (gain) { lambda = fmin(lambda * nu, lm_max); nu *= 2.0; }
         else lambda = fmin(lambda * lm_up, lm_max);

@@ -508,7 +508,7 @@ void launch_bucket(avt_ctx* c, int nframes, bool clear_after) {
 // tiles a vertex's rows touch, then ascending id), so that batches of 16 matched points share their live tiles.
 // =================================================================================================
 __global__ __launch_bounds__(1024) void k_finalize(DeviceModel dm, FrameBuffers fb, int first_icp) {
-    const double beta_pose = fb.params->beta_pose, beta_shape = fb.params->beta_shape, lambda0 = fb.params->lambda0;
+    const double beta_pose = fb.params->beta_pose, beta_shape = fb.params->beta_shape, lambda0 = fb.params->lambda0, nu0 = fb.params->lm_up;
     const int f = blockIdx.x + fb.f0, t = threadIdx.x, V = dm.d.V;
     AvtFrameCtl& ctl = fb.ctl[f];
     if (t < 2 * (AVT_MAX_PARTS + 1)) fb.part_cnt[(size_t)f * 2 * (AVT_MAX_PARTS + 1) + t] = 0;   // bucketing is over: restore the invariant
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(1024) void k_finalize(DeviceModel dm, FrameBuffers 
         ctl.sbs = beta_shape * sqrt((double)total_t) / 15.0;
         if (first_icp) {
             ctl.lambda = lambda0;
-            ctl.nu = 2.0; ctl.pred = 0.0;
+            ctl.nu = nu0; ctl.pred = 0.0;      // (read by the gain-ratio schedule only)
             ctl.gn_iterations = 0;
             ctl.accepted = 0;
         }

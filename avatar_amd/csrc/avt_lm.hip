@@ -955,10 +955,10 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     } else if (try_valid) {
         if (cost < cost_cur0) {
             accepted = true; cur = try0;
-            if (gain) {      // rho = actual / predicted decrease; lambda *= max(1/3, 1 - (2 rho - 1)^3), the rejection factor starts over
+            if (gain) {      // rho = actual / predicted decrease; lambda *= max(lm_down, 1 - (2 rho - 1)^3), the rejection factor starts over at lm_up
                 const double u = 2.0 * ((cost_cur0 - cost) / pred0) - 1.0;
-                lambda = fmin(fmax(lambda * fmax(1.0 / 3.0, 1.0 - u * u * u), lm_min), lm_max);
-                nu = 2.0;
+                lambda = fmin(fmax(lambda * fmax(lm_down, 1.0 - u * u * u), lm_min), lm_max);
+                nu = lm_up;
             } else lambda = fmax(lambda * lm_down, lm_min);
         } else if (gain) { lambda = fmin(lambda * nu, lm_max); nu *= 2.0; }
         else lambda = fmin(lambda * lm_up, lm_max);

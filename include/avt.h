@@ -89,8 +89,10 @@ typedef struct avt_options {
     int num_threads;            /* optimize(..., num_threads = 4): accepted, ignored on the GPU path */
     int lm_policy;              /* damping schedule: 0 (default) fixed factors lm_up / lm_down; 1 gain ratio (Nielsen): see DESIGN.md section 4 */
     double lm_lambda0;          /* initial damping (relative to diag H); default 1e-3 */
-    double lm_up;               /* damping multiplier on a rejected step; default 4 */
-    double lm_down;             /* damping multiplier on an accepted step; default 1/3 */
+    double lm_up;               /* > 1.  lm_policy 0: damping multiplier on a rejected step; default 4.  lm_policy 1: the multiplier of the FIRST
+                                   rejection after an accepted step (it doubles with every further one); Nielsen's 2, 16 on the bench frames */
+    double lm_down;             /* in (0, 1).  lm_policy 0: damping multiplier on an accepted step; default 1/3.  lm_policy 1: the floor of the
+                                   multiplier max(lm_down, 1 - (2 rho - 1)^3) an accepted step applies (Nielsen's 1/3) */
     double lm_lambda_min;       /* default 1e-12 */
     double lm_lambda_max;       /* default 1e8 */
 } avt_options;

@@ -1077,10 +1077,10 @@ int orc_optimize(const orc_model* m, int num_parts, const int* part_map, const d
         s.initial_cost = cur.cost;
         if (trace_cost) trace_cost[(size_t)icp * (o->max_iters_per_icp + 1)] = cur.cost;
         // damping schedule (avt_options::lm_policy): 0 = fixed factors lm_up / lm_down; 1 = gain ratio (Nielsen 1999):
-        // rho = actual / predicted decrease, predicted = 1/2 delta^T (lambda D delta - g); accepted: lambda *= max(1/3, 1 - (2 rho - 1)^3),
-        // nu = 2; rejected or not factorable: lambda *= nu, nu *= 2
+        // rho = actual / predicted decrease, predicted = 1/2 delta^T (lambda D delta - g); accepted: lambda *= max(lm_down, 1 - (2 rho - 1)^3),
+        // nu = lm_up; rejected or not factorable: lambda *= nu, nu *= 2   (Nielsen's constants are lm_down = 1/3, lm_up = 2)
         const bool gain = o->lm_policy == 1;
-        if (icp == 0) nu = 2.0;
+        if (icp == 0) nu = o->lm_up;
         auto reject = [&]() {
             if (gain) { lambda = std::min(lambda * nu, o->lm_lambda_max); nu *= 2.0; }
             else lambda = std::min(lambda * o->lm_up, o->lm_lambda_max);
@@ -1098,8 +1098,8 @@ int orc_optimize(const orc_model* m, int num_parts, const int* part_map, const d
                         for (int i = 0; i < P; ++i) pred += delta[i] * (lambda * cur.H[(size_t)i * P + i] * delta[i] - cur.g[i]);
                         pred *= 0.5;
                         const double rho = (cur.cost - tr.cost) / pred, u = 2.0 * rho - 1.0;
-                        lambda = std::min(std::max(lambda * std::max(1.0 / 3.0, 1.0 - u * u * u), o->lm_lambda_min), o->lm_lambda_max);
-                        nu = 2.0;
+                        lambda = std::min(std::max(lambda * std::max(o->lm_down, 1.0 - u * u * u), o->lm_lambda_min), o->lm_lambda_max);
+                        nu = o->lm_up;
                     } else {
                         lambda = std::max(lambda * o->lm_down, o->lm_lambda_min);
                     }

@@ -15,13 +15,13 @@ def _start(fr):
     return p0, api.rot_to_quat(R0), w0
 
 
-@pytest.mark.parametrize("frames,form", [(1, 0), (2, 0), (5, 0), (5, 1), (9, 0)])
-def test_gain_ratio_schedule_matches_oracle(smpl, omodel, gmodel, frames, form):
+@pytest.mark.parametrize("frames,form,lm_up", [(1, 0, None), (2, 0, None), (5, 0, None), (5, 1, None), (9, 0, None), (1, 0, 2.0), (5, 1, 2.0)])
+def test_gain_ratio_schedule_matches_oracle(smpl, omodel, gmodel, frames, form, lm_up):
     from avatar_amd import api
     pm = synth.identity_part_map()
     frs = [synth.make_frame(smpl, 40 + s) for s in range(frames)]
     starts = [_start(fr) for fr in frs]
-    opt = Options.demo(icp_iters=2, lm_policy=1)
+    opt = Options.demo(icp_iters=2, lm_policy=1) if lm_up is None else Options.demo(icp_iters=2, lm_policy=1, lm_up=lm_up, lm_down=0.25)      # (None: Options.GAIN_LM_UP)
     ctx = api.Context(gmodel, 24, pm, 60000, frames)
     ctx.set_data_term(form)
     P, Q, W, st = ctx.optimize_batch([fr["data"] for fr in frs], [fr["labels"] for fr in frs], opt, np.array([s[0] for s in starts]),
@@ -48,5 +48,6 @@ def test_gain_ratio_schedule_is_reproducible_and_rejects_bad_policy(smpl, gmodel
     a = ctx.optimize_batch([fr["data"]], [fr["labels"]], opt, p0[None], q0[None], w0[None])
     b = ctx.optimize_batch([fr["data"]], [fr["labels"]], opt, p0[None], q0[None], w0[None])
     assert all(np.array_equal(x, y) for x, y in zip(a[:3], b[:3]))
-    with pytest.raises(api.AvtError):
-        ctx.optimize_batch([fr["data"]], [fr["labels"]], Options.demo(lm_policy=7), p0[None], q0[None], w0[None])
+    for bad in (dict(lm_policy=7), dict(lm_up=1.0), dict(lm_down=1.0), dict(lm_policy=1, lm_down=0.0)):
+        with pytest.raises(api.AvtError):
+            ctx.optimize_batch([fr["data"]], [fr["labels"]], Options.demo(**bad), p0[None], q0[None], w0[None])

@@ -223,6 +223,25 @@ def test_lm_schedule_descends_and_recovers_ground_truth(smpl, omodel, frame0):
     assert np.abs(res2["cloud"] - res3["cloud"]).max() < 1e-8
 
 
+def test_gain_ratio_schedule_accepts_more_and_ends_lower_on_the_bench_seeds(smpl, omodel):
+    """avt_options.lm_policy = 1 with the demo constants (Options.GAIN_LM_UP: the first rejection's multiplier) on the 12 bench seeds: at
+    least 0.8 of the GN iterations move the estimate (the fixed factors: under 0.6) and no seed ends at a higher objective."""
+    from oracle import oracle as orc
+    pm = synth.identity_part_map()
+    acc = {0: [], 1: []}
+    lower = 0
+    for seed in range(12):
+        fr = synth.make_frame(smpl, seed)
+        w0, p0, R0 = fr["start"]
+        r = [omodel.optimize(pm, 24, fr["data"], fr["labels"], Options.demo(lm_policy=pol), p0, orc.rot_to_quat(R0), w0, aggregate=1)["stats"] for pol in (0, 1)]
+        for pol in (0, 1):
+            acc[pol].append(r[pol].accepted_steps / r[pol].gn_iterations)
+        lower += r[1].final_cost < r[0].final_cost
+    assert Options.demo(lm_policy=1).lm_up == Options.GAIN_LM_UP and Options.demo(lm_policy=1, lm_up=2.0).lm_up == 2.0 and Options.demo().lm_up == 4.0
+    assert np.mean(acc[1]) >= 0.8 and np.mean(acc[0]) < 0.6, (np.mean(acc[0]), np.mean(acc[1]))
+    assert lower == 12
+
+
 def test_lm_not_worse_than_scipy_bfgs(smpl, omodel, frame0):
     """Closest available stand-in for the reference's Ceres BFGS line search (AvatarOptimizer.cpp:1322-1326): scipy
     BFGS on the same cost/gradient with the same correspondences and 10 iterations must not reach a lower objective."""
