@@ -105,11 +105,11 @@ avt_tuning tuning_from_environment() {
     avt_tuning t;
     std::memset(&t, 0, sizeof t);
     t.use_graph = 1; t.groups = 0; t.g = 0; t.gcap = 128; t.vis_frame_min = 64; t.ride = 1; t.ride_strips = 0; t.ride_sizing_groups = 0;
-    t.asm_parts = 1; t.spec_cost = 1; t.nspec = AVT_MAX_SPEC; t.nn_force_part = 0; t.nn_slab = 1; t.mom_min_frames = 32; t.debug = 0; t.ride_timeout_us = 2000000;
+    t.asm_parts = 1; t.spec_cost = 1; t.xcd_frames = 1; t.nspec = AVT_MAX_SPEC; t.nn_force_part = 0; t.nn_slab = 1; t.mom_min_frames = 32; t.debug = 0; t.ride_timeout_us = 2000000;
     struct Knob { const char* name; int* field; };
     const Knob knobs[] = {{"AVT_USE_GRAPH", &t.use_graph}, {"AVT_GROUPS", &t.groups}, {"AVT_G", &t.g}, {"AVT_GCAP", &t.gcap}, {"AVT_VIS_FRAME_MIN", &t.vis_frame_min},
                           {"AVT_RIDE", &t.ride}, {"AVT_RIDE_STRIPS", &t.ride_strips}, {"AVT_RIDE_SIZING_GROUPS", &t.ride_sizing_groups}, {"AVT_NSPEC", &t.nspec},
-                          {"AVT_NN_FORCE_PART", &t.nn_force_part}, {"AVT_NN_SLAB", &t.nn_slab}, {"AVT_MOM_MIN_FRAMES", &t.mom_min_frames}, {"AVT_ASM_PARTS", &t.asm_parts}, {"AVT_LBS_FRAMES", &t.lbs_frames}, {"AVT_SPEC_COST", &t.spec_cost}, {"AVT_DEBUG", &t.debug}};
+                          {"AVT_NN_FORCE_PART", &t.nn_force_part}, {"AVT_NN_SLAB", &t.nn_slab}, {"AVT_MOM_MIN_FRAMES", &t.mom_min_frames}, {"AVT_ASM_PARTS", &t.asm_parts}, {"AVT_LBS_FRAMES", &t.lbs_frames}, {"AVT_SPEC_COST", &t.spec_cost}, {"AVT_XCD_FRAMES", &t.xcd_frames}, {"AVT_DEBUG", &t.debug}};
     // names other parts of the repository own (the batch split, the Python loader, bench.py, instrumented builds)
     const char* others[] = {"AVT_LIB", "AVT_RCCL_LIB", "AVT_SHARD_SELF_SENDRECV", "AVT_SHARD_LOOPBACK_TIMEOUT_S", "AVT_BENCH_SHARE_GPU0", "AVT_TIMING"};
     for (char** e = environ; e && *e; ++e) {
@@ -135,7 +135,7 @@ avt_tuning tuning_from_environment() {
 
 int validate_tuning(const avt_tuning& t) {
     if (t.groups < 0 || t.groups > AVT_MAX_GROUPS || t.g < 0 || t.gcap < 2 || t.vis_frame_min < 0 || t.nspec < 0 || t.nspec > AVT_MAX_SPEC ||
-        (t.ride_strips != 0 && t.ride_strips != 4 && t.ride_strips != 8) || t.mom_min_frames < 1 || t.ride_timeout_us < 0 || (t.lbs_frames != 0 && t.lbs_frames != 1 && t.lbs_frames != 2 && t.lbs_frames != 4) || t.spec_cost < 0 || t.spec_cost > 1) {
+        (t.ride_strips != 0 && t.ride_strips != 4 && t.ride_strips != 8) || t.mom_min_frames < 1 || t.ride_timeout_us < 0 || (t.lbs_frames != 0 && t.lbs_frames != 1 && t.lbs_frames != 2 && t.lbs_frames != 4) || t.spec_cost < 0 || t.spec_cost > 1 || t.xcd_frames < 0 || t.xcd_frames > 1) {
         avt_set_error("avt_tuning: a field is out of range (include/avt.h)");
         return 1;
     }
@@ -711,6 +711,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
     HIP_OK(hipMemsetAsync(fb.ride_ctr, 0, (size_t)max_frames * sizeof(unsigned), c->stream));
     HIP_OK(hipMemsetAsync(fb.fault, 0, (size_t)max_frames * sizeof(unsigned), c->stream));
     fb.ride_timeout = c->tun.ride_timeout_us * 100;      // wall_clock64() ticks at 100 MHz; 0 makes every wait that is not already satisfied fail (tests)
+    fb.xcd_frames = c->tun.xcd_frames;
     HIP_OK(hipMemsetAsync(fb.spec, 0, (size_t)max_frames * sizeof(AvtSpecCtl), c->stream));
     fb.nspec = 0; fb.seq = 0;
     HIP_OK(hipMemsetAsync(fb.part_cnt, 0, (size_t)max_frames * 2 * (AVT_MAX_PARTS + 1) * sizeof(int), c->stream));   // invariant of launch_bucket
@@ -1141,6 +1142,7 @@ int avt_ctx_set_tuning(avt_ctx* c, const avt_tuning* t) {
     c->tun = *t;
     c->vis_frame_min = avt_visibility_frame_lds(c->dm.d) <= 150 * 1024 ? c->tun.vis_frame_min : 0;
     c->fb.ride_timeout = c->tun.ride_timeout_us * 100;
+    c->fb.xcd_frames = c->tun.xcd_frames;
     return 0;
     AVT_API_GUARD_END("avt_ctx_set_tuning")
 }

@@ -69,6 +69,29 @@ __device__ __forceinline__ void fk_chain(int J, const int* __restrict__ parent, 
     }
 }
 
+// Grids of shape (workgroups of a frame, frames) whose workgroups share per-frame data.  The dispatcher deals workgroups to the eight
+// XCDs round-robin in linear order (block b -> XCD b % 8: observed, not promised), so a frame's workgroups land on all of them and the
+// frame's data is fetched into eight L2s.  The remap gives every XCD a contiguous range of the (frame, block) space instead - whole
+// frames, up to one split at each end - and is bijective for every grid size (q, r: the guide's variant for nwg % 8 != 0).
+// A speed choice only: nothing depends on where a workgroup runs.  Returns the frame index RELATIVE to the launch (add fb.f0).
+__device__ __forceinline__ void xcd_frame_block(const FrameBuffers& fb, int& bx, int& fy) {
+    bx = blockIdx.x; fy = blockIdx.y;
+    if (!fb.xcd_frames || gridDim.y < 8) return;
+    const unsigned nb = gridDim.x, nwg = nb * gridDim.y, lin = blockIdx.x + nb * blockIdx.y;
+    const unsigned q = nwg >> 3, r = nwg & 7, x = lin & 7;
+    const unsigned vid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (lin >> 3);
+    fy = (int)(vid / nb); bx = (int)(vid - (unsigned)fy * nb);
+}
+
+// the same for grids (frames, 1) - one workgroup per frame -: the frame this workgroup takes, relative to the launch, so that it runs on
+// the XCD the frame's workgroups of the (blocks, frames) grids ran on (whole frames per XCD when the launch has a multiple of 8 frames)
+__device__ __forceinline__ int xcd_frame_1d(const FrameBuffers& fb) {
+    const unsigned F = gridDim.x, lin = blockIdx.x;
+    if (!fb.xcd_frames || F < 8 || gridDim.y != 1) return (int)lin;
+    const unsigned q = F >> 3, r = F & 7, x = lin & 7;
+    return (int)((x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (lin >> 3));
+}
+
 // 0.5*sum_i |d_i - dbar_m(i)|^2: the part of the data cost that does not depend on the parameters once the
 // correspondences are fixed.  Deterministic two-level reduction in original data order (block partials,
 // summed in a fixed order by the solve kernel).

@@ -235,6 +235,7 @@ struct FrameBuffers {
     int seq;                      // which solve of the ICP iteration the current k_solve launch is (1 = FIRST): the riding reduction counts up to seq x its workgroups (k_eval: the solve that FOLLOWS it)
     int max_iters;                // GN iterations per ICP iteration of the call being enqueued (the accept tests a launch sequence may take ahead of its launches are bounded by it)
     int f0;                       // first frame of the frame group a launch covers (grid frame index is relative to it)
+    int xcd_frames;               // avt_tuning::xcd_frames (xcd_frame_block, avt_device.h)
     // raw inputs
     double* data_raw;     // [max_frames*max_points][3]
     int* labels_raw;      // [max_frames*max_points]

@@ -35,7 +35,9 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
                                              int from_state, int vis_init, int nlbs, int with_init, int decide, int write_pc, int pack) {
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, V = d.V;
-    const int f = blockIdx.y + fb.f0, t = threadIdx.x;
+    int wx, fy;
+    xcd_frame_block(fb, wx, fy);      // (frame batches: a frame's workgroups on one XCD, the one its later kernels run on)
+    const int f = fy + fb.f0, t = threadIdx.x;
     // decide (from_state == 2 only): the accept test of the last trial point happens here, in every wave (avt_decide.h)
     // (its requests go out first; the skeleton tables of both slots follow in the same round trip)
     LastDecisionInputs dec_in;
@@ -44,8 +46,8 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
     // own on the dependency chain - (few frames) the trial point of the ICP iteration that follows (prep_init_block), (first
     // launch of optimize()) the label histogram of the data points
     extern __shared__ __attribute__((aligned(16))) char lbs_dyn[];
-    if ((int)blockIdx.x >= nlbs) {
-        const int bx = (int)blockIdx.x - nlbs;
+    if (wx >= nlbs) {
+        const int bx = wx - nlbs;
         if (with_init && bx == 0) prep_init_block(dm, fb, f, lbs_dyn, decide ? lm_last_decide(dm, fb, f, dec_in, false) : fb.ctl[f].cur_slot);
         else bucket_count_block(dm, fb, f, bx - (with_init ? 1 : 0));
         return;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
                 ka = p0[prep_off_off(d) + e % 3]; kb = p1[prep_off_off(d) + e % 3];
                 wa = p0[prep_off_w(d) + k]; wb = p1[prep_off_w(d) + k];
             }
-            const int dec_slot = lm_last_decide(dm, fb, f, dec_in, blockIdx.x == 0 && t == 0);
+            const int dec_slot = lm_last_decide(dm, fb, f, dec_in, wx == 0 && t == 0);
 #pragma unroll
             for (int i = 0; i < NR; ++i) if (t + 256 * i < 9 * J) s_Rw[t + 256 * i] = dec_slot ? rb[i] : ra[i];
             if (t < 3 * J) { s_o[t] = dec_slot ? ob : oa; s_jp[t] = dec_slot ? jb + kb : ja + ka; }
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
         s_T[12 * j + 3 * c + r] = s_Rw[e];
     }
     __syncthreads();
-    if (blockIdx.x == 0) {
+    if (wx == 0) {
         if (t < 3 * J) fb.jointpos[(size_t)f * 3 * J + t] = s_o[t];
         for (int e = t; e < 12 * J; e += 256) fb.jointtrans[(size_t)f * 12 * J + e] = s_T[e];
         // the launch that closes optimize(): the frame's result record (what k_pack_results wrote in a 4.9 us launch of its own behind every
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
         // workgroup - lies two barriers back: the control block is final.
         if (pack) pack_result_row(fb, f, d.xsize, t, 256);
     }
-    const int v = blockIdx.x * 256 + t;
+    const int v = wx * 256 + t;
     if (v >= V) return;
     // shapedCloud = keyClouds * w + baseCloud  (Avatar.cpp:26)
     double sx = 0.0, sy = 0.0, sz = 0.0;
@@ -226,9 +228,11 @@ template <int FT>
 __global__ __launch_bounds__(256) void k_lbs_multi(DeviceModel dm, FrameBuffers fb, int from_state, int vis_init, int nlbs, int nb, int nframes, int write_pc, int pack) {
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, V = d.V;
-    const int t = threadIdx.x, y0 = blockIdx.y * FT;
-    if ((int)blockIdx.x >= nlbs) {      // trailing workgroups: the label histogram of one 2048-point tile of one of my frames
-        const int bx = (int)blockIdx.x - nlbs, fi = bx / nb;
+    int wx, fy;
+    xcd_frame_block(fb, wx, fy);
+    const int t = threadIdx.x, y0 = fy * FT;
+    if (wx >= nlbs) {      // trailing workgroups: the label histogram of one 2048-point tile of one of my frames
+        const int bx = wx - nlbs, fi = bx / nb;
         if (y0 + fi < nframes) bucket_count_block(dm, fb, fb.f0 + y0 + fi, bx - fi * nb);
         return;
     }
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(256) void k_lbs_multi(DeviceModel dm, FrameBuffers 
         s_T[(size_t)i * 12 * J + 12 * j + 3 * c + r] = s_Rw[e];
     }
     __syncthreads();
-    if (blockIdx.x == 0) {
+    if (wx == 0) {
 #pragma unroll
         for (int i = 0; i < FT; ++i) {
             if (!on[i]) continue;
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(256) void k_lbs_multi(DeviceModel dm, FrameBuffers 
             if (pack) pack_result_row(fb, f, d.xsize, t, 256);      // (the closing launch of optimize(): the frame's result record, see k_lbs)
         }
     }
-    const int v = blockIdx.x * 256 + t;
+    const int v = wx * 256 + t;
     if (v >= V) return;
     // shapedCloud = keyClouds * w + baseCloud  (Avatar.cpp:26): every plane value is loaded once and used by all FT frames
     double sx[FT], sy[FT], sz[FT];
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(256) void k_visibility(DeviceModel dm, FrameBuffers
 // which rides in k_visibility's grid, rides in k_compact's here (a 1024-thread workgroup with 117 KB of LDS is no place for it).
 __global__ __launch_bounds__(1024) void k_visibility_frame(DeviceModel dm, FrameBuffers fb) {
     const int F = dm.d.F, V = dm.d.V;
-    const int f = blockIdx.x + fb.f0, t = threadIdx.x;
+    const int f = xcd_frame_1d(fb) + fb.f0, t = threadIdx.x;
     extern __shared__ __attribute__((aligned(16))) char vis_dyn[];
     double2* s_xy = (double2*)vis_dyn;
     unsigned char* s_flag = (unsigned char*)(s_xy + V);
@@ -509,7 +513,7 @@ void launch_bucket(avt_ctx* c, int nframes, bool clear_after) {
 // =================================================================================================
 __global__ __launch_bounds__(1024) void k_finalize(DeviceModel dm, FrameBuffers fb, int first_icp) {
     const double beta_pose = fb.params->beta_pose, beta_shape = fb.params->beta_shape, lambda0 = fb.params->lambda0, nu0 = fb.params->lm_up;
-    const int f = blockIdx.x + fb.f0, t = threadIdx.x, V = dm.d.V;
+    const int f = xcd_frame_1d(fb) + fb.f0, t = threadIdx.x, V = dm.d.V;
     AvtFrameCtl& ctl = fb.ctl[f];
     if (t < 2 * (AVT_MAX_PARTS + 1)) fb.part_cnt[(size_t)f * 2 * (AVT_MAX_PARTS + 1) + t] = 0;   // bucketing is over: restore the invariant
     if (t == 0) { fb.ride_ctr[f] = 0; fb.spec[f].n = 0; fb.spec[f].next = 0; fb.spec[f].ahead = 0; }

@@ -739,7 +739,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     __builtin_amdgcn_s_setprio(3);   // one dependency chain per frame: issue ahead of the evaluation waves of another frame group on this CU
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, P = d.P, HS = d.HS;
-    const int f = blockIdx.x + fb.f0, t = threadIdx.x;
+    const int f = (RIDE ? (int)blockIdx.x : xcd_frame_1d(fb)) + fb.f0, t = threadIdx.x;      // (frame batches: on the XCD the frame's assembly ran on)
     AvtFrameCtl& ctl = fb.ctl[f];
     const int NBk = HS >> 2;                                // 4-row blocks covering rows 0..P (22 for SMPL)
     // W = L diag(d) of the factorisation H = L diag(d) L^T, block layout [pivot block kb][row block bi][18]: a 4x4

@@ -141,8 +141,9 @@ __device__ __forceinline__ void moments_store(const FrameBuffers& fb, const AvtD
 template <int NTP>
 __global__ __launch_bounds__(256, 4) void k_moments(DeviceModel dm, FrameBuffers fb) {
     const AvtDims& d = dm.d;
-    const int f = blockIdx.y + fb.f0, t = threadIdx.x, V = d.V, NP = d.mom_np;
-    const int bx = blockIdx.x;
+    int bx, fy;
+    xcd_frame_block(fb, bx, fy);      // a frame's workgroups share its counts and sums (cnt, fsum: 193 KB per SMPL frame, gathered by every pair)
+    const int f = fy + fb.f0, t = threadIdx.x, V = d.V, NP = d.mom_np;
     __shared__ unsigned s_off[MOM_SEG + 4 * MOM_UN];
     __shared__ double s_w[MOM_SEG + 4 * MOM_UN], s_bd[3 * (MOM_SEG + 4 * MOM_UN)];
     __shared__ int s_wcnt[4];
@@ -334,7 +335,7 @@ __device__ __forceinline__ double mom_row_sum(double v) {
 }
 
 #ifdef AVT_TIMING
-#define PPROBE(i) do { if (threadIdx.x == 0 && blockIdx.x == 5) fb.trace[(size_t)f * 64 + 24 + (i)] = (double)clock64(); } while (0)
+#define PPROBE(i) do { if (threadIdx.x == 0 && bx == 5) fb.trace[(size_t)f * 64 + 24 + (i)] = (double)clock64(); } while (0)
 #else
 #define PPROBE(i) do {} while (0)
 #endif
@@ -343,20 +344,22 @@ __global__ __launch_bounds__(16 * MOM_PP_PAIRS) void k_pairpass(DeviceModel dm, 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTH = 16 * MOM_PP_PAIRS;
     const AvtDims& d = dm.d;
-    const int f = blockIdx.y + fb.f0, t = threadIdx.x;
+    int bx, fy;
+    xcd_frame_block(fb, bx, fy);      // the frame's k_assemble_parts and k_solve workgroups run on the same XCD (what this launch writes is what they read)
+    const int f = fy + fb.f0, t = threadIdx.x;
     const int J = d.J, K = KC ? KC : d.K, S1 = K + 1, NP = d.mom_np, NPSI = KC ? 3 * (KC + 1) + 1 : d.mom_npsi;
     const int TS = mom_tstride(NPSI), JS = 15 + 3 * K, GS = (2 * JS + S1 + 1) & ~1;      // doubles of a pair's T block / of one joint's tables / of a group's slice
     const int try_slot = 1 - fb.ctl[f].cur_slot;
     double* scr = fb.mom_rec + (size_t)f * mom_frame_scratch(d);
     double* X16 = scr;
     double* REC = scr + mom_off_rec(d);
-    if ((int)blockIdx.x >= mom_nwg(d)) {      // trailing workgroups: the GMM pose prior of the trial point, one component each (avt_prior.h)
-        prior_component<NTH>(dm, fb, f, (int)blockIdx.x - mom_nwg(d), try_slot, (double*)smem);
+    if (bx >= mom_nwg(d)) {      // trailing workgroups: the GMM pose prior of the trial point, one component each (avt_prior.h)
+        prior_component<NTH>(dm, fb, f, bx - mom_nwg(d), try_slot, (double*)smem);
         return;
     }
     const int gid = t >> 4, sl = t & 15;
     PPROBE(0);
-    const int p = blockIdx.x * MOM_PP_PAIRS + gid;
+    const int p = bx * MOM_PP_PAIRS + gid;
     const bool pair_on = p < NP, lane_on = sl < S1;
     const int pc = pair_on ? p : 0;
     const int k = dm.mom_pair[2 * pc], k2 = dm.mom_pair[2 * pc + 1];
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(16 * MOM_PP_PAIRS) void k_pairpass(DeviceModel dm, 
         zr[K * K + (sl - 1)] = pair_on ? yx : 0.0;
     }
     __syncthreads();
-    double* Zg = scr + mom_off_z(d) + (size_t)blockIdx.x * (K * K + K);
+    double* Zg = scr + mom_off_z(d) + (size_t)bx * (K * K + K);
     for (int e = t; e < K * K + K; e += NTH) {
         double a = 0.0;
 #pragma unroll
@@ -614,8 +617,10 @@ __global__ __launch_bounds__(16 * MOM_PP_PAIRS) void k_pairpass(DeviceModel dm, 
 // grid every one of these small workgroups would hold that kernel's 52 KB of LDS, a third of a CU
 __global__ __launch_bounds__(128) void k_prior(DeviceModel dm, FrameBuffers fb) {
     __shared__ double s_scratch[5 * AVT_MAX_JOINTS];
-    const int f = blockIdx.y + fb.f0;
-    prior_component<128>(dm, fb, f, blockIdx.x, 1 - fb.ctl[f].cur_slot, s_scratch);
+    int bx, fy;
+    xcd_frame_block(fb, bx, fy);
+    const int f = fy + fb.f0;
+    prior_component<128>(dm, fb, f, bx, 1 - fb.ctl[f].cur_slot, s_scratch);
 }
 
 static size_t pairpass_lds_bytes(const AvtDims& d) {
@@ -1280,7 +1285,9 @@ __device__ __forceinline__ void asm_role_rotrot(const DeviceModel& dm, const Fra
 template <int KC>
 __global__ __launch_bounds__(MOM_PARTS_NTH) void k_assemble_parts(DeviceModel dm, FrameBuffers fb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int f = blockIdx.y + fb.f0, role = blockIdx.x;
+    int role, fy;
+    xcd_frame_block(fb, role, fy);
+    const int f = fy + fb.f0;
     if (role == 0) asm_role_core<KC>(dm, fb, f, smem);
     else if (role <= MOM_ASM_NA) asm_role_shape<KC>(dm, fb, f, role - 1, smem);
     else asm_role_rotrot(dm, fb, f, role - 1 - MOM_ASM_NA, smem);

@@ -401,7 +401,9 @@ __device__ __forceinline__ double nn_wave_reduce(double v) {
 typedef const __attribute__((address_space(4))) double* nn_cptr;
 
 __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb) {
-    const int f = blockIdx.y + fb.f0, t = threadIdx.x, lane = t & 63;
+    int bx, fy;
+    xcd_frame_block(fb, bx, fy);      // the chunks of a part all scan the part's candidates, a frame's workgroups add to the same counts and sums
+    const int f = fy + fb.f0, t = threadIdx.x, lane = t & 63;
     const int V = dm.d.V, np = dm.d.num_parts;
     const AvtFrameCtl& ctl = fb.ctl[f];
     const int* po = fb.part_off + (size_t)f * (np + 1);
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb
     int incl = nbq;
 #pragma unroll
     for (int sft = 1; sft < 64; sft <<= 1) { const int v = __shfl_up(incl, sft, 64); if (lane >= sft) incl += v; }
-    const int excl = incl - nbq, blk = blockIdx.x;
+    const int excl = incl - nbq, blk = bx;
     const unsigned long long hit = __ballot(lane < np && blk >= excl && blk < incl);
     if (hit == 0ull) return;                                  // past the last chunk of the last part (grid is an upper bound)
     const int q = __ffsll((long long)hit) - 1;
@@ -594,7 +596,9 @@ __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb
 // from_cloud: the coordinates come from the cloud through the vertex id (frame batches inside optimize(): k_lbs then skips
 // the part-sorted copy, three scattered stores per vertex) instead of from pcx/pcy/pcz.
 __global__ __launch_bounds__(256) void k_compact(DeviceModel dm, FrameBuffers fb, int from_cloud, int sort_y) {
-    const int f = blockIdx.y + fb.f0, q = blockIdx.x, t = threadIdx.x, V = dm.d.V, np = dm.d.num_parts;
+    int bx, fy;
+    xcd_frame_block(fb, bx, fy);      // what it writes is what the frame's k_nn_part workgroups read
+    const int f = fy + fb.f0, q = bx, t = threadIdx.x, V = dm.d.V, np = dm.d.num_parts;
     if (q >= np) { bucket_scatter_block<true>(dm, fb, f, q - np); return; }
     const int b = dm.part_start[q], e = dm.part_start[q + 1];
     __shared__ int s_wcnt[4];

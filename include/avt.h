@@ -267,6 +267,9 @@ typedef struct avt_tuning {
     int spec_cost;           /* riding shapes: 1 (default) the COST of the first queued speculative LM step is evaluated beside the trial point, so that the solve
                               * launch that rejects the trial point takes that step's accept test as well when it fails too - two rejections in one launch pair
                               * (DESIGN section 4); 0: one launch pair per rejection */
+    int xcd_frames;          /* frame-batch kernels whose workgroups share per-frame data (k_moments, the nearest neighbour's throughput shape): 1 (default) the
+                              * workgroups of a frame run on ONE of the eight XCDs (grid remap, xcd_frame_block), so that the frame's data is fetched into one
+                              * L2 instead of eight; 0: grid order */
 } avt_tuning;
 int avt_ctx_get_tuning(avt_ctx* c, avt_tuning* out);
 int avt_ctx_set_tuning(avt_ctx* c, const avt_tuning* t);

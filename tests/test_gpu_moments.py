@@ -375,3 +375,35 @@ def test_skinning_several_frames_per_workgroup_gives_the_same_bits(smpl, gmodel)
         for pa, pb in zip(res[1][2], res[ft][2]):
             assert all(np.array_equal(a, b) for a, b in zip(pa, pb)), ft
         assert all(np.array_equal(a, b) for a, b in zip(res[1][3], res[ft][3])), ft
+
+
+@pytest.mark.parametrize("frames,form", [(21, 1), (35, 1), (13, 0)])
+def test_frames_mapped_to_xcds_give_the_same_bits(smpl, gmodel, frames, form):
+    """avt_tuning.xcd_frames (frame-batch kernels take their (frame, block) from a remap of the grid that keeps a frame's workgroups on one
+    XCD, avt_device.h xcd_frame_block / xcd_frame_1d) against the grid order: a permutation of which workgroup does what - every result equal
+    bit for bit, with launch sizes that are not multiples of 8 (the remap's uneven split) and with two frame groups."""
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    frs = [synth.make_frame(smpl, 80 + (s % 5)) for s in range(frames)]
+    sel = slice(0, None, 6)
+    datas = [f["data"][sel] for f in frs]; labs = [f["labels"][sel] for f in frs]
+    nmax = max(len(l) for l in labs)
+    rng = np.random.default_rng(5)
+    p0 = np.array([f["start"][1] for f in frs]) + 0.01 * rng.standard_normal((frames, 3))
+    q0 = np.array([api.rot_to_quat(f["start"][2]) for f in frs]); w0 = np.array([f["start"][0] for f in frs])
+    opt = Options.demo(icp_iters=2, max_iters_per_icp=3)
+    res = {}
+    for xf in (0, 1):
+        ctx = api.Context(gmodel, 24, pm, nmax, frames)
+        ctx.set_data_term(ctx.DATA_TERM_MOMENTS if form else ctx.DATA_TERM_ROWS)
+        ctx.set_tuning(xcd_frames=xf)
+        assert ctx.tuning().xcd_frames == xf
+        out = ctx.optimize_batch(datas, labs, opt, p0, q0, w0)
+        res[xf] = (out, [ctx.cloud(i) for i in range(frames)], [ctx.correspondences(i, len(labs[i])) for i in range(frames)],
+                   [(s.accepted_steps, s.final_cost, s.lambda_) for s in out[3]])
+    for a, b in zip(res[0][0][:3], res[1][0][:3]):
+        assert np.array_equal(a, b)
+    assert all(np.array_equal(a, b) for a, b in zip(res[0][1], res[1][1]))
+    assert all(np.array_equal(a, b) for a, b in zip(res[0][2], res[1][2]))
+    assert res[0][3] == res[1][3]
+    assert len({tuple(x) for x in res[1][0][0].round(12).tolist()}) > 1        # the frames are not all the same frame
