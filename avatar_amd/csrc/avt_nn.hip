@@ -24,6 +24,12 @@
 #define NN_TILE 1024
 #define NN_SORTED_FLAG 0x40000000      // in FrameBuffers::vcount: the part's compacted candidates are sorted by (y, vertex id)
 #define NN_SORT_CAP 1024               // largest part k_compact sorts (bitonic sort in LDS)
+#ifndef NN_PART_NQ
+#define NN_PART_NQ 2                  // k_nn_part: queries per lane (every candidate fetched is used for that many distances)
+#endif
+#ifndef NN_PART_GROUP
+#define NN_PART_GROUP 4               // k_nn_part: candidates per group of the scan (one compare against the best per group)
+#endif
 #define NN_ACC_CAP 512                // candidates of a part whose match counts / sums k_nn_part accumulates in LDS (14 KB)
 #ifndef NN_SLAB_CHUNK
 #define NN_SLAB_CHUNK 32                // candidates per side and round of the slab scan (a multiple of the group size)
@@ -401,6 +407,10 @@ __device__ __forceinline__ double nn_wave_reduce(double v) {
 typedef const __attribute__((address_space(4))) double* nn_cptr;
 
 __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb) {
+    // NQ queries per lane: every candidate a wave fetches (scalar loads: one request per 32 bytes, a miss in the scalar cache for every other
+    // one - the candidates are streamed, 28 % of the requests missed with one query per lane and the kernel ran at the rate of those misses,
+    // neither shorter instruction streams nor requesting a group ahead moved it) is used for NQ distances instead of one.
+    constexpr int NQ = NN_PART_NQ, CH = 256 * NQ;      // queries per lane / per workgroup: wave w owns CH / 4 consecutive ones, lane l the (64 u + l)-th of them
     int bx, fy;
     xcd_frame_block(fb, bx, fy);      // the chunks of a part all scan the part's candidates, a frame's workgroups add to the same counts and sums
     const int f = fy + fb.f0, t = threadIdx.x, lane = t & 63;
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb
     const AvtFrameCtl& ctl = fb.ctl[f];
     const int* po = fb.part_off + (size_t)f * (np + 1);
     const int po_l = (lane <= np) ? po[min(lane, np)] : 0, po_n = (lane < np) ? po[lane + 1] : 0;
-    const int nbq = (lane < np) ? (po_n - po_l + 255) >> 8 : 0;
+    const int nbq = (lane < np) ? (po_n - po_l + CH - 1) / CH : 0;
     int incl = nbq;
 #pragma unroll
     for (int sft = 1; sft < 64; sft <<= 1) { const int v = __shfl_up(incl, sft, 64); if (lane >= sft) incl += v; }
@@ -416,12 +426,19 @@ __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb
     const unsigned long long hit = __ballot(lane < np && blk >= excl && blk < incl);
     if (hit == 0ull) return;                                  // past the last chunk of the last part (grid is an upper bound)
     const int q = __ffsll((long long)hit) - 1;
-    const int s_beg = __shfl(po_l, q, 64) + (blk - __shfl(excl, q, 64)) * 256, s_end = __shfl(po_n, q, 64);
+    const int s_beg = __shfl(po_l, q, 64) + (blk - __shfl(excl, q, 64)) * CH, s_end = __shfl(po_n, q, 64);
     const size_t base = (size_t)f * fb.max_points;
-    const int s = s_beg + t;
-    const bool active = s < s_end;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    if (active) { a0 = fb.dx[base + s]; a1 = fb.dy[base + s]; a2 = fb.dz[base + s]; }
+    int s[NQ];
+    bool active[NQ], any_active = false;
+    double a0[NQ], a1[NQ], a2[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        s[u] = s_beg + (t >> 6) * (64 * NQ) + 64 * u + lane;
+        active[u] = s[u] < s_end;
+        any_active = any_active || active[u];
+        a0[u] = 0.0; a1[u] = 0.0; a2[u] = 0.0;
+        if (active[u]) { a0[u] = fb.dx[base + s[u]]; a1[u] = fb.dy[base + s[u]]; a2[u] = fb.dz[base + s[u]]; }
+    }
     const int pb = __builtin_amdgcn_readfirstlane(dm.part_start[q]);
     const int vc = __builtin_amdgcn_readfirstlane(fb.vcount[(size_t)f * np + q]);
     const bool sorted = (vc & NN_SORTED_FLAG) != 0;                    // k_compact sorted them by (y, vertex id): slab scan below
@@ -432,61 +449,76 @@ __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb
 #endif
     const nn_cptr cx = (nn_cptr)(uintptr_t)(fb.vcx + (size_t)f * V), cy = (nn_cptr)(uintptr_t)(fb.vcy + (size_t)f * V),
                   cz = (nn_cptr)(uintptr_t)(fb.vcz + (size_t)f * V);
-    auto dist2 = [&](double px, double py, double pz) {
-        const double d0 = a0 - px, d1 = a1 - py, d2 = a2 - pz;
+    auto dist2 = [&](int u, double px, double py, double pz) {
+        const double d0 = a0[u] - px, d1 = a1[u] - py, d2 = a2[u] - pz;
         double r = d0 * d0;
         r = r + d1 * d1;
         r = r + d2 * d2;
         return r;
     };
-    constexpr int NN_GROUP = 4;
-    double best = 1.7976931348623157e308;
-    int gpos = -1;
-    bool tie = false;             // (slab scan only) two candidates at exactly the minimum distance: settled by vertex id below
-    // one group of (up to) NN_GROUP consecutive candidates starting at c (a multiple of NN_GROUP past pb; members clipped by hi)
+    constexpr int NN_GROUP = NN_PART_GROUP;
+    double best[NQ];
+    int gpos[NQ];
+    bool tie[NQ];                 // (slab scan only) two candidates at exactly the minimum distance: settled by vertex id below
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) { best[u] = 1.7976931348623157e308; gpos[u] = -1; tie[u] = false; }
+    // the groups of NN_GROUP consecutive candidates of [lo, hi) (lo a multiple of NN_GROUP past pb), then the members of the last, partial one
     auto scan_groups = [&](int lo, int hi, bool watch_ties) {
         int c = lo;
         for (; c + NN_GROUP <= hi; c += NN_GROUP) {
-            double r[NN_GROUP];
+            double px[NN_GROUP], py[NN_GROUP], pz[NN_GROUP];
 #pragma unroll
-            for (int u = 0; u < NN_GROUP; ++u) r[u] = dist2(cx[c + u], cy[c + u], cz[c + u]);
+            for (int g = 0; g < NN_GROUP; ++g) { px[g] = cx[c + g]; py[g] = cy[c + g]; pz[g] = cz[c + g]; }
 #pragma unroll
-            for (int w = 1; w < NN_GROUP; w <<= 1)
+            for (int u = 0; u < NQ; ++u) {
+                double r[NN_GROUP];
 #pragma unroll
-                for (int u = 0; u + w < NN_GROUP; u += 2 * w) r[u] = __builtin_fmin(r[u], r[u + w]);
-            if (watch_ties) tie = tie || (r[0] == best);
-            gpos = (r[0] < best) ? c : gpos;
-            best = __builtin_fmin(best, r[0]);
+                for (int g = 0; g < NN_GROUP; ++g) r[g] = dist2(u, px[g], py[g], pz[g]);
+#pragma unroll
+                for (int w = 1; w < NN_GROUP; w <<= 1)
+#pragma unroll
+                    for (int g = 0; g + w < NN_GROUP; g += 2 * w) r[g] = __builtin_fmin(r[g], r[g + w]);
+                if (watch_ties) tie[u] = tie[u] || (r[0] == best[u]);
+                gpos[u] = (r[0] < best[u]) ? c : gpos[u];
+                best[u] = __builtin_fmin(best[u], r[0]);
+            }
         }
         for (; c < hi; ++c) {
-            const double r = dist2(cx[c], cy[c], cz[c]);
-            if (watch_ties) tie = tie || (r == best);
-            gpos = (r < best) ? c : gpos;
-            best = __builtin_fmin(best, r);
+            const double px = cx[c], py = cy[c], pz = cz[c];
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const double r = dist2(u, px, py, pz);
+                if (watch_ties) tie[u] = tie[u] || (r == best[u]);
+                gpos[u] = (r < best[u]) ? c : gpos[u];
+                best[u] = __builtin_fmin(best[u], r);
+            }
         }
     };
     if (!sorted) {
         scan_groups(pb, pe, false);      // ascending vertex order: strict '<' alone implements the tie rule
     } else {
-        // ---- slab scan.  k_compact sorted this part's visible candidates by (y, vertex id).  A wave's 64 queries are consecutive
-        // pixels of one part - one to three image rows, i.e. a thin slab in y - so the scan starts at the candidate nearest to the
+        // ---- slab scan.  k_compact sorted this part's visible candidates by (y, vertex id).  A wave's 64 NQ queries are consecutive
+        // pixels of one part - a few image rows, i.e. a thin slab in y - so the scan starts at the candidate nearest to the
         // slab and walks outwards on both sides, NN_SLAB_CHUNK candidates a side per round, until on each side the next candidate is further
         // from the slab IN Y ALONE than the worst current best distance of the wave: every candidate beyond it has
         // (y_c - y_q)^2 >= (y_edge - y_slab)^2 > max_q best_q, so its rounded distance exceeds every lane's best (margin 1e-12 >>
         // the 5 ulp the rounding of the two expressions can differ by) and it can neither win nor tie.  Exact: same distance
         // expression, same winner as the full ascending scan - ties (equal distances, measure zero) are detected and settled by
-        // vertex id in a full rescan.  On the synthetic frames 41-45 % of the candidates are evaluated (tools/nn_slab_sim.py).
-        const double ylo = nn_wave_reduce<false>(active ? a1 : 1.7976931348623157e308), yhi = nn_wave_reduce<true>(active ? a1 : -1.7976931348623157e308);
+        // vertex id in a full rescan.  (tools/nn_slab_sim.py, tools/nn_count_probe.py: the share of the candidates evaluated.)
+        double ymin = 1.7976931348623157e308, ymax = -1.7976931348623157e308;
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) if (active[u]) { ymin = __builtin_fmin(ymin, a1[u]); ymax = __builtin_fmax(ymax, a1[u]); }
+        const double ylo = nn_wave_reduce<false>(ymin), yhi = nn_wave_reduce<true>(ymax);
         const int n = pe - pb;
         bool rdone = true, ldone = true;
         int R = pb, L = pb;
-        if (__ballot(active) != 0ull && n > 0) {
+        if (__ballot(any_active) != 0ull && n > 0) {
             const double ymid = 0.5 * (ylo + yhi);
             const int step = (n + 63) >> 6;                                  // 64 samples of the sorted y's locate the slab
             const int si = lane * step;
             const double ys = fb.vcy[(size_t)f * V + pb + min(si, n - 1)];
             const int below = __popcll(__ballot(si < n && ys < ymid));
-            const int st = pb + ((min(max(below - 1, 0) * step, n - 1)) & ~(NN_GROUP - 1));   // groups stay aligned to pb + 4k
+            const int st = pb + ((min(max(below - 1, 0) * step, n - 1)) & ~(NN_GROUP - 1));   // groups stay aligned to pb + NN_GROUP k
             R = L = __builtin_amdgcn_readfirstlane(st);
             rdone = R >= pe; ldone = L <= pb;
         }
@@ -502,7 +534,10 @@ __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb
 #endif
             if (!rdone) { scan_groups(R, e, true); R = e; }
             if (!ldone) { scan_groups(b, L, true); L = b; }
-            const double dmax = nn_wave_max_nonneg(active ? best : 0.0);
+            double worst = 0.0;
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) worst = __builtin_fmax(worst, active[u] ? best[u] : 0.0);
+            const double dmax = nn_wave_max_nonneg(worst);
             const double bound = dmax * (1.0 + 1e-12);
             if (!rdone) {
                 const double gap = edge_r - yhi;
@@ -514,49 +549,61 @@ __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb
             }
         }
 #ifdef AVT_NN_COUNT   // tools/nn_count_probe.py (make libavatar_hip_nn_count.so): waves, candidates evaluated / available, rounds, slab width
-        if (lane == 0 && __ballot(active) != 0ull) {
+        if (lane == 0 && __ballot(any_active) != 0ull) {
             double* tr = fb.trace + (size_t)f * 64;
             atomicAdd(tr + 58, 1.0); atomicAdd(tr + 60, (double)cnt_eval); atomicAdd(tr + 61, (double)n); atomicAdd(tr + 62, (double)cnt_rounds); atomicAdd(tr + 63, yhi - ylo);
         }
 #endif
     }
-    int bi = 0x7fffffff;
+    int bi[NQ];
     const double* pcx = fb.vcx + (size_t)f * V;
     const double* pcy = fb.vcy + (size_t)f * V;
     const double* pcz = fb.vcz + (size_t)f * V;
-    if (gpos >= 0) {      // the first member of the winning group whose distance is the minimum
-        double r[NN_GROUP];
+    bool any_tie = false;
 #pragma unroll
-        for (int u = 0; u < NN_GROUP; ++u) {
-            const int pos = min(gpos + u, pe - 1);
-            r[u] = dist2(pcx[pos], pcy[pos], pcz[pos]);
+    for (int u = 0; u < NQ; ++u) {
+        bi[u] = 0x7fffffff;
+        if (gpos[u] >= 0) {      // the first member of the winning group whose distance is the minimum
+            double r[NN_GROUP];
+#pragma unroll
+            for (int g = 0; g < NN_GROUP; ++g) {
+                const int pos = min(gpos[u] + g, pe - 1);
+                r[g] = dist2(u, pcx[pos], pcy[pos], pcz[pos]);
+            }
+            int hits = 0;
+#pragma unroll
+            for (int g = NN_GROUP - 1; g >= 0; --g)
+                if (gpos[u] + g < pe && r[g] == best[u]) { bi[u] = gpos[u] + g; ++hits; }
+            if (sorted && hits > 1) tie[u] = true;
         }
-        int hits = 0;
-#pragma unroll
-        for (int u = NN_GROUP - 1; u >= 0; --u)
-            if (gpos + u < pe && r[u] == best) { bi = gpos + u; ++hits; }
-        if (sorted && hits > 1) tie = true;
+        any_tie = any_tie || tie[u];
     }
 #ifdef AVT_NN_COUNT
-    if (sorted && __ballot(tie) != 0ull && lane == 0) atomicAdd(fb.trace + (size_t)f * 64 + 59, 1.0);
+    if (sorted && __ballot(any_tie) != 0ull && lane == 0) atomicAdd(fb.trace + (size_t)f * 64 + 59, 1.0);
 #endif
-    if (sorted && __ballot(tie) != 0ull) {      // exact ties: the candidate with the smallest vertex id among those at the minimum distance
+    if (sorted && __ballot(any_tie) != 0ull) {      // exact ties: the candidate with the smallest vertex id among those at the minimum distance
         const int* ids = fb.vcid + (size_t)f * V;
-        double tb = 1.7976931348623157e308;
-        int tid = 0x7fffffff, tpos = 0x7fffffff;
-        for (int c = pb; c < pe; ++c) {
-            const double r = dist2(cx[c], cy[c], cz[c]);
-            const int id = ids[c];
-            if (r < tb || (r == tb && id < tid)) { tb = r; tid = id; tpos = c; }
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            double tb = 1.7976931348623157e308;
+            int tid = 0x7fffffff, tpos = 0x7fffffff;
+            for (int c = pb; c < pe; ++c) {
+                const double r = dist2(u, cx[c], cy[c], cz[c]);
+                const int id = ids[c];
+                if (r < tb || (r == tb && id < tid)) { tb = r; tid = id; tpos = c; }
+            }
+            if (tie[u]) bi[u] = tpos;
         }
-        if (tie) bi = tpos;
     }
-    const int mv = (active && bi != 0x7fffffff) ? fb.vcid[(size_t)f * V + bi] : -1;
+    int mv[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) mv[u] = (active[u] && bi[u] != 0x7fffffff) ? fb.vcid[(size_t)f * V + bi[u]] : -1;
     if (pe - pb > NN_ACC_CAP) {        // a part with more candidates than the accumulators below hold: per-match atomics, merged in-wave
-        nn_record<1>(fb, ctl, f, V, base, s, active, 0, mv, a0, a1, a2);
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) nn_record<1>(fb, ctl, f, V, base, s[u], active[u], 0, mv[u], a0[u], a1[u], a2[u]);
         return;
     }
-    // ---- bookkeeping.  The workgroup's 256 queries belong to ONE part, so their matches are among that part's candidates: counts
+    // ---- bookkeeping.  The workgroup's queries belong to ONE part, so their matches are among that part's candidates: counts
     // and fixed-point sums are accumulated per candidate POSITION in LDS (integer atomics: order-independent) and every matched
     // candidate is flushed to the per-vertex arrays once per workgroup - a vertex's matches are neighbouring pixels, mostly of one
     // workgroup, so the global atomics fall from one per run of equal matches in a wave (~12 k x 4 per frame) to ~1.3 per matched
@@ -566,15 +613,17 @@ __global__ __launch_bounds__(256) void k_nn_part(DeviceModel dm, FrameBuffers fb
     const int nacc = pe - pb;
     for (int i = t; i < nacc; i += 256) { s_acnt[i] = 0; s_asum[0][i] = 0ull; s_asum[1][i] = 0ull; s_asum[2][i] = 0ull; }
     __syncthreads();
-    if (active) {
-        fb.corr_sorted[base + s] = mv;
-        fb.corr[base + fb.dorig[base + s]] = mv;
-        if (mv >= 0) {
-            const int i = bi - pb;
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        if (!active[u]) continue;
+        fb.corr_sorted[base + s[u]] = mv[u];
+        fb.corr[base + fb.dorig[base + s[u]]] = mv[u];
+        if (mv[u] >= 0) {
+            const int i = bi[u] - pb;
             atomicAdd(&s_acnt[i], 1);
-            atomicAdd(&s_asum[0][i], (unsigned long long)rint_to_ll((a0 - ctl.centre[0]) * AVT_FIX_SCALE));
-            atomicAdd(&s_asum[1][i], (unsigned long long)rint_to_ll((a1 - ctl.centre[1]) * AVT_FIX_SCALE));
-            atomicAdd(&s_asum[2][i], (unsigned long long)rint_to_ll((a2 - ctl.centre[2]) * AVT_FIX_SCALE));
+            atomicAdd(&s_asum[0][i], (unsigned long long)rint_to_ll((a0[u] - ctl.centre[0]) * AVT_FIX_SCALE));
+            atomicAdd(&s_asum[1][i], (unsigned long long)rint_to_ll((a1[u] - ctl.centre[1]) * AVT_FIX_SCALE));
+            atomicAdd(&s_asum[2][i], (unsigned long long)rint_to_ll((a2[u] - ctl.centre[2]) * AVT_FIX_SCALE));
         }
     }
     __syncthreads();
@@ -728,5 +777,5 @@ void launch_nn(avt_ctx* c, int nframes) {
     hipLaunchKernelGGL(k_compact, dim3(c->dm.d.num_parts + nscat, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb, c->nn_from_cloud ? 1 : 0,
                        (!few && !no_slab) ? 1 : 0);
     if (few) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nn<4>), dim3((maxN + 63) / 64, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
-    else hipLaunchKernelGGL(k_nn_part, dim3((maxN + 255) / 256 + c->dm.d.num_parts, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);
+    else hipLaunchKernelGGL(k_nn_part, dim3((maxN + 256 * NN_PART_NQ - 1) / (256 * NN_PART_NQ) + c->dm.d.num_parts, nframes), dim3(256), 0, c->cur_stream, c->dm, c->fb);      // (an upper bound of the parts' chunks)
 }
