@@ -19,7 +19,7 @@
 //   k_moments    grid (np + cost-constant blocks, frames): workgroup p < np accumulates T_p (packed upper triangle) and, for a
 //                diagonal pair, D_k; the others sum |d_i - centre|^2 over the matched data points;
 //   k_pairpass   grid (ceil(np / 4) [+ GMM components], frames), 64 threads: one 16-lane group per joint pair contracts its T with the
-//                trial state (phase A); up to 128 frames per launch trailing workgroups evaluate the pose prior there, one component
+//                trial state (phase A); up to 256 frames per launch trailing workgroups evaluate the pose prior there, one component
 //                each - above that the prior is a launch of its own (k_prior);
 //   k_assemble   grid (1, frames): turns the pair results into the dense system of the trial point in Hraw (the layout k_reduce
 //                produces: full symmetric, row / column P = J^T r, [P][P] = sum c |r|^2).
@@ -1311,10 +1311,13 @@ static size_t assemble_lds_bytes(const AvtDims& d) {
 void launch_assemble(avt_ctx* c, int nframes) {
     const AvtDims& d = c->dm.d;
     {
-        // the pose prior: workgroups in the pair pass's grid up to 128 frames per launch (one launch and its boundary less on the chain: 64 frames
-        // per GPU 1.25 -> 1.17 ms), a launch of its own above (its 2 k small workgroups then take the slots of the pair workgroups the kernel
-        // is made of: 512 frames per GPU 4.28 against 4.42 ms)
-        const bool prior_rides = 16 * MOM_PP_PAIRS >= 64 && nframes <= 128;
+        // the pose prior: workgroups in the pair pass's grid up to 256 frames per launch (one launch and its boundary less on the chain: 64 frames
+        // per GPU 1.25 -> 1.17 ms in round 4; 256 frames per launch 3.965 -> 3.903 ms per 512-frame step in round 5, after the pair pass's LDS went
+        // from 52 to 26 KB - with 52 KB its 2 k small workgroups took the slots of the pair workgroups: 4.42 against 4.28 ms), a launch of its own above
+#ifndef MOM_PRIOR_RIDE_MAX
+#define MOM_PRIOR_RIDE_MAX 256
+#endif
+        const bool prior_rides = 16 * MOM_PP_PAIRS >= 64 && nframes <= MOM_PRIOR_RIDE_MAX;
         if (d.ncomps > 0 && !prior_rides) hipLaunchKernelGGL(k_prior, dim3(d.ncomps, nframes), dim3(128), 0, c->cur_stream, c->dm, c->fb);
         const dim3 grid(mom_nwg(d) + (prior_rides ? d.ncomps : 0), nframes);
         const size_t lds = pairpass_lds_bytes(d);

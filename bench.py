@@ -293,6 +293,12 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
         nn_ms = nnp[0] / nnp[1]
         nn_tfl = 8.0 * cand0 * nfg / (nn_ms * 1e-3) / 1e12
         nn_bytes = nfg * (24 * Nmean + 4 * Nmean + 24 * V + 4 * Nmean)
+        batch_shape = nfg * Nmean > 400000      # k_compact + k_nn_part (avt_nn_few in avt_nn.hip)
+        if batch_shape and args.icp_iters == 1:
+            # the first ICP iteration of a frame batch buckets the data points inside k_compact's grid (the scatter pass of avt_bucket.h) and the
+            # scan reads the bucketed copy: raw points and labels in, bucketed points + original index out, bucketed points in again, the
+            # part-sorted candidates (x, y, z, id) out and in, two correspondence arrays out
+            nn_bytes = nfg * ((24 + 4) * Nmean + (24 + 4) * Nmean + 24 * Nmean + (28 + 24) * V + 8 * Nmean)
         res["roofline_nn"] = {"kernel": "k_nn_vis<4>" if nfg * Nmean <= 400000 else "k_compact + k_nn_part", "bound": "valu_f64", "achieved": round(nn_tfl, 4),
                               "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(nn_tfl / FP64_VALU_PEAK_TFLOPS, 6),
                               "traffic": pmc_traffic(nfg, "nn", Nmean), "algorithmic_bytes_per_launch": int(nn_bytes),
