@@ -206,6 +206,14 @@ __device__ __forceinline__ double fast_rcp(double d) {
     return fma(r0, t2, r0);
 }
 
+// entry k of one of AvtSpecCtl's arrays by compares: an index the compiler does not know puts the whole snapshot of the structure into
+// scratch memory, and every field the decision reads - next, n, valid[k] one after the other - becomes a dependent scratch round trip on
+// the install path of every riding k_solve launch (104 bytes of scratch, three dependent loads in the builds up to round 5's first)
+template <typename T>
+__device__ __forceinline__ T spec_pick(int k, T a0, T a1, T a2, T a3) {      // (k past the end: the last entry, like the clamped index it replaces)
+    return k >= 3 ? a3 : (k == 2 ? a2 : (k == 1 ? a1 : a0));
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -275,7 +283,7 @@ __device__ __forceinline__ void backsub_blocked(const double* __restrict__ Lblk,
         const double d1 = r1 * fma(-w21, d2, fma(-w31, d3, u1));
         const double d0 = r0 * fma(-w10, d1, fma(-w20, d2, fma(-w30, d3, u0)));
         acc0 += fma(cc0[0], d0, cc0[1] * d1) + fma(cc0[2], d2, cc0[3] * d3);
-        acc1 += fma(cc1[0], d0, cc1[1] * d1) + fma(cc1[2], d2, cc1[3] * d3);
+        if (NBC == 0 || 4 * kb > 64) acc1 += fma(cc1[0], d0, cc1[1] * d1) + fma(cc1[2], d2, cc1[3] * d3);      // (unrolled: the sums of the columns from 64 on are read for the last time at block 16; below it their coefficients are the constant 0, which the compiler may not fold)
         if (t == 0) { d2v* o = (d2v*)(s_delta + base); o[0] = (d2v){d0, d1}; o[1] = (d2v){d2, d3}; }
     }
 }
@@ -804,12 +812,26 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     double mraw[TRI ? 1 : 2][TRI ? 1 : 6][4];
     // RIDE: the snapshot every solver role decides on (AvtSolveSnap) is requested now, before the wait for the reduction
     AvtFrameCtl snap_ctl;
-    AvtSpecCtl snap_sp;
+    // (the speculative-step queue field by field, never as a structure: an entry chosen by an index the compiler does not know would put a copy of
+    // the structure into scratch memory - 104 bytes and three dependent scratch round trips on the install path of every riding launch in the
+    // round-4 build: next, n, valid[k] -; spec_pick chooses among values)
+    static_assert(AVT_MAX_SPEC == 4, "the queue's entries are named one by one below");
+    int sq_next = 0, sq_n = 0, sq_ahead = 0, sq_v0 = 0, sq_v1 = 0, sq_v2 = 0, sq_v3 = 0;
+    double sq_l0 = 0.0, sq_l1 = 0.0, sq_l2 = 0.0, sq_l3 = 0.0, sq_p0 = 0.0, sq_p1 = 0.0, sq_p2 = 0.0, sq_p3 = 0.0;
     double snap_xw[AVT_MAX_SHAPE];
     unsigned fault_at_start = 0;      // (requested with everything else: a load of its own in front of the wait would be a round trip on the chain)
     if constexpr (RIDE) {
         fault_at_start = fb.fault[f];
-        snap_ctl = fb.snap[f].ctl; snap_sp = fb.snap[f].sp;
+        snap_ctl = fb.snap[f].ctl;
+        const AvtSpecCtl& gq = fb.snap[f].sp;
+        // (wave-uniform values, made scalars at once and never put into an array: the compiler folds a choice among array elements back into
+        // a choice among addresses; the kernel has scalar registers to spare, no vector ones)
+        auto uni_i = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+        auto uni_d = [](double v) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v))); };
+        sq_next = uni_i(gq.next); sq_n = uni_i(gq.n); sq_ahead = uni_i(gq.ahead);
+        sq_v0 = uni_i(gq.valid[0]); sq_v1 = uni_i(gq.valid[1]); sq_v2 = uni_i(gq.valid[2]); sq_v3 = uni_i(gq.valid[3]);
+        sq_l0 = uni_d(gq.lambda[0]); sq_l1 = uni_d(gq.lambda[1]); sq_l2 = uni_d(gq.lambda[2]); sq_l3 = uni_d(gq.lambda[3]);
+        sq_p0 = uni_d(gq.pred[0]); sq_p1 = uni_d(gq.pred[1]); sq_p2 = uni_d(gq.pred[2]); sq_p3 = uni_d(gq.pred[3]);
 #pragma unroll
         for (int k = 0; k < AVT_MAX_SHAPE; ++k) snap_xw[k] = k < K ? fb.snap[f].xw[k] : 0.0;
     }
@@ -825,7 +847,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     constexpr int SPN = RIDE ? (1496 + 120 + NTH - 1) / NTH : 1;
     double sp_pre[SPN];
     if constexpr (RIDE) {
-        const int k = min(snap_sp.next, AVT_MAX_SPEC - 1), ncopy = xs + d.prep_size;
+        const int k = min(sq_next, AVT_MAX_SPEC - 1), ncopy = xs + d.prep_size;
         const double* xsrc = fb.x_spec + ((size_t)f * AVT_MAX_SPEC + k) * xs;
         const double* psrc = fb.prep_spec + ((size_t)f * AVT_MAX_SPEC + k) * d.prep_size;
 #pragma unroll
@@ -969,8 +991,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     // a speculative workgroup of the last full solve launch has already made.  The solver then installs it (trial state and
     // skeleton tables copied into the trial slot) instead of factoring, and the speculative workgroups of this launch go home.
     AvtSpecCtl& sp = fb.spec[f];
-    const AvtSpecCtl& spin = snap_sp;                       // (RIDE only)
-    const int sp_next = RIDE ? spin.next : 0, sp_n = RIDE ? spin.n : 0;
+    const int sp_next = RIDE ? sq_next : 0, sp_n = RIDE ? sq_n : 0;
     const bool rejected = mode != SOLVE_FIRST && try_valid && !accepted;
     // Folded rejections (RIDE shapes whose k_eval evaluated the queued speculative steps' costs, fb.nspec_cost): the trial point has just
     // been rejected, so the next trial point is the first queued step - made from the SAME system with the lambda this rejection leaves.
@@ -999,7 +1020,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         nu = (fold && gain) ? nu * 2.0 : nu;
     }
     const int sp_use = sp_next + nfold;
-    const bool use_spec = RIDE && rejected && sp_use < sp_n && sp_use < AVT_MAX_SPEC && spin.valid[min(sp_use, AVT_MAX_SPEC - 1)] != 0;
+    const bool use_spec = RIDE && rejected && sp_use < sp_n && sp_use < AVT_MAX_SPEC && spec_pick(sp_use, sq_v0, sq_v1, sq_v2, sq_v3) != 0;
     if (RIDE && role > 0 && use_spec) return;
     if (RIDE && role > 0) {      // my damping: what `role` rejections in a row would make of the solver's
         for (int i = 0; i < role; ++i) {
@@ -1044,12 +1065,12 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
             else if (e < xs + d.prep_size) prep0[(size_t)tr * d.prep_size + (e - xs)] = sp_pre[i];
         }
         if (t == 0) {
-            const double lam = spin.lambda[k];
-            sp.next = k + 1; sp.ahead = spin.ahead + nfold;
+            const double lam = spec_pick(k, sq_l0, sq_l1, sq_l2, sq_l3), prd = spec_pick(k, sq_p0, sq_p1, sq_p2, sq_p3);
+            sp.next = k + 1; sp.ahead = sq_ahead + nfold;
             ctl.lambda = lam; ctl.try_valid = 1;
             ctl.dec_cur_slot = cur; ctl.dec_try_valid = 1; ctl.dec_cost_cur = cost_cur; ctl.dec_lambda = lam;
             // (the accept test above already took this rejection into lambda / nu: the installed step was made with exactly that lambda)
-            ctl.pred = spin.pred[k]; ctl.nu = nu; ctl.dec_pred = spin.pred[k]; ctl.dec_nu = nu;
+            ctl.pred = prd; ctl.nu = nu; ctl.dec_pred = prd; ctl.dec_nu = nu;
         }
         return;
     }
@@ -1223,7 +1244,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         // what the accept test of the trial point just made reads if no further solve follows (avt_decide.h)
         ctl.dec_cur_slot = cur; ctl.dec_try_valid = ok ? 1 : 0; ctl.dec_cost_cur = cost_cur; ctl.dec_lambda = lambda;
         ctl.pred = pred_new; ctl.nu = nu; ctl.dec_pred = pred_new; ctl.dec_nu = nu;
-        if (RIDE) { sp.next = 0; sp.n = fb.nspec; sp.ahead = (mode == SOLVE_FIRST ? 0 : spin.ahead) + nfold; }          // the speculative workgroups of this launch are making steps 0 .. nspec - 1
+        if (RIDE) { sp.next = 0; sp.n = fb.nspec; sp.ahead = (mode == SOLVE_FIRST ? 0 : sq_ahead) + nfold; }          // the speculative workgroups of this launch are making steps 0 .. nspec - 1
     }
     if (RIDE && t == 0 && role > 0) { sp.valid[role - 1] = ok ? 1 : 0; sp.lambda[role - 1] = lambda; sp.pred[role - 1] = pred_new; }
     if (RIDE && role > 0 && !ok) return;                     // (a refused speculative factorisation: the slot stays invalid)

@@ -68,7 +68,7 @@ def algorithmic_bytes_per_gn_iter(N, V, K, P):
 # symbol-name fragments (eval: the full evaluation k_eval<.., false>; solve: k_solve<.., SOLVE_NORMAL>; reduce: k_reduce<1> / k_reduce_strip<NS>)
 KERNEL_SYMBOL = {"eval": "Lb0EEv11DeviceModel12FrameBuffersi", "solve": "k_solveILi256ELb0ELi2", "reduce": "k_reduce", "lbs": "k_lbs",
                  "nn": ("k_nn", "?k_compact"),      # the class is k_nn_vis<4> alone (few frames) or k_compact + k_nn_part (batches): BOTH kernels' bytes
-                 "eval_moments": ("?k_prior", "k_pairpass", "k_assemble"),      # moment form: the evaluation class is the pair pass + the assembly (+ k_prior above 128 frames per launch)
+                 "eval_moments": ("?k_prior", "k_pairpass", "k_assemble"),      # moment form: the evaluation class is the pair pass + the assembly (+ k_prior above 256 frames per launch)
                  "moments": "k_moments"}
 # (a fragment that starts with "?" is optional: a kernel some launch shapes of the class do not have)
 
@@ -240,7 +240,7 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
         mom_iter, mom_pairs = moment_bytes_per_gn_iter(smpl, K, P)
         bytes_launch = nfg * mom_iter
         achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
-    res["roofline"] = {"kernel": "k_prior + k_pairpass + k_assemble" if dom_key == "eval_moments" else "k_" + dominant, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    res["roofline"] = {"kernel": ("k_prior + " if nfg > 256 else "") + "k_pairpass + k_assemble_parts" if dom_key == "eval_moments" else "k_" + dominant, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(nfg, "solve" if dom_key == "solve_moments" else dom_key, Nmean),
                        "chosen_because": ("two frame groups overlap: the evaluation bounds the step" if (groups >= 2 and not moments_run) else "largest share of device time"),
                        "limiter": LIMITER.get(dom_key, "?"),
@@ -249,7 +249,7 @@ def measure(api, synth, Options, torch, dist, smpl, gm, args, F, steps, warmup, 
                        "algorithmic_bytes_per_launch": int(bytes_launch), "survey_8d_equivalent": survey_equiv,
                        "pipeline": {"achieved": round(pipe, 3), "unit": "GB/s", "frac": round(pipe / HBM_PEAK_GBS, 6),
                                     "note": "frames x SURVEY 8(d) bytes per GN iteration x GN iterations per step / median step time (all kernels)"},
-                       "note": ("achieved = frames per launch x bytes the moment form moves per GN iteration (packed pair moments + data moments in, system out) / mean launch time of k_prior + k_pairpass + k_assemble "
+                       "note": ("achieved = frames per launch x bytes the moment form moves per GN iteration (packed pair moments + data moments in, system out) / mean launch time of k_pairpass (the pose prior rides in its grid) + k_assemble_parts "
                                 if dom_key == "eval_moments" else
                                 "achieved = frames per launch x (both slots' 88 x 88 systems in, trial state + skeleton tables out) / mean launch time of k_solve: a latency chain, see chain_us "
                                 if dom_key == "solve_moments" else "achieved = frames per launch x SURVEY 8(d) bytes per GN iteration / mean launch time of the dominant kernel class ") +
