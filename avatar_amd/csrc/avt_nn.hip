@@ -396,8 +396,8 @@ __device__ __forceinline__ double nn_wave_reduce(double v) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// k_nn_part: the throughput shape (frame batches).  A workgroup owns up to 256 consecutive bucketed data points of ONE part
-// (one per lane), so every lane scans the same candidates: the part's visible model points are read with SCALAR loads
+// k_nn_part: the throughput shape (frame batches).  A workgroup owns up to 256 NN_PART_NQ consecutive bucketed data points of ONE part
+// (NN_PART_NQ per lane), so every lane scans the same candidates: the part's visible model points are read with SCALAR loads
 // (constant address space: k_compact wrote them in an earlier kernel) straight into the VALU's scalar operand - no LDS
 // tile, no barrier, no per-lane range arithmetic; what remains per candidate is 8 flops and one v_min_f64.  Same distance
 // expression, same strict '<' in ascending candidate order, hence the same index as k_nn and nanoflann.
