@@ -235,11 +235,32 @@ __device__ __forceinline__ int wblk(int kb, int bi, int NB) {
 
 template <int NBC>
 __device__ __forceinline__ void backsub_blocked(const double* __restrict__ Lblk, const double* __restrict__ s_R, int NBrt, int P, int t,
-                                                double* __restrict__ s_delta) {
+                                                double* __restrict__ s_delta, double* __restrict__ s_M) {
     const int NB = NBC > 0 ? NBC : NBrt;
     auto Wat = [&](int i, int l) { return Lblk[((size_t)(l >> 2) * NB + (i >> 2)) * 18 + (i & 3) * 4 + (l & 3)]; };
     const double wp0 = (t < P) ? Wat(P, t) : 0.0;
     const double wp1 = (t + 64 < P) ? Wat(P, t + 64) : 0.0;
+    // ---- the 4x4 triangular solves of all blocks as matrices, made once by one lane per block (round 5, review item 1b).  A step's
+    //   d3 = r3 u3,  d2 = r2 (u2 - w32 d3),  d1 = r1 (u1 - w21 d2 - w31 d3),  d0 = r0 (u0 - w10 d1 - w20 d2 - w30 d3)
+    // is d = M u with M upper triangular, a function of the factor alone; with M in hand the four unknowns of a step are sums of products of
+    // the same depth (3) instead of a chain of 7 dependent operations.  Measured (tools/solve_phase_probe.py): 7.6 k -> 7.4 k clocks - the
+    // step is not its dependency chain but its ~65 instructions at one issue per ~5 clocks of a lone wave.
+    // s_M: [NB][10] in the panel buffer (free since the factorisation's last barrier): M00 M01 M02 M03 | M11 M12 M13 | M22 M23 | M33.
+    if (t < NB) {
+        const d2v* Wd = (const d2v*)(Lblk + ((size_t)t * NB + t) * 18);
+        const d2v a = Wd[2], bq = Wd[4], c = Wd[6], e = Wd[7];
+        const double w10 = a.x, w20 = bq.x, w21 = bq.y, w30 = c.x, w31 = c.y, w32 = e.x;
+        const d2v* Rq = (const d2v*)(s_R + 4 * t);
+        const d2v ra = Rq[0], rb = Rq[1];
+        const double r0 = ra.x, r1 = ra.y, r2 = rb.x, r3 = rb.y;
+        const double M33 = r3;
+        const double M22 = r2, M23 = -r2 * (w32 * M33);
+        const double M11 = r1, M12 = -r1 * (w21 * M22), M13 = -r1 * fma(w21, M23, w31 * M33);
+        const double M00 = r0, M01 = -r0 * (w10 * M11), M02 = -r0 * fma(w10, M12, w20 * M22), M03 = -r0 * fma(w10, M13, fma(w20, M23, w30 * M33));
+        d2v* o = (d2v*)(s_M + 10 * t);
+        o[0] = (d2v){M00, M01}; o[1] = (d2v){M02, M03}; o[2] = (d2v){M11, M12}; o[3] = (d2v){M13, M22}; o[4] = (d2v){M23, M33};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     double acc0 = 0.0, acc1 = 0.0;
     // column t (and t+64) of the rows of block kb: entries (k*4 + (t&3)) of block [t>>2][kb]
     const double* col0 = Lblk + (size_t)(t >> 2) * NB * 18 + (t & 3);
@@ -249,21 +270,16 @@ __device__ __forceinline__ void backsub_blocked(const double* __restrict__ Lblk,
     // strictly lower triangular and the blocks above the diagonal were zeroed at kernel start, so W(k,l) reads as 0
     // for every l >= k.  A lone wave issues one instruction every ~5 clocks: the step is kept to ~40 instructions.
     constexpr int DEPTH = NBC > 0 ? 3 : 1;                            // runtime NB: no unrolling, no ring
-    double c0[DEPTH][4], c1[DEPTH][4], wd[DEPTH][6], rr[DEPTH][4];
+    double c0[DEPTH][4], c1[DEPTH][4], md[DEPTH][10];
     auto fetch = [&](int kb, int sl) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             c0[sl][k] = col0[(size_t)kb * 18 + 4 * k];
             c1[sl][k] = (4 * kb > 64) ? col1[(size_t)kb * 18 + 4 * k] : 0.0;
         }
-        // the diagonal block's strictly-lower entries W(base+k, base+i) at [k*4+i] and the reciprocal pivots (0 for the
-        // rows >= P of the last block, see the factorisation)
-        const d2v* Wd = (const d2v*)(Lblk + ((size_t)kb * NB + kb) * 18);
-        const d2v a = Wd[2], bq = Wd[4], c = Wd[6], e = Wd[7];
-        wd[sl][0] = a.x; wd[sl][1] = bq.x; wd[sl][2] = bq.y; wd[sl][3] = c.x; wd[sl][4] = c.y; wd[sl][5] = e.x;
-        const d2v* Rq = (const d2v*)(s_R + 4 * kb);
-        const d2v ra = Rq[0], rb = Rq[1];
-        rr[sl][0] = ra.x; rr[sl][1] = ra.y; rr[sl][2] = rb.x; rr[sl][3] = rb.y;
+        const d2v* Mq = (const d2v*)(s_M + 10 * kb);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { const d2v m = Mq[i]; md[sl][2 * i] = m.x; md[sl][2 * i + 1] = m.y; }
     };
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i)
@@ -271,19 +287,19 @@ __device__ __forceinline__ void backsub_blocked(const double* __restrict__ Lblk,
 #pragma unroll
     for (int kb = NB - 1; kb >= 0; --kb) {
         const int base = 4 * kb, sl = kb % DEPTH;
-        const double w10 = wd[sl][0], w20 = wd[sl][1], w21 = wd[sl][2], w30 = wd[sl][3], w31 = wd[sl][4], w32 = wd[sl][5];
-        const double r0 = rr[sl][0], r1 = rr[sl][1], r2 = rr[sl][2], r3 = rr[sl][3];
+        const double M00 = md[sl][0], M01 = md[sl][1], M02 = md[sl][2], M03 = md[sl][3], M11 = md[sl][4], M12 = md[sl][5], M13 = md[sl][6],
+                     M22 = md[sl][7], M23 = md[sl][8], M33 = md[sl][9];
         const double cc0[4] = {c0[sl][0], c0[sl][1], c0[sl][2], c0[sl][3]}, cc1[4] = {c1[sl][0], c1[sl][1], c1[sl][2], c1[sl][3]};
         if (kb - DEPTH >= 0) fetch(kb - DEPTH, sl);
         const double u = (base >= 64) ? wp1 - acc1 : wp0 - acc0;
         const double u0 = readlane_f64(u, base & 63), u1 = readlane_f64(u, (base + 1) & 63);
         const double u2 = readlane_f64(u, (base + 2) & 63), u3 = readlane_f64(u, (base + 3) & 63);
-        const double d3 = r3 * u3;
-        const double d2 = r2 * fma(-w32, d3, u2);
-        const double d1 = r1 * fma(-w21, d2, fma(-w31, d3, u1));
-        const double d0 = r0 * fma(-w10, d1, fma(-w20, d2, fma(-w30, d3, u0)));
+        const double d3 = M33 * u3;
+        const double d2 = fma(M23, u3, M22 * u2);
+        const double d1 = fma(M13, u3, fma(M12, u2, M11 * u1));
+        const double d0 = fma(M01, u1, M00 * u0) + fma(M03, u3, M02 * u2);
         acc0 += fma(cc0[0], d0, cc0[1] * d1) + fma(cc0[2], d2, cc0[3] * d3);
-        acc1 += fma(cc1[0], d0, cc1[1] * d1) + fma(cc1[2], d2, cc1[3] * d3);      // (skipping the dead sums of the columns from 64 on below block 16 - their coefficients are the constant 0 there - measured no shorter: 7.6 k clocks either way)
+        acc1 += fma(cc1[0], d0, cc1[1] * d1) + fma(cc1[2], d2, cc1[3] * d3);
         if (t == 0) { d2v* o = (d2v*)(s_delta + base); o[0] = (d2v){d0, d1}; o[1] = (d2v){d2, d3}; }
     }
 }
@@ -1177,8 +1193,8 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         // ---- back substitution by wave 0 (the other waves wait at the barrier)
         if (t < 64) {
             if constexpr (TRI) backsub_tri(Lblk, s_R, NB, P, t, s_delta);
-            else if (NB == 22) backsub_blocked<22>(Lblk, s_R, NB, P, t, s_delta);
-            else backsub_blocked<0>(Lblk, s_R, NB, P, t, s_delta);
+            else if (NB == 22) backsub_blocked<22>(Lblk, s_R, NB, P, t, s_delta, s_PB);
+            else backsub_blocked<0>(Lblk, s_R, NB, P, t, s_delta, s_PB);
             if (gain) {
                 // Predicted decrease of the quadratic model, 1/2 delta^T (lambda D delta - g), by the same wave (fixed butterfly).  g and the
                 // undamped diagonal D are formed again from the reduced system and the priors, entry by entry as sys_tile forms them
