@@ -745,6 +745,9 @@ def compact_line(out):
                                 "reference_structure_all_cores": cb.get("reference_structure_all_cores_spawn_join"),
                                 "batch_all_cores": (cb.get("batch_all_cores") or {}).get("value"), "sample": str(cb.get("sample", ""))[:200]}
         line["speedup_vs_cpu"] = out.get("speedup_vs_cpu_port")
+        ref = cb.get("reference_structure_all_cores_spawn_join")
+        if ref:      # the reference's own evaluation structure (one residual block at a time, pool spawned and joined per evaluation, serial NN queries) on all host cores
+            line["speedup_vs_cpu_reference_structure_all_cores"] = round(out["value"] / ref, 1)
     if out.get("eval_kernel"):
         line["mfma"] = _mfma(out["eval_kernel"])
     if out.get("host_to_host"):
