@@ -20,8 +20,14 @@
 
 #ifdef AVT_TIMING
 #define TPROBE(i) do { if (threadIdx.x == 0 && blockIdx.y == 0) fb.trace[(size_t)(blockIdx.x + fb.f0) * 64 + 40 + (i)] = (double)clock64(); } while (0)
+// the start of the launch is kept in a register and written with probe 1: the launches that install a step or only decide return in front of
+// probe 1, and their start must not overwrite that of the last full solve
+#define TPROBE_START() const long long tprobe_start = clock64()
+#define TPROBE_FIRST() do { if (threadIdx.x == 0 && blockIdx.y == 0) { double* tp_ = fb.trace + (size_t)(blockIdx.x + fb.f0) * 64 + 40; tp_[0] = (double)tprobe_start; tp_[1] = (double)clock64(); } } while (0)
 #else
 #define TPROBE(i) do {} while (0)
+#define TPROBE_START() do {} while (0)
+#define TPROBE_FIRST() do {} while (0)
 #endif
 
 #include "avt_prep.h"
@@ -813,7 +819,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         prep_run<NTH>(dm, L, B, s_items, s_level, xc + 3, prep0 + (size_t)tr * d.prep_size);
         return;
     }
-    TPROBE(0);
+    TPROBE_START();
     // ---- a. one round trip for everything the LM decision and the system need: the control block, the objective
     // terms of BOTH state slots and (256-thread shape) this lane's entries of BOTH data-term matrices (the slot is chosen
     // below).  The system is the bordered (P+1)x(P+1) matrix [[H + lambda diag H, .],[-g^T, .]] (row P carries the rhs so
@@ -1090,7 +1096,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         }
         return;
     }
-    TPROBE(1);
+    TPROBE_FIRST();
 
     // ---- b. the damped system of the current point, straight into registers (second, short round trip: the
     // precision block and gradient of the chosen GMM component, read-only data) ------------------------------
