@@ -105,7 +105,7 @@ avt_tuning tuning_from_environment() {
     avt_tuning t;
     std::memset(&t, 0, sizeof t);
     t.use_graph = 1; t.groups = 0; t.g = 0; t.gcap = 128; t.vis_frame_min = 64; t.ride = 1; t.ride_strips = 0; t.ride_sizing_groups = 0;
-    t.asm_parts = 1; t.spec_cost = 1; t.xcd_frames = 1; t.nspec = AVT_MAX_SPEC; t.nn_force_part = 0; t.nn_slab = 1; t.mom_min_frames = 32; t.debug = 0; t.ride_timeout_us = 2000000;
+    t.asm_parts = 1; t.spec_cost = 1; t.xcd_frames = 1; t.nspec = AVT_MAX_SPEC; t.nn_force_part = 0; t.nn_slab = 1; t.mom_min_frames = 8; t.debug = 0; t.ride_timeout_us = 2000000;
     struct Knob { const char* name; int* field; };
     const Knob knobs[] = {{"AVT_USE_GRAPH", &t.use_graph}, {"AVT_GROUPS", &t.groups}, {"AVT_G", &t.g}, {"AVT_GCAP", &t.gcap}, {"AVT_VIS_FRAME_MIN", &t.vis_frame_min},
                           {"AVT_RIDE", &t.ride}, {"AVT_RIDE_STRIPS", &t.ride_strips}, {"AVT_RIDE_SIZING_GROUPS", &t.ride_sizing_groups}, {"AVT_NSPEC", &t.nspec},
@@ -693,7 +693,10 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         HIP_OK(hipMemsetAsync(fb.mom_D, 0, (size_t)max_frames * J * d.mom_npsi * 3 * sizeof(double), c->stream));      // joints no vertex is assigned to keep zeros
     }
     c->data_term = AVT_DATA_TERM_AUTO;
-    // (tun.mom_min_frames = 32: tools/data_term_sweep.sh, ms per step moments / rows: 16 frames per launch 1.01 / 0.95, 24: 1.10 / 1.08, 32: 1.18 / 1.22, 64: 1.57 / 1.92, 128: 2.33 / 3.39, 256: 4.31 / 6.34)
+    // (tun.mom_min_frames = 8, round 5 - ms per step moments / rows, frames per launch [frames per GPU]: 4 [4] 0.701 / 0.648, 6 [6] 0.710 / 0.692, 8 [8] 0.709 / 0.724,
+    //  12 [12] 0.747 / 0.787, 16 [16] 0.737 / 0.800, 12 [24] 0.777 / 0.877, 16 [32] 0.838 / 0.938, 24 [48] 0.934 / 1.075, 28 [56] 0.985 / 1.186; dense frames 8 [8] 0.757 / 0.777,
+    //  16 [16] 0.817 / 0.884; tools/ab_env.sh AVT_MOM_MIN_FRAMES.  Round 4's crossover was 32 frames per launch: the assembly as role workgroups, the decide-only closing
+    //  pass and the XCD frame mapping took 15 % off the moment form's GN iteration since)
     c->last_run_moments = false;
     {
         AvtRunParams* pr = nullptr;

@@ -223,7 +223,7 @@ int avt_get_normal_equations(avt_ctx* c, int frame, double* H /* P x P */, doubl
  *                          every iteration (AvatarCostFunctorCache::updateData + the ICP cost functor, AvatarOptimizer.cpp:505-644);
  *   AVT_DATA_TERM_MOMENTS  the correspondences' sufficient statistics are accumulated once per ICP iteration and every iteration
  *                          contracts them with the state (avt_moments.hip);
- *   AVT_DATA_TERM_AUTO     (default) the moment form from 32 frames per launch on (avt_tuning.mom_min_frames), where it is the faster one; rows below.
+ *   AVT_DATA_TERM_AUTO     (default) the moment form from 8 frames per launch on (avt_tuning.mom_min_frames), where it is the faster one; rows below.
  * Takes effect for the following calls; avt_get_normal_equations evaluates with the form selected here (AUTO: the form the last
  * optimize() ran), so tests can compare the two on the same correspondences. */
 enum { AVT_DATA_TERM_ROWS = 0, AVT_DATA_TERM_MOMENTS = 1, AVT_DATA_TERM_AUTO = 2 };
@@ -259,7 +259,7 @@ typedef struct avt_tuning {
     int nspec;               /* speculative solver workgroups per frame beside the solver (0 .. 4) */
     int nn_force_part;       /* 1: the throughput shape of the nearest neighbour on small inputs too */
     int nn_slab;             /* 1: that shape walks y-sorted candidates outwards from the wave's slab of queries; 0: full scan */
-    int mom_min_frames;      /* AVT_DATA_TERM_AUTO: frames per launch from which the moment form is used (32) */
+    int mom_min_frames;      /* AVT_DATA_TERM_AUTO: frames per launch from which the moment form is used (8: the measured crossover of round 5; 32 in round 4) */
     int debug;               /* 1: occupancy report on stderr at context creation */
     int asm_parts;           /* moment form: 1 (default) the assembly of a frame runs as six independent 256-thread role workgroups, 0 as one 1024-thread workgroup */
     long long ride_timeout_us; /* how long a solver role waits for the riding reduction before it raises the frame's fault (2 000 000) */
