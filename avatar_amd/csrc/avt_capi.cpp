@@ -60,7 +60,9 @@ int dev_upload(avt_ctx* c, T** p, const std::vector<T>& v) {
 
 // frame groups of one optimize(): measured on MI355X, two groups pay off from ~32 frames, more never do (avt_tuning::groups overrides)
 int choose_groups(int nframes, const avt_tuning& tun) {
-    int n = nframes >= 32 ? 2 : 1;      // measured: 24 frames 0.866 (one group) / 0.899 ms (two), 32: 0.964 / 0.954, 40: 1.075 / 1.026
+    // two groups from 44 frames on - measured, round 5 (moment form from 8 frames per launch on), ms per step one / two groups: 16 frames 0.737 / 0.798, 24: 0.777 / 0.822,
+    // 32: 0.810 / 0.838, 36: 0.865 / 0.878, 40: 0.880 / 0.892, 44: 0.938 / 0.913, 48: 0.952 / 0.928, 64: 1.077 / 1.011 (round 4, rows below 64 frames: the crossover was 32)
+    int n = nframes >= 44 ? 2 : 1;
     if (tun.groups > 0) n = tun.groups;
     return std::max(1, std::min(std::min(n, AVT_MAX_GROUPS), nframes));
 }

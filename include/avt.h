@@ -249,7 +249,7 @@ int avt_debug_mfma_count(avt_ctx* c, int frame, long long* eval_rows, long long*
  * validates, drops the cached launch graphs and takes effect for the following calls. */
 typedef struct avt_tuning {
     int use_graph;           /* 1: optimize() replays one hipGraph per launch shape; 0: plain launches (AVT_NO_GRAPH=1 sets 0) */
-    int groups;              /* frame groups (streams) of one optimize(); 0 = automatic (2 from 32 frames on, one frame per group for 2-3 frames) */
+    int groups;              /* frame groups (streams) of one optimize(); 0 = automatic (2 from 44 frames on, one frame per group for 2-3 frames) */
     int g;                   /* row form: evaluation workgroups per frame, 0 = automatic */
     int gcap;                /* ... and their cap in the few-frames shape (128) */
     int vis_frame_min;       /* frames per launch from which visibility runs as one workgroup per frame (64; 0 = never) */
