@@ -106,7 +106,7 @@ extern "C" char** environ;
 avt_tuning tuning_from_environment() {
     avt_tuning t;
     std::memset(&t, 0, sizeof t);
-    t.use_graph = 1; t.groups = 0; t.g = 0; t.gcap = 128; t.vis_frame_min = 64; t.ride = 1; t.ride_strips = 0; t.ride_sizing_groups = 0;
+    t.use_graph = 1; t.groups = 0; t.g = 0; t.gcap = 128; t.vis_frame_min = 32; t.ride = 1; t.ride_strips = 0; t.ride_sizing_groups = 0;
     t.asm_parts = 1; t.spec_cost = 1; t.xcd_frames = 1; t.nspec = AVT_MAX_SPEC; t.nn_force_part = 0; t.nn_slab = 1; t.mom_min_frames = 8; t.debug = 0; t.ride_timeout_us = 2000000;
     struct Knob { const char* name; int* field; };
     const Knob knobs[] = {{"AVT_USE_GRAPH", &t.use_graph}, {"AVT_GROUPS", &t.groups}, {"AVT_G", &t.g}, {"AVT_GCAP", &t.gcap}, {"AVT_VIS_FRAME_MIN", &t.vis_frame_min},

@@ -252,7 +252,7 @@ typedef struct avt_tuning {
     int groups;              /* frame groups (streams) of one optimize(); 0 = automatic (2 from 44 frames on, one frame per group for 2-3 frames) */
     int g;                   /* row form: evaluation workgroups per frame, 0 = automatic */
     int gcap;                /* ... and their cap in the few-frames shape (128) */
-    int vis_frame_min;       /* frames per launch from which visibility runs as one workgroup per frame (64; 0 = never) */
+    int vis_frame_min;       /* frames per launch from which visibility runs as one workgroup per frame (32: 64 frames per GPU 1.013 -> 1.003 ms against 64, the round-4 value; 0 = never) */
     int ride;                /* 1: up to three frames the reduction rides in k_solve's launch */
     int ride_strips;         /* 0 = automatic, else 4 or 8 strips per tile pair */
     int ride_sizing_groups;  /* 1: size the riding shapes by the frame groups running side by side instead of by the one launch */
