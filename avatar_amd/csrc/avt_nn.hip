@@ -32,7 +32,7 @@
 #endif
 #define NN_ACC_CAP 512                // candidates of a part whose match counts / sums k_nn_part accumulates in LDS (14 KB)
 #ifndef NN_SLAB_CHUNK
-#define NN_SLAB_CHUNK 32                // candidates per side and round of the slab scan (a multiple of the group size)
+#define NN_SLAB_CHUNK 16                // candidates per side and round of the slab scan (a multiple of the group size; with two queries per lane 16 / 24 / 32 / 48: 498 / 500 / 507 / 513 us per 256-frame launch of the class)
 #endif
 
 
