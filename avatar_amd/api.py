@@ -494,6 +494,7 @@ class AvatarOptimizer:
         self.nnStep = 20                                   # :33
         self.maxItersPerICP = 10                           # :36
         self.enableOcclusion = True                        # :39
+        self.functionTolerance = 1e-4                      # not a member of the reference's class: what its optimize() hard-codes at AvatarOptimizer.cpp:1333 (0 = no early exit)
         self.r = np.zeros((J, 4)); self.r[:, 3] = 1.0      # quaternions (x,y,z,w), :25
         self.ctx = Context(ava.model, self.numParts, self.partMap, max_points, 1)
         self.last_stats = None
@@ -503,6 +504,7 @@ class AvatarOptimizer:
         o.beta_pose, o.beta_shape = self.betaPose, self.betaShape
         o.nn_step, o.max_iters_per_icp = self.nnStep, self.maxItersPerICP
         o.enable_occlusion, o.icp_iters, o.num_threads = int(self.enableOcclusion), icp_iters, num_threads
+        o.function_tolerance = self.functionTolerance
         return o
 
     def optimize(self, data_cloud, data_part_labels, icp_iters=1, num_threads=4):

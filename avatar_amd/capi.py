@@ -42,32 +42,45 @@ class Options(C.Structure):
         ("nn_step", C.c_int), ("max_iters_per_icp", C.c_int), ("enable_occlusion", C.c_int),
         ("icp_iters", C.c_int), ("num_threads", C.c_int), ("lm_policy", C.c_int),
         ("lm_lambda0", C.c_double), ("lm_up", C.c_double), ("lm_down", C.c_double),
-        ("lm_lambda_min", C.c_double), ("lm_lambda_max", C.c_double),
+        ("lm_lambda_min", C.c_double), ("lm_lambda_max", C.c_double), ("function_tolerance", C.c_double),
     ]
+
+    LM_FIXED_FACTORS, LM_GAIN_RATIO = 0, 1      # include/avt.h AVT_LM_*
 
     @classmethod
     def reference_defaults(cls):
-        """AvatarOptimizer.h:28-39 member defaults + the LM step-rule defaults."""
+        """AvatarOptimizer.h:28-39 member defaults, the reference's function_tolerance (AvatarOptimizer.cpp:1333) and the step rule's defaults
+        (the gain-ratio schedule since round 6).  Mirrors avt_options_default (avt_model.cpp), the one place the defaults
+        are set: tests/test_oracle_cpu.py::test_python_option_defaults_are_the_c_defaults compares the two field by field."""
         return cls(beta_pose=0.1, beta_shape=1.0, nn_step=20, max_iters_per_icp=10, enable_occlusion=1,
-                   icp_iters=1, num_threads=4, lm_policy=0, lm_lambda0=1e-3, lm_up=4.0, lm_down=1.0 / 3.0,
-                   lm_lambda_min=1e-12, lm_lambda_max=1e8)
+                   icp_iters=1, num_threads=4, lm_policy=cls.LM_GAIN_RATIO, lm_lambda0=1e-3, lm_up=cls.GAIN_LM_UP, lm_down=1.0 / 3.0,
+                   lm_lambda_min=1e-12, lm_lambda_max=1e8, function_tolerance=1e-4)
 
     @classmethod
     def demo(cls, **kw):
-        """The knobs the reference's trackers run with (demo.cpp:54-57,139-143)."""
+        """The knobs the reference's trackers run with (demo.cpp:54-57,139-143).  `lm_policy=0` without an `lm_up` selects the fixed-factor
+        schedule of rounds 1-5 with the constant it was tuned with (avt_options_fixed_factors)."""
         o = cls.reference_defaults()
         o.beta_pose, o.beta_shape = 0.05, 0.12
         for k, v in kw.items():
             setattr(o, k, v)
-        if o.lm_policy == 1 and "lm_up" not in kw:
-            o.lm_up = cls.GAIN_LM_UP
+        if "lm_up" not in kw:
+            o.lm_up = cls.GAIN_LM_UP if o.lm_policy == cls.LM_GAIN_RATIO else cls.FIXED_LM_UP
         return o
+
+    @classmethod
+    def counted(cls, **kw):
+        """demo() with the stopping rule off: exactly max_iters_per_icp iterations per ICP iteration (what the benchmark counts and what tests
+        that compare iteration by iteration want)."""
+        kw.setdefault("function_tolerance", 0.0)
+        return cls.demo(**kw)
 
     # gain-ratio schedule (lm_policy = 1): the multiplier of the first rejection after an accepted step.  Nielsen's 2 climbs too slowly for
     # these frames (three rejections in a row after the second step of most of them); over the 12 bench seeds (tools/damping_policy_compare.py)
     # 2 / 4 / 8 / 16 / 32 accept 0.76 / 0.80 / 0.83 / 0.87 / 0.86 of the iterations of one ICP iteration and end at a mean objective of
     # 28.39 / 28.10 / 27.91 / 27.98 / 27.87 (fixed factors: 0.57, 28.98)
     GAIN_LM_UP = 16.0
+    FIXED_LM_UP = 4.0       # the fixed-factor schedule's rejection multiplier (rounds 1-5)
 
 
 class Tuning(C.Structure):
@@ -271,7 +284,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = [
-    "avt_last_error", "avt_kernel_name", "avt_options_default", "avt_model_create", "avt_model_destroy",
+    "avt_last_error", "avt_kernel_name", "avt_options_default", "avt_options_fixed_factors", "avt_model_create", "avt_model_destroy",
     "avt_model_dims", "avt_model_main_joint", "avt_model_joint_regression", "avt_model_tile_layout", "avt_ctx_create", "avt_ctx_destroy",
     "avt_sync", "avt_lbs_update", "avt_visibility", "avt_nn", "avt_optimize", "avt_optimize_batch",
     "avt_frames_upload", "avt_synth_render_frames", "avt_synth_render_frames_mode", "avt_synth_render_images", "avt_frames_download", "avt_state_upload", "avt_optimize_resident", "avt_state_reset", "avt_state_download",
@@ -280,5 +293,5 @@ EXPORTED_SYMBOLS = [
     "avt_shard_owner", "avt_shard_local_count", "avt_shard_local_index", "avt_shard_global_frame", "avt_model_pack_size", "avt_model_pack",
     "avt_model_unpack", "avt_shard_unique_id", "avt_shard_create", "avt_shard_create_loopback", "avt_shard_create_shm", "avt_shard_destroy", "avt_shard_rank", "avt_shard_world", "avt_shard_backend",
     "avt_shard_broadcast_model", "avt_shard_scatter_frames", "avt_shard_gather_enqueue", "avt_shard_gather_wait", "avt_shard_gather_download",
-    "avt_shard_gather_results", "avt_shard_barrier",
+    "avt_shard_gather_results", "avt_shard_barrier", "avt_shard_set_self_exchange",
 ]

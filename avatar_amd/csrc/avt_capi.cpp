@@ -113,7 +113,7 @@ avt_tuning tuning_from_environment() {
                           {"AVT_RIDE", &t.ride}, {"AVT_RIDE_STRIPS", &t.ride_strips}, {"AVT_RIDE_SIZING_GROUPS", &t.ride_sizing_groups}, {"AVT_NSPEC", &t.nspec},
                           {"AVT_NN_FORCE_PART", &t.nn_force_part}, {"AVT_NN_SLAB", &t.nn_slab}, {"AVT_MOM_MIN_FRAMES", &t.mom_min_frames}, {"AVT_ASM_PARTS", &t.asm_parts}, {"AVT_LBS_FRAMES", &t.lbs_frames}, {"AVT_SPEC_COST", &t.spec_cost}, {"AVT_XCD_FRAMES", &t.xcd_frames}, {"AVT_DEBUG", &t.debug}};
     // names other parts of the repository own (the batch split, the Python loader, bench.py, instrumented builds)
-    const char* others[] = {"AVT_LIB", "AVT_RCCL_LIB", "AVT_SHARD_SELF_SENDRECV", "AVT_SHARD_LOOPBACK_TIMEOUT_S", "AVT_BENCH_SHARE_GPU0", "AVT_TIMING"};
+    const char* others[] = {"AVT_LIB", "AVT_RCCL_LIB", "AVT_SHARD_LOOPBACK_TIMEOUT_S", "AVT_BENCH_SHARE_GPU0", "AVT_TIMING"};
     for (char** e = environ; e && *e; ++e) {
         if (std::strncmp(*e, "AVT_", 4) != 0) continue;
         const char* eq = std::strchr(*e, '=');
@@ -247,6 +247,7 @@ int sync_params(avt_ctx* c, const avt_options* o) {
     std::memset(&pr, 0, sizeof pr);
     pr.beta_pose = o->beta_pose; pr.beta_shape = o->beta_shape; pr.lambda0 = o->lm_lambda0;
     pr.lm_up = o->lm_up; pr.lm_down = o->lm_down; pr.lm_min = o->lm_lambda_min; pr.lm_max = o->lm_lambda_max; pr.lm_policy = o->lm_policy == 1 ? 1.0 : 0.0;
+    pr.ftol = o->function_tolerance;
     if (c->params_valid && std::memcmp(&pr, &c->params_host, sizeof pr) == 0) return 0;
     c->params_host = pr;
     HIP_OK(hipMemcpyAsync((void*)c->fb.params, &c->params_host, sizeof pr, hipMemcpyHostToDevice, c->stream));
@@ -278,6 +279,7 @@ int run_optimize(avt_ctx* c, const avt_options* o) {
     if (o->max_iters_per_icp < 0 || o->max_iters_per_icp > 62 || o->icp_iters < 0) { avt_set_error("avt_optimize: bad iteration counts"); return 1; }
     if (o->lm_policy != 0 && o->lm_policy != 1) { avt_set_error("avt_optimize: lm_policy must be 0 (fixed factors) or 1 (gain ratio)"); return 1; }
     if (!(o->lm_up > 1.0) || !(o->lm_down > 0.0 && o->lm_down < 1.0)) { avt_set_error("avt_optimize: lm_up must be > 1 and lm_down in (0, 1)"); return 1; }
+    if (!(o->function_tolerance >= 0.0 && o->function_tolerance < 1.0)) { avt_set_error("avt_optimize: function_tolerance must be in [0, 1) (0 = no early exit)"); return 1; }
     if (sync_params(c, o)) return 1;
     c->ran_max_iters = o->max_iters_per_icp;
     // Large batches run as several frame groups: the latency-bound single-workgroup-per-frame kernels of one group
@@ -443,6 +445,7 @@ int download_state(avt_ctx* c, double* p, double* q, double* w, avt_stats* st) {
                  fault[bad], (fault[bad] & AVT_FAULT_RIDE_TIMEOUT) ? ": a solver gave up waiting for the in-launch reduction" : "");
         HIP_OK(hipMemsetAsync(c->fb.fault, 0, (size_t)c->fb.max_frames * sizeof(unsigned), c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));
+        c->results_fresh = false;      //  the result records carry the word that was just cleared: a later gather packs them again
         avt_set_error(msg);
         return AVT_STATUS_DEVICE_FAULT;
     }
@@ -487,7 +490,9 @@ int optimize_host_to_host(avt_ctx* c, int nframes, const double* data, const int
     const size_t b_data = (size_t)total * 24, b_lab = ((size_t)total * 4 + 15) & ~(size_t)15, b_x = (size_t)nframes * 2 * xs * 8,
                  b_ctl = (size_t)nframes * sizeof(AvtFrameCtl), b_res = (size_t)nframes * stride * 8;
     const size_t need = b_data + b_lab + b_x + b_ctl + b_res + 64;
-    if (c->host_pin_cap < need) {
+    //  the pinned block grows with the largest call and shrinks again when a call needs less than a quarter of it: a tracker that once
+    // fitted a dense 512-frame batch does not keep gigabytes pinned for its one-frame calls
+    if (c->host_pin_cap < need || (c->host_pin_cap > (64u << 20) && need < c->host_pin_cap / 4)) {
         HIP_OK(hipStreamSynchronize(c->stream));
         if (c->host_pin) (void)hipHostFree(c->host_pin);
         c->host_pin = nullptr; c->host_pin_cap = 0;
@@ -529,7 +534,7 @@ int optimize_host_to_host(avt_ctx* c, int nframes, const double* data, const int
     HIP_OK(hipMemcpyAsync(c->fb.ctl_start, c->fb.ctl, b_ctl, hipMemcpyDeviceToDevice, c->stream));
     c->frames_valid = c->state_valid = true;
     c->results_fresh = false;
-    if (run_optimize(c, o)) return 1;
+    if (run_optimize(c, o)) { c->results_fresh = false; return 1; }
     if (!c->results_fresh) { launch_pack_results(c, nframes, c->fb.results, stride); c->results_fresh = true; }      // (a call without ICP iterations has no closing k_lbs launch)
     HIP_OK(hipMemcpyAsync(h_res, c->fb.results, b_res, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));      // the one synchronisation of the call
@@ -545,6 +550,7 @@ int optimize_host_to_host(avt_ctx* c, int nframes, const double* data, const int
                  badbits, (badbits & AVT_FAULT_RIDE_TIMEOUT) ? ": a solver gave up waiting for the in-launch reduction" : "");
         HIP_OK(hipMemsetAsync(c->fb.fault, 0, (size_t)c->fb.max_frames * sizeof(unsigned), c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));
+        c->results_fresh = false;      //  the records carry the word that was just cleared: a later gather packs them again
         avt_set_error(msg);
         return AVT_STATUS_DEVICE_FAULT;
     }
@@ -981,7 +987,9 @@ int avt_optimize_resident(avt_ctx* c, const avt_options* opt) {
     AVT_API_GUARD_BEGIN
     if (!c || !opt) { avt_set_error("avt_optimize_resident: null argument"); return 1; }
     HIP_OK(hipSetDevice(c->device));
-    return run_optimize(c, opt);
+    const int rc = run_optimize(c, opt);
+    if (rc) c->results_fresh = false;      //  a call that failed left no result records
+    return rc;
     AVT_API_GUARD_END("avt_optimize_resident")
 }
 

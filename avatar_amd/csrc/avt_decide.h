@@ -16,10 +16,10 @@ struct LastDecisionInputs {
     double v[AVT_G_MAX / 64];                  // this lane's partial sums of sum c|r|^2 of the trial point (workgroups lane, lane + 64, ..) ...
     unsigned long long m[AVT_G_MAX / 64];      // ... and the written-masks of the workgroups they come from
     double pv;                                 // this lane's prior score / shape coefficient (above)
-    unsigned cw;                               // lane l < 40: 32-bit word l of the frame's control block; lanes 40..55: of AvtRunParams
+    unsigned cw;                               // lane l < 40: 32-bit word l of the frame's control block; lanes 40..59: of AvtRunParams
 };
 static_assert(AVT_MAX_COMPS == 16 && AVT_MAX_SHAPE == 16, "lane layout of LastDecisionInputs::pv");
-static_assert(sizeof(AvtFrameCtl) == 160 && sizeof(AvtRunParams) == 64, "lane layout of LastDecisionInputs::cw");
+static_assert(sizeof(AvtFrameCtl) == 160 && sizeof(AvtRunParams) == 80, "lane layout of LastDecisionInputs::cw");
 
 __device__ __forceinline__ LastDecisionInputs lm_last_load(const DeviceModel& dm, const FrameBuffers& fb, int f) {
     const AvtDims& d = dm.d;
@@ -40,7 +40,7 @@ __device__ __forceinline__ LastDecisionInputs lm_last_load(const DeviceModel& dm
     const double* src = is_prior ? fb.prior + (((size_t)f * 2 + sl) * AVT_MAX_COMPS + (there ? c : 0)) * AVT_PRIOR_STRIDE
                                  : fb.x + ((size_t)f * 2 + sl) * xs + 3 + 4 * J + (there ? c : 0);
     in.pv = *src;
-    const unsigned* cws = lane < 40 ? (const unsigned*)(fb.ctl + f) + lane : (const unsigned*)fb.params + ((lane - 40) & 15);
+    const unsigned* cws = lane < 40 ? (const unsigned*)(fb.ctl + f) + lane : (const unsigned*)fb.params + min(lane - 40, 19);
     in.cw = *cws;
     return in;
 }
@@ -101,6 +101,8 @@ __device__ __forceinline__ int lm_last_decide(const DeviceModel& dm, const Frame
         }
         cost += 0.5 * s;
     }
+    // the frame met the stopping rule earlier in this ICP iteration (avt_options::function_tolerance, k_solve): there is no trial point and no test
+    if (try_valid == AVT_TRY_DONE) return cur0;
     bool accepted = false;
     double nu = nu0;
     if (try_valid) {      // the same rule as k_solve's (avt_lm.hip)

@@ -1,5 +1,6 @@
 // avt_device.h — small device helpers shared by the kernels (gfx950, wave64).
 #pragma once
+#include <cstddef>
 #include "avt_internal.h"
 
 #define AVT_INF (__builtin_inf())
@@ -68,6 +69,12 @@ __device__ __forceinline__ void fk_chain(int J, const int* __restrict__ parent, 
         __syncthreads();
     }
 }
+
+// (cur_slot, try_valid) of a frame's control block as one 8-byte load.  The kernels of a Gauss-Newton iteration need the first for the address of
+// everything they read next; the second says whether there is a trial point at all: AVT_TRY_DONE = the frame met the stopping rule
+// (avt_options::function_tolerance, k_solve) and the launches left in this ICP iteration have nothing to do for it.
+static_assert(offsetof(AvtFrameCtl, cur_slot) % 8 == 0 && offsetof(AvtFrameCtl, try_valid) == offsetof(AvtFrameCtl, cur_slot) + 4, "frame_slot_state reads both as one int2");
+__device__ __forceinline__ int2 frame_slot_state(const FrameBuffers& fb, int f) { return *(const int2*)&fb.ctl[f].cur_slot; }
 
 // Grids of shape (workgroups of a frame, frames) whose workgroups share per-frame data.  The dispatcher deals workgroups to the eight
 // XCDs round-robin in linear order (block b -> XCD b % 8: observed, not promised), so a frame's workgroups land on all of them and the

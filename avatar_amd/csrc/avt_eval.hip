@@ -366,8 +366,10 @@ __device__ __forceinline__ void eval_body(const DeviceModel& dm, const FrameBuff
     } else if ((id -= nspecwg) >= nframes * G) {   // trailing workgroups: pose prior of the trial point, one (frame, GMM component) each
         const int id2 = id - nframes * G, fp = id2 / d.ncomps + fb.f0;
         if (!COST && FIXED && fb.nspec_cost > 0 && fp < fb.spec_frames && fb.seq >= 2 && fb.seq + fb.spec[fp].ahead > fb.max_iters) return;      // past the iteration budget
+        const int2 cs = *(const int2*)&fb.ctl[fp].cur_slot;      // (cur_slot, try_valid): one load
+        if (cs.y == AVT_TRY_DONE) return;                         // the frame met the stopping rule (avt_options::function_tolerance): no trial point
         extern __shared__ __attribute__((aligned(16))) char smem_prior[];
-        prior_component(dm, fb, fp, id2 % d.ncomps, 1 - fb.ctl[fp].cur_slot, (double*)smem_prior);
+        prior_component(dm, fb, fp, id2 % d.ncomps, 1 - cs.x, (double*)smem_prior);
         return;
     }
     const int f = id / G + fb.f0, g = id % G;
@@ -400,6 +402,7 @@ __device__ __forceinline__ void eval_body(const DeviceModel& dm, const FrameBuff
     if (strided && g < d.nb_max) prefetch(g);
     const int M = ctl.M;
     const int try_slot = 1 - ctl.cur_slot;
+    const int try_state = ctl.try_valid;      // (requested with the rest of the control block, tested behind the staging below like the budget word)
     if (!COST && g == G - 1 && t < 64) {      // what the solver roles of the k_solve launch behind this one decide on (AvtSolveSnap); the last workgroup of a frame has the fewest batches
         static_assert(sizeof(AvtFrameCtl) == 160 && sizeof(AvtSpecCtl) == 96, "snapshot copy below");
         double* sn = (double*)(fb.snap + f);
@@ -435,6 +438,9 @@ __device__ __forceinline__ void eval_body(const DeviceModel& dm, const FrameBuff
     if (t < 9) s_ident[t] = (t == 0 || t == 4 || t == 8) ? 1.0 : 0.0;
     if (t < RS) s_Jt[(size_t)NC * RS + t] = 0.0;
     if (budget_watch && fb.seq + ahead_now > fb.max_iters) return;      // (workgroup-uniform; nothing has been written yet)
+    // the frame met the stopping rule in this ICP iteration (avt_options::function_tolerance, k_solve): there is no trial point to evaluate
+    // (the snapshot above says so to the solver roles of the launch behind)
+    if (try_state == AVT_TRY_DONE) return;
     // MFMA operand fragments: lane l reads storage column tile_col[tile*16 + (l&15)] (padding -> the zero column), rows k0 + (l>>4)
     // six-tile shape: my wave's five dealt pairs (pair index = bit of the batch word, operand fragments, diagonal or not) and my
     // k-steps of the split pair

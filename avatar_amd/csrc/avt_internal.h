@@ -116,7 +116,8 @@ struct AvtFrameCtl {
     double sbp, sbs;          // scaledBetaPose / scaledBetaShape (AvatarOptimizer.cpp:1457-1458)
     double centre[3];         // fixed-point centring offset of this frame's data
     int cur_slot;             // which state/H slot holds the current point
-    int try_valid;            // trial point is a real LM step (Cholesky succeeded)
+    int try_valid;            // 1: the trial point is a real LM step (the factorisation succeeded); 0: it is not (no accept test); AVT_TRY_DONE (2): the
+                              // frame met the stopping rule (avt_options::function_tolerance) - no trial point, every further launch of this ICP iteration is idle for it
     int M;                    // matched model points
     int T;                    // total correspondences
     int gn_iterations;
@@ -163,8 +164,10 @@ struct AvtSolveSnap {
 #define AVT_FAULT_NOT_RESIDENT 2u   // (batch split) the owning rank's context did not hold the frame when the results were gathered
 #define AVT_FAULT_RIDE_TIMEOUT 1u   // a solver role of a riding k_solve launch gave up waiting for the reduction workgroups of its launch
 
+#define AVT_TRY_DONE 2
 struct AvtRunParams {
     double beta_pose, beta_shape, lambda0, lm_up, lm_down, lm_min, lm_max, lm_policy;      // lm_policy: avt_options::lm_policy as a double (0 / 1)
+    double ftol, pad;                                                                       // avt_options::function_tolerance (0 = off)
 };
 
 struct DeviceModel {

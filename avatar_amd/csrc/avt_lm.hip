@@ -687,7 +687,7 @@ __device__ __forceinline__ void reduce_spec_cost(const DeviceModel& dm, const Fr
                 for (int kk = 0; kk < AVT_MAX_SHAPE; ++kk) if (kk < d.K) { const double rr = s_xw[kk] * sbs; sa += rr * rr; }
                 ck += 0.5 * sa;
             }
-            const bool may = have && slot == 0 && try_valid != 0 && spn < sp_n && spn < AVT_MAX_SPEC && valid != 0 && fb.seq >= 2 &&
+            const bool may = have && slot == 0 && try_valid == 1 && spn < sp_n && spn < AVT_MAX_SPEC && valid != 0 && fb.seq >= 2 &&
                              (fb.seq - 1 + ahead) + 1 <= fb.max_iters - 1;
             // The verdicts travel IN THE RIDE COUNTER (AVT_RIDE_* below), the one word of this launch every solver role reads anyway
             // (its poll): a load of their own for them taxed every k_solve launch 0.25-0.5 us, a branch on the snapshot's `ahead` 0.75 us
@@ -902,7 +902,8 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         // (behind the second barrier instead - after the requests for the system's entries - this costs an install-type launch 0.2 instead of 0.6 us,
         // but an idle launch 7.6 instead of 4.8 us: measured both ways, the frames whose rejections come in runs gain more from cheap idle launches)
         ride_word = (unsigned)s_failf[1];
-        idle = MODE == SOLVE_NORMAL && (ride_word & AVT_RIDE_IDLE) != 0;      // past the iteration budget: nothing to decide, nothing to solve
+        // (or the frame met the stopping rule in an earlier launch of this ICP iteration: AVT_TRY_DONE in the snapshot, which arrived long ago)
+        idle = MODE == SOLVE_NORMAL && ((ride_word & AVT_RIDE_IDLE) != 0 || snap_ctl.try_valid == AVT_TRY_DONE);      // past the iteration budget: nothing to decide, nothing to solve
         if (idle) return;
     }
     auto hload = [&](const double* q) { if constexpr (RIDE) return ld_agent(q); else return *q; };
@@ -940,6 +941,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
 
     const double lm_up = fb.params->lm_up, lm_down = fb.params->lm_down, lm_min = fb.params->lm_min, lm_max = fb.params->lm_max;   // same round trip
     const bool gain = fb.params->lm_policy != 0.0;          // gain-ratio damping schedule (avt_options::lm_policy)
+    const double ftol = fb.params->ftol;                    // the stopping rule (avt_options::function_tolerance; 0 = off)
     // RIDE: every solver role decides on the snapshot the evaluation launch made (AvtSolveSnap): the solver rewrites the live
     // control block further down, and a speculative workgroup may start late
     const AvtFrameCtl& cin = RIDE ? snap_ctl : ctl;
@@ -972,6 +974,8 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
                 if (c < d.ncomps && pr[sl][c] < best[sl]) { best[sl] = pr[sl][c]; bcomp[sl] = c; }
     }
     __syncthreads();   // the staged state slots are visible; every lane has read the control block
+    // the frame met the stopping rule in an earlier launch of this ICP iteration: no trial point, no test, no iteration (the riding shapes left above)
+    if (!RIDE && mode != SOLVE_FIRST && try_valid == AVT_TRY_DONE) return;
     if (mode == SOLVE_FIRST) cost_const = s_cc;
     const int try0 = 1 - cur0;
     const double* xt = s_x + try0 * xs;
@@ -993,12 +997,17 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     }
     int cur = cur0;
     bool accepted = false;
+    // The reference's stopping rule (options.function_tolerance, AvatarOptimizer.cpp:1333; Ceres' line-search minimiser: |cost change| <=
+    // function_tolerance x the cost the step started from): an ACCEPTED step that small ends the frame's iterations of this ICP iteration.
+    // Every solver role takes the test on the same numbers, so the speculative ones leave with the solver.
+    bool converged = false;
     if (mode == SOLVE_FIRST) {
         accepted = true;
         cur = try0;
-    } else if (try_valid) {
+    } else if (try_valid == 1) {
         if (cost < cost_cur0) {
             accepted = true; cur = try0;
+            converged = ftol > 0.0 && (cost_cur0 - cost) <= ftol * cost_cur0;
             if (gain) {      // rho = actual / predicted decrease; lambda *= max(lm_down, 1 - (2 rho - 1)^3), the rejection factor starts over at lm_up
                 const double u = 2.0 * ((cost_cur0 - cost) / pred0) - 1.0;
                 lambda = fmin(fmax(lambda * fmax(lm_down, 1.0 - u * u * u), lm_min), lm_max);
@@ -1014,7 +1023,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     // skeleton tables copied into the trial slot) instead of factoring, and the speculative workgroups of this launch go home.
     AvtSpecCtl& sp = fb.spec[f];
     const int sp_next = RIDE ? sq_next : 0, sp_n = RIDE ? sq_n : 0;
-    const bool rejected = mode != SOLVE_FIRST && try_valid && !accepted;
+    const bool rejected = mode != SOLVE_FIRST && try_valid == 1 && !accepted;
     // Folded rejections (RIDE shapes whose k_eval evaluated the queued speculative steps' costs, fb.nspec_cost): the trial point has just
     // been rejected, so the next trial point is the first queued step - made from the SAME system with the lambda this rejection leaves.
     // Its cost is known; if it fails the accept test as well, that test (the next GN iteration's) is taken here and now, lambda advances
@@ -1061,6 +1070,14 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
             it += 1; ctl.gn_iterations = it; if (accepted) ctl.accepted += 1;
         }
         if (it < 40) fb.trace[(size_t)f * 64 + it] = cost_cur;
+    }
+    if (converged) {      // (never in SOLVE_FIRST) the accepted point stays; nothing follows it in this ICP iteration
+        if (t == 0 && role == 0) {
+            ctl.lambda = lambda; ctl.nu = nu; ctl.try_valid = AVT_TRY_DONE;
+            ctl.dec_cur_slot = cur; ctl.dec_try_valid = AVT_TRY_DONE; ctl.dec_cost_cur = cost_cur; ctl.dec_lambda = lambda; ctl.dec_nu = nu;
+            if (RIDE) { sp.next = 0; sp.n = 0; }      // no speculative steps: k_eval's spec-cost workgroups find the queue empty
+        }
+        return;
     }
     if constexpr (MODE == SOLVE_DECIDE) {
         // The accept test of the LAST trial point of an ICP iteration in the moment form (no solve follows it): the accept / reject update of

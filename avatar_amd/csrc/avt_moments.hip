@@ -349,7 +349,9 @@ __global__ __launch_bounds__(16 * MOM_PP_PAIRS) void k_pairpass(DeviceModel dm, 
     const int f = fy + fb.f0, t = threadIdx.x;
     const int J = d.J, K = KC ? KC : d.K, S1 = K + 1, NP = d.mom_np, NPSI = KC ? 3 * (KC + 1) + 1 : d.mom_npsi;
     const int TS = mom_tstride(NPSI), JS = 15 + 3 * K, GS = (2 * JS + S1 + 1) & ~1;      // doubles of a pair's T block / of one joint's tables / of a group's slice
-    const int try_slot = 1 - fb.ctl[f].cur_slot;
+    const int2 slot_state = frame_slot_state(fb, f);
+    if (slot_state.y == AVT_TRY_DONE) return;      // the frame met the stopping rule in this ICP iteration: no trial point (the prior workgroups in this grid too)
+    const int try_slot = 1 - slot_state.x;
     double* scr = fb.mom_rec + (size_t)f * mom_frame_scratch(d);
     double* X16 = scr;
     double* REC = scr + mom_off_rec(d);
@@ -620,7 +622,9 @@ __global__ __launch_bounds__(128) void k_prior(DeviceModel dm, FrameBuffers fb) 
     int bx, fy;
     xcd_frame_block(fb, bx, fy);
     const int f = fy + fb.f0;
-    prior_component<128>(dm, fb, f, bx, 1 - fb.ctl[f].cur_slot, s_scratch);
+    const int2 slot_state = frame_slot_state(fb, f);
+    if (slot_state.y == AVT_TRY_DONE) return;      // the frame met the stopping rule in this ICP iteration: no trial point
+    prior_component<128>(dm, fb, f, bx, 1 - slot_state.x, s_scratch);
 }
 
 static size_t pairpass_lds_bytes(const AvtDims& d) {
@@ -653,7 +657,9 @@ __global__ __launch_bounds__(NTH) void k_assemble(DeviceModel dm, FrameBuffers f
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const AvtDims& d = dm.d;
     const int f = blockIdx.y + fb.f0, t = threadIdx.x;
-    const int try_slot = 1 - fb.ctl[f].cur_slot;
+    const int2 slot_state = frame_slot_state(fb, f);
+    if (slot_state.y == AVT_TRY_DONE) return;      // the frame met the stopping rule in this ICP iteration: no trial point, no system
+    const int try_slot = 1 - slot_state.x;
     const int J = d.J, K = KC ? KC : d.K, S1 = K + 1, NP = d.mom_np, NPSI = d.mom_npsi, P = d.P, HS = d.HS;
     double* skm = (double*)smem;
     double* X16 = skm + mom_skel_doubles(d);    // [2 NP + 1][16]
@@ -962,7 +968,9 @@ template <int KC>
 __device__ __forceinline__ void asm_role_core(const DeviceModel& dm, const FrameBuffers& fb, int f, char* smem) {
     constexpr int NTH = MOM_PARTS_NTH;
     const AvtDims& d = dm.d;
-    const int t = threadIdx.x, try_slot = 1 - fb.ctl[f].cur_slot;
+    const int2 slot_state = frame_slot_state(fb, f);
+    if (slot_state.y == AVT_TRY_DONE) return;      // the frame met the stopping rule in this ICP iteration: no trial point, no system
+    const int t = threadIdx.x, try_slot = 1 - slot_state.x;
     const int J = d.J, K = KC ? KC : d.K, S1 = K + 1, NP = d.mom_np, NPSI = d.mom_npsi, P = d.P, HS = d.HS;
     double* skm = (double*)smem;
     double* PK = skm + mom_skel_doubles(d);     // [J + 1][16]
@@ -1133,7 +1141,9 @@ template <int KC>
 __device__ __forceinline__ void asm_role_shape(const DeviceModel& dm, const FrameBuffers& fb, int f, int h, char* smem) {
     constexpr int NTH = MOM_PARTS_NTH;
     const AvtDims& d = dm.d;
-    const int t = threadIdx.x, try_slot = 1 - fb.ctl[f].cur_slot;
+    const int2 slot_state = frame_slot_state(fb, f);
+    if (slot_state.y == AVT_TRY_DONE) return;      // the frame met the stopping rule in this ICP iteration: no trial point, no system
+    const int t = threadIdx.x, try_slot = 1 - slot_state.x;
     const int J = d.J, K = KC ? KC : d.K, NP = d.mom_np, HS = d.HS;
     const int s0 = (h * K) / MOM_ASM_NA, s1 = ((h + 1) * K) / MOM_ASM_NA, Kh = s1 - s0;
     double* Rw = (double*)smem;                 // [J][9]
@@ -1199,7 +1209,9 @@ __device__ __forceinline__ void asm_role_shape(const DeviceModel& dm, const Fram
 __device__ __forceinline__ void asm_role_rotrot(const DeviceModel& dm, const FrameBuffers& fb, int f, int r, char* smem) {
     constexpr int NTH = MOM_PARTS_NTH;
     const AvtDims& d = dm.d;
-    const int t = threadIdx.x, try_slot = 1 - fb.ctl[f].cur_slot;
+    const int2 slot_state = frame_slot_state(fb, f);
+    if (slot_state.y == AVT_TRY_DONE) return;      // the frame met the stopping rule in this ICP iteration: no trial point, no system
+    const int t = threadIdx.x, try_slot = 1 - slot_state.x;
     const int J = d.J, NP = d.mom_np, HS = d.HS;
     const int b0 = d.mom_rsplit[r], b1 = d.mom_rsplit[r + 1];
     double* Rw = (double*)smem;                 // [J][9]

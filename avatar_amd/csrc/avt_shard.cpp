@@ -449,7 +449,7 @@ thread_local ShmPending shm_pending;
 ncclResult_t shm_progress(ShmComm* sc, std::vector<ShmXfer>& sends, std::vector<ShmXfer>& recvs, hipStream_t st) {
     if (hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;      // what I send is ready
     if (sc->hdr()->broken.load(std::memory_order_acquire)) return ncclSystemError;
-    const auto t0 = std::chrono::steady_clock::now();
+    auto t0 = std::chrono::steady_clock::now();
     size_t left = 0;
     for (auto& x : sends) left += x.bytes == 0 ? 0 : 1;
     for (auto& x : recvs) left += x.bytes == 0 ? 0 : 1;
@@ -484,7 +484,8 @@ ncclResult_t shm_progress(ShmComm* sc, std::vector<ShmXfer>& sends, std::vector<
             if (x.done == x.bytes) --left;
         }
         if (!left) break;
-        if (!moved) {
+        if (moved) t0 = std::chrono::steady_clock::now();      //  the time-out bounds INACTIVITY, not the length of a long exchange
+        else {
             if (sc->hdr()->broken.load(std::memory_order_acquire)) return ncclSystemError;
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > sc->timeout_s) {
                 sc->hdr()->broken.store(1, std::memory_order_release);
@@ -571,6 +572,7 @@ struct avt_shard {
     void* d_stage = nullptr; size_t stage_cap = 0;                              // scatter / broadcast staging, bytes
     void* d_stage2 = nullptr; size_t stage2_cap = 0;
     hipStream_t gather_stream = nullptr;   // the stream the last all-gather was enqueued on
+    bool self_exchange = false;            // avt_shard_set_self_exchange: a rank's own blocks go through the transport as well (dry runs)
 };
 
 #define NCCL_OK(s, expr)                                                                                       \
@@ -885,7 +887,7 @@ extern "C" int avt_shard_scatter_frames(avt_shard* s, avt_ctx* c, int root, int 
         if (grow(&s->d_stage, &s->stage_cap, (size_t)mine * 28 + 64)) return 1;
         d_data = (double*)s->d_stage; d_lab = (int*)((char*)s->d_stage + (size_t)mine * 24);
     }
-    const bool self_loop = getenv("AVT_SHARD_SELF_SENDRECV") != nullptr;   // dry runs: push the root's own block through RCCL too
+    const bool self_loop = s->self_exchange;   // dry runs (avt_shard_set_self_exchange): push the root's own block through RCCL too
     double* my_data = d_data; int* my_lab = d_lab;
     if (is_root) { my_data = d_data + rank_off[s->rank] * 3; my_lab = d_lab + rank_off[s->rank]; }
     double* loop_data = nullptr; int* loop_lab = nullptr;
@@ -956,8 +958,8 @@ extern "C" int avt_shard_gather_enqueue(avt_shard* s, avt_ctx* c, int B) {
     // per step, 0.62 ms): this costs 6 us per step; putting the all-gather on the shard's own stream instead - so that the
     // exchange of step k overlaps step k+1 - costs 25 us, because the event record / cross-stream wait the hand-over needs
     // sit in the context stream's critical path (double-buffering the send block and waiting on the host: 24 us).
-    // (AVT_SHARD_SELF_SENDRECV - the dry-run switch that pushes a lone rank's own blocks through the transport - keeps the one-rank all-gather too)
-    const bool direct = W == 1 && !mismatch && getenv("AVT_SHARD_SELF_SENDRECV") == nullptr;
+    // (avt_shard_set_self_exchange - the dry-run switch that pushes a lone rank's own blocks through the transport - keeps the one-rank all-gather too)
+    const bool direct = W == 1 && !mismatch && !s->self_exchange;
     if (mismatch) {
         std::vector<double> rows(blk, 0.0);
         for (int i = 0; i < per; ++i) rows[(size_t)i * stride + c->dm.d.xsize + 7] = (double)AVT_FAULT_NOT_RESIDENT;
@@ -972,10 +974,19 @@ extern "C" int avt_shard_gather_enqueue(avt_shard* s, avt_ctx* c, int B) {
     // device-to-device copy kernel on the stream, 4.3 us per step for the identity.
     const double* send = (mismatch || (size_t)per > (size_t)c->fb.max_frames) ? s->d_send : c->fb.results;
     if (!mismatch && send == s->d_send && nloc) HIP_OK(hipMemcpyAsync(s->d_send, c->fb.results, (size_t)nloc * stride * 8, hipMemcpyDeviceToDevice, c->stream));
+    //  ... as a SNAPSHOT, like every other world size: enqueue -> optimize -> download returns the rows of the call the gather was enqueued
+    // behind, not the later call's (include/avt_shard.h: "into a device buffer owned by the shard"); one rank: a plain device-to-device copy
     if (!direct) NCCL_OK(s, s->api->AllGather(send, s->d_recv, blk, ncclDouble, s->comm, c->stream));
-    s->gathered = direct ? c->fb.results : s->d_recv;
+    else if (nloc) HIP_OK(hipMemcpyAsync(s->d_recv, send, (size_t)nloc * stride * 8, hipMemcpyDeviceToDevice, c->stream));
+    s->gathered = s->d_recv;
     s->gather_stream = c->stream;
     if (mismatch) { avt_set_error("avt_shard_gather_enqueue: resident frames differ from this rank's share of the batch (its rows were gathered as faulty)"); return 1; }
+    return 0;
+}
+
+extern "C" int avt_shard_set_self_exchange(avt_shard* s, int on) {
+    if (!s) { avt_set_error("avt_shard_set_self_exchange: null argument"); return 1; }
+    s->self_exchange = on != 0;
     return 0;
 }
 
@@ -994,7 +1005,7 @@ extern "C" int avt_shard_gather_download(avt_shard* s, avt_ctx* c, int B, double
     if (s->gather_cap < blk || !s->d_recv || !s->gathered) { avt_set_error("avt_shard_gather_download: nothing was gathered"); return 1; }
     HIP_OK(hipSetDevice(s->device));
     std::vector<double> host(blk * W);
-    HIP_OK(hipMemcpyAsync(host.data(), s->gathered, (s->gathered == s->d_recv ? host.size() : std::min(host.size(), (size_t)c->fb.max_frames * stride)) * 8, hipMemcpyDeviceToHost, c->stream));   // behind the all-gather
+    HIP_OK(hipMemcpyAsync(host.data(), s->gathered, host.size() * 8, hipMemcpyDeviceToHost, c->stream));   // behind the all-gather
     HIP_OK(hipStreamSynchronize(c->stream));
     int bad = -1;
     for (int f = 0; f < B; ++f) {
@@ -1012,6 +1023,7 @@ extern "C" int avt_shard_gather_download(avt_shard* s, avt_ctx* c, int B, double
     }
     if (bad >= 0) {
         (void)hipMemsetAsync(c->fb.fault, 0, (size_t)c->fb.max_frames * sizeof(unsigned), c->stream);   // reported once
+        c->results_fresh = false;      //  the result records still carry the word that was just cleared: the next gather packs them again
         avt_set_error("avt_shard_gather_download: frame " + std::to_string(bad) + " carries a device fault (rank " + std::to_string(bad % W) + "); its result is not valid");
         return AVT_STATUS_DEVICE_FAULT;
     }

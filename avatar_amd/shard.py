@@ -144,6 +144,10 @@ class Shard:
         self.gather_enqueue(ctx, num_frames)
         return self.gather_download(ctx, num_frames)
 
+    def set_self_exchange(self, on=True):
+        """Dry runs: a rank's own blocks go through the transport as well (include/avt_shard.h, avt_shard_set_self_exchange)."""
+        _check(self._lib.avt_shard_set_self_exchange(self.h, C.c_int(int(bool(on)))))
+
     def barrier(self, ctx=None):
         _check(self._lib.avt_shard_barrier(self.h, ctx.h if ctx is not None else None))
 

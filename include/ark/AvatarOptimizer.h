@@ -36,6 +36,7 @@ class AvatarOptimizer {
         avt_options_default(&o);
         o.beta_pose = betaPose; o.beta_shape = betaShape; o.nn_step = nnStep; o.max_iters_per_icp = maxItersPerICP;
         o.enable_occlusion = enableOcclusion ? 1 : 0; o.icp_iters = icp_iters; o.num_threads = num_threads;
+        o.function_tolerance = functionTolerance;
         std::vector<double> q(4 * (size_t)J);
         for (int i = 0; i < J; ++i) for (int c = 0; c < 4; ++c) q[4 * i + c] = r[i].c[c];
         ARK_AVT_CHECK(avt_optimize(ctx, data_cloud.data(), data_part_labels.data(), N, &o, ava.p.data(), q.data(), ava.w.data(), &lastStats));
@@ -62,6 +63,10 @@ class AvatarOptimizer {
     int maxItersPerICP = 10;
     /** Whether to elimiate occluded points before NN matching */
     bool enableOcclusion = true;
+    /** Not a member of the reference's class: the value its optimize() hard-codes as options.function_tolerance
+     *  (AvatarOptimizer.cpp:1333) - a step that lowers the objective by no more than this fraction ends the inner iterations
+     *  of the ICP iteration; 0 = always maxItersPerICP iterations (include/avt.h, avt_options::function_tolerance) */
+    double functionTolerance = 1e-4;
 
     Avatar& ava;
     const CameraIntrin& intrin;

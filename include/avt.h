@@ -87,15 +87,25 @@ typedef struct avt_options {
     int enable_occlusion;       /* enableOcclusion = true: back-face visibility (AvatarOptimizer.cpp:1349-1367) */
     int icp_iters;              /* optimize(..., icp_iters = 1, ...) */
     int num_threads;            /* optimize(..., num_threads = 4): accepted, ignored on the GPU path */
-    int lm_policy;              /* damping schedule: 0 (default) fixed factors lm_up / lm_down; 1 gain ratio (Nielsen): see DESIGN.md section 4 */
+    int lm_policy;              /* damping schedule: AVT_LM_GAIN_RATIO (1, the default since round 6: Nielsen's gain-ratio update, the better
+                                   optimiser on every bench seed) or AVT_LM_FIXED_FACTORS (0: lm_up / lm_down as plain factors); DESIGN.md section 4 */
     double lm_lambda0;          /* initial damping (relative to diag H); default 1e-3 */
-    double lm_up;               /* > 1.  lm_policy 0: damping multiplier on a rejected step; default 4.  lm_policy 1: the multiplier of the FIRST
-                                   rejection after an accepted step (it doubles with every further one); Nielsen's 2, 16 on the bench frames */
-    double lm_down;             /* in (0, 1).  lm_policy 0: damping multiplier on an accepted step; default 1/3.  lm_policy 1: the floor of the
-                                   multiplier max(lm_down, 1 - (2 rho - 1)^3) an accepted step applies (Nielsen's 1/3) */
+    double lm_up;               /* > 1.  gain ratio: the multiplier of the FIRST rejection after an accepted step (it doubles with every further
+                                   one); default AVT_LM_UP_GAIN_RATIO = 16 (Nielsen's own constant is 2).  fixed factors: the damping multiplier
+                                   on every rejected step; AVT_LM_UP_FIXED_FACTORS = 4 is the value that schedule was tuned with */
+    double lm_down;             /* in (0, 1); default 1/3.  gain ratio: the floor of the multiplier max(lm_down, 1 - (2 rho - 1)^3) an accepted
+                                   step applies (Nielsen's 1/3).  fixed factors: the damping multiplier on an accepted step */
     double lm_lambda_min;       /* default 1e-12 */
     double lm_lambda_max;       /* default 1e8 */
+    double function_tolerance;  /* >= 0, < 1.  The reference's stopping rule, options.function_tolerance = 1e-4 (AvatarOptimizer.cpp:1333; Ceres'
+                                   line-search minimiser stops when |cost change| <= function_tolerance x cost): an ACCEPTED step whose decrease is
+                                   at most this fraction of the objective it started from ends the Gauss-Newton iterations of that ICP iteration
+                                   for that frame - the remaining launches of the iteration are idle for it, avt_stats.gn_iterations counts what
+                                   ran.  Default 1e-4 as in the reference; 0 = always max_iters_per_icp iterations (what bench.py's headline counts). */
 } avt_options;
+enum { AVT_LM_FIXED_FACTORS = 0, AVT_LM_GAIN_RATIO = 1 };
+#define AVT_LM_UP_GAIN_RATIO 16.0
+#define AVT_LM_UP_FIXED_FACTORS 4.0
 
 typedef struct avt_stats {
     double initial_cost;        /* 0.5*sum r^2 at entry to the last ICP iteration (data + priors) */
@@ -103,7 +113,7 @@ typedef struct avt_stats {
     double lambda;              /* damping at exit */
     int num_correspondences;    /* ICP residual blocks in the last ICP iteration (totalResiduals, :1441-1451) */
     int matched_model_points;   /* model points with >= 1 correspondence (caches, :1419-1431) */
-    int gn_iterations;          /* GN iterations executed over all ICP iterations */
+    int gn_iterations;          /* GN iterations executed over all ICP iterations (fewer than icp_iters x max_iters_per_icp when function_tolerance ended some early) */
     int accepted_steps;
 } avt_stats;
 
@@ -119,7 +129,9 @@ typedef struct avt_profile {
 
 const char* avt_last_error(void);
 const char* avt_kernel_name(int kernel_class);
-void avt_options_default(avt_options* o);      /* reference defaults (AvatarOptimizer.h:28-39) + LM defaults */
+void avt_options_default(avt_options* o);      /* reference defaults (AvatarOptimizer.h:28-39, function_tolerance :1333) + the step rule's: the ONE place
+                                                * the defaults are set (gain-ratio schedule, lm_up 16, lm_down 1/3); avatar_amd/capi.py mirrors it and a test compares */
+void avt_options_fixed_factors(avt_options* o); /* the same with the fixed-factor schedule of rounds 1-5 (lm_policy 0, lm_up 4) */
 
 /* ---- model: replaces `AvatarModel::AvatarModel` data preparation (AvatarModel.cpp:74-127) and the
  * pose-independent parts of `AvatarEvaluationCommonData` (AvatarOptimizer.cpp:187-245) and

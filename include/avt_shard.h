@@ -99,6 +99,15 @@ int avt_shard_gather_wait(avt_shard* s);
 int avt_shard_gather_download(avt_shard* s, avt_ctx* ctx, int num_frames, double* p, double* q, double* w, avt_stats* stats);
 int avt_shard_gather_results(avt_shard* s, avt_ctx* ctx, int num_frames, double* p, double* q, double* w, avt_stats* stats);
 
+/* ---- dry runs.  With `on` != 0 a rank's OWN blocks travel through the transport as well: the scatter sends the root's share to itself
+ * (grouped ncclSend / ncclRecv) and a one-rank gather keeps its ncclAllGather, so that a single GPU exercises the calls an N-rank run makes.
+ * Off by default (a rank's own share is a device-to-device copy).  (Rounds 2-5 read the environment variable AVT_SHARD_SELF_SENDRECV at
+ * every call; nothing on the exchange path reads the environment now.)
+ * What IS read from the environment, ONCE, when a handle is created: AVT_RCCL_LIB (avt_shard_create: the first library name tried
+ * before librccl.so.1 / librccl.so and torch's bundled copy) and AVT_SHARD_LOOPBACK_TIMEOUT_S (avt_shard_create_loopback /
+ * avt_shard_create_shm: how long an exchange may see no progress before the group is declared broken; 60 s). */
+int avt_shard_set_self_exchange(avt_shard* s, int on);
+
 /* ---- barrier on the device (a 1-double all-gather), for hosts without another rendezvous */
 int avt_shard_barrier(avt_shard* s, avt_ctx* ctx);
 

@@ -1037,7 +1037,8 @@ void orc_evaluate(const orc_model* m, const double* p, const double* q, const do
 // AvatarOptimizer::optimize() (AvatarOptimizer.cpp:1246-1517) with the Ceres BFGS solve (:1486) replaced by
 // the damped Gauss-Newton schedule of DESIGN.md "step rule".
 //   trace_cost (optional): icp_iters*(max_iters+1) doubles: cost at entry then after every GN iteration
-//   trace_acc  (optional): icp_iters*max_iters ints: 1 accepted / 0 rejected / -1 Cholesky failure
+//   trace_acc  (optional): icp_iters*max_iters ints: 1 accepted / 0 rejected / -1 Cholesky failure / -2 not run (the stopping rule ended the
+//                          ICP iteration's Gauss-Newton iterations earlier: avt_options::function_tolerance, AvatarOptimizer.cpp:1333)
 //   corr_out   (optional): N ints: correspondences of the last ICP iteration
 //   cloud_out  (optional): 3V doubles: ava.cloud after the final update()
 int orc_optimize(const orc_model* m, int num_parts, const int* part_map, const double* data, const int* labels, int N,
@@ -1085,14 +1086,23 @@ int orc_optimize(const orc_model* m, int num_parts, const int* part_map, const d
             if (gain) { lambda = std::min(lambda * nu, o->lm_lambda_max); nu *= 2.0; }
             else lambda = std::min(lambda * o->lm_up, o->lm_lambda_max);
         };
+        bool converged = false;
         for (int it = 0; it < o->max_iters_per_icp; ++it) {
             int acc = 0;
+            if (converged) {      // (the traces keep their shape: the objective stays, the iteration is marked as not run)
+                if (trace_acc) trace_acc[(size_t)icp * o->max_iters_per_icp + it] = -2;
+                if (trace_cost) trace_cost[(size_t)icp * (o->max_iters_per_icp + 1) + it + 1] = cur.cost;
+                continue;
+            }
             if (corr.total > 0 && lm_solve(cur.H.data(), cur.g.data(), P, lambda, delta.data())) {
                 retract(*m, p, q, w, delta.data(), p2.data(), q2.data(), w2.data());
                 evaluate(*m, cm, p2.data(), q2.data(), w2.data(), corr, data, o->beta_pose, o->beta_shape, true, aggregate,
                          nthreads, tr);
                 if (tr.cost < cur.cost) {
                     acc = 1;
+                    // the reference's stopping rule (options.function_tolerance = 1e-4, AvatarOptimizer.cpp:1333; Ceres' line-search minimiser:
+                    // |cost change| <= function_tolerance x the cost the step started from): an accepted step that small is the last of this ICP iteration
+                    converged = o->function_tolerance > 0.0 && (cur.cost - tr.cost) <= o->function_tolerance * cur.cost;
                     if (gain) {
                         double pred = 0.0;
                         for (int i = 0; i < P; ++i) pred += delta[i] * (lambda * cur.H[(size_t)i * P + i] * delta[i] - cur.g[i]);

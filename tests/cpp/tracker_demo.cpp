@@ -5,9 +5,11 @@
 //           int top, left, bottom, right; width*height*3 float xyz; width*height uint8 mask
 //   argv[3] output.bin: per frame: int fitted; 3V doubles cloud, 3 p, K w   (cloud etc. as left by the last fit)
 //   argv[4] (optional) repeat count for timing: the sequence minus its first frame is replayed that many times
+//   argv[5] (optional) AvatarOptimizer::functionTolerance (default: the reference's 1e-4, AvatarOptimizer.cpp:1333; 0 = every fit runs its full budget)
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "ark/FrameTracker.h"
@@ -38,6 +40,7 @@ int main(int argc, char** argv) {
     ark::AvatarOptimizer avaOpt(ava, intrin, ark::Size(W, H), J, partMap);
     avaOpt.betaPose = 0.05;      // demo.cpp:139-143
     avaOpt.betaShape = 0.12;
+    if (argc > 5) avaOpt.functionTolerance = std::atof(argv[5]);
     ark::FrameTracker tracker(avaOpt);
     tracker.interval = hdr[3]; tracker.frameICPIters = hdr[4]; tracker.reinitICPIters = tracker.initialICPIters = hdr[5]; tracker.reinitCnz = hdr[6];
     FILE* o = std::fopen(argv[3], "wb");
@@ -53,12 +56,15 @@ int main(int argc, char** argv) {
     std::fclose(o);
     const int reps = argc > 4 ? std::atoi(argv[4]) : 0;
     if (reps > 0 && nframes > 1) {
-        long n = 0;
+        long n = 0, gn = 0;
         const auto t0 = std::chrono::steady_clock::now();
         for (int r = 0; r < reps; ++r)
-            for (int i = 1; i < nframes; ++i) n += tracker.process(frames[i].xyz.data(), frames[i].mask.data(), W, H, frames[i].box);
+            for (int i = 1; i < nframes; ++i) {
+                const bool fit = tracker.process(frames[i].xyz.data(), frames[i].mask.data(), W, H, frames[i].box);
+                n += fit; gn += fit ? avaOpt.lastStats.gn_iterations : 0;
+            }
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        std::printf("tracker_demo timing: %ld frames, %.4f ms per frame\n", n, ms / (double)n);
+        std::printf("tracker_demo timing: %ld frames, %.4f ms per frame, %.2f GN iterations per frame\n", n, ms / (double)n, (double)gn / (double)n);
     }
     std::printf("tracker_demo: %d frames, %ld fitted, reinit=%d\n", nframes, tracker.framesFitted, (int)tracker.reinit);
     return 0;

@@ -21,12 +21,12 @@ def test_gain_ratio_schedule_matches_oracle(smpl, omodel, gmodel, frames, form, 
     pm = synth.identity_part_map()
     frs = [synth.make_frame(smpl, 40 + s) for s in range(frames)]
     starts = [_start(fr) for fr in frs]
-    opt = Options.demo(icp_iters=2, lm_policy=1) if lm_up is None else Options.demo(icp_iters=2, lm_policy=1, lm_up=lm_up, lm_down=0.25)      # (None: Options.GAIN_LM_UP)
+    opt = Options.counted(icp_iters=2, lm_policy=1) if lm_up is None else Options.counted(icp_iters=2, lm_policy=1, lm_up=lm_up, lm_down=0.25)      # (None: Options.GAIN_LM_UP)
     ctx = api.Context(gmodel, 24, pm, 60000, frames)
     ctx.set_data_term(form)
     P, Q, W, st = ctx.optimize_batch([fr["data"] for fr in frs], [fr["labels"] for fr in frs], opt, np.array([s[0] for s in starts]),
                                      np.array([s[1] for s in starts]), np.array([s[2] for s in starts]))
-    fixed = Options.demo(icp_iters=2)
+    fixed = Options.counted(icp_iters=2, lm_policy=0)
     differs = 0
     for i, fr in enumerate(frs):
         ref = omodel.optimize(pm, 24, fr["data"], fr["labels"], opt, *starts[i], aggregate=1)

@@ -269,7 +269,7 @@ def test_dense_batch_on_the_moment_form_is_the_oracles_fit(smpl, omodel, gmodel)
     p0 = np.array([s[1] for s in starts]); w0 = np.array([s[0] for s in starts])
     q0 = api.rot_to_quat(np.array([s[2] for s in starts]).reshape(-1, 3, 3)).reshape(F, 24, 4)
     ctx.state_upload(p0, q0, w0)
-    opt = Options.demo()
+    opt = Options.counted()
     assert ctx.data_term() == ctx.DATA_TERM_AUTO and ctx.launch_shape()[:2] == (2, 32)      # two groups of 32 frames per launch: AUTO => moments
     ctx.optimize_resident(opt)
     p, q, w, st = ctx.state_download()

@@ -121,7 +121,7 @@ def test_optimize_two_icp_iterations(smpl, omodel, gmodel):
     pm = synth.identity_part_map()
     fr = synth.make_frame(smpl, 3)
     p0, q0, w0 = _start_state(fr)
-    opt = Options.demo(icp_iters=2, max_iters_per_icp=5)
+    opt = Options.counted(icp_iters=2, max_iters_per_icp=5)
     ref = omodel.optimize(pm, 24, fr["data"], fr["labels"], opt, p0, q0, w0, aggregate=1)
     ctx = api.Context(gmodel, 24, pm, 60000, 1)
     p, q, w, st = ctx.optimize_batch([fr["data"]], [fr["labels"]], opt, p0[None], q0[None], w0[None])

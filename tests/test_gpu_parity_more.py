@@ -220,7 +220,8 @@ def test_512_frames_per_gpu_rendered_on_the_gpu(smpl, omodel, gmodel):
     p2, q2, w2, _ = ctx.state_download()
     assert np.array_equal(p, p2) and np.array_equal(q, q2) and np.array_equal(w, w2)
     assert np.isfinite(p).all() and np.isfinite(q).all() and np.isfinite(w).all()
-    assert all(s.gn_iterations == 10 and s.final_cost <= s.initial_cost and s.num_correspondences > 0 for s in st)
+    # (Options.demo() carries the reference's stopping rule, function_tolerance = 1e-4: a frame may end its iterations early)
+    assert all(1 <= s.gn_iterations <= 10 and s.final_cost <= s.initial_cost and s.num_correspondences > 0 for s in st)
     assert np.abs(np.linalg.norm(q, axis=2) - 1.0).max() < 1e-9
     for i in (0, 255, 256, 511):
         d, l = ctx.frame_download(i)
@@ -415,7 +416,7 @@ def test_folded_accept_tests_do_not_change_a_bit(smpl, omodel, gmodel):
         fr = synth.make_frame(smpl, seed)
         p0, q0, w0 = _start(fr)
         n = len(fr["labels"])
-        opt = Options.demo(icp_iters=icp, lm_policy=policy)
+        opt = Options.counted(icp_iters=icp, lm_policy=policy)
         out = {}
         for sc in (0, 1):
             ctx = api.Context(gmodel, 24, pm, n, 1)

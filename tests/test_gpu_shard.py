@@ -1,6 +1,6 @@
 """The batch split of include/avt_shard.h on hardware: a ONE-rank RCCL communicator on this GPU (the only size a 1-GPU
 box can build: RCCL refuses two ranks on one device) pushes the model broadcast, the cloud scatter (grouped
-ncclSend/ncclRecv, the root's own block looped through RCCL by AVT_SHARD_SELF_SENDRECV) and the result all-gather
+ncclSend/ncclRecv, the root's own block looped through RCCL by avt_shard_set_self_exchange) and the result all-gather
 through the real library on device buffers, and everything must come out bit-identical to the plain single-context path."""
 import ctypes
 import os
@@ -54,12 +54,12 @@ def test_scatter_optimize_gather_equals_plain_path(smpl, gmodel, one_rank_shard)
     ctx_a = api.Context(gmodel, 24, pm, 16384, B, device=0)
     pa, qa, wa, sta = ctx_a.optimize_batch(datas, labels, opt, p0, q0, w0)
     # split path (one rank owns every frame), the root's block going through ncclSend/ncclRecv
-    os.environ["AVT_SHARD_SELF_SENDRECV"] = "1"
+    one_rank_shard.set_self_exchange(True)
     try:
         ctx_b = api.Context(gmodel, 24, pm, 16384, B, device=0)
         one_rank_shard.scatter_frames(ctx_b, B, datas, labels, p0, q0, w0, root=0)
     finally:
-        del os.environ["AVT_SHARD_SELF_SENDRECV"]
+        one_rank_shard.set_self_exchange(False)
     ctx_b._N = np.array([len(l) for l in labels], np.int32)
     for f in range(B):
         d, l = ctx_b.frame_download(f)
@@ -83,6 +83,15 @@ def test_scatter_optimize_gather_equals_plain_path(smpl, gmodel, one_rank_shard)
     assert np.array_equal(pg2, pa) and np.array_equal(qg2, qa) and np.array_equal(wg2, wa)
     assert all(stg2[f].final_cost == sta[f].final_cost for f in range(B))
     one_rank_shard.barrier(ctx_b)
+    # the gathered block is a SNAPSHOT at every world size - enqueue, then a further optimize() that moves the states on (warm start:
+    # no reset), then download: the rows are those of the call the gather was enqueued behind, not the later call's
+    ctx_b.state_reset(); ctx_b.optimize_resident(opt)
+    one_rank_shard.gather_enqueue(ctx_b, B)
+    ctx_b.optimize_resident(opt)
+    pg3, qg3, wg3, stg3 = one_rank_shard.gather_download(ctx_b, B)
+    pl3, ql3, wl3, _ = ctx_b.state_download()
+    assert np.array_equal(pg3, pa) and np.array_equal(qg3, qa) and np.array_equal(wg3, wa)
+    assert not np.array_equal(pl3, pa)
 
 
 def test_frames_swap_under_resident_state(smpl, gmodel):

@@ -237,9 +237,48 @@ def test_gain_ratio_schedule_accepts_more_and_ends_lower_on_the_bench_seeds(smpl
         for pol in (0, 1):
             acc[pol].append(r[pol].accepted_steps / r[pol].gn_iterations)
         lower += r[1].final_cost < r[0].final_cost
-    assert Options.demo(lm_policy=1).lm_up == Options.GAIN_LM_UP and Options.demo(lm_policy=1, lm_up=2.0).lm_up == 2.0 and Options.demo().lm_up == 4.0
+    # the gain-ratio schedule is the default (round 6); lm_policy=0 without an lm_up selects the fixed factors with the constant they were tuned with
+    assert Options.demo().lm_policy == 1 and Options.demo().lm_up == Options.GAIN_LM_UP and Options.demo(lm_policy=1, lm_up=2.0).lm_up == 2.0
+    assert Options.demo(lm_policy=0).lm_up == Options.FIXED_LM_UP == 4.0 and Options.demo(lm_policy=0, lm_up=8.0).lm_up == 8.0
     assert np.mean(acc[1]) >= 0.8 and np.mean(acc[0]) < 0.6, (np.mean(acc[0]), np.mean(acc[1]))
     assert lower == 12
+
+
+def test_stopping_rule_ends_the_inner_iterations_of_an_icp_iteration(smpl, omodel):
+    """avt_options.function_tolerance (the reference's options.function_tolerance = 1e-4, AvatarOptimizer.cpp:1333): an accepted step whose decrease
+    is at most that fraction of the objective it started from is the last GN iteration of its ICP iteration - the next ICP iteration starts over.
+    0 switches the rule off; a run with the rule on is the prefix of the run without it up to the first stop."""
+    from oracle import oracle as orc
+    pm = synth.identity_part_map()
+    fr = synth.make_frame(smpl, 0)
+    sel = np.arange(0, len(fr["labels"]), 6)
+    data, labels = fr["data"][sel], fr["labels"][sel]
+    w0, p0, R0 = fr["start"]
+    q0 = orc.rot_to_quat(R0)
+    off = omodel.optimize(pm, 24, data, labels, Options.counted(icp_iters=3), p0, q0, w0, aggregate=1)
+    on = omodel.optimize(pm, 24, data, labels, Options.demo(icp_iters=3), p0, q0, w0, aggregate=1)
+    assert Options.demo().function_tolerance == 1e-4 and Options.counted().function_tolerance == 0.0
+    assert off["stats"].gn_iterations == 30 and (off["trace_acc"] != -2).all()
+    acc, tc = on["trace_acc"].reshape(3, 10), on["trace_cost"].reshape(3, 11)
+    assert on["stats"].gn_iterations == int((acc != -2).sum()) < 30      # this frame stops early in a later ICP iteration
+    first = int(np.argmax((acc == -2).any(axis=1)))
+    k = int(np.argmax(acc[first] == -2))      # iterations k .. 9 of ICP iteration `first` did not run; k - 1 is the step that met the rule
+    assert k >= 1 and acc[first, k - 1] == 1 and (acc[first, k:] == -2).all()
+    dec = tc[first, k - 1] - tc[first, k]
+    assert 0.0 < dec <= 1e-4 * tc[first, k - 1] and (tc[first, k:] == tc[first, k]).all()
+    # no accepted step in front of it met the rule
+    for i in range(k - 1):
+        if acc[first, i] == 1:
+            assert tc[first, i] - tc[first, i + 1] > 1e-4 * tc[first, i]
+    # identical to the run without the rule up to there
+    n = first * 10 + k
+    assert np.array_equal(on["trace_acc"][:n], off["trace_acc"][:n]) and np.array_equal(tc.reshape(-1)[:first * 11 + k + 1], off["trace_cost"][:first * 11 + k + 1])
+    # a tolerance that every accepted step meets: one iteration per ICP iteration when the first step is accepted
+    one = omodel.optimize(pm, 24, data, labels, Options.demo(icp_iters=2, function_tolerance=0.999), p0, q0, w0, aggregate=1)
+    a1 = one["trace_acc"].reshape(2, 10)
+    for i in range(2):
+        kk = int(np.argmax(a1[i] == 1))
+        assert (a1[i, :kk] != 1).all() and (a1[i, kk + 1:] == -2).all()
 
 
 def test_lm_not_worse_than_scipy_bfgs(smpl, omodel, frame0):
@@ -277,9 +316,25 @@ def test_abi_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    assert ctypes.sizeof(capi.Options) == 8 * 2 + 4 * 6 + 8 * 5
+    assert ctypes.sizeof(capi.Options) == 8 * 2 + 4 * 6 + 8 * 6
     assert ctypes.sizeof(capi.Stats) == 8 * 3 + 4 * 4
     assert ctypes.sizeof(capi.Profile) == (12 * capi.AVT_K_COUNT + 7) // 8 * 8          # doubles, ints, tail padding to 8
+
+
+def test_python_option_defaults_are_the_c_defaults():
+    """avt_options_default (avt_model.cpp) is the one place the defaults are set: the Python mirror agrees field by field, and
+    avt_options_fixed_factors is Options.demo(lm_policy=0) with the reference's member defaults for the two prior weights."""
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    c = Options()
+    lib.avt_options_default(ctypes.byref(c))
+    py = Options.reference_defaults()
+    for name, _ in Options._fields_:
+        assert getattr(c, name) == getattr(py, name), name
+    assert c.lm_policy == Options.LM_GAIN_RATIO and c.lm_up == 16.0 and c.function_tolerance == 1e-4      # AvatarOptimizer.cpp:1333
+    lib.avt_options_fixed_factors(ctypes.byref(c))
+    fx = Options.reference_defaults(); fx.lm_policy = 0; fx.lm_up = Options.FIXED_LM_UP
+    for name, _ in Options._fields_:
+        assert getattr(c, name) == getattr(fx, name), name
 
 
 def test_model_create_host_side(smpl, omodel):
