@@ -653,7 +653,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
     if (dev_upload(c, &dm.vrec, m->vrec) || dev_upload(c, &dm.shape_planes, m->shape_planes) || dev_upload(c, &dm.lbs_w, m->lbs_w) || dev_upload(c, &dm.lbs_j, m->lbs_j) ||
         dev_upload(c, &dm.asg_w, m->asg_w) || dev_upload(c, &dm.asg_j, m->asg_j) || dev_upload(c, &dm.anc_n, m->anc_n) ||
         dev_upload(c, &dm.anc, m->anc) || dev_upload(c, &dm.mesh, m->mesh_soa) || dev_upload(c, &dm.parent, m->parent) || dev_upload(c, &dm.jlevel, m->jlevel) || dev_upload(c, &dm.fk_items, m->fk_items) || dev_upload(c, &dm.tile_col, m->tile_col) || dev_upload(c, &dm.deal_col, m->deal_col) || dev_upload(c, &dm.tile_param, m->tile_param) ||
-        dev_upload(c, &dm.joint_col, m->joint_col) || dev_upload(c, &dm.vorder, m->vorder) || dev_upload(c, &dm.vmask, m->vmask) || dev_upload(c, &dm.fk_level_off, m->fk_level_off) ||
+        dev_upload(c, &dm.joint_col, m->joint_col) || dev_upload(c, &dm.vorder, m->vorder) || dev_upload(c, &dm.vmask, m->vmask) || dev_upload(c, &dm.fk_level_off, m->fk_level_off) || dev_upload(c, &dm.fk_titems, m->fk_titems) ||
         dev_upload(c, &dm.jsr_base, m->jsr_base) || dev_upload(c, &dm.jsr, m->jsr) || dev_upload(c, &dm.S, m->S) ||
         dev_upload(c, &dm.Sp, m->Sp) || dev_upload(c, &dm.prior_mean, m->prior_mean) || dev_upload(c, &dm.prior_prec, m->prior_prec) ||
         dev_upload(c, &dm.prior_clog, m->prior_clog) || dev_upload(c, &dm.part_of_vertex, pov) ||

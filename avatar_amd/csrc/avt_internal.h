@@ -37,6 +37,7 @@ struct AvtDims {
     int anc_max;             // actual max #ancestors in this model
     int ncomps, ndims;       // GMM
     int nlevels;             // depth of the kinematic tree + 1
+    int fk_reg;              // the skeleton pass's work items also exist as DeviceModel::fk_titems (<= AVT_PREP_LEVELS_REG levels of <= AVT_PREP_TITEM_THREADS items)
     int HS;                  // row stride of the dense normal-equation block: 4*ceil((P+1)/4)
     int rec_quad;            // doubles per 4-point matched-point record (avt_eval.hip): 12K + 84
     int nb_max;              // eval batches a frame can have: ceil(V/16)
@@ -106,6 +107,9 @@ __host__ __device__ inline PrepLayout prep_layout(int J, int K, int xsize) {
     L.nitems = J * (12 + 3 * K);
     return L;
 }
+
+#define AVT_PREP_LEVELS_REG 10      // tree levels whose work items a thread of the skeleton pass keeps in registers (SMPL: 9; deeper trees / wider levels: items from LDS, level by level)
+#define AVT_PREP_TITEM_THREADS 256
 
 // per-frame scalar control block
 struct AvtFrameCtl {
@@ -198,6 +202,8 @@ struct DeviceModel {
     double* vrec;         // [V][rec_quad / 4] = record fields of the vertex, the mean-data-point and sqrt(count) fields zero
     int* fk_items;        // [J*(12+3K)][2] per-level work items of k_solve's skeleton pass (see avt_lm.hip), grouped by level
     int* fk_level_off;    // [nlevels+1] offsets into fk_items
+    int* fk_titems;       // [AVT_PREP_LEVELS_REG][AVT_PREP_TITEM_THREADS][2] the same items by (level, thread of a 256-thread workgroup), -1 -1 = none: a thread requests its item of
+                          // every level at kernel start, one independent load each (AvtDims::fk_reg)
     double* jsr_base;     // [3J] initialJointPos
     double* jsr;          // [3J][K] row-major jointShapeReg
     double* S;            // [J][3][K]
@@ -309,7 +315,7 @@ struct avt_model {
     AvtDims d;
     // host copies (used by avt_ctx_create to build the device model and by accessors)
     std::vector<double> shape_planes, lbs_w, asg_w, jsr_base, jsr, S, Sp, vrec;
-    std::vector<int> lbs_j, asg_j, mesh_soa, parent, main_joint, jlevel, fk_items, fk_level_off;
+    std::vector<int> lbs_j, asg_j, mesh_soa, parent, main_joint, jlevel, fk_items, fk_level_off, fk_titems;
     std::vector<int> tile_col, tile_param, joint_col, vorder, deal_col;
     std::vector<unsigned char> anc_n;
     std::vector<unsigned short> anc, vmask;

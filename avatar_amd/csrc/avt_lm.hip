@@ -305,7 +305,9 @@ __device__ __forceinline__ void backsub_blocked(const double* __restrict__ Lblk,
         const double d1 = fma(M13, u3, fma(M12, u2, M11 * u1));
         const double d0 = fma(M01, u1, M00 * u0) + fma(M03, u3, M02 * u2);
         acc0 += fma(cc0[0], d0, cc0[1] * d1) + fma(cc0[2], d2, cc0[3] * d3);
-        acc1 += fma(cc1[0], d0, cc1[1] * d1) + fma(cc1[2], d2, cc1[3] * d3);
+        // (the columns l + 64 have no rows in the blocks up to row 67: with the unrolled loop the compiler drops their four operations and four
+        // register copies for 17 of the 22 steps - a step is bound by its instruction count)
+        if (NBC == 0 || 4 * kb > 64) acc1 += fma(cc1[0], d0, cc1[1] * d1) + fma(cc1[2], d2, cc1[3] * d3);
         if (t == 0) { d2v* o = (d2v*)(s_delta + base); o[0] = (d2v){d0, d1}; o[1] = (d2v){d2, d3}; }
     }
 }
@@ -784,7 +786,8 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     // shape has no LDS left for it (P = 178: 158.5 of 159.5 KB) and keeps it in the frame's global scratch - written and read by
     // this workgroup only, a barrier in between
     // (SOLVE_DECIDE - the accept test alone, moment form - touches nothing of the above: its launch asks for the two state slots only)
-    double* s_x = MODE == SOLVE_DECIDE ? (double*)smem : s_delta + HS + 2;      // [2][xsize] both state slots
+    double* s_gD = s_delta + HS + 2;                        // (256-thread shape) [2][HS]: g | D, left there by the assembly (sys_tile)
+    double* s_x = MODE == SOLVE_DECIDE ? (double*)smem : s_gD + (TRI ? 0 : 2 * HS);      // [2][xsize] both state slots
     const PrepLayout L = prep_layout(J, K, d.xsize);
     // skeleton scratch: behind the factor (SMPL shape: staged at kernel start, hidden behind the factorisation) or ON it
     // (triangular shape: the factor is dead once the back substitution is done)
@@ -797,6 +800,10 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     double* prep0 = fb.prep + ((size_t)f * 2) * d.prep_size;
 
     // everything that does not depend on the LM decision is requested now: both state slots and the skeleton constants
+    // (256-thread shape: this thread's work items of the skeleton pass, every tree level - constants of the model, far in front of their use; the
+    // 1024-thread shape stages the items behind the back substitution and reads them there)
+    PrepItems prep_items;
+    if constexpr (!TRI && MODE != SOLVE_DECIDE && MODE != SOLVE_INIT) prep_items = prep_preload_items_global(dm);
     for (int e = t; e < 2 * xs; e += NTH) s_x[e] = x0[e];
     if ((!TRI || mode == SOLVE_INIT) && mode != SOLVE_DECIDE) prep_stage_constants<NTH>(dm, L, B, s_items, s_level);
     if (!TRI && mode != SOLVE_INIT && mode != SOLVE_DECIDE) {   // the never-written blocks of the factor must read as zeros (back substitution)
@@ -816,7 +823,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         for (int e = t; e < xs; e += NTH) x0[(size_t)tr * xs + e] = xc[e];
         prep_set_state(d, L, B, xc + 3, xc + 3 + 4 * J, xc);
         __syncthreads();
-        prep_run<NTH>(dm, L, B, s_items, s_level, xc + 3, prep0 + (size_t)tr * d.prep_size);
+        prep_run<NTH>(dm, L, B, s_items, s_level, xc + 3, prep0 + (size_t)tr * d.prep_size, prep_preload_items<NTH>(d, s_items, s_level));
         return;
     }
     TPROBE_START();
@@ -976,6 +983,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     __syncthreads();   // the staged state slots are visible; every lane has read the control block
     // the frame met the stopping rule in an earlier launch of this ICP iteration: no trial point, no test, no iteration (the riding shapes left above)
     if (!RIDE && mode != SOLVE_FIRST && try_valid == AVT_TRY_DONE) return;
+
     if (mode == SOLVE_FIRST) cost_const = s_cc;
     const int try0 = 1 - cur0;
     const double* xt = s_x + try0 * xs;
@@ -1131,7 +1139,10 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     // 16 rb + 4 v + g4 (v = 0..3) of column 16 cb + c16.  raw(v) = the data-term entry; the priors come from a second, short
     // round trip (precision entries and gradient of the chosen GMM component, read-only data).  All loads unconditional on
     // clamped indices, the conditions applied as selects: loads in flight together, no branches.
-    auto sys_tile = [&](int rb, int cb, bool own, const double (&raw)[4]) __attribute__((always_inline)) {
+    // (dgn: the UNDAMPED diagonal entry this lane holds in the tile, if it holds one - what the predicted decrease of the gain-ratio schedule needs beside
+    // the gradient, which is the negated row P of the tile.  Returned in a register: a store to LDS in here makes the compiler re-request the prior's
+    // tables after it, tile by tile - 11 k clocks, measured)
+    auto sys_tile = [&](int rb, int cb, bool own, const double (&raw)[4], double& dgn) __attribute__((always_inline)) {
         const int col = 16 * cb + mf_c16, pc = col - 6, sk = col - (3 + 3 * J);
         const int pcc = min(max(pc, 0), max(n - 1, 0)), skc = min(max(sk, 0), max(K - 1, 0));
         const double gqc = use_pose ? pri[2 + pcc] : 0.0, xqc = xc[3 + 4 * J + skc];
@@ -1146,7 +1157,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
             // rows < P: H + priors, diagonal damped
             double vh = v0;
             vh += (in_pose_c && pr_ >= 0 && pr_ < n) ? sc2 * prv : 0.0;
-            if (row == col) { vh += shape_c ? sbs * sbs : 0.0; vh += lambda * vh; }
+            if (row == col) { vh += shape_c ? sbs * sbs : 0.0; dgn = vh; vh += lambda * vh; }
             // row P: -(J^T r) including the priors
             double vg = v0;
             vg += in_pose_c ? gs * gqc : 0.0;
@@ -1159,6 +1170,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     };
     if constexpr (!TRI) {
         v4f64 tile[6];
+        double dgn[6];
 #pragma unroll
         for (int ti = 0; ti < 6; ++ti) {
             const bool first = ti <= mf_rA;
@@ -1166,7 +1178,21 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
             double raw[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) raw[v] = cur ? mraw[TRI ? 0 : 1][TRI ? 0 : ti][v] : mraw[0][TRI ? 0 : ti][v];
-            tile[ti] = sys_tile(rb, cb, first || cb <= mf_rB, raw);
+            dgn[ti] = 0.0;
+            tile[ti] = sys_tile(rb, cb, first || cb <= mf_rB, raw, dgn[ti]);
+        }
+        if (gain) {      // g and D for the predicted decrease (wave 1, behind the back substitution): every entry has exactly one owner
+#pragma unroll
+            for (int ti = 0; ti < 6; ++ti) {
+                const bool first = ti <= mf_rA;
+                const int rb = first ? mf_rA : max(mf_rB, 0), cb = first ? ti : ti - mf_rA - 1;
+                const bool own = first || cb <= mf_rB;
+                const int col = 16 * cb + mf_c16, v = (mf_c16 - mf_g4) >> 2;      // the diagonal of a diagonal tile: row 4 v + g4 = column c16
+                if (own && rb == cb && ((mf_c16 - mf_g4) & 3) == 0 && v >= 0 && col < P) s_gD[HS + col] = dgn[ti];
+                const int vP = (P & 15) >> 2;      // row P = 16 (P >> 4) + 4 vP + (P & 3) holds -g
+                const double mg = vP == 0 ? tile[ti][0] : (vP == 1 ? tile[ti][1] : (vP == 2 ? tile[ti][2] : tile[ti][3]));
+                if (own && rb == (P >> 4) && mf_g4 == (P & 3) && col < P) s_gD[col] = -mg;
+            }
         }
         TPROBE(2);
         // ---- c. LDL^T, four pivots and two barriers per round, the trailing matrix in the accumulators (mf_rounds) ----
@@ -1197,7 +1223,8 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
             double raw[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) raw[v] = Hc[(size_t)min(16 * rb + 4 * v + mf_g4, HS - 1) * HS + min(16 * cb + mf_c16, HS - 1)];
-            acc[sl] = sys_tile(rb, cb, S.rb[sl] >= 0, raw);
+            double dgn_unused = 0.0;
+            acc[sl] = sys_tile(rb, cb, S.rb[sl] >= 0, raw, dgn_unused);
         }
         TPROBE(2);
         if (t == 0) s_failf[0] = 0;
@@ -1218,7 +1245,8 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
             if constexpr (TRI) backsub_tri(Lblk, s_R, NB, P, t, s_delta);
             else if (NB == 22) backsub_blocked<22>(Lblk, s_R, NB, P, t, s_delta, s_PB);
             else backsub_blocked<0>(Lblk, s_R, NB, P, t, s_delta, s_PB);
-            if (gain) {
+            if (TRI && gain) {
+                // (1024-thread shape: no LDS left for g and D)
                 // Predicted decrease of the quadratic model, 1/2 delta^T (lambda D delta - g), by the same wave (fixed butterfly).  g and the
                 // undamped diagonal D are formed again from the reduced system and the priors, entry by entry as sys_tile forms them
                 // (same operations, same bits) - only this schedule pays for them, the fixed-factor one never sees this block.
@@ -1245,18 +1273,49 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
             __syncthreads();
         }
         TPROBE(4);
+        if constexpr (!TRI) {
+            // Behind the back substitution's barrier three things run side by side on different waves: the retraction (wave 0, below), the
+            // predicted decrease of the quadratic model (wave 1) and the joint positions of the new shape (waves 2 and 3) - round 6: the
+            // last two sat on wave 0's path before and behind the retraction (2.7 k + 1.4 k clocks of the 84 k-clock pass).
+            if (gain && t >= 64 && t < 128) {
+                // 1/2 delta^T (lambda D delta - g), fixed butterfly.  g and the undamped diagonal D are what the assembly (sys_tile) formed
+                // and left in LDS: the same values the lone wave used to rebuild from the reduced system with 170 global loads.
+                double a = 0.0;
+                for (int i = t - 64; i < P; i += 64) {
+                    const double dl = s_delta[i];
+                    a += dl * (lambda * s_gD[HS + i] * dl - s_gD[i]);
+                }
+                pred_new = 0.5 * wave_sum(a);
+            }
+            // (the shape coefficients of the new point: formed again here by the operation the retraction stores them with)
+            if (t >= 128) prep_joint_positions(d, L, B, s_level, t - 128, [&](int k) { return xc[3 + 4 * J + k] + s_delta[3 + 3 * J + k]; });
+        }
         // retraction (FakeQuaternionParameterization::Plus, :123-143): the new trial point goes to global memory for
         // the kernels that follow and straight into the skeleton scratch
-        if (t < 3) { const double v = xc[t] + s_delta[t]; xn[t] = v; B[L.dv + t] = v; }
-        if (t < K) { const double v = xc[3 + 4 * J + t] + s_delta[3 + 3 * J + t]; xn[3 + 4 * J + t] = v; B[L.w + t] = v; }
+        // (position and shape coefficients: lanes of the last wave in the 256-thread shape - on wave 0 they were two more divergent sections, each with
+        // its own LDS round trip, in front of the quaternions)
+        { const int tp = TRI ? t : t - 224; if (tp >= 0 && tp < 3) { const double v = xc[tp] + s_delta[tp]; xn[tp] = v; B[L.dv + tp] = v; } }
+        { const int tw = TRI ? t : t - 232; if (tw >= 0 && tw < K) { const double v = xc[3 + 4 * J + tw] + s_delta[3 + 3 * J + tw]; xn[3 + 4 * J + tw] = v; B[L.w + tw] = v; } }
         if (t < J) {
             const double* dl = s_delta + 3 + 3 * t;
             const double* q = xc + 3 + 4 * t;
-            const double nd = sqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
+            // delta q = (sin|d| / |d| d, cos|d|): both factors are even power series in |d|, so up to |d| = 1/2 (a rotation of one radian in ONE
+            // step) they are two interleaved Horner chains in z = |d|^2 - no square root, no division, no argument reduction (truncation
+            // < 1e-21, rounding ~1 ulp; the library calls were 2.9 k clocks of the pass).  Larger steps take the library's functions.
+            const double z = dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2];
             double qo[4];
-            if (nd > 0.0) {
-                const double sdd = sin(nd) / nd;
-                const double a0 = sdd * dl[0], a1 = sdd * dl[1], a2 = sdd * dl[2], a3 = cos(nd);
+            if (z > 0.0) {
+                // sin x / x = sum (-1)^k z^k / (2k+1)!,  cos x = sum (-1)^k z^k / (2k)!,  k = 0 .. 8
+                double sdd = fma(z, 1.0 / 355687428096000.0, -1.0 / 1307674368000.0), a3 = fma(z, 1.0 / 20922789888000.0, -1.0 / 87178291200.0);
+                sdd = fma(sdd, z, 1.0 / 6227020800.0);  a3 = fma(a3, z, 1.0 / 479001600.0);
+                sdd = fma(sdd, z, -1.0 / 39916800.0);   a3 = fma(a3, z, -1.0 / 3628800.0);
+                sdd = fma(sdd, z, 1.0 / 362880.0);      a3 = fma(a3, z, 1.0 / 40320.0);
+                sdd = fma(sdd, z, -1.0 / 5040.0);       a3 = fma(a3, z, -1.0 / 720.0);
+                sdd = fma(sdd, z, 1.0 / 120.0);         a3 = fma(a3, z, 1.0 / 24.0);
+                sdd = fma(sdd, z, -1.0 / 6.0);          a3 = fma(a3, z, -0.5);
+                sdd = fma(sdd, z, 1.0);                 a3 = fma(a3, z, 1.0);
+                if (!(z < 0.25)) { const double nd = sqrt(z); sdd = sin(nd) / nd; a3 = cos(nd); }
+                const double a0 = sdd * dl[0], a1 = sdd * dl[1], a2 = sdd * dl[2];
                 qo[3] = a3 * q[3] - a0 * q[0] - a1 * q[1] - a2 * q[2];
                 qo[0] = a3 * q[0] + a0 * q[3] + a1 * q[2] - a2 * q[1];
                 qo[1] = a3 * q[1] + a1 * q[3] + a2 * q[0] - a0 * q[2];
@@ -1275,6 +1334,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         for (int e = t; e < 4 * J; e += NTH) s_qnew[e] = xc[3 + e];
         if constexpr (TRI) { __syncthreads(); prep_stage_constants<NTH>(dm, L, B, s_items, s_level); __syncthreads(); }
         prep_set_state(d, L, B, xc + 3, xc + 3 + 4 * J, xc);
+        if constexpr (!TRI) { if (t >= 128) prep_joint_positions(d, L, B, s_level, t - 128, [&](int k) { return xc[3 + 4 * J + k]; }); }
         if (gain) { lambda = fmin(lambda * nu, lm_max); nu *= 2.0; }
         else lambda = fmin(lambda * lm_up, lm_max);
     }
@@ -1282,15 +1342,21 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         ctl.lambda = lambda; ctl.try_valid = ok ? 1 : 0;
         // what the accept test of the trial point just made reads if no further solve follows (avt_decide.h)
         ctl.dec_cur_slot = cur; ctl.dec_try_valid = ok ? 1 : 0; ctl.dec_cost_cur = cost_cur; ctl.dec_lambda = lambda;
-        ctl.pred = pred_new; ctl.nu = nu; ctl.dec_pred = pred_new; ctl.dec_nu = nu;
+        ctl.nu = nu; ctl.dec_nu = nu;
         if (RIDE) { sp.next = 0; sp.n = fb.nspec; sp.ahead = (mode == SOLVE_FIRST ? 0 : sq_ahead) + nfold; }          // the speculative workgroups of this launch are making steps 0 .. nspec - 1
     }
-    if (RIDE && t == 0 && role > 0) { sp.valid[role - 1] = ok ? 1 : 0; sp.lambda[role - 1] = lambda; sp.pred[role - 1] = pred_new; }
+    if (RIDE && t == 0 && role > 0) { sp.valid[role - 1] = ok ? 1 : 0; sp.lambda[role - 1] = lambda; }
+    // (the predicted decrease is with the wave that formed it: wave 1 in the 256-thread shape, wave 0 in the 1024-thread one; 0 when the factorisation was refused)
+    if (t == (TRI ? 0 : 64)) {
+        if (role == 0) { ctl.pred = pred_new; ctl.dec_pred = pred_new; }
+        else if (RIDE) sp.pred[role - 1] = pred_new;
+    }
     if (RIDE && role > 0 && !ok) return;                     // (a refused speculative factorisation: the slot stays invalid)
     __syncthreads();
     TPROBE(5);
     // ---- d. skeleton tables of the new trial point ----------------------------------------------------
-    prep_run<NTH>(dm, L, B, s_items, s_level, s_qnew, prep_out);
+    if constexpr (TRI) prep_items = prep_preload_items<NTH>(d, s_items, s_level);
+    prep_run<NTH, !TRI>(dm, L, B, s_items, s_level, s_qnew, prep_out, prep_items);      // (256-thread shape: the joint positions are made - waves 2 and 3, beside the retraction)
     TPROBE(6);
 #ifdef AVT_TIMING
     __syncthreads();
@@ -1317,7 +1383,7 @@ static size_t solve_lds_bytes(const AvtDims& d) {
     const PrepLayout L = prep_layout(d.J, d.K, d.xsize);
     const size_t nblk = solve_big(d) ? (size_t)NB * (NB + 1) / 2 : (size_t)NB * NB;
     const size_t prep_bytes = sizeof(double) * (size_t)L.ndoubles + sizeof(int) * (2 * (size_t)L.nitems + 2 * AVT_MAX_JOINTS + 4);
-    const size_t fixed = sizeof(double) * (((std::max(HS, 4 * d.J) + 3) & ~1) + HS + 2 + ((2 * d.xsize + 1) & ~1));
+    const size_t fixed = sizeof(double) * (((std::max(HS, 4 * d.J) + 3) & ~1) + HS + 2 + (solve_big(d) ? 0 : 2 * HS) + ((2 * d.xsize + 1) & ~1));
     const size_t factor = sizeof(double) * nblk * 18;
     return (solve_big(d) ? std::max(factor, prep_bytes) + sizeof(double) * MFG_PB_DOUBLES + fixed
                          : factor + sizeof(double) * MF_PB_DOUBLES + fixed + prep_bytes) + 64;

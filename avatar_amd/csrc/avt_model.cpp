@@ -395,6 +395,18 @@ static int avt_model_create_impl(const avt_model_desc* desc, avt_model** out) {
             }
             m->fk_level_off[lv + 1] = (int)m->fk_items.size() / 2;
         }
+        // the same items by (level, thread) for the 256-thread skeleton pass (avt_prep.h)
+        d.fk_reg = d.nlevels <= AVT_PREP_LEVELS_REG;
+        for (int lv = 0; lv < d.nlevels; ++lv) d.fk_reg = d.fk_reg && m->fk_level_off[lv + 1] - m->fk_level_off[lv] <= AVT_PREP_TITEM_THREADS;
+        m->fk_titems.assign((size_t)AVT_PREP_LEVELS_REG * AVT_PREP_TITEM_THREADS * 2, -1);
+        if (d.fk_reg)
+            for (int lv = 0; lv < d.nlevels; ++lv)
+                for (int i = m->fk_level_off[lv]; i < m->fk_level_off[lv + 1]; ++i) {
+                    // (the threads of the LAST waves first: wave 0 runs the back substitution in front of the pass and does the retraction's quaternions)
+                    const int th = AVT_PREP_TITEM_THREADS - 1 - (i - m->fk_level_off[lv]);
+                    m->fk_titems[((size_t)lv * AVT_PREP_TITEM_THREADS + th) * 2] = m->fk_items[2 * (size_t)i];
+                    m->fk_titems[((size_t)lv * AVT_PREP_TITEM_THREADS + th) * 2 + 1] = m->fk_items[2 * (size_t)i + 1];
+                }
     }
 
     // shape planes

@@ -42,45 +42,94 @@ __device__ __forceinline__ void prep_set_state(const AvtDims& d, const PrepLayou
     if (t < 3) B[L.dv + t] = p[t];          // the root's "offset from its parent" is the global position
 }
 
-// callers: a barrier separates prep_set_state() from prep_run()
-template <int NTH>
-__device__ __forceinline__ void prep_run(const DeviceModel& dm, const PrepLayout& L, double* __restrict__ B, const int2* __restrict__ items,
-                         const int* __restrict__ level, const double* __restrict__ q, double* __restrict__ prep) {
-    const AvtDims d = dm.d;
-    const int J = d.J, K = d.K, t = threadIdx.x;
-    // CalcShape (AvatarOptimizer.cpp:249-281): jointPosInit = base + jointShapeReg*w, and each joint's offset from its
-    // parent (the parent's position is recomputed by the same lane: same operations, same bits, no barrier)
-    auto joint_positions = [&](const int KK) {    // KK: constant for SMPL, so both dot products unroll and their LDS reads are in flight together
-        if (t < 3 * J) {
-            const int j = t / 3, c = t - 3 * j;
-            const int tp = j > 0 ? 3 * level[AVT_MAX_JOINTS + 2 + j] + c : t;
+// CalcShape (AvatarOptimizer.cpp:249-281): jointPosInit = base + jointShapeReg*w, and each joint's offset from its parent (the
+// parent's position is recomputed by the same lane: same operations, same bits, no barrier).  Lane tl in [0, 3J) takes coordinate tl;
+// wk(k) = shape coefficient k of the state (a functor: the scratch entry, or - k_solve - the sum the retraction stores there, formed
+// again by the same operation so that this pass need not wait for that store).
+template <typename WK>
+__device__ __forceinline__ void prep_joint_positions(const AvtDims& d, const PrepLayout& L, double* __restrict__ B, const int* __restrict__ level, int tl, WK wk) {
+    const int J = d.J, K = d.K;
+    auto run = [&](const int KK) {    // KK: constant for SMPL, so both dot products unroll and their LDS reads are in flight together
+        if (tl >= 0 && tl < 3 * J) {
+            const int j = tl / 3, c = tl - 3 * j;
+            const int tp = j > 0 ? 3 * level[AVT_MAX_JOINTS + 2 + j] + c : tl;
             double a = 0.0, ap = 0.0;
             for (int k = 0; k < KK; ++k) {
-                const double wk = B[L.w + k];
-                a += B[L.jsr + t * KK + k] * wk;
-                ap += B[L.jsr + tp * KK + k] * wk;
+                const double w = wk(k);
+                a += B[L.jsr + tl * KK + k] * w;
+                ap += B[L.jsr + tp * KK + k] * w;
             }
-            const double mine = B[L.jsrb + t] + a;
-            B[L.jp + t] = mine;
-            if (j > 0) B[L.dv + t] = mine - (B[L.jsrb + tp] + ap);
+            const double mine = B[L.jsrb + tl] + a;
+            B[L.jp + tl] = mine;
+            if (j > 0) B[L.dv + tl] = mine - (B[L.jsrb + tp] + ap);
         }
     };
-    if (K == 10) joint_positions(10); else joint_positions(K);
-    __syncthreads();
+    if (K == 10) run(10); else run(K);
+}
+
+// The work items of prep_run's level loop are constants of the model (staged by prep_stage_constants): a thread's item of every level is read
+// ONCE, all levels together and as early as the caller likes (k_solve: at kernel start, in front of the factorisation), instead of one dependent
+// LDS round trip per level in front of the operand reads (round 6: level loop 4.8 k -> 3.8 k clocks; read inside prep_run the two round trips
+// of this function were 1.3 k clocks of their own on the chain).
+struct PrepItems { int2 v[AVT_PREP_LEVELS_REG]; bool reg; };
+// ... for a 256-thread workgroup straight from the model's (level, thread) table in global memory: independent loads that can be the first thing a
+// kernel requests (no staging, no barrier, no dependent address)
+__device__ __forceinline__ PrepItems prep_preload_items_global(const DeviceModel& dm) {
+    PrepItems pi;
+    pi.reg = dm.d.fk_reg != 0;
+    const int2* src = (const int2*)dm.fk_titems + threadIdx.x;
+#pragma unroll
+    for (int lv = 0; lv < AVT_PREP_LEVELS_REG; ++lv) pi.v[lv] = src[(size_t)lv * AVT_PREP_TITEM_THREADS];
+    return pi;
+}
+template <int NTH>
+__device__ __forceinline__ PrepItems prep_preload_items(const AvtDims& d, const int2* __restrict__ items, const int* __restrict__ level) {
+    PrepItems pi;
+    pi.reg = d.nlevels <= AVT_PREP_LEVELS_REG;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int lv = 0; lv < AVT_PREP_LEVELS_REG; ++lv) {
+        const int lo = level[min(lv, d.nlevels)], hi = level[min(lv + 1, d.nlevels)];
+        pi.reg = pi.reg && hi - lo <= NTH;
+        pi.v[lv] = (lo + t < hi) ? items[lo + t] : make_int2(-1, -1);
+    }
+    return pi;
+}
+
+// callers: a barrier separates prep_set_state() from prep_run().  JPDONE: the caller ran prep_joint_positions() in front of that barrier.
+template <int NTH, bool JPDONE = false>
+__device__ __forceinline__ void prep_run(const DeviceModel& dm, const PrepLayout& L, double* __restrict__ B, const int2* __restrict__ items,
+                         const int* __restrict__ level, const double* __restrict__ q, double* __restrict__ prep, const PrepItems& pi) {
+    const AvtDims d = dm.d;
+    const int J = d.J, K = d.K, t = threadIdx.x;
+    if constexpr (!JPDONE) {
+        prep_joint_positions(d, L, B, level, t, [&](int k) { return B[L.w + k]; });
+        __syncthreads();
+    }
 #ifdef AVT_TIMING
     if (threadIdx.x == 0) prep[d.prep_size - 1] = (double)clock64();
 #endif
     // one tree level per barrier
-    for (int lv = 0; lv < d.nlevels; ++lv) {
-        const int lo = level[lv], hi = level[lv + 1];
-        for (int idx = lo + t; idx < hi; idx += NTH) {
-            const int2 it = items[idx];
-            const int rp = it.x & 0x3fff, v = (it.x >> 14) & 0x3fff, scode = (unsigned)it.x >> 28;
-            const int st = scode == 3 ? K : (scode == 2 ? 3 : scode);
-            const int add = it.y & 0x3fff, out = (unsigned)it.y >> 14;
-            B[out] = (B[rp] * B[v] + B[rp + 1] * B[v + st] + B[rp + 2] * B[v + 2 * st]) + B[add];
+    auto do_item = [&](const int2 it) {
+        const int rp = it.x & 0x3fff, v = (it.x >> 14) & 0x3fff, scode = (unsigned)it.x >> 28;
+        const int st = scode == 3 ? K : (scode == 2 ? 3 : scode);
+        const int add = it.y & 0x3fff, out = (unsigned)it.y >> 14;
+        B[out] = (B[rp] * B[v] + B[rp + 1] * B[v + st] + B[rp + 2] * B[v + 2 * st]) + B[add];
+    };
+    if (pi.reg) {
+#pragma unroll
+        for (int lv = 0; lv < AVT_PREP_LEVELS_REG; ++lv) {
+            if (lv < d.nlevels) {      // (workgroup-uniform)
+                if (pi.v[lv].x != -1) do_item(pi.v[lv]);
+                __syncthreads();
+            }
         }
-        __syncthreads();
+    } else {
+        for (int lv = 0; lv < d.nlevels; ++lv) {
+            const int lo = level[lv], hi = level[lv + 1];
+            for (int idx = lo + t; idx < hi; idx += NTH) do_item(items[idx]);
+            __syncthreads();
+        }
     }
 #ifdef AVT_TIMING
     if (threadIdx.x == 0) prep[d.prep_size - 2] = (double)clock64();
@@ -135,5 +184,5 @@ __device__ __forceinline__ void prep_init_block(const DeviceModel& dm, const Fra
     for (int e = t; e < xs; e += 256) x0[(size_t)tr * xs + e] = s_x[e];
     prep_set_state(d, L, B, s_x + 3, s_x + 3 + 4 * J, s_x);
     __syncthreads();
-    prep_run<256>(dm, L, B, s_items, s_level, s_x + 3, fb.prep + ((size_t)f * 2 + tr) * d.prep_size);
+    prep_run<256>(dm, L, B, s_items, s_level, s_x + 3, fb.prep + ((size_t)f * 2 + tr) * d.prep_size, prep_preload_items<256>(d, s_items, s_level));
 }
