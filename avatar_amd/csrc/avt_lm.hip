@@ -802,10 +802,37 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     // everything that does not depend on the LM decision is requested now: both state slots and the skeleton constants
     // (256-thread shape: this thread's work items of the skeleton pass, every tree level - constants of the model, far in front of their use; the
     // 1024-thread shape stages the items behind the back substitution and reads them there)
+    // 256-thread solves: all of it is requested into registers here and stored to LDS further down, behind the requests for the system's entries -
+    // one round trip for everything instead of one per staging loop (avt_prep.h, prep_stage_request)
+    // (not the riding shapes: their solver roles wait for the reduction's hand-over anyway, the staging loops' round trips hide in that wait, and
+    // with the two-phase code beside them they measured 0.503 against 0.492 ms per step)
+    constexpr bool TWO_PHASE = !TRI && !RIDE && MODE != SOLVE_DECIDE && MODE != SOLVE_INIT;
     PrepItems prep_items;
-    if constexpr (!TRI && MODE != SOLVE_DECIDE && MODE != SOLVE_INIT) prep_items = prep_preload_items_global(dm);
-    for (int e = t; e < 2 * xs; e += NTH) s_x[e] = x0[e];
-    if ((!TRI || mode == SOLVE_INIT) && mode != SOLVE_DECIDE) prep_stage_constants<NTH>(dm, L, B, s_items, s_level);
+    const bool items_global = !TRI && MODE != SOLVE_DECIDE && MODE != SOLVE_INIT && d.fk_reg != 0;      // this thread's work items of the skeleton pass: requested now, from the model's (level, thread) table
+    if (items_global) prep_items = prep_preload_items_global(dm);
+    PrepStaged staged;
+    double staged_x[2] = {0.0, 0.0};
+    bool two_phase = false;
+    if constexpr (TWO_PHASE) {
+        two_phase = d.fk_reg != 0 && prep_stage_fits(d, 0) && 2 * xs <= 2 * NTH;      // (workgroup-uniform; SMPL-sized skeletons)
+        if (two_phase) {
+            staged_x[0] = t < 2 * xs ? x0[t] : 0.0; staged_x[1] = t + NTH < 2 * xs ? x0[t + NTH] : 0.0;
+            staged = prep_stage_request<false>(dm, L);
+        }
+    }
+    auto stage_store = [&]() {      // the LDS half of the two-phase staging: called once, in front of the barrier that publishes the state slots
+        if constexpr (TWO_PHASE) {
+            if (two_phase) {
+                if (t < 2 * xs) s_x[t] = staged_x[0];
+                if (t + NTH < 2 * xs) s_x[t + NTH] = staged_x[1];
+                prep_stage_store<false>(d, L, staged, B, s_items, s_level);
+            }
+        }
+    };
+    if (!two_phase) {
+        for (int e = t; e < 2 * xs; e += NTH) s_x[e] = x0[e];
+        if ((!TRI || mode == SOLVE_INIT) && mode != SOLVE_DECIDE) prep_stage_constants<NTH>(dm, L, B, s_items, s_level);
+    }
     if (!TRI && mode != SOLVE_INIT && mode != SOLVE_DECIDE) {   // the never-written blocks of the factor must read as zeros (back substitution)
         d2v* z = (d2v*)Lblk;
         for (int e = t; e < NBk * NBk * 9; e += NTH) z[e] = (d2v){0.0, 0.0};
@@ -885,6 +912,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
             sp_pre[i] = (role == 0 && e < ncopy) ? (e < xs ? xsrc[e] : psrc[e - xs]) : 0.0;
         }
     }
+    if constexpr (RIDE) stage_store();      // (riding shapes: the solver roles have time to spare in front of the reduction's hand-over)
     if constexpr (RIDE) {      // the reduction workgroups of this launch have all delivered their strips of the trial point's system
         if (t == 0) {
             // (the count runs on from launch to launch of an ICP iteration - k_finalize clears it -: several workgroups wait on it)
@@ -980,6 +1008,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
             for (int c = 0; c < AVT_MAX_COMPS; ++c)
                 if (c < d.ncomps && pr[sl][c] < best[sl]) { best[sl] = pr[sl][c]; bcomp[sl] = c; }
     }
+    if constexpr (!RIDE) stage_store();      // (behind the requests for the system's entries: one round trip for everything)
     __syncthreads();   // the staged state slots are visible; every lane has read the control block
     // the frame met the stopping rule in an earlier launch of this ICP iteration: no trial point, no test, no iteration (the riding shapes left above)
     if (!RIDE && mode != SOLVE_FIRST && try_valid == AVT_TRY_DONE) return;
@@ -1355,7 +1384,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     __syncthreads();
     TPROBE(5);
     // ---- d. skeleton tables of the new trial point ----------------------------------------------------
-    if constexpr (TRI) prep_items = prep_preload_items<NTH>(d, s_items, s_level);
+    if (!items_global) prep_items = prep_preload_items<NTH>(d, s_items, s_level);      // (staged items: the 1024-thread shape, skeletons without the per-thread table)
     prep_run<NTH, !TRI>(dm, L, B, s_items, s_level, s_qnew, prep_out, prep_items);      // (256-thread shape: the joint positions are made - waves 2 and 3, beside the retraction)
     TPROBE(6);
 #ifdef AVT_TIMING

@@ -33,6 +33,53 @@ __device__ __forceinline__ void prep_stage_constants(const DeviceModel& dm, cons
     if (t < J) level[AVT_MAX_JOINTS + 2 + t] = dm.parent[t];     // parents follow the level offsets
 }
 
+// The same staging in two phases for the 256-thread kernels, whose prologue is a dependency chain: every load is REQUESTED first, into registers
+// (prep_stage_request), and stored to LDS later (prep_stage_store), with whatever else the caller wants to request in between.  Written as loops of
+// "LDS[e] = global[e]" each array is a round trip of its own - load, wait, store, next loop - because the scheduler does not move a load across the
+// loop that waits for the previous one: six dependent round trips (9 k clocks) in front of the first instruction that needs any of the data
+// (round 6, found in the ISA).  Covers 3 J K <= 6 x 256 and (work items from LDS, skeletons without the per-thread table) J (12 + 3 K) <= 8 x 256.
+struct PrepStaged { double sp[6], s[6], jsr[6], jsrb; int lvl, par; int2 it[8]; };
+__device__ __forceinline__ bool prep_stage_fits(const AvtDims& d, int nitems) { return 3 * d.J * d.K <= 6 * 256 && 3 * d.J <= 256 && nitems <= 8 * 256; }
+template <bool ITEMS>
+__device__ __forceinline__ PrepStaged prep_stage_request(const DeviceModel& dm, const PrepLayout& L) {
+    const AvtDims& d = dm.d;
+    const int J = d.J, K = d.K, t = threadIdx.x, n = 3 * J * K;
+    PrepStaged st;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int e = t + 256 * i;
+        const bool on = e < n;
+        st.sp[i] = on ? dm.Sp[e] : 0.0; st.s[i] = on ? dm.S[e] : 0.0; st.jsr[i] = on ? dm.jsr[e] : 0.0;
+    }
+    st.jsrb = t < 3 * J ? dm.jsr_base[t] : 0.0;
+    st.lvl = t <= d.nlevels ? dm.fk_level_off[t] : 0;
+    st.par = t < J ? dm.parent[t] : 0;
+    if constexpr (ITEMS) {
+        const int2* gi = (const int2*)dm.fk_items;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int e = t + 256 * i; st.it[i] = e < L.nitems ? gi[e] : make_int2(0, 0); }
+    }
+    return st;
+}
+template <bool ITEMS>
+__device__ __forceinline__ void prep_stage_store(const AvtDims& d, const PrepLayout& L, const PrepStaged& st, double* __restrict__ B, int2* __restrict__ items, int* __restrict__ level) {
+    const int J = d.J, K = d.K, t = threadIdx.x, n = 3 * J * K;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int e = t + 256 * i;
+        if (e < n) { B[L.Sp + e] = st.sp[i]; B[L.S + e] = st.s[i]; B[L.jsr + e] = st.jsr[i]; }
+    }
+    if (t < 3 * J) B[L.jsrb + t] = st.jsrb;
+    if (t < 9) B[L.ident + t] = (t == 0 || t == 4 || t == 8) ? 1.0 : 0.0;
+    if (t < 3) B[L.zero + t] = 0.0;
+    if (t <= d.nlevels) level[t] = st.lvl;
+    if (t < J) level[AVT_MAX_JOINTS + 2 + t] = st.par;
+    if constexpr (ITEMS) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int e = t + 256 * i; if (e < L.nitems) items[e] = st.it[i]; }
+    }
+}
+
 // local rotations, shape parameters and root position of the state into the scratch (q, w, p: LDS or registers' source)
 __device__ __forceinline__ void prep_set_state(const AvtDims& d, const PrepLayout& L, double* __restrict__ B, const double* q,
                                                const double* w, const double* p) {
