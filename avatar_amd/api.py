@@ -476,6 +476,76 @@ class Avatar:
         c, jp, jt = self.model.default_ctx().lbs_update(self.w[None], self.p[None], self.r[None])
         self.cloud, self.jointPos, self.jointTrans = c[0], jp[0], jt[0]
 
+    # ---- the host-side members beside the tracker path (Avatar.cpp:77-193); include/ark/Avatar.h is the reference-faithful C++ side (std::mt19937
+    # draws in the reference's order, Eigen's closed forms) and tests/test_avatar_methods_cpu.py checks it; these mirror the behaviour with numpy
+    def smplParams(self):
+        """Axis-angle of every joint but the root, 3 (J - 1) numbers (Avatar.cpp:128-137)."""
+        from scipy.spatial.transform import Rotation
+        return Rotation.from_matrix(self.r[1:]).as_rotvec().reshape(-1)
+
+    def pdf(self):
+        """GMM likelihood of the joint rotations as the reference evaluates it (Avatar.cpp:139, GaussianMixture.cpp:22-93: constants normalised by
+        the smallest determinant; exponent |L (x - mu)|^2 with L = chol(cov^-1), not its transpose)."""
+        a = self.model.arrays
+        wt, mu, cov = a.prior_weight, a.prior_mean, a.prior_cov
+        n = mu.shape[1]
+        dets = np.array([np.prod(np.diag(np.linalg.cholesky(c))) for c in cov])
+        consts = wt / (2 * np.pi) ** (n * 0.5) / dets * dets.min()
+        x = self.smplParams()
+        return float(sum(consts[i] * np.exp(-0.5 * np.sum((np.linalg.cholesky(np.linalg.inv(cov[i])) @ (x - mu[i])) ** 2)) for i in range(len(wt))))
+
+    def randomize(self, randomize_pose=True, randomize_shape=True, randomize_root_pos_rot=True, seed=None):
+        """Avatar::randomize (Avatar.cpp:77-126) with numpy's generator (NOT std::mt19937's stream: the C++ facade has that): normal shape
+        coefficients, the pose from the prior's LAST component (the reference's component loop has no break), root position and rotation in
+        the reference's ranges."""
+        from scipy.spatial.transform import Rotation
+        rng = np.random.default_rng(seed)
+        J = self.model.numJoints()
+        if randomize_shape:
+            self.w = rng.normal(size=self.model.numShapeKeys())
+        if randomize_pose:
+            a = self.model.arrays
+            x = a.prior_mean[-1] + np.linalg.cholesky(a.prior_cov[-1]) @ rng.normal(size=a.prior_mean.shape[1])
+            self.r[1:] = Rotation.from_rotvec(x.reshape(J - 1, 3)).as_matrix()
+        if randomize_root_pos_rot:
+            self.p = np.array([rng.uniform(-1, 1), rng.uniform(-0.5, 0.5), rng.uniform(2.2, 4.5)])
+            up = rng.uniform(-np.pi / 3, np.pi / 3) + np.pi
+            th, ph = rng.uniform(0, 2 * np.pi), rng.uniform(-np.pi / 2, np.pi / 2)
+            axis = np.array([np.sin(ph) * np.cos(th), np.cos(ph), np.sin(ph) * np.sin(th)])
+            self.r[0] = Rotation.from_rotvec(axis * rng.normal(0, 0.2)).as_matrix() @ Rotation.from_rotvec([0, up, 0]).as_matrix()
+
+    def alignToJoints(self, joint_pos):
+        """Pose (and w[0]) from 24 target joint positions, NaN rows = not seen (Avatar.cpp:141-193, quirks included: see include/ark/Avatar.h)."""
+        pos = np.asarray(joint_pos, float).reshape(-1, 3)
+        ij, parent = self.model.initialJointPos, self.model.parent
+        assert len(pos) == 24 == self.model.numJoints()
+
+        def two(a, b):      # Quaternion::FromTwoVectors(a, b).toRotationMatrix()
+            a, b = a / np.linalg.norm(a), b / np.linalg.norm(b)
+            v, c = np.cross(a, b), float(a @ b)
+            if c < -1 + 1e-12:
+                e = np.eye(3)[int(np.argmin(np.abs(a)))]
+                ax = np.cross(e, a); ax /= np.linalg.norm(ax)
+                return 2 * np.outer(ax, ax) - np.eye(3)
+            K = np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+            return np.eye(3) + K + K @ K / (1 + c)
+        vr, vrt = ij[3] - ij[0], pos[3] - pos[0]
+        if not np.isnan(pos[0, 0]):
+            self.p = pos[0].copy()
+        self.r[0] = two(vr, vrt) if not (np.isnan(vr[0]) or np.isnan(vrt[0])) else np.eye(3)
+        rt = [None] * 24
+        rt[0] = self.r[0].copy()
+        scale = np.mean([np.linalg.norm(pos[i] - pos[parent[i]]) / np.linalg.norm(ij[i] - ij[parent[i]]) for i in range(1, 24)])
+        w0 = np.linalg.norm(ij[6] - ij[0]) * (scale - 1.0) * 32.0
+        self.w[0] = 1.5 if np.isnan(w0) else w0
+        for i in range(1, 24):
+            rt[i] = rt[parent[i]]
+            if not np.isnan(pos[i, 0]):
+                rt[i] = two(ij[i] - ij[parent[i]], pos[i] - pos[parent[i]])
+                self.r[i] = rt[parent[i]].T @ rt[i]
+            else:
+                self.r[i] = np.eye(3)
+
 
 class AvatarOptimizer:
     """`class AvatarOptimizer` (AvatarOptimizer.h:11-61).  `intrin` and `image_size` are accepted for signature

@@ -5,10 +5,15 @@
 #include <dirent.h>
 
 #include <algorithm>
+#include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <limits>
+#include <map>
 #include <memory>
+#include <random>
 #include <string>
 #include <utility>
 #include <vector>
@@ -28,7 +33,15 @@
 
 namespace ark {
 
-struct GaussianMixture {  // GaussianMixture.h: data only; residual/Jacobian live on the device
+/** Joint ids of the SMPL skeleton in the model's breadth-first order (Avatar.h:27-59); alignToJoints() addresses three of them by name. */
+namespace SmplJoint {
+enum { ROOT_PELVIS = 0, L_HIP, R_HIP, SPINE1, L_KNEE, R_KNEE, SPINE2, L_ANKLE, R_ANKLE, SPINE3, L_FOOT, R_FOOT, NECK, L_COLLAR, R_COLLAR, HEAD,
+       L_SHOULDER, R_SHOULDER, L_ELBOW, R_ELBOW, L_WRIST, R_WRIST, L_HAND, R_HAND, _COUNT };
+}
+
+/** GaussianMixture.h.  The optimiser's residual / Jacobian of the prior live on the device (avt_model_create factors the components there); the
+ *  host-side members below serve Avatar::pdf() and Avatar::randomize() and are factored on first use. */
+struct GaussianMixture {
     int nComps = -1, nDims = 0;
     VectorXd weight, mean /* nComps x nDims row-major */, cov /* nComps x nDims x nDims */;
     int numComponents() const { return nComps; }
@@ -40,6 +53,108 @@ struct GaussianMixture {  // GaussianMixture.h: data only; residual/Jacobian liv
         for (auto& v : weight) ifs >> v;
         for (auto& v : mean) ifs >> v;
         for (auto& v : cov) ifs >> v;
+        factored = false;
+    }
+
+    /** Mixture density at x (GaussianMixture.cpp:83-93), as the reference evaluates it: the constants are normalised by the smallest
+     *  determinant (:64-76), and the exponent is |L (x - mu)|^2 with L = chol(cov^-1) - the reference multiplies by L, not by its
+     *  transpose, so this is not the Mahalanobis distance; restated as written. */
+    double pdf(const VectorXd& x) const {
+        factor();
+        const int n = nDims;
+        double prob = 0.0;
+        for (int i = 0; i < nComps; ++i) {
+            const double* L = &prec_cho[(size_t)i * n * n];
+            double s = 0.0;
+            for (int r = 0; r < n; ++r) {
+                double a = 0.0;
+                for (int c = 0; c <= r; ++c) a += L[(size_t)r * n + c] * (x[c] - mean[(size_t)i * n + c]);
+                s += a * a;
+            }
+            prob += consts[i] * std::exp(-0.5 * s);
+        }
+        return prob;
+    }
+
+    /** A sample (GaussianMixture.cpp:116-133).  As written there: the component loop has no break, so the component is the LAST one whose
+     *  running remainder is non-positive - with positive weights that is always the last component; the draw itself is mean + chol(cov) z
+     *  (the reference writes `r *= cov_cho`, a product whose dimensions only agree because they are dynamic: the intent is restated). */
+    VectorXd sample() const {
+        factor();
+        double randf = random_util::uniform(0.0f, 1.0f);
+        int component = nComps - 1;
+        for (int i = 0; i < nComps; ++i) { randf -= weight[i]; if (randf <= 0) component = i; }
+        const int n = nDims;
+        VectorXd z(n), out(n);
+        for (int i = 0; i < n; ++i) z[i] = random_util::randn();
+        const double* L = &cov_cho[(size_t)component * n * n];
+        for (int r = 0; r < n; ++r) {
+            double a = mean[(size_t)component * n + r];
+            for (int c = 0; c <= r; ++c) a += L[(size_t)r * n + c] * z[c];
+            out[r] = a;
+        }
+        return out;
+    }
+
+    /** chol(cov), chol(cov^-1) (lower triangular, row-major) and the constants of every component (GaussianMixture.cpp:22-76) */
+    mutable VectorXd cov_cho, prec_cho, consts, consts_log;
+
+   private:
+    mutable bool factored = false;
+    static bool cholesky(const double* A, int n, double* L) {      // A = L L^T, row-major, upper part of L zero
+        std::fill(L, L + (size_t)n * n, 0.0);
+        for (int j = 0; j < n; ++j) {
+            double d = A[(size_t)j * n + j];
+            for (int k = 0; k < j; ++k) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+            if (!(d > 0.0)) return false;
+            const double ljj = std::sqrt(d);
+            L[(size_t)j * n + j] = ljj;
+            for (int i = j + 1; i < n; ++i) {
+                double a = A[(size_t)i * n + j];
+                for (int k = 0; k < j; ++k) a -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
+                L[(size_t)i * n + j] = a / ljj;
+            }
+        }
+        return true;
+    }
+    void factor() const {
+        if (factored || nComps <= 0) return;
+        const int n = nDims;
+        const size_t nn = (size_t)n * n;
+        cov_cho.assign(nn * nComps, 0.0); prec_cho.assign(nn * nComps, 0.0); consts.assign(nComps, 0.0); consts_log.assign(nComps, 0.0);
+        const double pi = 3.14159265358979323846, sqrt_2_pi_n = std::pow(2 * pi, n * 0.5), log_sqrt_2_pi_n = n * 0.5 * std::log(2 * pi);
+        double minDet = std::numeric_limits<double>::max();
+        VectorXd Linv(nn), prec(nn);
+        for (int i = 0; i < nComps; ++i) {
+            consts_log[i] = std::log(weight[i]) - log_sqrt_2_pi_n;
+            consts[i] = weight[i] / sqrt_2_pi_n;
+            double* L = &cov_cho[i * nn];
+            if (!cholesky(&cov[i * nn], n, L)) { std::fprintf(stderr, "avatar (MI355X): pose prior covariance %d is not positive definite\n", i); std::exit(1); }
+            // cov^-1 = L^-T L^-1
+            std::fill(Linv.begin(), Linv.end(), 0.0);
+            for (int c = 0; c < n; ++c) {
+                Linv[(size_t)c * n + c] = 1.0 / L[(size_t)c * n + c];
+                for (int r = c + 1; r < n; ++r) {
+                    double a = 0.0;
+                    for (int k = c; k < r; ++k) a -= L[(size_t)r * n + k] * Linv[(size_t)k * n + c];
+                    Linv[(size_t)r * n + c] = a / L[(size_t)r * n + r];
+                }
+            }
+            for (int r = 0; r < n; ++r)
+                for (int c = 0; c <= r; ++c) {
+                    double a = 0.0;
+                    for (int k = r; k < n; ++k) a += Linv[(size_t)k * n + r] * Linv[(size_t)k * n + c];
+                    prec[(size_t)r * n + c] = prec[(size_t)c * n + r] = a;
+                }
+            if (!cholesky(prec.data(), n, &prec_cho[i * nn])) { std::fprintf(stderr, "avatar (MI355X): pose prior precision %d is not positive definite\n", i); std::exit(1); }
+            double det = 1.0;
+            for (int d = 0; d < n; ++d) det *= L[(size_t)d * n + d];
+            minDet = std::min(det, minDet);
+            consts[i] /= det;
+            consts_log[i] -= std::log(det);
+        }
+        for (int i = 0; i < nComps; ++i) { consts[i] *= minDet; consts_log[i] += std::log(minDet); }
+        factored = true;
     }
 };
 
@@ -299,6 +414,86 @@ class Avatar {
         jointPos.resize(3, model.numJoints());
         jointTrans.resize(12, model.numJoints());
         ARK_AVT_CHECK(avt_lbs_update(ctx, 1, w.data(), p.data(), r[0].data(), cloud.data(), jointPos.data(), jointTrans.data()));
+    }
+
+    /** Randomize pose and shape according to the PCA shape space and the GMM pose prior (Avatar.cpp:77-126), in the reference's order of draws:
+     *  K normal shape coefficients; the pose from posePrior.sample() - which draws from the library's OWN generators, not from the seeded one
+     *  (so, as in the reference, a seed does not pin the pose; random_util::reseed does) -; then root position x in [-1, 1), y in [-0.5, 0.5),
+     *  z in [2.2, 4.5), the root's turn about the vertical pi + U[-pi/3, pi/3), and a N(0, 0.2) rad perturbation about a random axis.
+     *  seed = -1: keep the generator's state. */
+    void randomize(bool randomize_pose = true, bool randomize_shape = true, bool randomize_root_pos_rot = true, uint32_t seed = (uint32_t)-1) {
+        thread_local static std::mt19937 rg(std::random_device{}());
+        if (~seed) rg.seed(seed);
+        if (randomize_shape)
+            for (int i = 0; i < model.numShapeKeys(); ++i) w[i] = random_util::randn(rg);
+        if (randomize_pose) {
+            if (!model.hasPosePrior()) { std::fprintf(stderr, "avatar (MI355X): randomize(pose) needs pose_prior.txt\n"); std::exit(1); }
+            const VectorXd samp = model.posePrior.sample();
+            for (int i = 0; i < model.numJoints() - 1; ++i) {
+                const double ax = samp[3 * i], ay = samp[3 * i + 1], az = samp[3 * i + 2], angle = std::sqrt(ax * ax + ay * ay + az * az);
+                r[i + 1] = Matrix3d::AngleAxis(angle, ax / angle, ay / angle, az / angle);
+            }
+        }
+        if (randomize_root_pos_rot) {
+            const double pi = 3.14159265358979323846;
+            p(0) = random_util::uniform(rg, -1.0, 1.0);
+            p(1) = random_util::uniform(rg, -0.5, 0.5);
+            p(2) = random_util::uniform(rg, 2.2, 4.5);
+            const double angle_up = random_util::uniform(rg, -pi / 3., pi / 3.) + pi;
+            const double theta = random_util::uniform(rg, 0, 2 * pi), phi = random_util::uniform(rg, -pi / 2, pi / 2);
+            // fromSpherical(1, theta, phi) (AvatarHelpers.cpp:55-59)
+            const double sx = std::sin(phi) * std::cos(theta), sy = std::cos(phi), sz = std::sin(phi) * std::sin(theta);
+            const double angle_perturb = random_util::randn(rg, 0.0, 0.2);
+            r[0] = Matrix3d::AngleAxis(angle_perturb, sx, sy, sz) * Matrix3d::AngleAxis(angle_up, 0., 1., 0.);
+        }
+    }
+
+    /** The SMPL pose parameters: axis-angle of every joint but the root, 3 (J - 1) numbers (Avatar.cpp:128-137). */
+    VectorXd smplParams() const {
+        VectorXd res((size_t)(model.numJoints() - 1) * 3);
+        for (int i = 1; i < model.numJoints(); ++i) {
+            double angle; Vector3d axis;
+            rotationToAngleAxis(r[i], angle, axis);
+            for (int c = 0; c < 3; ++c) res[(size_t)(i - 1) * 3 + c] = axis(c) * angle;
+        }
+        return res;
+    }
+
+    /** GMM likelihood of the current joint rotations (Avatar.cpp:139). */
+    double pdf() const { return model.posePrior.pdf(smplParams()); }
+
+    /** Pose (and the first shape coefficient) from target joint positions, 3 x 24 (Avatar.cpp:141-193): the root goes to joint 0, its rotation
+     *  takes the rest direction pelvis -> spine1 to the target's; every other joint's bone (parent -> joint) is turned from its rest
+     *  direction to the target's, r[i] = that turn relative to the PARENT's turn; w[0] from the mean bone-length ratio.  NaN columns leave
+     *  their joint at the identity (root: keeps p).  Quirks kept: r[i] names the turn of the bone that ENDS in joint i, and a joint whose
+     *  target is missing inherits its parent's turn for its children. */
+    void alignToJoints(const CloudType& pos) {
+        if ((int)pos.cols() != SmplJoint::_COUNT || model.numJoints() != SmplJoint::_COUNT) { std::fprintf(stderr, "avatar (MI355X): alignToJoints wants 24 joint positions on a 24-joint model\n"); std::exit(1); }
+        auto col = [](const CloudType& m, int i) { Vector3d v; for (int c = 0; c < 3; ++c) v(c) = m(c, (size_t)i); return v; };
+        const CloudType& ij = model.initialJointPos;
+        const Vector3d vr = col(ij, SmplJoint::SPINE1) - col(ij, SmplJoint::ROOT_PELVIS), vrt = col(pos, SmplJoint::SPINE1) - col(pos, SmplJoint::ROOT_PELVIS);
+        if (!std::isnan(pos(0, 0))) p = col(pos, 0);
+        if (!std::isnan(vr(0)) && !std::isnan(vrt(0))) r[0] = rotationFromTwoVectors(vr, vrt);
+        else r[0].setIdentity();
+        std::vector<Matrix3d> rotTrans(pos.cols());
+        rotTrans[0] = r[0];
+        double scaleAvg = 0.0;
+        for (int i = 1; i < (int)pos.cols(); ++i)
+            scaleAvg += norm(col(pos, i) - col(pos, model.parent[i])) / norm(col(ij, i) - col(ij, model.parent[i]));
+        scaleAvg /= (pos.cols() - 1.0);
+        const double baseScale = norm(col(ij, SmplJoint::SPINE2) - col(ij, SmplJoint::ROOT_PELVIS)) * (scaleAvg - 1.0);
+        const double PC1_DIST_FACT = 32.0;      // shape key 0 per metre of width (Avatar.cpp:171-173)
+        w[0] = baseScale * PC1_DIST_FACT;
+        if (std::isnan(w[0])) w[0] = 1.5;
+        for (int i = 1; i < (int)pos.cols(); ++i) {
+            rotTrans[i] = rotTrans[model.parent[i]];
+            if (!std::isnan(pos(0, (size_t)i))) {
+                rotTrans[i] = rotationFromTwoVectors(col(ij, i) - col(ij, model.parent[i]), col(pos, i) - col(pos, model.parent[i]));
+                r[i] = transpose(rotTrans[model.parent[i]]) * rotTrans[i];
+            } else {
+                r[i].setIdentity();
+            }
+        }
     }
 
     const AvatarModel& model;

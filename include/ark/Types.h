@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstddef>
 #include <limits>
+#include <random>
 #include <vector>
 
 namespace ark {
@@ -40,6 +41,21 @@ struct Matrix3d {  // column-major
         return R;
     }
 };
+
+inline Matrix3d operator*(const Matrix3d& a, const Matrix3d& b) {
+    Matrix3d o;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) o(r, c) = a(r, 0) * b(0, c) + a(r, 1) * b(1, c) + a(r, 2) * b(2, c);
+    return o;
+}
+inline Matrix3d transpose(const Matrix3d& a) {
+    Matrix3d o;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) o(r, c) = a(c, r);
+    return o;
+}
+inline Vector3d operator-(const Vector3d& a, const Vector3d& b) { Vector3d o; for (int i = 0; i < 3; ++i) o(i) = a(i) - b(i); return o; }
+inline double norm(const Vector3d& a) { return std::sqrt(a(0) * a(0) + a(1) * a(1) + a(2) * a(2)); }
 
 struct Quaterniond {  // coefficient order (x, y, z, w) as Eigen stores it
     double c[4] = {0, 0, 0, 1};
@@ -87,6 +103,80 @@ struct CameraIntrin {  // Calibration.h:11-77: API-surface type only, does not i
 
 // Eigen 3.3 closed forms used by optimize() to move between rotation matrices and quaternions
 // (AvatarOptimizer.cpp:1250-1254: Matrix3 -> Quaternion -> AngleAxis -> Quaternion; :1494-1496 back).
+/** Eigen's AngleAxis::fromRotationMatrix (through the quaternion of the matrix): angle in [0, pi], unit axis ((1,0,0) for the identity). */
+inline void rotationToAngleAxis(const Matrix3d& m, double& angle, Vector3d& axis) {
+    double q[4];
+    double t = m(0, 0) + m(1, 1) + m(2, 2);
+    if (t > 0.0) {
+        t = std::sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t;
+        q[0] = (m(2, 1) - m(1, 2)) * t; q[1] = (m(0, 2) - m(2, 0)) * t; q[2] = (m(1, 0) - m(0, 1)) * t;
+    } else {
+        int i = 0;
+        if (m(1, 1) > m(0, 0)) i = 1;
+        if (m(2, 2) > m(i, i)) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(m(i, i) - m(j, j) - m(k, k) + 1.0); q[i] = 0.5 * t; t = 0.5 / t;
+        q[3] = (m(k, j) - m(j, k)) * t; q[j] = (m(j, i) + m(i, j)) * t; q[k] = (m(k, i) + m(i, k)) * t;
+    }
+    double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    if (n < std::numeric_limits<double>::epsilon()) {
+        const double mx = std::fmax(std::fabs(q[0]), std::fmax(std::fabs(q[1]), std::fabs(q[2])));
+        if (mx > 0.0) { const double a = q[0] / mx, b = q[1] / mx, c = q[2] / mx; n = mx * std::sqrt(a * a + b * b + c * c); }
+        else n = 0.0;
+    }
+    angle = 0.0; axis(0) = 1.0; axis(1) = 0.0; axis(2) = 0.0;
+    if (n != 0.0) {
+        angle = 2.0 * std::atan2(n, std::fabs(q[3]));
+        if (q[3] < 0) n = -n;
+        axis(0) = q[0] / n; axis(1) = q[1] / n; axis(2) = q[2] / n;
+    }
+}
+
+/** Eigen's Quaternion::FromTwoVectors(a, b).toRotationMatrix(): the rotation that takes the direction of a to the direction of b about their
+ *  common normal.  (Opposite directions: Eigen takes the axis from an SVD; any unit vector normal to a serves - here the one built from a's
+ *  smallest component.) */
+inline Matrix3d rotationFromTwoVectors(const Vector3d& a, const Vector3d& b) {
+    const double na = norm(a), nb = norm(b);
+    Vector3d v0, v1;
+    for (int i = 0; i < 3; ++i) { v0(i) = a(i) / na; v1(i) = b(i) / nb; }
+    const double c = v0(0) * v1(0) + v0(1) * v1(1) + v0(2) * v1(2);
+    Quaterniond q;
+    if (c < -1.0 + 1e-12) {
+        int s = 0;
+        if (std::fabs(v0(1)) < std::fabs(v0(s))) s = 1;
+        if (std::fabs(v0(2)) < std::fabs(v0(s))) s = 2;
+        Vector3d e; e(s) = 1.0;
+        Vector3d ax;      // e x v0, normalised
+        ax(0) = e(1) * v0(2) - e(2) * v0(1); ax(1) = e(2) * v0(0) - e(0) * v0(2); ax(2) = e(0) * v0(1) - e(1) * v0(0);
+        const double n = norm(ax), w2 = (1.0 + c) * 0.5, sw = std::sqrt(std::fmax(0.0, 1.0 - w2));
+        q.c[3] = std::sqrt(std::fmax(0.0, w2)); q.c[0] = ax(0) / n * sw; q.c[1] = ax(1) / n * sw; q.c[2] = ax(2) / n * sw;
+    } else {
+        const double s = std::sqrt((1.0 + c) * 2.0), invs = 1.0 / s;
+        q.c[0] = (v0(1) * v1(2) - v0(2) * v1(1)) * invs; q.c[1] = (v0(2) * v1(0) - v0(0) * v1(2)) * invs; q.c[2] = (v0(0) * v1(1) - v0(1) * v1(0)) * invs;
+        q.c[3] = s * 0.5;
+    }
+    // (declared below)
+    const double tx = 2 * q.c[0], ty = 2 * q.c[1], tz = 2 * q.c[2];
+    const double twx = tx * q.c[3], twy = ty * q.c[3], twz = tz * q.c[3], txx = tx * q.c[0], txy = ty * q.c[0], txz = tz * q.c[0];
+    const double tyy = ty * q.c[1], tyz = tz * q.c[1], tzz = tz * q.c[2];
+    Matrix3d R;
+    R(0, 0) = 1 - (tyy + tzz); R(0, 1) = txy - twz;       R(0, 2) = txz + twy;
+    R(1, 0) = txy + twz;       R(1, 1) = 1 - (txx + tzz); R(1, 2) = tyz - twx;
+    R(2, 0) = txz - twy;       R(2, 1) = tyz + twx;       R(2, 2) = 1 - (txx + tyy);
+    return R;
+}
+
+/** The reference's random_util (Util.h:264-277, Util.cpp:312-332): float distributions over std::mt19937; the two-argument forms draw from a
+ *  generator of their own per thread, seeded from std::random_device - reseed() (not in the reference) makes them reproducible for tests. */
+namespace random_util {
+inline std::mt19937& threadGenerator(int which) { thread_local static std::mt19937 rg[2] = {std::mt19937(std::random_device{}()), std::mt19937(std::random_device{}())}; return rg[which]; }
+inline float uniform(std::mt19937& rg, float min_inc = 0.f, float max_exc = 1.f) { std::uniform_real_distribution<float> d(min_inc, max_exc); return d(rg); }
+inline float randn(std::mt19937& rg, float mean = 0.f, float variance = 1.f) { std::normal_distribution<float> d(mean, variance); return d(rg); }      // (the reference passes its "variance" as the distribution's sigma)
+inline float uniform(float min_inc = 0.f, float max_exc = 1.f) { return uniform(threadGenerator(0), min_inc, max_exc); }
+inline float randn(float mean = 0.f, float variance = 1.f) { return randn(threadGenerator(1), mean, variance); }
+inline void reseed(unsigned seed) { threadGenerator(0).seed(seed); threadGenerator(1).seed(seed + 1u); }
+}  // namespace random_util
+
 inline Quaterniond rotationToQuaternion(const Matrix3d& m) {
     double q[4];
     double t = m(0, 0) + m(1, 1) + m(2, 2);
