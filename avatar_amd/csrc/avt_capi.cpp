@@ -187,7 +187,10 @@ void enqueue_optimize(avt_ctx* c, const avt_options* o, int f0, int nf, hipStrea
     const bool fuse_bucket = o->icp_iters > 0;
     // Few frames (the latency shape, G >= 64): the trial point of every ICP iteration (trial := current + its skeleton tables)
     // is set up by a workgroup in the grid of the k_lbs launch in front of it instead of by a k_solve INIT launch behind k_records.
-    const bool fuse_init = c->fb.G >= 64 && avt_lbs_can_init(c->dm.d);
+    // (round 6: small frame batches on the moment form too - up to 16 frames per launch: 0.737 -> 0.726 ms; the launch then asks for the
+    // workgroup's 90 KB of LDS for EVERY workgroup of the skinning, one per CU, and at 32 frames per launch that costs more than the INIT launch
+    // saves: 0.980 -> 0.990 ms.  The row form's batches need k_solve INIT's deal of the evaluation ranges.)
+    const bool fuse_init = (c->fb.G >= 64 || (c->fb.use_moments && nf <= 16)) && avt_lbs_can_init(c->dm.d);
     if (!fuse_bucket) { ProfScope ps(c, AVT_K_BUCKET); launch_bucket(c, nf, true); }
     // frame batches: k_compact gathers its candidates from the cloud, so k_lbs does not write the part-sorted copy of it
     const bool few = avt_nn_few(c, nf);

@@ -63,6 +63,52 @@ __host__ __device__ inline int mom_tstride(int n) { return (tri_size(n) + 1) & ~
 // the rounds of one compacted list segment for wave WV: its tiles are g = WV, WV + 4, .. of [upper tile pairs | D tiles].
 // The segment is padded to a multiple of 4 MOM_UN entries with weight-zero entries (no masks in the loop), an entry is the byte offset of its
 // psi row, its weight and - for a diagonal pair - a_mk (sum_i d_i - c centre), all in LDS: the only global loads here are the psi fragments.
+#ifndef MOM_PSI_LDS
+#define MOM_PSI_LDS 0         // 1: the psi rows of a group of entries are fetched ONCE per workgroup (a quarter by every wave) and handed round through LDS; 0: every wave gathers its own fragments (the shipped form)
+#endif
+#define MOM_GROUP_ROUNDS (4 * MOM_UN)      // rounds per shared group: one step of MOM_UN rounds fetched by each of the four waves
+#define MOM_PSI_ROW 48                     // doubles of a psi row in the shared buffer (16 NTP, NTP = 3: the SMPL shape)
+// rounds [r_begin, r_end) of the current group with the psi fragments read from the shared buffer psi_s[entry in group][48]
+template <int NTP, int WV, bool diag>
+__device__ __forceinline__ void moments_consume(const double* __restrict__ psi_s, const double* __restrict__ s_w, const double* __restrict__ s_bd, int r_begin, int r_end, int ln,
+                                                v4f64 (&acc)[(NTP * (NTP + 1) / 2 + NTP + 3) / 4]) {
+    constexpr int NTPAIR = NTP * (NTP + 1) / 2, NSLOT = (NTPAIR + NTP + 3) / 4;
+    constexpr int firstD = ((NTPAIR - WV + 3) / 4) * 4 + WV;
+    constexpr bool hasD = firstD < NTPAIR + NTP;
+    const int r16 = ln & 15, kk = ln >> 4;
+    const double* bdrow = s_bd + (r16 < 3 ? r16 : 0) * (MOM_SEG + 4 * MOM_UN);
+    const int rb = __builtin_amdgcn_readfirstlane(r_begin), re = __builtin_amdgcn_readfirstlane(r_end);
+    for (int r0 = rb; r0 < re; r0 += MOM_UN) {
+        double fr[MOM_UN][NTP], wgt[MOM_UN], bd[MOM_UN];
+#pragma unroll
+        for (int u = 0; u < MOM_UN; ++u) {
+            const int idx = 4 * (r0 + u) + kk;
+            const double* ps = psi_s + (size_t)(4 * (r0 - rb + u) + kk) * MOM_PSI_ROW + r16;
+            wgt[u] = s_w[idx];
+#pragma unroll
+            for (int q = 0; q < NTP; ++q) fr[u][q] = ps[16 * q];
+            bd[u] = 0.0;
+            if (hasD && diag) { const double b = bdrow[idx]; bd[u] = r16 < 3 ? b : 0.0; }
+        }
+#pragma unroll
+        for (int u = 0; u < MOM_UN; ++u) {
+#pragma unroll
+            for (int sl = 0; sl < NSLOT; ++sl) {
+                const int g = WV + 4 * sl;
+                if (g < NTPAIR) {
+                    int ti = 0, pp = g;
+#pragma unroll
+                    for (int i = 0; i < NTP; ++i) if (pp >= NTP - ti && ti == i) { pp -= NTP - ti; ++ti; }
+                    const int tj = ti + pp;
+                    acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[u][ti] * wgt[u], fr[u][tj], acc[sl], 0, 0, 0);
+                } else if (g < NTPAIR + NTP) {
+                    if (diag) acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[u][g - NTPAIR], bd[u], acc[sl], 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
 template <int NTP, int WV, bool diag>
 __device__ __forceinline__ void moments_rounds(const DeviceModel& dm, const unsigned* __restrict__ s_off, const double* __restrict__ s_w,
                                                const double* __restrict__ s_bd, int mseg, int ln,
@@ -148,6 +194,7 @@ __global__ __launch_bounds__(256, 4) void k_moments(DeviceModel dm, FrameBuffers
     __shared__ double s_w[MOM_SEG + 4 * MOM_UN], s_bd[3 * (MOM_SEG + 4 * MOM_UN)];
     __shared__ int s_wcnt[4];
     __shared__ double s_red[4];
+    __shared__ __attribute__((aligned(16))) double s_psi[(MOM_PSI_LDS && NTP == 3) ? 4 * MOM_GROUP_ROUNDS * MOM_PSI_ROW : 2];      // [32 entries of a group][48]
     const int* cnt = fb.cnt + (size_t)f * V;
     const long long* fs = fb.fsum + (size_t)f * 3 * V;
     if (bx >= NP) {
@@ -229,6 +276,32 @@ __global__ __launch_bounds__(256, 4) void k_moments(DeviceModel dm, FrameBuffers
         }
         __syncthreads();
         KPROBE(2);
+        if constexpr (MOM_PSI_LDS && NTP == 3) {
+            // psi shared through LDS: a group = 4 MOM_UN rounds = 32 entries; wave w fetches the rows of entries 8 w .. 8 w + 7 of the group (lane: entry
+            // l >> 3, 48-byte chunk l & 7: three 16-byte loads), the NEXT group's rows while this one is contracted; two barriers per group
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            const int nr = (mseg + 4 * MOM_UN - 1) / (4 * MOM_UN) * MOM_UN;      // rounds of this segment (a whole number of MOM_UN trips)
+            d2 pf[3];
+            auto fetch = [&](int g0) {      // rounds g0 .. g0 + MOM_GROUP_ROUNDS - 1: my step's 8 entries
+                const int idx = min(4 * g0 + 8 * wv + (ln >> 3), 4 * nr - 1);
+                const d2* row = (const d2*)((const char*)dm.mom_psi + s_off[idx]) + 3 * (ln & 7);
+                pf[0] = row[0]; pf[1] = row[1]; pf[2] = row[2];
+            };
+            fetch(0);
+            for (int g0 = 0; g0 < nr; g0 += MOM_GROUP_ROUNDS) {
+                if (g0 > 0) __syncthreads();      // the previous group has been contracted by every wave
+                { d2* dst = (d2*)(s_psi + (size_t)(8 * wv + (ln >> 3)) * MOM_PSI_ROW) + 3 * (ln & 7); dst[0] = pf[0]; dst[1] = pf[1]; dst[2] = pf[2]; }
+                __syncthreads();
+                if (g0 + MOM_GROUP_ROUNDS < nr) fetch(g0 + MOM_GROUP_ROUNDS);
+                const int r_end = min(nr, g0 + MOM_GROUP_ROUNDS);
+                switch (wv) {
+                    case 0: { if (diag) moments_consume<NTP, 0, true>(s_psi, s_w, s_bd, g0, r_end, ln, acc); else moments_consume<NTP, 0, false>(s_psi, s_w, s_bd, g0, r_end, ln, acc); } break;
+                    case 1: { if (diag) moments_consume<NTP, 1, true>(s_psi, s_w, s_bd, g0, r_end, ln, acc); else moments_consume<NTP, 1, false>(s_psi, s_w, s_bd, g0, r_end, ln, acc); } break;
+                    case 2: { if (diag) moments_consume<NTP, 2, true>(s_psi, s_w, s_bd, g0, r_end, ln, acc); else moments_consume<NTP, 2, false>(s_psi, s_w, s_bd, g0, r_end, ln, acc); } break;
+                    default: { if (diag) moments_consume<NTP, 3, true>(s_psi, s_w, s_bd, g0, r_end, ln, acc); else moments_consume<NTP, 3, false>(s_psi, s_w, s_bd, g0, r_end, ln, acc); } break;
+                }
+            }
+        } else
         switch (wv) {
             case 0: { if (diag) moments_rounds<NTP, 0, true>(dm, s_off, s_w, s_bd, mseg, ln, acc); else moments_rounds<NTP, 0, false>(dm, s_off, s_w, s_bd, mseg, ln, acc); } break;
             case 1: { if (diag) moments_rounds<NTP, 1, true>(dm, s_off, s_w, s_bd, mseg, ln, acc); else moments_rounds<NTP, 1, false>(dm, s_off, s_w, s_bd, mseg, ln, acc); } break;
