@@ -224,12 +224,25 @@ __device__ __forceinline__ void prep_init_block(const DeviceModel& dm, const Fra
     AvtFrameCtl& ctl = fb.ctl[f];
     const int tr = 1 - cur;
     double* x0 = fb.x + ((size_t)f * 2) * xs;
-    for (int e = t; e < xs; e += 256) s_x[e] = x0[(size_t)cur * xs + e];
-    prep_stage_constants<256>(dm, L, B, s_items, s_level);
+    // (two-phase staging, round 6: the state, the constants and this thread's work items of every tree level are requested together - one round trip
+    // instead of eight - and stored behind it; skeletons the register forms do not cover stage the old way)
+    const bool fast = d.fk_reg != 0 && prep_stage_fits(d, 0) && xs <= 256;
+    PrepItems items;
+    if (fast) {
+        items = prep_preload_items_global(dm);
+        const double xv = t < xs ? x0[(size_t)cur * xs + t] : 0.0;
+        const PrepStaged st = prep_stage_request<false>(dm, L);
+        if (t < xs) s_x[t] = xv;
+        prep_stage_store<false>(d, L, st, B, s_items, s_level);
+    } else {
+        for (int e = t; e < xs; e += 256) s_x[e] = x0[(size_t)cur * xs + e];
+        prep_stage_constants<256>(dm, L, B, s_items, s_level);
+    }
     __syncthreads();
     if (t == 0) ctl.try_valid = 1;
     for (int e = t; e < xs; e += 256) x0[(size_t)tr * xs + e] = s_x[e];
     prep_set_state(d, L, B, s_x + 3, s_x + 3 + 4 * J, s_x);
+    if (!fast) items = prep_preload_items<256>(d, s_items, s_level);
     __syncthreads();
-    prep_run<256>(dm, L, B, s_items, s_level, s_x + 3, fb.prep + ((size_t)f * 2 + tr) * d.prep_size, prep_preload_items<256>(d, s_items, s_level));
+    prep_run<256>(dm, L, B, s_items, s_level, s_x + 3, fb.prep + ((size_t)f * 2 + tr) * d.prep_size, items);
 }
