@@ -78,7 +78,7 @@ __device__ __forceinline__ int lm_last_decide(const DeviceModel& dm, const Frame
 #pragma unroll
     for (int sft = 32; sft >= 1; sft >>= 1) a += __shfl_xor(a, sft, 64);     // a + b == b + a: every lane ends with the same bits
     const int try0 = 1 - cur0;
-    double cost = 0.5 * a + cost_const;
+    double cost = lm_objective_data(a, cost_const);      // (avt_device.h: the one spelling of the objective)
     int comp_try = -1;
     {   // strict '<' in ascending component order (GaussianMixture.cpp:103); absent components read as the largest double
         double best = 1.7976931348623157e308;
@@ -89,17 +89,16 @@ __device__ __forceinline__ int lm_last_decide(const DeviceModel& dm, const Frame
             const double v = try0 ? s1 : s0;
             if (v < best) { best = v; bc = c; }
         }
-        if (sbp > 0.0 && d.ncomps > 0) { comp_try = bc; cost += 0.5 * sbp * sbp * best; }
+        if (sbp > 0.0 && d.ncomps > 0) { comp_try = bc; cost = lm_objective_add_pose(cost, sbp, best); }
     }
     if (sbs > 0.0) {
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < AVT_MAX_SHAPE; ++k) {      // absent coefficients read as zero
             const double x0 = decide_readlane(pv, 32 + k), x1 = decide_readlane(pv, 48 + k);
-            const double r = (try0 ? x1 : x0) * sbs;
-            s += r * r;
+            s = lm_shape_term_add(s, try0 ? x1 : x0, sbs);
         }
-        cost += 0.5 * s;
+        cost = lm_objective_add_shape(cost, s);
     }
     // the frame met the stopping rule earlier in this ICP iteration (avt_options::function_tolerance, k_solve): there is no trial point and no test
     if (try_valid == AVT_TRY_DONE) return cur0;

@@ -70,6 +70,15 @@ __device__ __forceinline__ void fk_chain(int J, const int* __restrict__ parent, 
     }
 }
 
+// The objective of a point from its parts - 1/2 sum c|r|^2 + the constant of the data term, the pose prior's best component, the shape prior - formed
+// by ONE sequence of individually rounded operations wherever an accept test needs it (k_solve, the folded test of reduce_spec_cost, the closing
+// test in k_lbs: avt_decide.h).  The three places used to spell the same expression out separately and relied on the compiler contracting
+// multiplies and adds the same way in three inlined contexts for their "bit for bit" agreement; nothing here can be contracted.
+__device__ __forceinline__ double lm_objective_data(double sum_cr2, double cost_const) { return __dadd_rn(__dmul_rn(0.5, sum_cr2), cost_const); }
+__device__ __forceinline__ double lm_objective_add_pose(double cost, double sbp, double best_score) { return __dadd_rn(cost, __dmul_rn(__dmul_rn(__dmul_rn(0.5, sbp), sbp), best_score)); }
+__device__ __forceinline__ double lm_shape_term_add(double acc, double w_k, double sbs) { const double r = __dmul_rn(w_k, sbs); return __dadd_rn(acc, __dmul_rn(r, r)); }
+__device__ __forceinline__ double lm_objective_add_shape(double cost, double shape_acc) { return __dadd_rn(cost, __dmul_rn(0.5, shape_acc)); }
+
 // (cur_slot, try_valid) of a frame's control block as one 8-byte load.  The kernels of a Gauss-Newton iteration need the first for the address of
 // everything they read next; the second says whether there is a trial point at all: AVT_TRY_DONE = the frame met the stopping rule
 // (avt_options::function_tolerance, k_solve) and the launches left in this ICP iteration have nothing to do for it.

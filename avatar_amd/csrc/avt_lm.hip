@@ -677,17 +677,17 @@ __device__ __forceinline__ void reduce_spec_cost(const DeviceModel& dm, const Fr
 #pragma unroll
         for (int i = 0; i < NSL - 1; ++i) a += s_q[i * EL + el];
         if (e == d.res_elem) {
-            double ck = 0.5 * a + cost_const;
+            double ck = lm_objective_data(a, cost_const);      // (avt_device.h: the one spelling of the objective)
             if (sbp > 0.0 && d.ncomps > 0) {
                 double bs = 1.7976931348623157e308;
                 for (int c = 0; c < d.ncomps; ++c) if (s_pv[c] < bs) bs = s_pv[c];
-                ck += 0.5 * sbp * sbp * bs;
+                ck = lm_objective_add_pose(ck, sbp, bs);
             }
             if (sbs > 0.0) {
                 double sa = 0.0;
 #pragma unroll
-                for (int kk = 0; kk < AVT_MAX_SHAPE; ++kk) if (kk < d.K) { const double rr = s_xw[kk] * sbs; sa += rr * rr; }
-                ck += 0.5 * sa;
+                for (int kk = 0; kk < AVT_MAX_SHAPE; ++kk) if (kk < d.K) sa = lm_shape_term_add(sa, s_xw[kk], sbs);
+                ck = lm_objective_add_shape(ck, sa);
             }
             const bool may = have && slot == 0 && try_valid == 1 && spn < sp_n && spn < AVT_MAX_SPEC && valid != 0 && fb.seq >= 2 &&
                              (fb.seq - 1 + ahead) + 1 <= fb.max_iters - 1;
@@ -1016,21 +1016,21 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     if (mode == SOLVE_FIRST) cost_const = s_cc;
     const int try0 = 1 - cur0;
     const double* xt = s_x + try0 * xs;
-    double cost = 0.5 * (try0 ? hpp1 : hpp0) + cost_const;
+    double cost = lm_objective_data(try0 ? hpp1 : hpp0, cost_const);      // (avt_device.h: the one spelling of the objective)
     int comp_try = -1;
     if (sbp > 0.0 && d.ncomps > 0) {
         comp_try = try0 ? bcomp[1] : bcomp[0];
-        cost += 0.5 * sbp * sbp * (try0 ? best[1] : best[0]);
+        cost = lm_objective_add_pose(cost, sbp, try0 ? best[1] : best[0]);
     }
     if (sbs > 0.0) {
         double a = 0.0;
         if constexpr (RIDE) {
 #pragma unroll
-            for (int k = 0; k < AVT_MAX_SHAPE; ++k) if (k < K) { const double r = snap_xw[k] * sbs; a += r * r; }
+            for (int k = 0; k < AVT_MAX_SHAPE; ++k) if (k < K) a = lm_shape_term_add(a, snap_xw[k], sbs);
         } else {
-            for (int k = 0; k < K; ++k) { const double r = xt[3 + 4 * J + k] * sbs; a += r * r; }
+            for (int k = 0; k < K; ++k) a = lm_shape_term_add(a, xt[3 + 4 * J + k], sbs);
         }
-        cost += 0.5 * a;
+        cost = lm_objective_add_shape(cost, a);
     }
     int cur = cur0;
     bool accepted = false;

@@ -404,6 +404,32 @@ def test_limit_one_joint_per_point_matches_oracle(smpl, frame0):
 
 
 @pytest.mark.gpu
+def test_folded_accept_tests_twelve_seeds_both_policies(smpl, gmodel):
+    """the folded accept test forms the objective in reduce_spec_cost, the unfolded one in k_solve - one spelling of the expression now
+    (avt_device.h, lm_objective_*: individually rounded operations, nothing for the compiler to contract differently in the two places).  The
+    twelve bench seeds, both damping policies (the fixed factors reject in runs, which is where tests are folded): bit-identical with and without."""
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    folded_somewhere = 0
+    for seed in range(12):
+        fr = synth.make_frame(smpl, seed)
+        data, labels = fr["data"][::3], fr["labels"][::3]
+        p0, q0, w0 = _start(fr)
+        for policy in (0, 1):
+            opt = Options.counted(lm_policy=policy)
+            out = []
+            for sc in (0, 1):
+                ctx = api.Context(gmodel, 24, pm, len(labels), 1)
+                ctx.set_tuning(spec_cost=sc)
+                p, q, w, st = ctx.optimize_batch([data], [labels], opt, p0[None], q0[None], w0[None])
+                out.append((p, q, w, np.array([st[0].gn_iterations, st[0].accepted_steps]), np.array([st[0].lambda_, st[0].final_cost]), ctx.cost_trace(0)))
+            for a_, b_ in zip(*out):
+                assert np.array_equal(a_, b_), (seed, policy)
+            tr = out[0][5]
+            folded_somewhere += int(sum(1 for k in range(9) if tr[k + 1] == tr[k] and tr[k + 2] == tr[k + 1]) > 0)      # two rejections in a row
+    assert folded_somewhere > 0
+
+
 def test_folded_accept_tests_do_not_change_a_bit(smpl, omodel, gmodel):
     """Riding shapes: k_eval evaluates the COST of the queued speculative steps beside the trial point, and the solve launch that rejects
     the trial point takes the accept tests of the steps that would be rejected as well at once (avt_tuning.spec_cost; 0 = one launch
