@@ -434,13 +434,27 @@ __device__ __forceinline__ void eval_body(const DeviceModel& dm, const FrameBuff
     double* s_ident = s_rec + 4 * RQ;                             // [9]  R(-1,parent of the root) = I
 
     const double* prep = SPEC ? fb.prep_spec + ((size_t)f * AVT_MAX_SPEC + spec_s) * d.prep_size : fb.prep + ((size_t)f * 2 + try_slot) * d.prep_size;
-    for (int e = t; e < npre + K + 3; e += 256) s_prep[e] = prep[e < npre ? e : e + 4 * J];
-    if (t < 9) s_ident[t] = (t == 0 || t == 4 || t == 8) ? 1.0 : 0.0;
-    if (t < RS) s_Jt[(size_t)NC * RS + t] = 0.0;
+    // The skeleton tables are REQUESTED, then the two "nothing to do" tests are taken, then the tables are stored: the tests' inputs were requested in
+    // front of the tables and arrive in front of them, so an idle workgroup leaves a round trip earlier and a working one waits for nothing it would
+    // not have waited for (round 6; the six-tile shape - other skeletons keep the loop and test behind it).
+    constexpr int NST = FIXED ? (15 * CJ + 3 * CJ * CK + CK + 3 + 255) / 256 : 0;
+    double stg[NST ? NST : 1];
+    if constexpr (NST > 0) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) { const int e = t + 256 * i; stg[i] = e < npre + K + 3 ? prep[e < npre ? e : e + 4 * J] : 0.0; }
+    } else {
+        for (int e = t; e < npre + K + 3; e += 256) s_prep[e] = prep[e < npre ? e : e + 4 * J];
+    }
     if (budget_watch && fb.seq + ahead_now > fb.max_iters) return;      // (workgroup-uniform; nothing has been written yet)
     // the frame met the stopping rule in this ICP iteration (avt_options::function_tolerance, k_solve): there is no trial point to evaluate
     // (the snapshot above says so to the solver roles of the launch behind)
     if (try_state == AVT_TRY_DONE) return;
+    if constexpr (NST > 0) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) { const int e = t + 256 * i; if (e < npre + K + 3) s_prep[e] = stg[i]; }
+    }
+    if (t < 9) s_ident[t] = (t == 0 || t == 4 || t == 8) ? 1.0 : 0.0;
+    if (t < RS) s_Jt[(size_t)NC * RS + t] = 0.0;
     // MFMA operand fragments: lane l reads storage column tile_col[tile*16 + (l&15)] (padding -> the zero column), rows k0 + (l>>4)
     // six-tile shape: my wave's five dealt pairs (pair index = bit of the batch word, operand fragments, diagonal or not) and my
     // k-steps of the split pair

@@ -646,6 +646,7 @@ __device__ __forceinline__ void reduce_spec_cost(const DeviceModel& dm, const Fr
     const int t = threadIdx.x, el = t % EL, slice = t / EL;
     const bool have = f < fb.spec_frames;
     const AvtSolveSnap& sn = fb.snap[f];
+    if (sn.ctl.try_valid == AVT_TRY_DONE) return;      // the frame met the stopping rule: no solver role of this launch waits for this count
     const int spn = sn.sp.next, s = min(spn + slot, AVT_MAX_SPEC - 1);      // slot 0 = the first step still in the queue when k_eval ran
     const int pair = d.res_pair, strip = d.res_elem / EL;
     const int e = strip * EL + el;
@@ -716,11 +717,15 @@ __device__ __forceinline__ void reduce_ride_block(const DeviceModel& dm, const F
     const int G = fb.G, glo = (G * slice) / NSL, ghi = (G * (slice + 1)) / NSL, ng = ghi - glo;       // G <= AVT_G_MAX: ng <= NLD
     const double* part = fb.partial + ((size_t)f * G * NPAIR + pair) * 256 + e;
     const size_t st = (size_t)NPAIR * 256;
+    // (the snapshot: the solver of this launch rewrites the live block.  Requested FIRST, so that it arrives first: a frame that met the stopping
+    // rule has nothing to reduce, and the launch is as long as its strips - the solver roles of such a frame have left without waiting for them)
+    const int2 slot_state = *(const int2*)&fb.snap[f].ctl.cur_slot;
     double v[NLD];
 #pragma unroll
     for (int u = 0; u < NLD; ++u) v[u] = __builtin_nontemporal_load(part + (size_t)min(glo + u, G - 1) * st);
     const unsigned long long wmine = el < ng ? fb.wmask[(size_t)f * G + glo + el] : 0ull;
-    const int try_slot = 1 - fb.snap[f].ctl.cur_slot;      // (the snapshot: the solver of this launch rewrites the live block)
+    if (slot_state.y == AVT_TRY_DONE) return;
+    const int try_slot = 1 - slot_state.x;
     int p = pair, ti = 0;
     while (p >= NT - ti) { p -= NT - ti; ++ti; }
     const int tj = ti + p;
@@ -890,6 +895,9 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         sq_p0 = uni_d(gq.pred[0]); sq_p1 = uni_d(gq.pred[1]); sq_p2 = uni_d(gq.pred[2]); sq_p3 = uni_d(gq.pred[3]);
 #pragma unroll
         for (int k = 0; k < AVT_MAX_SHAPE; ++k) snap_xw[k] = k < K ? fb.snap[f].xw[k] : 0.0;
+        // The frame met the stopping rule in an earlier launch of this ICP iteration: nothing to decide, nothing to wait for (its strips leave as
+        // early).  The snapshot has just been waited for by the scalar reads above, so this branch costs the other launches nothing.
+        if (MODE == SOLVE_NORMAL && snap_ctl.try_valid == AVT_TRY_DONE) return;
     }
     // Past the iteration budget: earlier launches of this ICP iteration took accept tests ahead of their launches (folded rejections,
     // below), every test but the last - which belongs to the k_lbs launch - has been taken, and the trial point is waiting for that one.
