@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_MFMA_PEAK_TFLOPS = 78.6   # public MI355X spec, fp64 matrix (not listed in the guide's MFMA table)
 FP64_VALU_PEAK_TFLOPS = 78.6   # public MI355X spec, fp64 vector
-ROUND = "r05"
+ROUND = "r06"
 REGIONS = 15                   # the K-step timed region is repeated this many times; value = median region
 
 # what actually limits each kernel class (counters under profiles/): the HBM roofline is the yard-stick
@@ -791,7 +791,7 @@ def compact_line(out):
     bs = out.get("batch_split") or {}
     line["batch_split"] = {"enabled": bs.get("enabled"), "world": bs.get("world"), "backend": str(bs.get("backend", ""))[:24],
                            "ok": bool((bs.get("run") or {}).get("gathered_equals_local_on_every_rank", (bs.get("run") or {}).get("gathered_equals_local", False)))}
-    line["step_rule"] = out.get("step_rule")
+    line["step_rule"] = {k: v for k, v in (out.get("step_rule") or {}).items() if k != "note"}
     if out.get("fixed_factor_schedule"):
         g = out["fixed_factor_schedule"]
         line["fixed_factor_schedule"] = {k: g.get(k) for k in ("value", "accepted_fraction", "accepted_gn_iterations_per_s", "final_cost_frame0")}
