@@ -296,6 +296,19 @@ class Context:
                                             dptr(q), dptr(w), st))
         return p, q.reshape(F, -1, 4), w, list(st)
 
+    def optimize_posed(self, data, labels, opt: Options, p, q, w):
+        """One frame on host memory with the posed outputs of the closing update() in the same synchronisation (avt_optimize_posed): returns
+        p, q (J,4), w, stats, cloud (V,3), jointPos (J,3), jointTrans (J,12)."""
+        m = self.model
+        data = np.ascontiguousarray(np.asarray(data, np.float64).reshape(-1, 3)); lab = np.ascontiguousarray(np.asarray(labels, np.int32))
+        p = np.array(p, np.float64).reshape(3).copy(); q = np.array(q, np.float64).reshape(-1).copy(); w = np.array(w, np.float64).reshape(-1).copy()
+        st = Stats()
+        cloud = np.empty((m.numPoints(), 3)); jp = np.empty((m.numJoints(), 3)); jt = np.empty((m.numJoints(), 12))
+        _check(self._lib.avt_optimize_posed(self.h, dptr(data), iptr(lab), C.c_int(len(lab)), C.byref(opt), dptr(p), dptr(q), dptr(w), C.byref(st),
+                                            dptr(cloud), dptr(jp), dptr(jt)))
+        self._N = np.array([len(lab)], np.int32)
+        return p, q.reshape(-1, 4), w, st, cloud, jp, jt
+
     def host_optimize_call(self, data, labels, opt: Options, p0, q0, w0):
         """The reference's call shape - optimize(const CloudType&, const VectorXi&, ...) on HOST memory (AvatarOptimizer.h:17-19) - as a
         closure over prepared contiguous arrays: every call is ONE avt_optimize (H2D of the cloud and the start state, the fit, D2H of
@@ -580,9 +593,12 @@ class AvatarOptimizer:
     def optimize(self, data_cloud, data_part_labels, icp_iters=1, num_threads=4):
         ava = self.ava
         self.r = rot_to_quat(ava.r)                                              # :1250-1254
-        p, q, w, st = self.ctx.optimize_batch([data_cloud], [data_part_labels], self.options(icp_iters, num_threads),
-                                              ava.p[None], self.r[None], ava.w[None])
-        ava.p, self.r, ava.w = p[0], q[0], w[0]
+        if icp_iters >= 1:      # one call, one synchronisation: the fit and the outputs of the update() the launch sequence ends with (:1497)
+            ava.p, self.r, ava.w, self.last_stats, ava.cloud, ava.jointPos, ava.jointTrans = self.ctx.optimize_posed(
+                data_cloud, data_part_labels, self.options(icp_iters, num_threads), ava.p, self.r, ava.w)
+        else:
+            p, q, w, st = self.ctx.optimize_batch([data_cloud], [data_part_labels], self.options(icp_iters, num_threads),
+                                                  ava.p[None], self.r[None], ava.w[None])
+            ava.p, self.r, ava.w, self.last_stats = p[0], q[0], w[0], st[0]
+            ava.cloud, ava.jointPos, ava.jointTrans = self.ctx.posed(0)
         ava.r = quat_to_rot(self.r)                                              # :1494-1496
-        ava.cloud, ava.jointPos, ava.jointTrans = self.ctx.posed(0)              # :1497 (the update() the launch sequence ended with)
-        self.last_stats = st[0]

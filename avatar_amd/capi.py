@@ -286,7 +286,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "avt_last_error", "avt_kernel_name", "avt_options_default", "avt_options_fixed_factors", "avt_model_create", "avt_model_destroy",
     "avt_model_dims", "avt_model_main_joint", "avt_model_joint_regression", "avt_model_tile_layout", "avt_ctx_create", "avt_ctx_destroy",
-    "avt_sync", "avt_lbs_update", "avt_visibility", "avt_nn", "avt_optimize", "avt_optimize_batch",
+    "avt_sync", "avt_lbs_update", "avt_visibility", "avt_nn", "avt_optimize", "avt_optimize_posed", "avt_optimize_batch",
     "avt_frames_upload", "avt_synth_render_frames", "avt_synth_render_frames_mode", "avt_synth_render_images", "avt_frames_download", "avt_state_upload", "avt_optimize_resident", "avt_state_reset", "avt_state_download",
     "avt_get_correspondences", "avt_get_cloud", "avt_get_posed", "avt_get_normal_equations", "avt_ctx_get_tuning", "avt_ctx_set_tuning", "avt_set_data_term", "avt_get_data_term", "avt_debug_trace", "avt_debug_mfma_count", "avt_launch_shape", "avt_profile_begin", "avt_profile_select", "avt_profile_end",
     # include/avt_shard.h

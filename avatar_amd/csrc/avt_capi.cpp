@@ -477,8 +477,9 @@ int download_state(avt_ctx* c, double* p, double* q, double* w, avt_stats* st) {
 // and ONE copy brings it back.  (The four-stage path - upload, upload, run, download, a synchronisation each - measured 81 + 26 + 58 us
 // on top of the 0.41 ms fit of one 38 k-point frame, tools/host_call_breakdown.py.)  Leaves the context exactly as the staged calls do:
 // frames and start state resident, avt_state_reset / avt_optimize_resident usable afterwards.
+// (posed_*: optional - frame 0's ava.cloud / jointPos / jointTrans of the closing update(), brought back by the same synchronisation: avt_optimize_posed)
 int optimize_host_to_host(avt_ctx* c, int nframes, const double* data, const int* labels, const int* offs, const avt_options* o,
-                          double* p, double* q, double* w, avt_stats* st) {
+                          double* p, double* q, double* w, avt_stats* st, double* posed_cloud = nullptr, double* posed_jpos = nullptr, double* posed_jtrans = nullptr) {
     const AvtDims& d = c->dm.d;
     if (nframes <= 0 || nframes > c->fb.max_frames) { avt_set_error("frames: nframes out of range for this context"); return 1; }
     long long total = 0;
@@ -492,7 +493,9 @@ int optimize_host_to_host(avt_ctx* c, int nframes, const double* data, const int
     const int xs = d.xsize, stride = xs + 8;
     const size_t b_data = (size_t)total * 24, b_lab = ((size_t)total * 4 + 15) & ~(size_t)15, b_x = (size_t)nframes * 2 * xs * 8,
                  b_ctl = (size_t)nframes * sizeof(AvtFrameCtl), b_res = (size_t)nframes * stride * 8;
-    const size_t need = b_data + b_lab + b_x + b_ctl + b_res + 64;
+    const bool want_posed = posed_cloud || posed_jpos || posed_jtrans;
+    const size_t b_posed = want_posed ? (size_t)(3 * d.V + 15 * d.J) * 8 : 0;
+    const size_t need = b_data + b_lab + b_x + b_ctl + b_res + b_posed + 64;
     //  the pinned block grows with the largest call and shrinks again when a call needs less than a quarter of it: a tracker that once
     // fitted a dense 512-frame batch does not keep gigabytes pinned for its one-frame calls
     if (c->host_pin_cap < need || (c->host_pin_cap > (64u << 20) && need < c->host_pin_cap / 4)) {
@@ -540,6 +543,12 @@ int optimize_host_to_host(avt_ctx* c, int nframes, const double* data, const int
     if (run_optimize(c, o)) { c->results_fresh = false; return 1; }
     if (!c->results_fresh) { launch_pack_results(c, nframes, c->fb.results, stride); c->results_fresh = true; }      // (a call without ICP iterations has no closing k_lbs launch)
     HIP_OK(hipMemcpyAsync(h_res, c->fb.results, b_res, hipMemcpyDeviceToHost, c->stream));
+    double* h_posed = (double*)(pin + b_data + b_lab + b_x + b_ctl + b_res);
+    if (want_posed) {      // frame 0's posed outputs into the pinned block, behind the fit, in front of the one synchronisation
+        HIP_OK(hipMemcpyAsync(h_posed, c->fb.cloud, (size_t)3 * d.V * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipMemcpyAsync(h_posed + 3 * d.V, c->fb.jointpos, (size_t)3 * d.J * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipMemcpyAsync(h_posed + 3 * d.V + 3 * d.J, c->fb.jointtrans, (size_t)12 * d.J * 8, hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_OK(hipStreamSynchronize(c->stream));      // the one synchronisation of the call
     int bad = -1, nbad = 0;
     unsigned badbits = 0;
@@ -557,6 +566,9 @@ int optimize_host_to_host(avt_ctx* c, int nframes, const double* data, const int
         avt_set_error(msg);
         return AVT_STATUS_DEVICE_FAULT;
     }
+    if (posed_cloud) std::memcpy(posed_cloud, h_posed, (size_t)3 * d.V * 8);
+    if (posed_jpos) std::memcpy(posed_jpos, h_posed + 3 * d.V, (size_t)3 * d.J * 8);
+    if (posed_jtrans) std::memcpy(posed_jtrans, h_posed + 3 * d.V + 3 * d.J, (size_t)12 * d.J * 8);
     for (int f = 0; f < nframes; ++f) {
         const double* x = h_res + (size_t)f * stride;
         std::copy(x, x + 3, p + 3 * (size_t)f);
@@ -1025,6 +1037,17 @@ int avt_optimize(avt_ctx* c, const double* data, const int* labels, int N, const
                  avt_stats* stats) {
     const int offs[2] = {0, N};
     return avt_optimize_batch(c, 1, data, labels, offs, opt, p, q, w, stats);
+}
+
+int avt_optimize_posed(avt_ctx* c, const double* data, const int* labels, int N, const avt_options* opt, double* p, double* q, double* w,
+                       avt_stats* stats, double* cloud, double* joint_pos, double* joint_trans) {
+    AVT_API_GUARD_BEGIN
+    if (!c || !data || !labels || !opt || !p || !q || !w) { avt_set_error("avt_optimize_posed: null argument"); return 1; }
+    if (opt->icp_iters <= 0 && (cloud || joint_pos || joint_trans)) { avt_set_error("avt_optimize_posed: no ICP iteration, no closing update(): nothing posed to return"); return 1; }
+    HIP_OK(hipSetDevice(c->device));
+    const int offs[2] = {0, N};
+    return optimize_host_to_host(c, 1, data, labels, offs, opt, p, q, w, stats, cloud, joint_pos, joint_trans);
+    AVT_API_GUARD_END("avt_optimize_posed")
 }
 
 int avt_get_correspondences(avt_ctx* c, int frame, int* out) {

@@ -39,16 +39,21 @@ class AvatarOptimizer {
         o.function_tolerance = functionTolerance;
         std::vector<double> q(4 * (size_t)J);
         for (int i = 0; i < J; ++i) for (int c = 0; c < 4; ++c) q[4 * i + c] = r[i].c[c];
-        ARK_AVT_CHECK(avt_optimize(ctx, data_cloud.data(), data_part_labels.data(), N, &o, ava.p.data(), q.data(), ava.w.data(), &lastStats));
+        // :1497 ava.update(): the launch sequence ends with exactly that update; its outputs come back with the fit, in the call's one synchronisation
+        ava.cloud.resize(3, ava.model.numPoints());
+        ava.jointPos.resize(3, J);
+        ava.jointTrans.resize(12, J);
+        if (icp_iters >= 1) {
+            ARK_AVT_CHECK(avt_optimize_posed(ctx, data_cloud.data(), data_part_labels.data(), N, &o, ava.p.data(), q.data(), ava.w.data(), &lastStats,
+                                             ava.cloud.data(), ava.jointPos.data(), ava.jointTrans.data()));
+        } else {      // (no ICP iteration: no closing update in the sequence)
+            ARK_AVT_CHECK(avt_optimize(ctx, data_cloud.data(), data_part_labels.data(), N, &o, ava.p.data(), q.data(), ava.w.data(), &lastStats));
+            ARK_AVT_CHECK(avt_get_posed(ctx, 0, ava.cloud.data(), ava.jointPos.data(), ava.jointTrans.data()));
+        }
         for (int i = 0; i < J; ++i) {
             for (int c = 0; c < 4; ++c) r[i].c[c] = q[4 * i + c];
             ava.r[i] = quaternionToRotation(r[i]);                               // :1494-1496
         }
-        // :1497 ava.update(): the launch sequence ended with exactly that update; fetch its outputs
-        ava.cloud.resize(3, ava.model.numPoints());
-        ava.jointPos.resize(3, J);
-        ava.jointTrans.resize(12, J);
-        ARK_AVT_CHECK(avt_get_posed(ctx, 0, ava.cloud.data(), ava.jointPos.data(), ava.jointTrans.data()));
     }
 
     /** Rotation representation size */

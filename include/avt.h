@@ -176,6 +176,12 @@ int avt_nn(avt_ctx* c, const double* model_cloud_3xV, const unsigned char* visib
 int avt_optimize(avt_ctx* c, const double* data_3xN, const int* labels, int N, const avt_options* opt,
                  double* p, double* q, double* w, avt_stats* stats);
 
+/* ---- the same, returning what the update() that ends optimize() left (AvatarOptimizer.cpp:1494-1497: ava.cloud 3 x V, ava.jointPos 3 x J,
+ * ava.jointTrans 12 x J; any of the three may be NULL) in the SAME synchronisation as the fit - what ark::AvatarOptimizer::optimize binds: one
+ * call, one wait, instead of avt_optimize + avt_get_posed (three more copies to pageable memory and a second wait).  Needs icp_iters >= 1. */
+int avt_optimize_posed(avt_ctx* c, const double* data_3xN, const int* labels, int N, const avt_options* opt,
+                       double* p, double* q, double* w, avt_stats* stats, double* cloud_3xV, double* joint_pos_3xJ, double* joint_trans_12xJ);
+
 /* ---- batch of independent frames (one optimize() each).  frame f owns points
  * [frame_offsets[f], frame_offsets[f+1]) of data/labels; p/q/w/stats are per-frame, frame-major. */
 int avt_optimize_batch(avt_ctx* c, int nframes, const double* data, const int* labels,
