@@ -534,10 +534,15 @@ int optimize_host_to_host(avt_ctx* c, int nframes, const double* data, const int
         HIP_OK(hipMemcpyAsync(c->fb.data_raw + (size_t)f * c->fb.max_points * 3, h_data + off * 3, N * 24, hipMemcpyHostToDevice, c->stream));
         HIP_OK(hipMemcpyAsync(c->fb.labels_raw + (size_t)f * c->fb.max_points, h_lab + off, N * 4, hipMemcpyHostToDevice, c->stream));
     }
-    HIP_OK(hipMemcpyAsync(c->fb.x, h_x, b_x, hipMemcpyHostToDevice, c->stream));
-    HIP_OK(hipMemcpyAsync(c->fb.ctl, h_ctl, b_ctl, hipMemcpyHostToDevice, c->stream));
-    HIP_OK(hipMemcpyAsync(c->fb.x_start, c->fb.x, b_x, hipMemcpyDeviceToDevice, c->stream));
-    HIP_OK(hipMemcpyAsync(c->fb.ctl_start, c->fb.ctl, b_ctl, hipMemcpyDeviceToDevice, c->stream));
+    if (nframes == c->fb.max_frames) {      // [x | ctl] and [x_start | ctl_start] are contiguous on the device as they are in the pinned block
+        HIP_OK(hipMemcpyAsync(c->fb.x, h_x, b_x + b_ctl, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(c->fb.x_start, h_x, b_x + b_ctl, hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIP_OK(hipMemcpyAsync(c->fb.x, h_x, b_x, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(c->fb.ctl, h_ctl, b_ctl, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(c->fb.x_start, c->fb.x, b_x, hipMemcpyDeviceToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(c->fb.ctl_start, c->fb.ctl, b_ctl, hipMemcpyDeviceToDevice, c->stream));
+    }
     c->frames_valid = c->state_valid = true;
     c->results_fresh = false;
     if (run_optimize(c, o)) { c->results_fresh = false; return 1; }
@@ -694,6 +699,7 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
     for (int nf = 1; nf <= max_frames; ++nf)
         for (int k = 1; k <= std::min(AVT_MAX_GROUPS, nf); ++k) part_cap = std::max(part_cap, (size_t)nf * std::max(choose_G((nf + k - 1) / k, 1, widest), choose_G((nf + k - 1) / k, 2, widest)));
     char* cntsum = nullptr;
+    char* state_block = nullptr;
     if (dev_alloc(c, &fb.data_raw, FN * 3) || dev_alloc(c, &fb.labels_raw, FN) || dev_alloc(c, &fb.dx, FN) || dev_alloc(c, &fb.dy, FN) ||
         dev_alloc(c, &fb.dz, FN) || dev_alloc(c, &fb.dorig, FN) || dev_alloc(c, &fb.part_off, (size_t)max_frames * (num_parts + 1)) || dev_alloc(c, &fb.part_cnt, (size_t)max_frames * 2 * (AVT_MAX_PARTS + 1)) || dev_alloc(c, &fb.tile_hist, (size_t)max_frames * ((max_points + 2047) / 2048) * (AVT_MAX_PARTS + 1)) ||
         dev_alloc(c, &fb.corr, FN) || dev_alloc(c, &fb.corr_sorted, FN) || dev_alloc(c, &fb.cloud, FV * 3) || dev_alloc(c, &fb.pcx, FV) ||
@@ -701,13 +707,19 @@ static int ctx_create_impl(int device, const avt_model* m, int num_parts, const 
         dev_alloc(c, &fb.vcz, FV) || dev_alloc(c, &fb.vcid, FV) || dev_alloc(c, &fb.vcount, (size_t)max_frames * num_parts) || dev_alloc(c, &fb.vis_sorted, FV) || dev_alloc(c, &fb.ride_ctr, (size_t)max_frames) || dev_alloc(c, &fb.fault, (size_t)max_frames) || dev_alloc(c, &fb.spec, (size_t)max_frames) || dev_alloc(c, &fb.snap, (size_t)max_frames) || dev_alloc(c, &fb.x_spec, (size_t)max_frames * AVT_MAX_SPEC * d.xsize) || dev_alloc(c, &fb.prep_spec, (size_t)max_frames * AVT_MAX_SPEC * d.prep_size) ||
         dev_alloc(c, &cntsum, FV * (sizeof(int) + 3 * sizeof(long long)) + 64) || dev_alloc(c, &fb.matched, FV) ||
         dev_alloc(c, &fb.const_part, (size_t)max_frames * fb.const_blocks) ||
-        dev_alloc(c, &fb.x, (size_t)max_frames * 2 * d.xsize) || dev_alloc(c, &fb.x_start, (size_t)max_frames * 2 * d.xsize) ||
-        dev_alloc(c, &fb.ctl_start, (size_t)max_frames) || dev_alloc(c, &fb.prep, (size_t)max_frames * 2 * d.prep_size) ||
+        dev_alloc(c, &state_block, 2 * ((size_t)max_frames * 2 * d.xsize * sizeof(double) + (size_t)max_frames * sizeof(AvtFrameCtl))) ||
+        dev_alloc(c, &fb.prep, (size_t)max_frames * 2 * d.prep_size) ||
         dev_alloc(c, &fb.rec, (size_t)max_frames * d.nb_max * 4 * d.rec_quad) || dev_alloc(c, &fb.partial, part_cap * d.NPAIR * 256) || dev_alloc(c, &fb.wmask, part_cap) || dev_alloc(c, &fb.bmask, (size_t)max_frames * d.nb_max) || dev_alloc(c, &fb.erange, (size_t)max_frames * AVT_ERANGE) || dev_alloc(c, &fb.Hraw, (size_t)max_frames * 2 * d.HS * d.HS) ||
-        dev_alloc(c, &fb.prior, (size_t)max_frames * 2 * AVT_MAX_COMPS * AVT_PRIOR_STRIDE) || dev_alloc(c, &fb.ctl, (size_t)max_frames) ||
+        dev_alloc(c, &fb.prior, (size_t)max_frames * 2 * AVT_MAX_COMPS * AVT_PRIOR_STRIDE) ||
         dev_alloc(c, &fb.jointpos, (size_t)max_frames * 3 * J) || dev_alloc(c, &fb.jointtrans, (size_t)max_frames * 12 * J) ||
         dev_alloc(c, &fb.trace, (size_t)max_frames * 64) || dev_alloc(c, &fb.results, (size_t)max_frames * (d.xsize + 8)))
         return 1;
+    {   // the states and control blocks and their start copies are ONE allocation, [x | ctl | x_start | ctl_start]: a context used at its full frame
+        // count (the facade's: one frame) uploads state + control block with one copy and keeps the start copy with one more (round 6: they were four)
+        const size_t bx = (size_t)max_frames * 2 * d.xsize * sizeof(double), bc = (size_t)max_frames * sizeof(AvtFrameCtl);
+        fb.x = (double*)state_block; fb.ctl = (AvtFrameCtl*)(state_block + bx);
+        fb.x_start = (double*)(state_block + bx + bc); fb.ctl_start = (AvtFrameCtl*)(state_block + 2 * bx + bc);
+    }
     fb.use_moments = 0;
     if (d.mom_ok) {      // moment form of the data term (avt_moments.hip): T per (frame, joint pair), D per (frame, joint), scratch of the assembly
         if (dev_alloc(c, &fb.mom_T, (size_t)max_frames * avt_moments_T_doubles(d)) || dev_alloc(c, &fb.mom_D, (size_t)max_frames * J * d.mom_npsi * 3) ||
