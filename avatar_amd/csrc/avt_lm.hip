@@ -239,76 +239,135 @@ __device__ __forceinline__ int wblk(int kb, int bi, int NB) {
     return TRI ? kb * NB - (kb * (kb - 1)) / 2 + (bi - kb) : kb * NB + bi;
 }
 
-template <int NBC>
-__device__ __forceinline__ void backsub_blocked(const double* __restrict__ Lblk, const double* __restrict__ s_R, int NBrt, int P, int t,
-                                                double* __restrict__ s_delta, double* __restrict__ s_M) {
-    const int NB = NBC > 0 ? NBC : NBrt;
-    auto Wat = [&](int i, int l) { return Lblk[((size_t)(l >> 2) * NB + (i >> 2)) * 18 + (i & 3) * 4 + (l & 3)]; };
-    const double wp0 = (t < P) ? Wat(P, t) : 0.0;
-    const double wp1 = (t + 64 < P) ? Wat(P, t + 64) : 0.0;
-    // ---- the 4x4 triangular solves of all blocks as matrices, made once by one lane per block (round 5, review item 1b).  A step's
-    //   d3 = r3 u3,  d2 = r2 (u2 - w32 d3),  d1 = r1 (u1 - w21 d2 - w31 d3),  d0 = r0 (u0 - w10 d1 - w20 d2 - w30 d3)
-    // is d = M u with M upper triangular, a function of the factor alone; with M in hand the four unknowns of a step are sums of products of
-    // the same depth (3) instead of a chain of 7 dependent operations.  Measured (tools/solve_phase_probe.py): 7.6 k -> 7.4 k clocks - the
-    // step is not its dependency chain but its ~65 instructions at one issue per ~5 clocks of a lone wave.
-    // s_M: [NB][10] in the panel buffer (free since the factorisation's last barrier): M00 M01 M02 M03 | M11 M12 M13 | M22 M23 | M33.
-    if (t < NB) {
-        const d2v* Wd = (const d2v*)(Lblk + ((size_t)t * NB + t) * 18);
-        const d2v a = Wd[2], bq = Wd[4], c = Wd[6], e = Wd[7];
-        const double w10 = a.x, w20 = bq.x, w21 = bq.y, w30 = c.x, w31 = c.y, w32 = e.x;
-        const d2v* Rq = (const d2v*)(s_R + 4 * t);
-        const d2v ra = Rq[0], rb = Rq[1];
-        const double r0 = ra.x, r1 = ra.y, r2 = rb.x, r3 = rb.y;
-        const double M33 = r3;
-        const double M22 = r2, M23 = -r2 * (w32 * M33);
-        const double M11 = r1, M12 = -r1 * (w21 * M22), M13 = -r1 * fma(w21, M23, w31 * M33);
-        const double M00 = r0, M01 = -r0 * (w10 * M11), M02 = -r0 * fma(w10, M12, w20 * M22), M03 = -r0 * fma(w10, M13, fma(w20, M23, w30 * M33));
-        d2v* o = (d2v*)(s_M + 10 * t);
-        o[0] = (d2v){M00, M01}; o[1] = (d2v){M02, M03}; o[2] = (d2v){M11, M12}; o[3] = (d2v){M13, M22}; o[4] = (d2v){M23, M33};
+// Round 6: the 4x4 triangular solves are folded INTO THE FACTOR before the chain starts.  With M_kb the upper triangular matrix of a
+// step (d = M u: d3 = r3 u3, d2 = r2 (u2 - w32 d3) .., a function of the diagonal block alone), a step's update of the running
+// sums, acc_l += sum_k W(4kb+k, l) d_k, is acc_l += sum_j G_l[j] u_j with G = W^T M - four products per lane that do not wait for d.
+// backsub_fold (every thread of the workgroup, one 4x4 block each) replaces W's block (column block lb, row block kb > lb) by
+// -G in place ([column in block][j]: a lane's four coefficients of a step are 32 contiguous bytes), keeps row P of W (the
+// forward-substituted right-hand side, which lives in one of the overwritten block rows) in s_wp, and leaves the M's in s_M.
+// backsub_chain (wave 0) then carries v_l = W(P,l) - acc_l: per step 8 v_readlane + 5 operations on the chain instead of ~40
+// instructions, the unknowns themselves (delta = M u) are formed for all blocks at once behind the last step.
+// Item i of the fold: block (column block lb, row block kb > lb) for i < nblk, the matrix M of block i - nblk behind them.  Consecutive
+// items walk DOWN a block column (same lb, consecutive kb): their blocks are 144 bytes apart, 16 lanes cover the 64 banks with their 16-byte
+// accesses (along a block row, 3168 bytes apart, the same accesses collide eight-fold).  Packed lb | kb << 8; a function of the thread index and
+// the system's size alone, so k_solve computes its first item at kernel start, off the chain (45 instructions with the square root).
+__device__ __forceinline__ int backsub_fold_item(int i, int NB) {
+    const int nblk = (NB * (NB - 1)) >> 1;
+    if (i >= nblk) return (i - nblk) | ((i - nblk) << 8);
+    const int j = nblk - 1 - i;
+    int k2 = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)j)) * 0.5f);
+    k2 -= ((k2 * (k2 - 1)) >> 1) > j ? 1 : 0;
+    k2 += (((k2 + 1) * k2) >> 1) <= j ? 1 : 0;
+    return (NB - 1 - k2) | ((NB - 1 - (j - ((k2 * (k2 - 1)) >> 1))) << 8);
+}
+
+// one item of the fold: block (lb, kb) -> -G in place, or (is_M) the matrix N = -M of block kb into s_M
+__device__ __forceinline__ void backsub_fold_block(double* __restrict__ Lblk, const double* __restrict__ s_R, int NB, int Pb, int Pr, int lb, int kb, bool is_M,
+                                                   double* __restrict__ s_M, double* __restrict__ s_wp) {
+    const d2v* Wd = (const d2v*)(Lblk + ((size_t)kb * NB + kb) * 18);
+    d2v* blk = (d2v*)(Lblk + ((size_t)lb * NB + kb) * 18);
+    const d2v a = Wd[2], bq = Wd[4], c = Wd[6], e = Wd[7];
+    const d2v* Rq = (const d2v*)(s_R + 4 * kb);
+    const d2v ra = Rq[0], rb = Rq[1];
+    d2v w[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w[q] = blk[q];                  // W[k][c] = w[2 k + c / 2].(c % 2)   (is_M: the diagonal block once more)
+    // N = -M: d = M u with d3 = r3 u3, d2 = r2 (u2 - w32 d3), d1 = r1 (u1 - w21 d2 - w31 d3), d0 = r0 (u0 - w10 d1 - w20 d2 - w30 d3)
+    const double w10 = a.x, w20 = bq.x, w21 = bq.y, w30 = c.x, w31 = c.y, w32 = e.x;
+    const double r0 = ra.x, r1 = ra.y, r2 = rb.x, r3 = rb.y;
+    const double N33 = -r3;
+    const double N22 = -r2, N23 = -r2 * (w32 * N33);
+    const double N11 = -r1, N12 = -r1 * (w21 * N22), N13 = -r1 * fma(w21, N23, w31 * N33);
+    const double N00 = -r0, N01 = -r0 * (w10 * N11), N02 = -r0 * fma(w10, N12, w20 * N22), N03 = -r0 * fma(w10, N13, fma(w20, N23, w30 * N33));
+    if (kb == Pb) {      // row P of W, columns 4 lb ..
+        d2v* o = (d2v*)(s_wp + 4 * lb);
+        o[0] = Pr == 0 ? w[0] : (Pr == 1 ? w[2] : (Pr == 2 ? w[4] : w[6]));      // (by compares: a run-time index would put w into scratch memory)
+        o[1] = Pr == 0 ? w[1] : (Pr == 1 ? w[3] : (Pr == 2 ? w[5] : w[7]));
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double acc0 = 0.0, acc1 = 0.0;
-    // column t (and t+64) of the rows of block kb: entries (k*4 + (t&3)) of block [t>>2][kb]
-    const double* col0 = Lblk + (size_t)(t >> 2) * NB * 18 + (t & 3);
-    const double* col1 = Lblk + (size_t)((t + 64) >> 2) * NB * 18 + (t & 3);
-    // The LDS reads of a step are issued DEPTH steps ahead into a register ring (one wave alone sees ~150 clocks of LDS
-    // latency, a step's dependency chain is shorter).  No selects: the factorisation stores the diagonal W blocks
-    // strictly lower triangular and the blocks above the diagonal were zeroed at kernel start, so W(k,l) reads as 0
-    // for every l >= k.  A lone wave issues one instruction every ~5 clocks: the step is kept to ~40 instructions.
+    if (is_M) {          // N itself, rows padded to four entries: lane l of the chain reads row l & 3 of block l >> 2
+        d2v* o = (d2v*)(s_M + 16 * kb);
+        o[0] = (d2v){N00, N01}; o[1] = (d2v){N02, N03}; o[2] = (d2v){0.0, N11}; o[3] = (d2v){N12, N13};
+        o[4] = (d2v){0.0, 0.0}; o[5] = (d2v){N22, N23}; o[6] = (d2v){0.0, 0.0}; o[7] = (d2v){0.0, N33};
+        return;
+    }
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        const double W0 = (cc & 1) ? w[cc >> 1].y : w[cc >> 1].x, W1 = (cc & 1) ? w[2 + (cc >> 1)].y : w[2 + (cc >> 1)].x;
+        const double W2 = (cc & 1) ? w[4 + (cc >> 1)].y : w[4 + (cc >> 1)].x, W3 = (cc & 1) ? w[6 + (cc >> 1)].y : w[6 + (cc >> 1)].x;
+        const double G0 = W0 * N00;
+        const double G1 = fma(W0, N01, W1 * N11);
+        const double G2 = fma(W0, N02, fma(W1, N12, W2 * N22));
+        const double G3 = fma(W0, N03, W1 * N13) + fma(W2, N23, W3 * N33);
+        blk[2 * cc] = (d2v){G0, G1}; blk[2 * cc + 1] = (d2v){G2, G3};
+    }
+}
+
+// the whole fold behind the factorisation (systems of any size): every thread one item, the first one computed at kernel start
+template <int NTH>
+__device__ __forceinline__ void backsub_fold(double* __restrict__ Lblk, const double* __restrict__ s_R, int NB, int P, int t, int item0,
+                                             double* __restrict__ s_M, double* __restrict__ s_wp) {
+    const int nblk = (NB * (NB - 1)) >> 1;
+    for (int i = t; i < nblk + NB; i += NTH) {
+        const int item = i == t ? item0 : backsub_fold_item(i, NB);
+        backsub_fold_block(Lblk, s_R, NB, P >> 2, P & 3, item & 0xff, item >> 8, i >= nblk, s_M, s_wp);
+    }
+}
+
+template <int CTRL>
+__device__ __forceinline__ double quad_dpp(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int NBC>
+__device__ __forceinline__ void backsub_chain(const double* __restrict__ Lblk, int NBrt, int P, int t,
+                                              double* s_delta, const double* __restrict__ s_M, const double* s_wp) {      // (s_wp may be s_delta: read first, written last)
+    const int NB = NBC > 0 ? NBC : NBrt;
+    double v0 = (t < P) ? s_wp[t] : 0.0;                 // W(P,l) - acc_l, columns l = t and t + 64
+    double v1 = (t + 64 < P) ? s_wp[t + 64] : 0.0;
+    // row l & 3 of -M of my columns' blocks, for the unknowns themselves behind the chain (requested now, read there)
+    const d2v* Nq0 = (const d2v*)(s_M + 16 * (t >> 2) + 4 * (t & 3));
+    const d2v* Nq1 = (const d2v*)(s_M + 16 * (((t + 64) >> 2) < NB ? ((t + 64) >> 2) : 0) + 4 * (t & 3));
+    const d2v n0a = Nq0[0], n0b = Nq0[1], n1a = Nq1[0], n1b = Nq1[1];
+    // my column's coefficients of step kb: block [t >> 2][kb], entries (t & 3) * 4 + j.  Blocks above the diagonal were zeroed at kernel
+    // start (W(k,l) = 0 for l >= k); the diagonal blocks still hold W - what a lane of the step's own block adds to its v is never read
+    // again (its unknown was taken at the head of the step).
+    const double* col0 = Lblk + (size_t)(t >> 2) * NB * 18 + (t & 3) * 4;
+    const double* col1 = Lblk + (size_t)((t + 64) >> 2) * NB * 18 + (t & 3) * 4;
     constexpr int DEPTH = NBC > 0 ? 3 : 1;                            // runtime NB: no unrolling, no ring
-    double c0[DEPTH][4], c1[DEPTH][4], md[DEPTH][10];
+    d2v g0[DEPTH][2], g1[DEPTH][2];
     auto fetch = [&](int kb, int sl) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            c0[sl][k] = col0[(size_t)kb * 18 + 4 * k];
-            c1[sl][k] = (4 * kb > 64) ? col1[(size_t)kb * 18 + 4 * k] : 0.0;
-        }
-        const d2v* Mq = (const d2v*)(s_M + 10 * kb);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) { const d2v m = Mq[i]; md[sl][2 * i] = m.x; md[sl][2 * i + 1] = m.y; }
+        const d2v* q0 = (const d2v*)(col0 + (size_t)kb * 18);
+        g0[sl][0] = q0[0]; g0[sl][1] = q0[1];
+        if (4 * kb > 64) { const d2v* q1 = (const d2v*)(col1 + (size_t)kb * 18); g1[sl][0] = q1[0]; g1[sl][1] = q1[1]; }
+        else { g1[sl][0] = (d2v){0.0, 0.0}; g1[sl][1] = (d2v){0.0, 0.0}; }
     };
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i)
         if (NB - 1 - i >= 0) fetch(NB - 1 - i, (NB - 1 - i) % DEPTH);
+    double uf0 = 0.0, uf1 = 0.0;                                       // my unknowns' u, taken at their steps
 #pragma unroll
     for (int kb = NB - 1; kb >= 0; --kb) {
         const int base = 4 * kb, sl = kb % DEPTH;
-        const double M00 = md[sl][0], M01 = md[sl][1], M02 = md[sl][2], M03 = md[sl][3], M11 = md[sl][4], M12 = md[sl][5], M13 = md[sl][6],
-                     M22 = md[sl][7], M23 = md[sl][8], M33 = md[sl][9];
-        const double cc0[4] = {c0[sl][0], c0[sl][1], c0[sl][2], c0[sl][3]}, cc1[4] = {c1[sl][0], c1[sl][1], c1[sl][2], c1[sl][3]};
+        const d2v ga = g0[sl][0], gb = g0[sl][1], ha = g1[sl][0], hb = g1[sl][1];
         if (kb - DEPTH >= 0) fetch(kb - DEPTH, sl);
-        const double u = (base >= 64) ? wp1 - acc1 : wp0 - acc0;
+        const double u = (base >= 64) ? v1 : v0;
+        const bool mine = (t >> 2) == (kb & 15);
+        if (base >= 64) uf1 = mine ? u : uf1; else uf0 = mine ? u : uf0;
         const double u0 = readlane_f64(u, base & 63), u1 = readlane_f64(u, (base + 1) & 63);
         const double u2 = readlane_f64(u, (base + 2) & 63), u3 = readlane_f64(u, (base + 3) & 63);
-        const double d3 = M33 * u3;
-        const double d2 = fma(M23, u3, M22 * u2);
-        const double d1 = fma(M13, u3, fma(M12, u2, M11 * u1));
-        const double d0 = fma(M01, u1, M00 * u0) + fma(M03, u3, M02 * u2);
-        acc0 += fma(cc0[0], d0, cc0[1] * d1) + fma(cc0[2], d2, cc0[3] * d3);
-        // (the columns l + 64 have no rows in the blocks up to row 67: with the unrolled loop the compiler drops their four operations and four
-        // register copies for 17 of the 22 steps - a step is bound by its instruction count)
-        if (NBC == 0 || 4 * kb > 64) acc1 += fma(cc1[0], d0, cc1[1] * d1) + fma(cc1[2], d2, cc1[3] * d3);
-        if (t == 0) { d2v* o = (d2v*)(s_delta + base); o[0] = (d2v){d0, d1}; o[1] = (d2v){d2, d3}; }
+        v0 = fma(ga.x, u0, fma(gb.x, u2, v0)) + fma(ga.y, u1, gb.y * u3);
+        if (NBC == 0 || 4 * kb > 64) v1 = fma(ha.x, u0, fma(hb.x, u2, v1)) + fma(ha.y, u1, hb.y * u3);
+    }
+    // delta_l = sum_j M[l & 3][j] u_(quad's j): the quad's four u's by quad_perm broadcasts, no LDS round trip
+    {
+        const double q0 = quad_dpp<0x00>(uf0), q1 = quad_dpp<0x55>(uf0), q2 = quad_dpp<0xAA>(uf0), q3 = quad_dpp<0xFF>(uf0);
+        const double dl = fma(n0a.x, q0, n0a.y * q1) + fma(n0b.x, q2, n0b.y * q3);
+        s_delta[t] = -dl;
+        const double p0 = quad_dpp<0x00>(uf1), p1 = quad_dpp<0x55>(uf1), p2 = quad_dpp<0xAA>(uf1), p3 = quad_dpp<0xFF>(uf1);
+        const double dh = fma(n1a.x, p0, n1a.y * p1) + fma(n1b.x, p2, n1b.y * p3);
+        if (t + 64 < 4 * NB) s_delta[t + 64] = -dh;
     }
 }
 
@@ -864,6 +923,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     // below).  The system is the bordered (P+1)x(P+1) matrix [[H + lambda diag H, .],[-g^T, .]] (row P carries the rhs so
     // D^-1 L^-1 (-g) falls out of the factorisation as row P of the unit-lower factor).
     const int NB = HS >> 2;
+    const int fold_item0 = TRI ? 0 : backsub_fold_item(t, NB);      // this thread's block of the back substitution's fold (index arithmetic, off the chain)
     const double* H0 = fb.Hraw + ((size_t)f * 2) * HS * HS;
     // 256-thread shape: the system goes straight into the MFMA accumulator layout - wave w owns tile row rA = 5 - w (tile
     // slots 0..5) and, for w >= 2, tile row rB = w - 2 (slots 6, 7); lane (g4 = l >> 4, c16 = l & 15) holds rows 4v + g4 of
@@ -1278,10 +1338,16 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     double pred_new = 0.0;                                  // (wave 0)
     if (ok) {
         // ---- back substitution by wave 0 (the other waves wait at the barrier)
+        if constexpr (!TRI) {      // (all waves) the steps' 4x4 solves folded into the factor; the M's take the panel buffer, row P of W waits in s_delta
+            backsub_fold<NTH>(Lblk, s_R, NB, P, t, fold_item0, s_PB, s_delta);
+            TPROBE(8);
+            __syncthreads();
+            TPROBE(9);
+        }
         if (t < 64) {
             if constexpr (TRI) backsub_tri(Lblk, s_R, NB, P, t, s_delta);
-            else if (NB == 22) backsub_blocked<22>(Lblk, s_R, NB, P, t, s_delta, s_PB);
-            else backsub_blocked<0>(Lblk, s_R, NB, P, t, s_delta, s_PB);
+            else if (NB == 22) backsub_chain<22>(Lblk, NB, P, t, s_delta, s_PB, s_delta);
+            else backsub_chain<0>(Lblk, NB, P, t, s_delta, s_PB, s_delta);
             if (TRI && gain) {
                 // (1024-thread shape: no LDS left for g and D)
                 // Predicted decrease of the quadratic model, 1/2 delta^T (lambda D delta - g), by the same wave (fixed butterfly).  g and the

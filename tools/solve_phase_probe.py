@@ -27,6 +27,8 @@ lib.avt_debug_trace(ctx.h, 0, buf.ctypes.data_as(C.POINTER(C.c_double)))
 s = np.diff(buf[40:47])
 print("F=%d k_solve (last full solve of frame 0), shader clocks: loads + LM decision %.0f | system assembly %.0f | LDL^T %.0f | back substitution %.0f | retraction %.0f | skeleton pass %.0f | total %.0f"
       % (F, s[0], s[1], s[2], s[3], s[4], s[5], buf[46] - buf[40]))
+if buf[48] > 0:
+    print("back substitution: fold %.0f | barrier %.0f | chain + unknowns %.0f clocks" % (buf[48] - buf[43], buf[49] - buf[48], buf[44] - buf[49]))
 # skeleton-pass internal probes live in the last two doubles of the prep block of the try slot
 print("skeleton pass: joint positions + barrier %.0f | level loop %.0f | outputs %.0f clocks" % (buf[62] - buf[45], buf[63] - buf[62], buf[46] - buf[63]))
 
