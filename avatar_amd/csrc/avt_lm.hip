@@ -819,10 +819,22 @@ __device__ __forceinline__ void reduce_ride_block(const DeviceModel& dm, const F
 // =================================================================================================
 // MODE (SOLVE_INIT / FIRST / NORMAL) is a template parameter so that the three roles are three symbols in a kernel trace
 // (their durations differ six-fold) and the short ones do not carry the factorisation's code.
-template <int NTH, bool TRI, int MODE, int RIDE = 0>      // RIDE: 0, or the riding reduction's strips per tile pair
-__global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) {
+// SM: the model has SMPL's dimensions (24 joints, 10 shape keys, a 69-dimensional pose prior: solve_dims_smpl on the host) and the kernel
+// is compiled for them - every count below that follows from them is a literal, so the index arithmetic of the system's loads, of its
+// assembly and of the skeleton pass folds away (the loads of the system alone were ~27 instructions and two branches per entry pair with the
+// row stride in a register: ~4.5 k clocks between the hand-over and the last request, one wave per SIMD issuing ~one instruction per 5 clocks)
+__host__ __device__ inline void solve_dims_smpl_set(AvtDims& d) {
+    d.J = 24; d.K = 10; d.P = 85; d.HS = 88; d.xsize = 109; d.NT = 6; d.NPAIR = 21; d.ndims = 69;
+    d.prep_size = ((19 * 24 + 3 * 24 * 10 + 10 + 3) + 7) & ~7;
+}
+template <int NTH, bool TRI, int MODE, int RIDE = 0, bool SM = false>      // RIDE: 0, or the riding reduction's strips per tile pair
+__global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers fb) {
     constexpr int mode = MODE;
     static_assert(!RIDE || (NTH == 256 && !TRI && MODE != SOLVE_INIT), "the riding reduction exists for the 256-thread solves");
+    static_assert(!SM || (NTH == 256 && !TRI), "SMPL is a 256-thread solve");
+    DeviceModel dm_local = dm_arg;
+    if constexpr (SM) solve_dims_smpl_set(dm_local.d);
+    const DeviceModel& dm = dm_local;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // RIDE: grid (frames, 1 + nspec + RIDE NPAIR): y = 0 the solver, y = 1 .. nspec the speculative solvers (the same system with
     // lambda up, lambda up^2 ..: the steps a run of rejected trial points will ask for), the rest the reduction in front of them
@@ -991,13 +1003,19 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
             // (download_state, avt_shard_gather_download) instead of handing out a fit made from a half-reduced system.
             const unsigned want = (unsigned)(fb.seq * (RIDE * d.NPAIR + fb.nspec_cost));      // (< 2^16: AVT_RIDE_COUNT_MASK)
             const long long t0 = wall_clock64();
+            TPROBE(10);
+            int spins_ = 0;
             // (a frame that already carries a fault of this call fails fast: every later launch would wait the full time again)
             const long long limit = fault_at_start ? 0 : fb.ride_timeout;
             bool there;
             unsigned word;
             while (!(there = ((word = __hip_atomic_load(fb.ride_ctr + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & AVT_RIDE_COUNT_MASK) >= want) &&
                    wall_clock64() - t0 < limit)
-                __builtin_amdgcn_s_sleep(1);
+                { __builtin_amdgcn_s_sleep(1); ++spins_; }
+            TPROBE(11);
+#ifdef AVT_TIMING
+            if (blockIdx.y == 0) fb.trace[(size_t)(blockIdx.x + fb.f0) * 64 + 52] = (double)spins_;
+#endif
             if (!there) atomicOr(fb.fault + f, AVT_FAULT_RIDE_TIMEOUT);
             s_failf[1] = (int)word;      // the spec-cost workgroup's verdicts ride in the word (reduce_spec_cost): handed to the other threads across the barrier
         }
@@ -1042,6 +1060,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     }
     const double hpp0 = hload(H0 + (size_t)P * HS + P), hpp1 = hload(H0 + (size_t)HS * HS + (size_t)P * HS + P);
 
+    TPROBE(13);
     const double lm_up = fb.params->lm_up, lm_down = fb.params->lm_down, lm_min = fb.params->lm_min, lm_max = fb.params->lm_max;   // same round trip
     const bool gain = fb.params->lm_policy != 0.0;          // gain-ratio damping schedule (avt_options::lm_policy)
     const double ftol = fb.params->ftol;                    // the stopping rule (avt_options::function_tolerance; 0 = off)
@@ -1053,6 +1072,9 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     double cost_const = cin.cost_const;
     double lambda = cin.lambda, nu = cin.nu;
     const double pred0 = cin.pred;
+    // (the iteration counters too: read where they are bumped - behind the first stores to the control block - they were a memory round trip of
+    // their own on wave 0, between the decision and the system's assembly)
+    const int gn_iterations0 = cin.gn_iterations, accepted0 = cin.accepted;
     __shared__ double s_cc;
     if (mode == SOLVE_FIRST && t < 64) {   // the constant part of the data cost (k_records' trailing workgroups), once per ICP iteration
         double a = 0.0;
@@ -1078,6 +1100,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     }
     if constexpr (!RIDE) stage_store();      // (behind the requests for the system's entries: one round trip for everything)
     __syncthreads();   // the staged state slots are visible; every lane has read the control block
+    TPROBE(14);
     // the frame met the stopping rule in an earlier launch of this ICP iteration: no trial point, no test, no iteration (the riding shapes left above)
     if (!RIDE && mode != SOLVE_FIRST && try_valid == AVT_TRY_DONE) return;
 
@@ -1123,6 +1146,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
     }
     const double cost_cur = accepted ? cost : cost_cur0;
     const int comp = accepted ? comp_try : comp_cur0;
+    TPROBE(15);
     // Speculative steps (RIDE shapes): a rejected trial point is followed by a solve of the SAME system with lambda up - which
     // a speculative workgroup of the last full solve launch has already made.  The solver then installs it (trial state and
     // skeleton tables copied into the trial slot) instead of factoring, and the speculative workgroups of this launch go home.
@@ -1168,11 +1192,11 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm, FrameBuffers fb) 
         ctl.cur_slot = cur;
         ctl.cost_cur = cost_cur;
         ctl.comp_cur = comp;
-        int it = ctl.gn_iterations;
+        int it = gn_iterations0;
         if (mode == SOLVE_FIRST) { ctl.cost_initial = cost; ctl.cost_const = cost_const; }
         else {
             for (int i = 0; i < nfold; ++i) { it += 1; if (it < 40) fb.trace[(size_t)f * 64 + it] = cost_cur; }      // the folded tests: rejections, the objective stays
-            it += 1; ctl.gn_iterations = it; if (accepted) ctl.accepted += 1;
+            it += 1; ctl.gn_iterations = it; if (accepted) ctl.accepted = accepted0 + 1;
         }
         if (it < 40) fb.trace[(size_t)f * 64 + it] = cost_cur;
     }
@@ -1504,8 +1528,23 @@ void launch_reduce(avt_ctx* c, int nframes) {
     }
 }
 
+// the model has the dimensions k_solve<.., SM = true> is compiled for (solve_dims_smpl_set)
+static bool solve_dims_smpl(const AvtDims& d) {
+    AvtDims e = d;
+    solve_dims_smpl_set(e);
+    return d.ncomps > 0 && d.J == e.J && d.K == e.K && d.P == e.P && d.HS == e.HS && d.xsize == e.xsize && d.NT == e.NT && d.NPAIR == e.NPAIR &&
+           d.ndims == e.ndims && d.prep_size == e.prep_size;
+}
+
 template <int NTH, bool TRI>
 static void launch_solve_shape(avt_ctx* c, int nframes, int mode, size_t lds) {
+    if constexpr (NTH == 256 && !TRI) {
+        if (solve_dims_smpl(c->dm.d) && (mode == SOLVE_FIRST || mode == SOLVE_NORMAL)) {
+            if (mode == SOLVE_FIRST) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256, false, SOLVE_FIRST, 0, true>), dim3(nframes), dim3(256), lds, c->cur_stream, c->dm, c->fb);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256, false, SOLVE_NORMAL, 0, true>), dim3(nframes), dim3(256), lds, c->cur_stream, c->dm, c->fb);
+            return;
+        }
+    }
     switch (mode) {
         case SOLVE_INIT: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<NTH, TRI, SOLVE_INIT>), dim3(nframes), dim3(NTH), lds, c->cur_stream, c->dm, c->fb); break;
         case SOLVE_FIRST: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<NTH, TRI, SOLVE_FIRST>), dim3(nframes), dim3(NTH), lds, c->cur_stream, c->dm, c->fb); break;
@@ -1552,9 +1591,14 @@ void launch_solve(avt_ctx* c, int nframes, int mode, int seq) {
         c->fb.nspec = ride_nspec(c, nframes, rs);
         c->fb.nspec_cost = std::min(c->fb.nspec, ride_spec_cost(c));
         const dim3 grid(nframes, 1 + c->fb.nspec + rs * d.NPAIR + c->fb.nspec_cost);
-#define AVT_RIDE(M, S) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256, false, M, S>), grid, dim3(256), solve_lds_bytes(d), c->cur_stream, c->dm, c->fb)
-        if (mode == SOLVE_FIRST) { if (rs == 8) AVT_RIDE(SOLVE_FIRST, 8); else AVT_RIDE(SOLVE_FIRST, 4); }
-        else { if (rs == 8) AVT_RIDE(SOLVE_NORMAL, 8); else AVT_RIDE(SOLVE_NORMAL, 4); }
+#define AVT_RIDE(M, S, SMD) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256, false, M, S, SMD>), grid, dim3(256), solve_lds_bytes(d), c->cur_stream, c->dm, c->fb)
+        if (solve_dims_smpl(d)) {
+            if (mode == SOLVE_FIRST) { if (rs == 8) AVT_RIDE(SOLVE_FIRST, 8, true); else AVT_RIDE(SOLVE_FIRST, 4, true); }
+            else { if (rs == 8) AVT_RIDE(SOLVE_NORMAL, 8, true); else AVT_RIDE(SOLVE_NORMAL, 4, true); }
+        } else {
+            if (mode == SOLVE_FIRST) { if (rs == 8) AVT_RIDE(SOLVE_FIRST, 8, false); else AVT_RIDE(SOLVE_FIRST, 4, false); }
+            else { if (rs == 8) AVT_RIDE(SOLVE_NORMAL, 8, false); else AVT_RIDE(SOLVE_NORMAL, 4, false); }
+        }
 #undef AVT_RIDE
         return;
     }
@@ -1576,5 +1620,11 @@ int avt_solve_set_attributes() {
            hipFuncSetAttribute((const void*)k_solve<256, false, SOLVE_FIRST, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
            hipFuncSetAttribute((const void*)k_solve<256, false, SOLVE_NORMAL, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
            hipFuncSetAttribute((const void*)k_solve<256, false, SOLVE_FIRST, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
-           hipFuncSetAttribute((const void*)k_solve<256, false, SOLVE_NORMAL, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess;
+           hipFuncSetAttribute((const void*)k_solve<256, false, SOLVE_NORMAL, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_solve<256, false, SOLVE_FIRST, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_solve<256, false, SOLVE_NORMAL, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_solve<256, false, SOLVE_FIRST, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_solve<256, false, SOLVE_NORMAL, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_solve<256, false, SOLVE_FIRST, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_solve<256, false, SOLVE_NORMAL, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess;
 }

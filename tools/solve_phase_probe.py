@@ -19,7 +19,7 @@ frs = [frs[s % len(frs)] for s in range(F)]
 pm = synth.identity_part_map()
 ctx = api.Context(gm, 24, pm, 60000, F)
 p0 = np.array([f['start'][1] for f in frs]); q0 = np.array([api.rot_to_quat(f['start'][2]) for f in frs]); w0 = np.array([f['start'][0] for f in frs])
-opt = Options.demo()
+opt = Options.demo(**({"lm_policy": int(os.environ["PROBE_LM_POLICY"])} if "PROBE_LM_POLICY" in os.environ else {}))
 for i in range(2):
     ctx.optimize_batch([f['data'] for f in frs], [f['labels'] for f in frs], opt, p0, q0, w0)
 lib = capi.load_library(); buf = np.zeros(64)
@@ -29,6 +29,9 @@ print("F=%d k_solve (last full solve of frame 0), shader clocks: loads + LM deci
       % (F, s[0], s[1], s[2], s[3], s[4], s[5], buf[46] - buf[40]))
 if buf[48] > 0:
     print("back substitution: fold %.0f | barrier %.0f | chain + unknowns %.0f clocks" % (buf[48] - buf[43], buf[49] - buf[48], buf[44] - buf[49]))
+if buf[50] > 0:
+    print("riding hand-over: kernel start to poll %.0f | polling %.0f (%d spins) | poll end to decision made %.0f clocks" % (buf[50] - buf[40], buf[51] - buf[50], int(buf[52]), buf[41] - buf[51]))
+    print("  poll end to: system requested %.0f | barrier (everything arrived) %.0f | accept test taken %.0f | control block written, roles sorted %.0f" % (buf[53] - buf[51], buf[54] - buf[53], buf[55] - buf[54], buf[41] - buf[55]))
 # skeleton-pass internal probes live in the last two doubles of the prep block of the try slot
 print("skeleton pass: joint positions + barrier %.0f | level loop %.0f | outputs %.0f clocks" % (buf[62] - buf[45], buf[63] - buf[62], buf[46] - buf[63]))
 
