@@ -942,7 +942,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
     // column c16 of a tile.  Raw data-term entries of BOTH slots are requested now (indices clamped, selected later).
     const int mf_wv = t >> 6, mf_g4 = (t >> 4) & 3, mf_c16 = t & 15, mf_rA = 5 - mf_wv, mf_rB = mf_wv - 2;
     // (six tile slots per wave: slot s <= rA is tile (rA, s), the slots behind are tiles (rB, 0..rB))
-    double mraw[TRI ? 1 : 2][TRI ? 1 : 6][4];
+    double mraw[(TRI || RIDE) ? 1 : 2][TRI ? 1 : 6][4];
     // RIDE: the snapshot every solver role decides on (AvtSolveSnap) is requested now, before the wait for the reduction
     AvtFrameCtl snap_ctl;
     // (the speculative-step queue field by field, never as a structure: an entry chosen by an index the compiler does not know would put a copy of
@@ -1028,9 +1028,15 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
         if (idle) return;
     }
     auto hload = [&](const double* q) { if constexpr (RIDE) return ld_agent(q); else return *q; };
+    // Riding shapes know the slots from the snapshot (it arrived in front of the wait) and request the TRIAL slot's system alone: an accepted
+    // trial point (87 % of them under the default step rule) is the point the system is needed at; a rejected one is followed by an installed
+    // speculative step (no system at all) or - the queue empty - by a solve of the current slot's system, requested then (a round trip more on
+    // that rare path, 24 instead of 48 requests per lane on every other).  The batch shapes learn the slots in this very round trip: both.
+    int ride_slot = RIDE ? 1 - snap_ctl.cur_slot : 0;
+    const double* Hl = H0 + (size_t)(4 * 0 + mf_g4) * HS + mf_c16;
+    auto load_system = [&]() __attribute__((always_inline)) {
     if constexpr (!TRI && MODE != SOLVE_DECIDE) {
         // (one copy per wave role: tile rows and columns are compile-time constants there, an entry's address is one add)
-        const double* Hl = H0 + (size_t)(4 * 0 + mf_g4) * HS + mf_c16;
         auto load_role = [&](auto role) {
             constexpr int W = decltype(role)::value, rA = 5 - W, rB = W - 2;
 #pragma unroll
@@ -1046,8 +1052,11 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
                     const bool inb = row + 3 < HS && col + 15 < HS;
                     const size_t off = inb ? (size_t)row * HS + col
                                            : (size_t)(min(row + mf_g4, HS - 1) - mf_g4) * HS + (min(col + mf_c16, HS - 1) - mf_c16);
-                    mraw[0][ti][v] = own ? hload(Hl + off) : 0.0;
-                    mraw[1][ti][v] = own ? hload(Hl + (size_t)HS * HS + off) : 0.0;
+                    if (RIDE) mraw[0][ti][v] = own ? hload(Hl + ride_slot * ((size_t)HS * HS) + off) : 0.0;      // (one slot, see above)
+                    else {
+                        mraw[0][ti][v] = own ? hload(Hl + off) : 0.0;
+                        mraw[TRI || RIDE ? 0 : 1][ti][v] = own ? hload(Hl + (size_t)HS * HS + off) : 0.0;
+                    }
                 }
             }
         };
@@ -1058,7 +1067,11 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
             default: load_role(std::integral_constant<int, 3>{}); break;
         }
     }
-    const double hpp0 = hload(H0 + (size_t)P * HS + P), hpp1 = hload(H0 + (size_t)HS * HS + (size_t)P * HS + P);
+    };
+    load_system();
+    double hpp0, hpp1;
+    if constexpr (RIDE) { hpp0 = hpp1 = hload(H0 + ride_slot * ((size_t)HS * HS) + (size_t)P * HS + P); }
+    else { hpp0 = hload(H0 + (size_t)P * HS + P); hpp1 = hload(H0 + (size_t)HS * HS + (size_t)P * HS + P); }
 
     TPROBE(13);
     const double lm_up = fb.params->lm_up, lm_down = fb.params->lm_down, lm_min = fb.params->lm_min, lm_max = fb.params->lm_max;   // same round trip
@@ -1242,6 +1255,12 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
         }
         return;
     }
+    if constexpr (RIDE) {
+        if (cur != ride_slot) {      // (workgroup-uniform) a rejected trial point and no speculative step to install: the current slot's system after all
+            ride_slot = cur;
+            load_system();
+        }
+    }
     TPROBE_FIRST();
 
     // ---- b. the damped system of the current point, straight into registers (second, short round trip: the
@@ -1298,7 +1317,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
             const int rb = first ? mf_rA : max(mf_rB, 0), cb = first ? ti : ti - mf_rA - 1;
             double raw[4];
 #pragma unroll
-            for (int v = 0; v < 4; ++v) raw[v] = cur ? mraw[TRI ? 0 : 1][TRI ? 0 : ti][v] : mraw[0][TRI ? 0 : ti][v];
+            for (int v = 0; v < 4; ++v) raw[v] = RIDE ? mraw[0][TRI ? 0 : ti][v] : (cur ? mraw[TRI ? 0 : 1][TRI ? 0 : ti][v] : mraw[0][TRI ? 0 : ti][v]);
             dgn[ti] = 0.0;
             tile[ti] = sys_tile(rb, cb, first || cb <= mf_rB, raw, dgn[ti]);
         }
