@@ -1311,28 +1311,42 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
     if constexpr (!TRI) {
         v4f64 tile[6];
         double dgn[6];
-#pragma unroll
-        for (int ti = 0; ti < 6; ++ti) {
-            const bool first = ti <= mf_rA;
-            const int rb = first ? mf_rA : max(mf_rB, 0), cb = first ? ti : ti - mf_rA - 1;
-            double raw[4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) raw[v] = RIDE ? mraw[0][TRI ? 0 : ti][v] : (cur ? mraw[TRI ? 0 : 1][TRI ? 0 : ti][v] : mraw[0][TRI ? 0 : ti][v]);
-            dgn[ti] = 0.0;
-            tile[ti] = sys_tile(rb, cb, first || cb <= mf_rB, raw, dgn[ti]);
-        }
-        if (gain) {      // g and D for the predicted decrease (wave 1, behind the back substitution): every entry has exactly one owner
+        // One copy per wave role (as the loads above): a tile's block row and column are compile-time constants there, and with SMPL's dimensions
+        // literal as well (SM) nearly every select of sys_tile folds - which rows and columns the priors touch, where the diagonal and row P lie,
+        // what is padding.  Written for run-time tile coordinates the assembly was ~70 instructions per entry, 8.6 k clocks of every full pass.
+        auto asm_role = [&](auto role_c) __attribute__((always_inline)) {
+            constexpr int W = decltype(role_c)::value, rA = 5 - W, rB = W - 2;
 #pragma unroll
             for (int ti = 0; ti < 6; ++ti) {
-                const bool first = ti <= mf_rA;
-                const int rb = first ? mf_rA : max(mf_rB, 0), cb = first ? ti : ti - mf_rA - 1;
-                const bool own = first || cb <= mf_rB;
-                const int col = 16 * cb + mf_c16, v = (mf_c16 - mf_g4) >> 2;      // the diagonal of a diagonal tile: row 4 v + g4 = column c16
-                if (own && rb == cb && ((mf_c16 - mf_g4) & 3) == 0 && v >= 0 && col < P) s_gD[HS + col] = dgn[ti];
-                const int vP = (P & 15) >> 2;      // row P = 16 (P >> 4) + 4 vP + (P & 3) holds -g
-                const double mg = vP == 0 ? tile[ti][0] : (vP == 1 ? tile[ti][1] : (vP == 2 ? tile[ti][2] : tile[ti][3]));
-                if (own && rb == (P >> 4) && mf_g4 == (P & 3) && col < P) s_gD[col] = -mg;
+                const bool first = ti <= rA;
+                const int rb = first ? rA : (rB > 0 ? rB : 0), cb = first ? ti : ti - rA - 1;
+                const bool own = first || (rB >= 0 && cb <= rB);
+                double raw[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) raw[v] = RIDE ? mraw[0][TRI ? 0 : ti][v] : (cur ? mraw[(TRI || RIDE) ? 0 : 1][TRI ? 0 : ti][v] : mraw[0][TRI ? 0 : ti][v]);
+                dgn[ti] = 0.0;
+                if (own) tile[ti] = sys_tile(rb, cb, true, raw, dgn[ti]);
+                else tile[ti] = (v4f64){0.0, 0.0, 0.0, 0.0};
             }
+            if (gain) {      // g and D for the predicted decrease (wave 1, behind the back substitution): every entry has exactly one owner
+#pragma unroll
+                for (int ti = 0; ti < 6; ++ti) {
+                    const bool first = ti <= rA;
+                    const int rb = first ? rA : (rB > 0 ? rB : 0), cb = first ? ti : ti - rA - 1;
+                    const bool own = first || (rB >= 0 && cb <= rB);
+                    const int col = 16 * cb + mf_c16, v = (mf_c16 - mf_g4) >> 2;      // the diagonal of a diagonal tile: row 4 v + g4 = column c16
+                    if (own && rb == cb && ((mf_c16 - mf_g4) & 3) == 0 && v >= 0 && col < P) s_gD[HS + col] = dgn[ti];
+                    const int vP = (P & 15) >> 2;      // row P = 16 (P >> 4) + 4 vP + (P & 3) holds -g
+                    const double mg = vP == 0 ? tile[ti][0] : (vP == 1 ? tile[ti][1] : (vP == 2 ? tile[ti][2] : tile[ti][3]));
+                    if (own && rb == (P >> 4) && mf_g4 == (P & 3) && col < P) s_gD[col] = -mg;
+                }
+            }
+        };
+        switch (mf_wv) {
+            case 0: asm_role(std::integral_constant<int, 0>{}); break;
+            case 1: asm_role(std::integral_constant<int, 1>{}); break;
+            case 2: asm_role(std::integral_constant<int, 2>{}); break;
+            default: asm_role(std::integral_constant<int, 3>{}); break;
         }
         TPROBE(2);
         // ---- c. LDL^T, four pivots and two barriers per round, the trailing matrix in the accumulators (mf_rounds) ----

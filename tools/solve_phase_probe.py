@@ -20,6 +20,7 @@ pm = synth.identity_part_map()
 ctx = api.Context(gm, 24, pm, 60000, F)
 p0 = np.array([f['start'][1] for f in frs]); q0 = np.array([api.rot_to_quat(f['start'][2]) for f in frs]); w0 = np.array([f['start'][0] for f in frs])
 opt = Options.demo(**({"lm_policy": int(os.environ["PROBE_LM_POLICY"])} if "PROBE_LM_POLICY" in os.environ else {}))
+if "PROBE_BETA_POSE" in os.environ: opt.beta_pose = float(os.environ["PROBE_BETA_POSE"])
 for i in range(2):
     ctx.optimize_batch([f['data'] for f in frs], [f['labels'] for f in frs], opt, p0, q0, w0)
 lib = capi.load_library(); buf = np.zeros(64)
