@@ -550,8 +550,8 @@ __device__ __forceinline__ bool mf_round(v4f64 (&accA)[6], v4f64 (&accB)[2], int
 template <int W, int CB>
 __device__ __forceinline__ bool mf_block_column(v4f64 (&accA)[6], v4f64 (&accB)[2], double* __restrict__ PB,
                                                   double* __restrict__ Lblk, double* __restrict__ s_R, int* s_fail, int P, int NB, int NR, int t) {
-#pragma unroll 1
-    for (int jq = 0; jq < 3; ++jq) {
+#pragma unroll
+    for (int jq = 0; jq < 3; ++jq) {      // (unrolled: as a loop the accumulators are copied from one turn's registers to the next's, 8 to 32 v_accvgpr_mov per round)
         if (4 * CB + jq >= NR) return true;
         if (!mf_round<W, CB, CB>(accA, accB, jq, PB, Lblk, s_R, s_fail, P, NB, NR, t)) return false;
     }
