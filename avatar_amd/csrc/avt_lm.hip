@@ -853,9 +853,12 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
     // W = L diag(d) of the factorisation H = L diag(d) L^T, block layout [pivot block kb][row block bi][18]: a 4x4
     // block is 16 doubles + 2 of padding (144 B), so lanes reading different blocks spread over the LDS banks; row P
     // carries L^-1 rhs
-    double* Lblk = (double*)smem;
+    // (256-thread shape: the small arrays every round of the factorisation touches - panel, reciprocal pivots - lie IN FRONT of the 70 KB factor:
+    // below 64 KB an LDS address is an immediate offset of the instruction, above it three instructions that build it in a register)
     const size_t nblk = TRI ? (size_t)NBk * (NBk + 1) / 2 : (size_t)NBk * NBk;
-    double* s_PB = Lblk + nblk * 18;                        // [96 or 192][4] the four panel columns of a round
+    const size_t small_doubles = (size_t)(TRI ? MFG_PB_DOUBLES : MF_PB_DOUBLES) + ((max(HS, 4 * J) + 3) & ~1) + HS + 2 + (TRI ? 0 : 2 * HS);
+    double* Lblk = TRI ? (double*)smem : (double*)smem + small_doubles;
+    double* s_PB = TRI ? Lblk + nblk * 18 : (double*)smem;  // [96 or 192][4] the four panel columns of a round
     double* s_W = s_PB + (TRI ? MFG_PB_DOUBLES : MF_PB_DOUBLES);         // [max(HS, 4J) + 2]  reciprocal pivots, later the new quaternions
     double* s_delta = s_W + ((max(HS, 4 * J) + 3) & ~1);    // [HS]
     // [2][HS] gradient and diagonal of the undamped system (predicted decrease of the step, gain-ratio schedule); the 1024-thread
@@ -863,7 +866,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
     // this workgroup only, a barrier in between
     // (SOLVE_DECIDE - the accept test alone, moment form - touches nothing of the above: its launch asks for the two state slots only)
     double* s_gD = s_delta + HS + 2;                        // (256-thread shape) [2][HS]: g | D, left there by the assembly (sys_tile)
-    double* s_x = MODE == SOLVE_DECIDE ? (double*)smem : s_gD + (TRI ? 0 : 2 * HS);      // [2][xsize] both state slots
+    double* s_x = MODE == SOLVE_DECIDE ? (double*)smem : (TRI ? s_gD : Lblk + nblk * 18);      // [2][xsize] both state slots
     const PrepLayout L = prep_layout(J, K, d.xsize);
     // skeleton scratch: behind the factor (SMPL shape: staged at kernel start, hidden behind the factorisation) or ON it
     // (triangular shape: the factor is dead once the back substitution is done)
