@@ -527,7 +527,8 @@ __device__ __forceinline__ bool mf_round(v4f64 (&accA)[6], v4f64 (&accB)[2], int
     double fAB = 0.0;
     if constexpr (useB) fAB = (4 * (rB > 0 ? rB : 0) + (c16 >> 2) < NB) ? Wk[(rB > 0 ? rB : 0) * 4 * 18] : 0.0;
     const double rk = s_R[4 * kb + k];
-    if (*s_fail) return false;
+    // (a refused pivot - *s_fail, set by the row phase - is looked at ONCE, behind the last round: read here, the flag's LDS round trip and a branch sat
+    // in front of every round's fragment loads; a factorisation that goes on past a refused pivot computes garbage from fixed addresses, nothing else)
     if (kb + 1 >= NR) return true;
     if constexpr (CBN <= rA) {
         double fb[6];
@@ -1388,6 +1389,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
         fail = !mfg_rounds(acc, S, s_PB, Lblk, s_R, &s_failf[0], P, NB, T, t);
     }
     __syncthreads();
+    if constexpr (!TRI) fail = s_failf[0] != 0;      // (256-thread shape: the rounds do not stop at a refused pivot, see mf_round)
     TPROBE(3);
     const bool ok = !fail;
     const int ntry = 1 - cur;

@@ -160,6 +160,32 @@ def test_ragged_batch_with_empty_frame_and_determinism(smpl, omodel, gmodel):
         assert np.abs(p1[f] - ref["p"]).max() < 1e-6 and np.abs(w1[f] - ref["w"]).max() < 1e-5
 
 
+def test_refused_factorisation_leaves_the_state_untouched(smpl, omodel, gmodel):
+    """No priors and three data points: most joints have no matched point, their rows of H are zero, H + lambda diag H is singular and
+    every factorisation is refused - on the device (whose rounds run on past the refused pivot and look at the flag once, behind the
+    last one: avt_lm.hip, mf_round) as in the oracle.  The state comes back bit for bit, nothing is NaN, and the other frames of the
+    batch do what the oracle does with them."""
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    fr = synth.make_frame(smpl, 9)
+    start = _start(fr)
+    opt = Options.demo(max_iters_per_icp=4)
+    opt.beta_pose = 0.0; opt.beta_shape = 0.0
+    for frames in (1, 5):
+        ctx = api.Context(gmodel, 24, pm, 60000, frames)
+        datas = [fr["data"][:3]] + [fr["data"]] * (frames - 1)
+        labs = [fr["labels"][:3]] + [fr["labels"]] * (frames - 1)
+        p0 = np.repeat(start[0][None], frames, 0); q0 = np.repeat(start[1][None], frames, 0); w0 = np.repeat(start[2][None], frames, 0)
+        p, q, w, st = ctx.optimize_batch(datas, labs, opt, p0, q0, w0)
+        ref = omodel.optimize(pm, 24, datas[0], labs[0], opt, *start, aggregate=1)
+        assert ref["stats"].accepted_steps == 0 and st[0].accepted_steps == 0
+        assert np.array_equal(p[0], start[0]) and np.array_equal(q[0], start[1]) and np.array_equal(w[0], start[2])
+        assert np.isfinite(p).all() and np.isfinite(q).all() and np.isfinite(w).all()
+        if frames > 1:      # (the full frames of the batch: whatever the oracle does with them without priors, step or refuse)
+            ref1 = omodel.optimize(pm, 24, datas[1], labs[1], opt, *start, aggregate=1)
+            assert st[1].accepted_steps == ref1["stats"].accepted_steps and np.abs(p[1] - ref1["p"]).max() < 1e-6
+
+
 def test_translation_equivariance_and_monotone_cost(smpl, gmodel):
     """Size-independent properties at full size: shifting the data and the start by t shifts the fit by t (the model
     enters only through p + R(...)); the LM objective never increases."""
