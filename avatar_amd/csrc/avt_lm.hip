@@ -997,6 +997,12 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
         }
     }
     if constexpr (RIDE) stage_store();      // (riding shapes: the solver roles have time to spare in front of the reduction's hand-over)
+    double prt[AVT_MAX_COMPS];      // (riding shapes) the prior's score of every component at the trial slot: the previous launch made them
+    if constexpr (RIDE) {
+#pragma unroll
+        for (int c = 0; c < AVT_MAX_COMPS; ++c)
+            prt[c] = (c < d.ncomps) ? fb.prior[(((size_t)f * 2 + (1 - snap_ctl.cur_slot)) * AVT_MAX_COMPS + c) * AVT_PRIOR_STRIDE] : 0.0;
+    }
     if constexpr (RIDE) {      // the reduction workgroups of this launch have all delivered their strips of the trial point's system
         if (t == 0) {
             // (the count runs on from launch to launch of an ICP iteration - k_finalize clears it -: several workgroups wait on it)
@@ -1036,7 +1042,48 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
     // trial point (87 % of them under the default step rule) is the point the system is needed at; a rejected one is followed by an installed
     // speculative step (no system at all) or - the queue empty - by a solve of the current slot's system, requested then (a round trip more on
     // that rare path, 24 instead of 48 requests per lane on every other).  The batch shapes learn the slots in this very round trip: both.
+    auto prior_entries_early = [&](int rb, int cb, bool up, const double* PrC, const double* priC, int nn, double (&prvs)[4], double& gqc) __attribute__((always_inline)) {
+        const int pcc = min(max(16 * cb + mf_c16 - 6, 0), max(nn - 1, 0));
+        gqc = up ? priC[2 + pcc] : 0.0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int prc = min(max(16 * rb + 4 * v + mf_g4 - 6, 0), max(nn - 1, 0));
+            prvs[v] = up ? PrC[(size_t)prc * nn + pcc] : 0.0;
+        }
+    };
     int ride_slot = RIDE ? 1 - snap_ctl.cur_slot : 0;
+    // ... and the pose prior's entries this lane adds to its tiles (precision matrix and gradient of ONE component at ONE slot, 24 + 6 values):
+    // riding shapes request them here, with the system - for the component the trial point sits in, whose scores arrived in front of the wait -
+    // instead of in a second round trip behind the decision (~2 k clocks of every full pass); the decision picking another point or component
+    // requests them again.  Batch shapes: behind the decision, as before (they learn slot and scores in this round trip).
+    double prv_pre[TRI ? 1 : 6][4], gq_pre[TRI ? 1 : 6];
+    int prior_comp = -2, prior_slot = -1;
+    auto load_prior = [&](int comp_sel, int slot_sel, double sbp_sel) __attribute__((always_inline)) {
+        if constexpr (!TRI && MODE != SOLVE_DECIDE) {
+            prior_comp = comp_sel; prior_slot = slot_sel;
+            const bool up = sbp_sel > 0.0 && d.ncomps > 0 && comp_sel >= 0;
+            const int nn = d.ndims, cs = comp_sel >= 0 ? comp_sel : 0;
+            const double* PrC = dm.prior_prec + (size_t)cs * nn * nn;
+            const double* priC = fb.prior + (((size_t)f * 2 + slot_sel) * AVT_MAX_COMPS + cs) * AVT_PRIOR_STRIDE;
+            auto role_fn = [&](auto role_c) __attribute__((always_inline)) {
+                constexpr int W = decltype(role_c)::value, rA = 5 - W, rB = W - 2;
+#pragma unroll
+                for (int ti = 0; ti < 6; ++ti) {
+                    const bool first = ti <= rA;
+                    const int rb = first ? rA : (rB > 0 ? rB : 0), cb = first ? ti : ti - rA - 1;
+                    const bool own = first || (rB >= 0 && cb <= rB);
+                    if (own) prior_entries_early(rb, cb, up, PrC, priC, nn, prv_pre[ti], gq_pre[ti]);
+                    else { gq_pre[ti] = 0.0; prv_pre[ti][0] = prv_pre[ti][1] = prv_pre[ti][2] = prv_pre[ti][3] = 0.0; }
+                }
+            };
+            switch (mf_wv) {
+                case 0: role_fn(std::integral_constant<int, 0>{}); break;
+                case 1: role_fn(std::integral_constant<int, 1>{}); break;
+                case 2: role_fn(std::integral_constant<int, 2>{}); break;
+                default: role_fn(std::integral_constant<int, 3>{}); break;
+            }
+        }
+    };
     const double* Hl = H0 + (size_t)(4 * 0 + mf_g4) * HS + mf_c16;
     auto load_system = [&]() __attribute__((always_inline)) {
     if constexpr (!TRI && MODE != SOLVE_DECIDE) {
@@ -1073,6 +1120,18 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
     }
     };
     load_system();
+    // prior score of every component: strict '<' in ascending component order (GaussianMixture.cpp:103)
+    double best[2] = {1.7976931348623157e308, 1.7976931348623157e308};
+    int bcomp[2] = {-1, -1};
+    if constexpr (RIDE) {
+        if (d.ncomps > 0) {
+#pragma unroll
+            for (int c = 0; c < AVT_MAX_COMPS; ++c)
+                if (c < d.ncomps && prt[c] < best[0]) { best[0] = prt[c]; bcomp[0] = c; }
+            best[1] = best[0]; bcomp[1] = bcomp[0];      // (the trial slot's: the current slot's component is the control block's)
+        }
+        load_prior(snap_ctl.sbp > 0.0 && d.ncomps > 0 ? bcomp[0] : -1, ride_slot, snap_ctl.sbp);
+    }
     double hpp0, hpp1;
     if constexpr (RIDE) { hpp0 = hpp1 = hload(H0 + ride_slot * ((size_t)HS * HS) + (size_t)P * HS + P); }
     else { hpp0 = hload(H0 + (size_t)P * HS + P); hpp1 = hload(H0 + (size_t)HS * HS + (size_t)P * HS + P); }
@@ -1099,10 +1158,8 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
         a = wave_sum(a);
         if (t == 0) s_cc = 0.5 * a;
     }
-    // prior score of every component at both slots: strict '<' in ascending component order (GaussianMixture.cpp:103)
-    double best[2] = {1.7976931348623157e308, 1.7976931348623157e308};
-    int bcomp[2] = {-1, -1};
-    if (d.ncomps > 0) {
+    // (batch shapes) prior score of every component at both slots
+    if (!RIDE && d.ncomps > 0) {
         double pr[2][AVT_MAX_COMPS];
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl)
@@ -1265,6 +1322,10 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
             load_system();
         }
     }
+    if constexpr (!TRI && MODE != SOLVE_DECIDE) {
+        const int comp_need = (sbp > 0.0 && d.ncomps > 0) ? comp : -1;
+        if (!RIDE || prior_comp != comp_need || prior_slot != cur) load_prior(comp_need, cur, sbp);      // (workgroup-uniform)
+    }
     TPROBE_FIRST();
 
     // ---- b. the damped system of the current point, straight into registers (second, short round trip: the
@@ -1286,17 +1347,17 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
     // (dgn: the UNDAMPED diagonal entry this lane holds in the tile, if it holds one - what the predicted decrease of the gain-ratio schedule needs beside
     // the gradient, which is the negated row P of the tile.  Returned in a register: a store to LDS in here makes the compiler re-request the prior's
     // tables after it, tile by tile - 11 k clocks, measured)
-    auto sys_tile = [&](int rb, int cb, bool own, const double (&raw)[4], double& dgn) __attribute__((always_inline)) {
+    auto sys_tile = [&](int rb, int cb, bool own, const double (&raw)[4], double& dgn, const double (&prvs)[4], double gqc) __attribute__((always_inline)) {
         const int col = 16 * cb + mf_c16, pc = col - 6, sk = col - (3 + 3 * J);
-        const int pcc = min(max(pc, 0), max(n - 1, 0)), skc = min(max(sk, 0), max(K - 1, 0));
-        const double gqc = use_pose ? pri[2 + pcc] : 0.0, xqc = xc[3 + 4 * J + skc];
+        const int skc = min(max(sk, 0), max(K - 1, 0));
+        const double xqc = xc[3 + 4 * J + skc];
         const bool in_pose_c = use_pose && pc >= 0 && pc < n;
         const bool shape_c = sbs > 0.0 && sk >= 0 && col < P;
         v4f64 out;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const int row = 16 * rb + 4 * v + mf_g4, pr_ = row - 6, prc = min(max(pr_, 0), max(n - 1, 0));
-            const double prv = use_pose ? Pr[(size_t)prc * n + pcc] : 0.0;
+            const int row = 16 * rb + 4 * v + mf_g4, pr_ = row - 6;
+            const double prv = prvs[v];
             const double v0 = raw[v];
             // rows < P: H + priors, diagonal damped
             double vh = v0;
@@ -1329,7 +1390,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
 #pragma unroll
                 for (int v = 0; v < 4; ++v) raw[v] = RIDE ? mraw[0][TRI ? 0 : ti][v] : (cur ? mraw[(TRI || RIDE) ? 0 : 1][TRI ? 0 : ti][v] : mraw[0][TRI ? 0 : ti][v]);
                 dgn[ti] = 0.0;
-                if (own) tile[ti] = sys_tile(rb, cb, true, raw, dgn[ti]);
+                if (own) tile[ti] = sys_tile(rb, cb, true, raw, dgn[ti], prv_pre[ti], gq_pre[ti]);
                 else tile[ti] = (v4f64){0.0, 0.0, 0.0, 0.0};
             }
             if (gain) {      // g and D for the predicted decrease (wave 1, behind the back substitution): every entry has exactly one owner
@@ -1381,8 +1442,9 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
             double raw[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) raw[v] = Hc[(size_t)min(16 * rb + 4 * v + mf_g4, HS - 1) * HS + min(16 * cb + mf_c16, HS - 1)];
-            double dgn_unused = 0.0;
-            acc[sl] = sys_tile(rb, cb, S.rb[sl] >= 0, raw, dgn_unused);
+            double dgn_unused = 0.0, prvs[4], gqc;
+            prior_entries_early(rb, cb, use_pose, Pr, pri, n, prvs, gqc);
+            acc[sl] = sys_tile(rb, cb, S.rb[sl] >= 0, raw, dgn_unused, prvs, gqc);
         }
         TPROBE(2);
         if (t == 0) s_failf[0] = 0;
