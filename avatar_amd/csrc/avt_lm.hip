@@ -845,6 +845,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
         if (role > fb.nspec + RIDE * dm.d.NPAIR) { reduce_spec_cost<RIDE>(dm, fb, blockIdx.x + fb.f0, role - 1 - fb.nspec - RIDE * dm.d.NPAIR, (double*)smem); return; }
         if (role > fb.nspec) { reduce_ride_block<RIDE>(dm, fb, blockIdx.x + fb.f0, role - 1 - fb.nspec, (double*)smem); return; }
     }
+    TPROBE_START();      // (the probes' time zero is the solver role's first instruction: its staging is part of what they measure)
     __builtin_amdgcn_s_setprio(3);   // one dependency chain per frame: issue ahead of the evaluation waves of another frame group on this CU
     const AvtDims d = dm.d;
     const int J = d.J, K = d.K, P = d.P, HS = d.HS;
@@ -933,7 +934,6 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
         prep_run<NTH>(dm, L, B, s_items, s_level, xc + 3, prep0 + (size_t)tr * d.prep_size, prep_preload_items<NTH>(d, s_items, s_level));
         return;
     }
-    TPROBE_START();
     // ---- a. one round trip for everything the LM decision and the system need: the control block, the objective
     // terms of BOTH state slots and (256-thread shape) this lane's entries of BOTH data-term matrices (the slot is chosen
     // below).  The system is the bordered (P+1)x(P+1) matrix [[H + lambda diag H, .],[-g^T, .]] (row P carries the rhs so
