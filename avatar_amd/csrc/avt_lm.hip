@@ -497,10 +497,6 @@ __device__ __forceinline__ bool mf_round(v4f64 (&accA)[6], v4f64 (&accB)[2], int
         const double r1 = fast_rcp(D11), l21 = D21 * r1, l31 = D31 * r1;
         D22 = fma(-l21, D21, D22); D32 = fma(-l31, D21, D32); D33 = fma(-l31, D31, D33);
         const double r2 = fast_rcp(D22), l32 = D32 * r2;
-        D33 = fma(-l32, D32, D33);
-        const double r3 = fast_rcp(D33);
-        const bool real1 = 4 * kb + 1 < P, real2 = 4 * kb + 2 < P, real3 = 4 * kb + 3 < P;
-        const bool bad = !(D00 > 0.0) | (real1 & !(D11 > 0.0)) | (real2 & !(D22 > 0.0)) | (real3 & !(D33 > 0.0));
         const double w0 = s01.x, w1 = fma(-w0, l10, s01.y), w2 = fma(-w1, l21, fma(-w0, l20, s23.x));
         const double w3 = fma(-w2, l32, fma(-w1, l31, fma(-w0, l30, s23.y)));
         const int rr = t - 4 * kb;     // row inside the trailing part; the diagonal block keeps its strictly lower part
@@ -509,11 +505,29 @@ __device__ __forceinline__ bool mf_round(v4f64 (&accA)[6], v4f64 (&accB)[2], int
             Wo[0] = (d2v){rr < 1 ? 0.0 : w0, rr < 2 ? 0.0 : w1};
             Wo[1] = (d2v){rr < 3 ? 0.0 : w2, rr < 4 ? 0.0 : w3};
         }
-        if (t == 0) {
-            d2v* Ro = (d2v*)(s_R + 4 * kb);
-            Ro[0] = (d2v){r0, real1 ? r1 : 0.0}; Ro[1] = (d2v){real2 ? r2 : 0.0, real3 ? r3 : 0.0};
-            if (bad) *s_fail = 1;
-        }
+    }
+    // The reciprocal pivots (what the matrix phase and the back substitution read) and the verdict on the pivots are the business of ONE lane of
+    // wave 2, which has no rows: on thread 0 they were ~25 instructions - the fourth reciprocal among them, which no row needs - behind its
+    // row's stores, on the wave every barrier of the factorisation waits for.  Same panel, same operations, same bits as the row threads'.
+    if (W == 2 && t == 128) {
+        const d2v* PB2 = (const d2v*)PB;
+        const d2v q0 = PB2[(4 * kb) * 2], q1 = PB2[(4 * kb + 1) * 2], q2a = PB2[(4 * kb + 2) * 2], q2b = PB2[(4 * kb + 2) * 2 + 1];
+        const d2v q3a = PB2[(4 * kb + 3) * 2], q3b = PB2[(4 * kb + 3) * 2 + 1];
+        const double D00 = q0.x, D10 = q1.x;
+        double D11 = q1.y, D20 = q2a.x, D21 = q2a.y, D22 = q2b.x, D30 = q3a.x, D31 = q3a.y, D32 = q3b.x, D33 = q3b.y;
+        const double r0 = fast_rcp(D00), l10 = D10 * r0, l20 = D20 * r0, l30 = D30 * r0;
+        D11 = fma(-l10, D10, D11); D21 = fma(-l20, D10, D21); D31 = fma(-l30, D10, D31);
+        D22 = fma(-l20, D20, D22); D32 = fma(-l30, D20, D32); D33 = fma(-l30, D30, D33);
+        const double r1 = fast_rcp(D11), l21 = D21 * r1, l31 = D31 * r1;
+        D22 = fma(-l21, D21, D22); D32 = fma(-l31, D21, D32); D33 = fma(-l31, D31, D33);
+        const double r2 = fast_rcp(D22), l32 = D32 * r2;
+        D33 = fma(-l32, D32, D33);
+        const double r3 = fast_rcp(D33);
+        const bool real1 = 4 * kb + 1 < P, real2 = 4 * kb + 2 < P, real3 = 4 * kb + 3 < P;
+        const bool bad = !(D00 > 0.0) | (real1 & !(D11 > 0.0)) | (real2 & !(D22 > 0.0)) | (real3 & !(D33 > 0.0));
+        d2v* Ro = (d2v*)(s_R + 4 * kb);
+        Ro[0] = (d2v){r0, real1 ? r1 : 0.0}; Ro[1] = (d2v){real2 ? r2 : 0.0, real3 ? r3 : 0.0};
+        if (bad) *s_fail = 1;
     }
     MFP(1);
     __syncthreads();                                         // W rows, reciprocal pivots and the failure flag are visible
