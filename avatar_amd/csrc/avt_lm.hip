@@ -502,8 +502,11 @@ __device__ __forceinline__ bool mf_round(v4f64 (&accA)[6], v4f64 (&accB)[2], int
         const int rr = t - 4 * kb;     // row inside the trailing part; the diagonal block keeps its strictly lower part
         if (rr >= 0 && (t >> 2) < NB) {     // (rows past the matrix have no block)
             d2v* Wo = (d2v*)(Lblk + ((size_t)kb * NB + (t >> 2)) * 18 + (t & 3) * 4);
-            Wo[0] = (d2v){rr < 1 ? 0.0 : w0, rr < 2 ? 0.0 : w1};
-            Wo[1] = (d2v){rr < 3 ? 0.0 : w2, rr < 4 ? 0.0 : w3};
+            // (the four rows of the diagonal block leave what they computed in its upper triangle too: nobody reads it as part of the factor - the
+            // matrix phase and the back substitution's chain only add it to rows and columns that are already final, the fold reads the strictly
+            // lower part by name - and zeroing it was four compares and eight selects per row and round)
+            Wo[0] = (d2v){w0, w1};
+            Wo[1] = (d2v){w2, w3};
         }
     }
     // The reciprocal pivots (what the matrix phase and the back substitution read) and the verdict on the pivots are the business of ONE lane of
