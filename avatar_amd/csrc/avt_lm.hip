@@ -936,6 +936,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
         for (int e = t; e < NBk * NBk * 9; e += NTH) z[e] = (d2v){0.0, 0.0};
     }
 
+    if constexpr (MODE != SOLVE_DECIDE && MODE != SOLVE_INIT) TPROBE(18);
     if (mode == SOLVE_INIT) {
         // trial point := current point (frame batches; few frames: prep_init_block in k_lbs's grid does this).  The constant part
         // of the data cost is summed by the FIRST solve.
@@ -1136,7 +1137,9 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
         }
     }
     };
+    if constexpr (MODE != SOLVE_DECIDE) TPROBE(16);
     load_system();
+    if constexpr (MODE != SOLVE_DECIDE) TPROBE(17);
     // prior score of every component: strict '<' in ascending component order (GaussianMixture.cpp:103)
     double best[2] = {1.7976931348623157e308, 1.7976931348623157e308};
     int bcomp[2] = {-1, -1};
@@ -1153,7 +1156,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
     if constexpr (RIDE) { hpp0 = hpp1 = hload(H0 + ride_slot * ((size_t)HS * HS) + (size_t)P * HS + P); }
     else { hpp0 = hload(H0 + (size_t)P * HS + P); hpp1 = hload(H0 + (size_t)HS * HS + (size_t)P * HS + P); }
 
-    TPROBE(13);
+    if constexpr (MODE != SOLVE_DECIDE) TPROBE(13);
     const double lm_up = fb.params->lm_up, lm_down = fb.params->lm_down, lm_min = fb.params->lm_min, lm_max = fb.params->lm_max;   // same round trip
     const bool gain = fb.params->lm_policy != 0.0;          // gain-ratio damping schedule (avt_options::lm_policy)
     const double ftol = fb.params->ftol;                    // the stopping rule (avt_options::function_tolerance; 0 = off)
@@ -1191,7 +1194,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
     }
     if constexpr (!RIDE) stage_store();      // (behind the requests for the system's entries: one round trip for everything)
     __syncthreads();   // the staged state slots are visible; every lane has read the control block
-    TPROBE(14);
+    if constexpr (MODE != SOLVE_DECIDE) TPROBE(14);
     // the frame met the stopping rule in an earlier launch of this ICP iteration: no trial point, no test, no iteration (the riding shapes left above)
     if (!RIDE && mode != SOLVE_FIRST && try_valid == AVT_TRY_DONE) return;
 
@@ -1237,7 +1240,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
     }
     const double cost_cur = accepted ? cost : cost_cur0;
     const int comp = accepted ? comp_try : comp_cur0;
-    TPROBE(15);
+    if constexpr (MODE != SOLVE_DECIDE) TPROBE(15);
     // Speculative steps (RIDE shapes): a rejected trial point is followed by a solve of the SAME system with lambda up - which
     // a speculative workgroup of the last full solve launch has already made.  The solver then installs it (trial state and
     // skeleton tables copied into the trial slot) instead of factoring, and the speculative workgroups of this launch go home.

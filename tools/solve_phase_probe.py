@@ -33,6 +33,9 @@ if buf[48] > 0:
 if buf[50] > 0:
     print("riding hand-over: kernel start to poll %.0f | polling %.0f (%d spins) | poll end to decision made %.0f clocks" % (buf[50] - buf[40], buf[51] - buf[50], int(buf[52]), buf[41] - buf[51]))
     print("  poll end to: system requested %.0f | barrier (everything arrived) %.0f | accept test taken %.0f | control block written, roles sorted %.0f" % (buf[53] - buf[51], buf[54] - buf[53], buf[55] - buf[54], buf[41] - buf[55]))
+if buf[50] <= 0 and buf[53] > 0:
+    print("  staging requested and factor zeroed %.0f | ... index arithmetic up to the system's first request %.0f | its requests issued %.0f" % (buf[58] - buf[40], buf[56] - buf[58], buf[57] - buf[56]))
+    print("batch shape, from the kernel's first instruction to: system requested %.0f | barrier (everything arrived) %.0f | accept test taken %.0f | prior's entries requested, control block written %.0f" % (buf[53] - buf[40], buf[54] - buf[53], buf[55] - buf[54], buf[41] - buf[55]))
 # skeleton-pass internal probes live in the last two doubles of the prep block of the try slot
 print("skeleton pass: joint positions + barrier %.0f | level loop %.0f | outputs %.0f clocks" % (buf[62] - buf[45], buf[63] - buf[62], buf[46] - buf[63]))
 
