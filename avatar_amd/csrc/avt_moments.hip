@@ -412,8 +412,15 @@ __device__ __forceinline__ double mom_row_sum(double v) {
 #else
 #define PPROBE(i) do {} while (0)
 #endif
-template <int KC>
+#define AVT_SMPL_PROMISES(d) do { __builtin_assume((d).J == 24); __builtin_assume((d).K == 10); __builtin_assume((d).P == 85); __builtin_assume((d).HS == 88); \
+                                   __builtin_assume((d).xsize == 109); __builtin_assume((d).ndims == 69); __builtin_assume((d).prep_size == 1192); } while (0)
+template <int KC, bool SM = false>      // SM: the model has SMPL's dimensions (AVT_SMPL_PROMISES)
 __global__ __launch_bounds__(16 * MOM_PP_PAIRS) void k_pairpass(DeviceModel dm, FrameBuffers fb) {
+    // SM (the host launches this copy for models with SMPL's dimensions, launch_assemble): promises about the dimensions where the structure lies -
+    // a private copy would live in scratch memory, its arrays are indexed at run time.  One wave per workgroup, six workgroups per CU: the kernel is
+    // short of issue slots and its index arithmetic folds; the prior's workgroups in this grid are the launch's longest and gain most (their loops over
+    // the 69 prior dimensions).  k_prior carries the same promises: the two homes of the prior must give the same bits.
+    if constexpr (SM) AVT_SMPL_PROMISES(dm.d);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTH = 16 * MOM_PP_PAIRS;
     const AvtDims& d = dm.d;
@@ -690,7 +697,9 @@ __global__ __launch_bounds__(16 * MOM_PP_PAIRS) void k_pairpass(DeviceModel dm, 
 
 // the GMM pose prior of the trial point, one workgroup per (component, frame) (avt_prior.h).  A launch of its own: in the pair pass's
 // grid every one of these small workgroups would hold that kernel's 52 KB of LDS, a third of a CU
+template <bool SM = false>
 __global__ __launch_bounds__(128) void k_prior(DeviceModel dm, FrameBuffers fb) {
+    if constexpr (SM) AVT_SMPL_PROMISES(dm.d);
     __shared__ double s_scratch[5 * AVT_MAX_JOINTS];
     int bx, fy;
     xcd_frame_block(fb, bx, fy);
@@ -1403,10 +1412,14 @@ void launch_assemble(avt_ctx* c, int nframes) {
 #define MOM_PRIOR_RIDE_MAX 256
 #endif
         const bool prior_rides = 16 * MOM_PP_PAIRS >= 64 && nframes <= MOM_PRIOR_RIDE_MAX;
-        if (d.ncomps > 0 && !prior_rides) hipLaunchKernelGGL(k_prior, dim3(d.ncomps, nframes), dim3(128), 0, c->cur_stream, c->dm, c->fb);
+        if (d.ncomps > 0 && !prior_rides) {
+            if (d.K == 10 && d.J == 24 && d.ndims == 69) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prior<true>), dim3(d.ncomps, nframes), dim3(128), 0, c->cur_stream, c->dm, c->fb);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prior<false>), dim3(d.ncomps, nframes), dim3(128), 0, c->cur_stream, c->dm, c->fb);
+        }
         const dim3 grid(mom_nwg(d) + (prior_rides ? d.ncomps : 0), nframes);
         const size_t lds = pairpass_lds_bytes(d);
-        if (d.K == 10) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairpass<10>), grid, dim3(16 * MOM_PP_PAIRS), lds, c->cur_stream, c->dm, c->fb);
+        if (d.K == 10 && d.J == 24 && d.ncomps > 0 && d.ndims == 69) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairpass<10, true>), grid, dim3(16 * MOM_PP_PAIRS), lds, c->cur_stream, c->dm, c->fb);
+        else if (d.K == 10) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairpass<10>), grid, dim3(16 * MOM_PP_PAIRS), lds, c->cur_stream, c->dm, c->fb);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairpass<0>), grid, dim3(16 * MOM_PP_PAIRS), lds, c->cur_stream, c->dm, c->fb);
     }
     if (c->tun.asm_parts || assemble_lds_bytes(d) > avt_moments_lds_cap()) {      // six role workgroups of 256 threads per frame (the default)
@@ -1457,5 +1470,6 @@ int avt_moments_set_attributes() {
            hipFuncSetAttribute((const void*)k_assemble_parts<10>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
            hipFuncSetAttribute((const void*)k_assemble_parts<0>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
            hipFuncSetAttribute((const void*)k_pairpass<10>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
-           hipFuncSetAttribute((const void*)k_pairpass<0>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess;
+           hipFuncSetAttribute((const void*)k_pairpass<0>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+           hipFuncSetAttribute((const void*)k_pairpass<10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess;
 }
