@@ -369,6 +369,9 @@ __device__ __forceinline__ void eval_body(const DeviceModel& dm, const FrameBuff
         const int2 cs = *(const int2*)&fb.ctl[fp].cur_slot;      // (cur_slot, try_valid): one load
         if (cs.y == AVT_TRY_DONE) return;                         // the frame met the stopping rule (avt_options::function_tolerance): no trial point
         extern __shared__ __attribute__((aligned(16))) char smem_prior[];
+        // (fixed-shape instantiation = SMPL's joint and key counts; a model with a prior has 3 (J - 1) prior dimensions (avt_model_create checks it):
+        // as constants they unroll the prior's loops over its rows - its passes become one memory round trip instead of one each)
+        if constexpr (FIXED && CJ == 24 && CK == 10) { __builtin_assume(dm.d.ndims == 69); __builtin_assume(dm.d.J == 24); __builtin_assume(dm.d.xsize == 109); }
         prior_component(dm, fb, fp, id2 % d.ncomps, 1 - cs.x, (double*)smem_prior);
         return;
     }
