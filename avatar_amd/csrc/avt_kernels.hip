@@ -138,12 +138,20 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
     if (v >= V) return;
     // shapedCloud = keyClouds * w + baseCloud  (Avatar.cpp:26)
     double sx = 0.0, sy = 0.0, sz = 0.0;
-    for (int k = 0; k < K; ++k) {
-        const double wk = s_w[k];
-        sx += dm.shape_planes[((size_t)k * 3 + 0) * V + v] * wk;
-        sy += dm.shape_planes[((size_t)k * 3 + 1) * V + v] * wk;
-        sz += dm.shape_planes[((size_t)k * 3 + 2) * V + v] * wk;
-    }
+    // (SMPL's ten keys as a compile-time trip count: the loop unrolls and its 30 plane values are requested together - with the count in a
+    // register every turn waited for its own three loads, ten memory round trips one after the other; same operations in the same order)
+    auto shape_sum = [&](auto kc) __attribute__((always_inline)) {
+        constexpr int KC = decltype(kc)::value;
+        const int Kn = KC ? KC : K;
+#pragma unroll
+        for (int k = 0; k < Kn; ++k) {
+            const double wk = s_w[k];
+            sx += dm.shape_planes[((size_t)k * 3 + 0) * V + v] * wk;
+            sy += dm.shape_planes[((size_t)k * 3 + 1) * V + v] * wk;
+            sz += dm.shape_planes[((size_t)k * 3 + 2) * V + v] * wk;
+        }
+    };
+    if (K == 10) shape_sum(std::integral_constant<int, 10>{}); else shape_sum(std::integral_constant<int, 0>{});
     sx += dm.shape_planes[((size_t)K * 3 + 0) * V + v];
     sy += dm.shape_planes[((size_t)K * 3 + 1) * V + v];
     sz += dm.shape_planes[((size_t)K * 3 + 2) * V + v];
@@ -151,11 +159,15 @@ __global__ __launch_bounds__(256) void k_lbs(DeviceModel dm, FrameBuffers fb, co
     double pt[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) pt[e] = 0.0;
+    double lw[4];
+    int lj[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { lw[a] = dm.lbs_w[(size_t)a * V + v]; lj[a] = dm.lbs_j[(size_t)a * V + v]; }      // (the joint index with the weight, not behind the test of it)
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        const double wt = dm.lbs_w[(size_t)a * V + v];
+        const double wt = lw[a];
         if (wt != 0.0) {
-            const double* T = s_T + 12 * dm.lbs_j[(size_t)a * V + v];
+            const double* T = s_T + 12 * lj[a];
 #pragma unroll
             for (int e = 0; e < 12; ++e) pt[e] += T[e] * wt;
         }
