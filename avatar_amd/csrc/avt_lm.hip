@@ -964,7 +964,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
     // column c16 of a tile.  Raw data-term entries of BOTH slots are requested now (indices clamped, selected later).
     const int mf_wv = t >> 6, mf_g4 = (t >> 4) & 3, mf_c16 = t & 15, mf_rA = 5 - mf_wv, mf_rB = mf_wv - 2;
     // (six tile slots per wave: slot s <= rA is tile (rA, s), the slots behind are tiles (rB, 0..rB))
-    double mraw[(TRI || RIDE) ? 1 : 2][TRI ? 1 : 6][4];
+    double mraw[1][TRI ? 1 : 6][4];      // (one slot: the riding shapes request the trial slot's system in front of the decision, the batch shapes the chosen slot's behind it)
     // RIDE: the snapshot every solver role decides on (AvtSolveSnap) is requested now, before the wait for the reduction
     AvtFrameCtl snap_ctl;
     // (the speculative-step queue field by field, never as a structure: an entry chosen by an index the compiler does not know would put a copy of
@@ -1121,11 +1121,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
                     const bool inb = row + 3 < HS && col + 15 < HS;
                     const size_t off = inb ? (size_t)row * HS + col
                                            : (size_t)(min(row + mf_g4, HS - 1) - mf_g4) * HS + (min(col + mf_c16, HS - 1) - mf_c16);
-                    if (RIDE) mraw[0][ti][v] = own ? hload(Hl + ride_slot * ((size_t)HS * HS) + off) : 0.0;      // (one slot, see above)
-                    else {
-                        mraw[0][ti][v] = own ? hload(Hl + off) : 0.0;
-                        mraw[TRI || RIDE ? 0 : 1][ti][v] = own ? hload(Hl + (size_t)HS * HS + off) : 0.0;
-                    }
+                    mraw[0][ti][v] = own ? hload(Hl + ride_slot * ((size_t)HS * HS) + off) : 0.0;      // (one slot, see above)
                 }
             }
         };
@@ -1137,8 +1133,11 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
         }
     }
     };
+    // (batch shapes, late round 6: they used to request BOTH slots' systems here - 98 requests, 3.1 k clocks of issue alone - and the prior's
+    // entries in a second round trip behind the decision.  The decision needs the control block, the scores and the two corner entries only: those
+    // go out here with the staging; the chosen slot's system and the prior's entries go out together behind the decision - one slot, one round trip)
     if constexpr (MODE != SOLVE_DECIDE) TPROBE(16);
-    load_system();
+    if constexpr (RIDE) load_system();
     if constexpr (MODE != SOLVE_DECIDE) TPROBE(17);
     // prior score of every component: strict '<' in ascending component order (GaussianMixture.cpp:103)
     double best[2] = {1.7976931348623157e308, 1.7976931348623157e308};
@@ -1341,6 +1340,9 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
             ride_slot = cur;
             load_system();
         }
+    } else {
+        ride_slot = cur;
+        load_system();
     }
     if constexpr (!TRI && MODE != SOLVE_DECIDE) {
         const int comp_need = (sbp > 0.0 && d.ncomps > 0) ? comp : -1;
@@ -1408,7 +1410,7 @@ __global__ __launch_bounds__(NTH) void k_solve(DeviceModel dm_arg, FrameBuffers 
                 const bool own = first || (rB >= 0 && cb <= rB);
                 double raw[4];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) raw[v] = RIDE ? mraw[0][TRI ? 0 : ti][v] : (cur ? mraw[(TRI || RIDE) ? 0 : 1][TRI ? 0 : ti][v] : mraw[0][TRI ? 0 : ti][v]);
+                for (int v = 0; v < 4; ++v) raw[v] = mraw[0][TRI ? 0 : ti][v];
                 dgn[ti] = 0.0;
                 if (own) tile[ti] = sys_tile(rb, cb, true, raw, dgn[ti], prv_pre[ti], gq_pre[ti]);
                 else tile[ti] = (v4f64){0.0, 0.0, 0.0, 0.0};
