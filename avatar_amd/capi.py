@@ -86,9 +86,9 @@ class Options(C.Structure):
 class Tuning(C.Structure):
     """include/avt.h avt_tuning: launch-shape and algorithm knobs of a context (defaults = the measured optima)."""
     _fields_ = [(n, C.c_int) for n in ("use_graph", "groups", "g", "gcap", "vis_frame_min", "ride", "ride_strips", "ride_sizing_groups", "nspec",
-                                       "nn_force_part", "nn_slab", "mom_min_frames", "debug", "asm_parts")] + [("ride_timeout_us", C.c_longlong), ("lbs_frames", C.c_int), ("spec_cost", C.c_int), ("xcd_frames", C.c_int)]
+                                       "nn_force_part", "nn_slab", "mom_min_frames", "debug", "asm_parts")] + [("ride_timeout_us", C.c_longlong), ("lbs_frames", C.c_int), ("spec_cost", C.c_int), ("xcd_frames", C.c_int), ("literal_dims", C.c_int)]
     DEFAULTS = dict(use_graph=1, groups=0, g=0, gcap=128, vis_frame_min=32, ride=1, ride_strips=0, ride_sizing_groups=0, nspec=4, nn_force_part=0,
-                    nn_slab=1, mom_min_frames=8, debug=0, asm_parts=1, ride_timeout_us=2000000, lbs_frames=0, spec_cost=1, xcd_frames=1)
+                    nn_slab=1, mom_min_frames=8, debug=0, asm_parts=1, ride_timeout_us=2000000, lbs_frames=0, spec_cost=1, xcd_frames=1, literal_dims=1)
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}

@@ -107,11 +107,11 @@ avt_tuning tuning_from_environment() {
     avt_tuning t;
     std::memset(&t, 0, sizeof t);
     t.use_graph = 1; t.groups = 0; t.g = 0; t.gcap = 128; t.vis_frame_min = 32; t.ride = 1; t.ride_strips = 0; t.ride_sizing_groups = 0;
-    t.asm_parts = 1; t.spec_cost = 1; t.xcd_frames = 1; t.nspec = AVT_MAX_SPEC; t.nn_force_part = 0; t.nn_slab = 1; t.mom_min_frames = 8; t.debug = 0; t.ride_timeout_us = 2000000;
+    t.asm_parts = 1; t.spec_cost = 1; t.xcd_frames = 1; t.literal_dims = 1; t.nspec = AVT_MAX_SPEC; t.nn_force_part = 0; t.nn_slab = 1; t.mom_min_frames = 8; t.debug = 0; t.ride_timeout_us = 2000000;
     struct Knob { const char* name; int* field; };
     const Knob knobs[] = {{"AVT_USE_GRAPH", &t.use_graph}, {"AVT_GROUPS", &t.groups}, {"AVT_G", &t.g}, {"AVT_GCAP", &t.gcap}, {"AVT_VIS_FRAME_MIN", &t.vis_frame_min},
                           {"AVT_RIDE", &t.ride}, {"AVT_RIDE_STRIPS", &t.ride_strips}, {"AVT_RIDE_SIZING_GROUPS", &t.ride_sizing_groups}, {"AVT_NSPEC", &t.nspec},
-                          {"AVT_NN_FORCE_PART", &t.nn_force_part}, {"AVT_NN_SLAB", &t.nn_slab}, {"AVT_MOM_MIN_FRAMES", &t.mom_min_frames}, {"AVT_ASM_PARTS", &t.asm_parts}, {"AVT_LBS_FRAMES", &t.lbs_frames}, {"AVT_SPEC_COST", &t.spec_cost}, {"AVT_XCD_FRAMES", &t.xcd_frames}, {"AVT_DEBUG", &t.debug}};
+                          {"AVT_NN_FORCE_PART", &t.nn_force_part}, {"AVT_NN_SLAB", &t.nn_slab}, {"AVT_MOM_MIN_FRAMES", &t.mom_min_frames}, {"AVT_ASM_PARTS", &t.asm_parts}, {"AVT_LBS_FRAMES", &t.lbs_frames}, {"AVT_SPEC_COST", &t.spec_cost}, {"AVT_XCD_FRAMES", &t.xcd_frames}, {"AVT_LITERAL_DIMS", &t.literal_dims}, {"AVT_DEBUG", &t.debug}};
     // names other parts of the repository own (the batch split, the Python loader, bench.py, instrumented builds)
     const char* others[] = {"AVT_LIB", "AVT_RCCL_LIB", "AVT_SHARD_LOOPBACK_TIMEOUT_S", "AVT_BENCH_SHARE_GPU0", "AVT_TIMING"};
     for (char** e = environ; e && *e; ++e) {
@@ -137,7 +137,7 @@ avt_tuning tuning_from_environment() {
 
 int validate_tuning(const avt_tuning& t) {
     if (t.groups < 0 || t.groups > AVT_MAX_GROUPS || t.g < 0 || t.gcap < 2 || t.vis_frame_min < 0 || t.nspec < 0 || t.nspec > AVT_MAX_SPEC ||
-        (t.ride_strips != 0 && t.ride_strips != 4 && t.ride_strips != 8) || t.mom_min_frames < 1 || t.ride_timeout_us < 0 || (t.lbs_frames != 0 && t.lbs_frames != 1 && t.lbs_frames != 2 && t.lbs_frames != 4) || t.spec_cost < 0 || t.spec_cost > 1 || t.xcd_frames < 0 || t.xcd_frames > 1) {
+        (t.ride_strips != 0 && t.ride_strips != 4 && t.ride_strips != 8) || t.mom_min_frames < 1 || t.ride_timeout_us < 0 || (t.lbs_frames != 0 && t.lbs_frames != 1 && t.lbs_frames != 2 && t.lbs_frames != 4) || t.spec_cost < 0 || t.spec_cost > 1 || t.xcd_frames < 0 || t.xcd_frames > 1 || t.literal_dims < 0 || t.literal_dims > 1) {
         avt_set_error("avt_tuning: a field is out of range (include/avt.h)");
         return 1;
     }

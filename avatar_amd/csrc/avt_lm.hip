@@ -1661,7 +1661,7 @@ static bool solve_dims_smpl(const AvtDims& d) {
 template <int NTH, bool TRI>
 static void launch_solve_shape(avt_ctx* c, int nframes, int mode, size_t lds) {
     if constexpr (NTH == 256 && !TRI) {
-        if (solve_dims_smpl(c->dm.d) && (mode == SOLVE_FIRST || mode == SOLVE_NORMAL)) {
+        if (c->tun.literal_dims && solve_dims_smpl(c->dm.d) && (mode == SOLVE_FIRST || mode == SOLVE_NORMAL)) {
             if (mode == SOLVE_FIRST) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256, false, SOLVE_FIRST, 0, true>), dim3(nframes), dim3(256), lds, c->cur_stream, c->dm, c->fb);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256, false, SOLVE_NORMAL, 0, true>), dim3(nframes), dim3(256), lds, c->cur_stream, c->dm, c->fb);
             return;
@@ -1714,7 +1714,7 @@ void launch_solve(avt_ctx* c, int nframes, int mode, int seq) {
         c->fb.nspec_cost = std::min(c->fb.nspec, ride_spec_cost(c));
         const dim3 grid(nframes, 1 + c->fb.nspec + rs * d.NPAIR + c->fb.nspec_cost);
 #define AVT_RIDE(M, S, SMD) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve<256, false, M, S, SMD>), grid, dim3(256), solve_lds_bytes(d), c->cur_stream, c->dm, c->fb)
-        if (solve_dims_smpl(d)) {
+        if (c->tun.literal_dims && solve_dims_smpl(d)) {
             if (mode == SOLVE_FIRST) { if (rs == 8) AVT_RIDE(SOLVE_FIRST, 8, true); else AVT_RIDE(SOLVE_FIRST, 4, true); }
             else { if (rs == 8) AVT_RIDE(SOLVE_NORMAL, 8, true); else AVT_RIDE(SOLVE_NORMAL, 4, true); }
         } else {

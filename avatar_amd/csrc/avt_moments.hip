@@ -1413,12 +1413,12 @@ void launch_assemble(avt_ctx* c, int nframes) {
 #endif
         const bool prior_rides = 16 * MOM_PP_PAIRS >= 64 && nframes <= MOM_PRIOR_RIDE_MAX;
         if (d.ncomps > 0 && !prior_rides) {
-            if (d.K == 10 && d.J == 24 && d.ndims == 69) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prior<true>), dim3(d.ncomps, nframes), dim3(128), 0, c->cur_stream, c->dm, c->fb);
+            if (c->tun.literal_dims && d.K == 10 && d.J == 24 && d.ndims == 69) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prior<true>), dim3(d.ncomps, nframes), dim3(128), 0, c->cur_stream, c->dm, c->fb);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prior<false>), dim3(d.ncomps, nframes), dim3(128), 0, c->cur_stream, c->dm, c->fb);
         }
         const dim3 grid(mom_nwg(d) + (prior_rides ? d.ncomps : 0), nframes);
         const size_t lds = pairpass_lds_bytes(d);
-        if (d.K == 10 && d.J == 24 && d.ncomps > 0 && d.ndims == 69) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairpass<10, true>), grid, dim3(16 * MOM_PP_PAIRS), lds, c->cur_stream, c->dm, c->fb);
+        if (c->tun.literal_dims && d.K == 10 && d.J == 24 && d.ncomps > 0 && d.ndims == 69) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairpass<10, true>), grid, dim3(16 * MOM_PP_PAIRS), lds, c->cur_stream, c->dm, c->fb);
         else if (d.K == 10) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairpass<10>), grid, dim3(16 * MOM_PP_PAIRS), lds, c->cur_stream, c->dm, c->fb);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairpass<0>), grid, dim3(16 * MOM_PP_PAIRS), lds, c->cur_stream, c->dm, c->fb);
     }

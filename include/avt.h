@@ -288,6 +288,9 @@ typedef struct avt_tuning {
     int xcd_frames;          /* frame-batch kernels whose workgroups share per-frame data (k_moments, the nearest neighbour's throughput shape): 1 (default) the
                               * workgroups of a frame run on ONE of the eight XCDs (grid remap, xcd_frame_block), so that the frame's data is fetched into one
                               * L2 instead of eight; 0: grid order */
+    int literal_dims;        /* 1 (default): a model with SMPL's dimensions (24 joints, 10 shape keys, a 69-dimensional pose prior) runs the copies of
+                              * k_solve, k_pairpass and k_prior that are compiled for them (every count a literal: DESIGN section 5, "Round 6, second
+                              * half"); 0: the run-time-dimension copies every other model runs - same results to rounding, ~25 % slower per solve */
 } avt_tuning;
 int avt_ctx_get_tuning(avt_ctx* c, avt_tuning* out);
 int avt_ctx_set_tuning(avt_ctx* c, const avt_tuning* t);

@@ -186,6 +186,32 @@ def test_refused_factorisation_leaves_the_state_untouched(smpl, omodel, gmodel):
             assert st[1].accepted_steps == ref1["stats"].accepted_steps and np.abs(p[1] - ref1["p"]).max() < 1e-6
 
 
+def test_literal_dimension_kernels_agree_with_the_runtime_dimension_copies(smpl, gmodel):
+    """avt_tuning.literal_dims: a model with SMPL's dimensions runs the copies of k_solve / k_pairpass / k_prior that are compiled for them
+    (every count a literal); with the knob at 0 it runs the run-time-dimension copies every other model runs.  Same source: the fits agree to
+    rounding - one frame (the riding shape), five frames (row form, batch shape), forty frames (moment form, two groups)."""
+    from avatar_amd import api
+    pm = synth.identity_part_map()
+    frs = [synth.make_frame(smpl, 60 + s) for s in range(4)]
+    opt = Options.demo(max_iters_per_icp=6)
+    for frames in (1, 5, 40):
+        pick = [i % len(frs) for i in range(frames)]
+        starts = [_start(frs[i]) for i in pick]
+        args = ([frs[i]["data"] for i in pick], [frs[i]["labels"] for i in pick], opt, np.array([s[0] for s in starts]), np.array([s[1] for s in starts]),
+                np.array([s[2] for s in starts]))
+        res = []
+        for lit in (1, 0):
+            ctx = api.Context(gmodel, 24, pm, 60000, frames)
+            ctx.set_tuning(literal_dims=lit)
+            assert ctx.tuning().literal_dims == lit
+            res.append(ctx.optimize_batch(*args))
+            del ctx
+        (p1, q1, w1, st1), (p0, q0, w0, st0) = res
+        assert np.abs(p1 - p0).max() < 1e-9 and np.abs(q1 - q0).max() < 1e-9 and np.abs(w1 - w0).max() < 1e-9, frames
+        assert [s.accepted_steps for s in st1] == [s.accepted_steps for s in st0] and [s.gn_iterations for s in st1] == [s.gn_iterations for s in st0]
+        assert all(abs(a.final_cost - b.final_cost) <= 1e-9 * abs(b.final_cost) for a, b in zip(st1, st0))
+
+
 def test_translation_equivariance_and_monotone_cost(smpl, gmodel):
     """Size-independent properties at full size: shifting the data and the start by t shifts the fit by t (the model
     enters only through p + R(...)); the LM objective never increases."""
